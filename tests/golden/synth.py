@@ -1,0 +1,139 @@
+"""Deterministic synthetic inputs shared by the golden generator, the oracle tests,
+the GPU parity tests and bench.py.  Pure numpy; never imports the reference.
+
+Shapes/semantics follow SURVEY.md section 8(d):
+  * image ~ N(0,1) clamped to [-3,3]  (reference CTs: clip[-991,500] -> z-score,
+    dataset_conversion/nii2npz.py:64-74; train_ddp.py:312-313 asserts |x|<=100)
+  * labels: multi-hot (B,C,D,H,W) organs as ellipsoids
+  * "mask" sample : lesion annotated per voxel, unk = mask = 0, volumes = 0
+  * "report" sample: lesion label 0, unk[lesion] = mask[lesion] = organ,
+                     1-3 tumours with diameters/volumes
+                     (training/dataset/dim3/dataset_abdomenatlas_UFO.py:1391-1407)
+"""
+import math
+import numpy as np
+
+TINY_CLASSES = ['kidney_left', 'kidney_lesion', 'kidney_right', 'pancreas', 'pancreatic_lesion']
+
+# dataset_conversion/label_names_mask_dataset_pancreas.yaml (26 entries, alphabetical)
+PANTS_CLASSES = [
+    'adrenal_gland_left', 'adrenal_gland_right', 'aorta', 'bladder', 'colon', 'common_bile_duct',
+    'duodenum', 'femur_left', 'femur_right', 'gall_bladder', 'kidney_left', 'kidney_right', 'liver',
+    'lung_left', 'lung_right', 'pancreas', 'pancreas_body', 'pancreas_head', 'pancreas_tail',
+    'pancreatic_lesion', 'postcava', 'prostate', 'spleen', 'stomach', 'superior_mesenteric_artery',
+    'veins']
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def det_param(shape, seed, scale=None):
+    """Deterministic parameter tensor: N(0, scale^2) with scale = 1/sqrt(fan_in)."""
+    shape = tuple(int(s) for s in shape)
+    n = int(np.prod(shape))
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else n
+    if scale is None:
+        scale = 1.0 / math.sqrt(max(fan_in, 1))
+    return (rng(seed).standard_normal(n).astype(np.float32) * np.float32(scale)).reshape(shape)
+
+
+def fill_state_dict(shapes, seed=0):
+    """shapes: dict name -> shape.  Returns dict name -> float32 ndarray.
+    Iterates in sorted-name order so reference module, oracle and product agree."""
+    out = {}
+    for i, name in enumerate(sorted(shapes)):
+        out[name] = det_param(shapes[name], seed * 100003 + i)
+    return out
+
+
+def image(B, S, seed=1234):
+    x = rng(seed).standard_normal((B, 1, S, S, S)).astype(np.float32)
+    # add smooth structure so IN statistics are not trivially N(0,1)
+    z = np.linspace(-1, 1, S, dtype=np.float32)
+    x += 0.5 * np.sin(3.0 * z)[None, None, :, None, None] * np.cos(2.0 * z)[None, None, None, :, None]
+    return np.clip(x, -3, 3).astype(np.float32)
+
+
+def _ellipsoid(S, center, radii):
+    z, y, x = np.meshgrid(np.arange(S), np.arange(S), np.arange(S), indexing='ij')
+    d = ((z - center[0]) / radii[0]) ** 2 + ((y - center[1]) / radii[1]) ** 2 + ((x - center[2]) / radii[2]) ** 2
+    return d <= 1.0
+
+
+def batch(B, S, classes, kinds, seed=7, diam_range=(5.0, 12.0), max_tumors=2):
+    """Build one synthetic mixed batch.
+
+    kinds: list of 'mask' | 'report' | 'healthy' per sample.
+    Returns dict of float32/uint8 ndarrays with the reference's batch keys
+    (train_ddp.py:247-256): label, unk_channels, mask, volumes, diameters.
+    """
+    C = len(classes)
+    g = rng(seed)
+    label = np.zeros((B, C, S, S, S), np.uint8)
+    unk = np.zeros_like(label)
+    mask = np.zeros_like(label)
+    volumes = np.zeros((B, 10), np.float32)
+    diameters = np.zeros((B, 10, 3), np.float32)
+    lesion_idx = [i for i, c in enumerate(classes) if 'lesion' in c]
+    organ_of = {}
+    for li in lesion_idx:
+        organ = classes[li].split('_lesion')[0].replace('pancreatic', 'pancreas')
+        cands = [i for i, c in enumerate(classes) if c == organ or c == organ + '_left']
+        organ_of[li] = cands[0] if cands else None
+    for b in range(B):
+        # organs: random ellipsoids, one per non-lesion class
+        for c in range(C):
+            if c in lesion_idx:
+                continue
+            ctr = g.uniform(0.25 * S, 0.75 * S, 3)
+            rad = g.uniform(S / 10.0, S / 5.0, 3)
+            if classes[c] == 'pancreas':
+                ctr = np.array([S / 2.0, S / 2.0, S / 2.0]) + g.uniform(-2, 2, 3)
+                rad = np.array([S / 5.0] * 3)
+            label[b, c] = _ellipsoid(S, ctr, rad)
+        kind = kinds[b]
+        li = lesion_idx[-1]  # pancreatic_lesion when present
+        oi = organ_of[li]
+        organ = label[b, oi].astype(bool)
+        if kind == 'mask':
+            ctr = np.array([S / 2.0] * 3) + g.uniform(-S / 12.0, S / 12.0, 3)
+            r = g.uniform(3.0, max(3.5, S / 12.0))
+            label[b, li] = _ellipsoid(S, ctr, (r, r, r)) & organ
+        elif kind == 'report':
+            unk[b, li] = organ
+            mask[b, li] = organ
+            nt = int(g.integers(1, max_tumors + 1))
+            for t in range(nt):
+                d = float(g.uniform(*diam_range))
+                diameters[b, t] = (d, 0.8 * d, 0.7 * d)
+                volumes[b, t] = (4.0 / 3.0) * math.pi * (d / 2.0) ** 3
+        elif kind == 'healthy':
+            pass
+        else:
+            raise ValueError(kind)
+    return dict(label=label, unk_channels=unk, mask=mask, volumes=volumes, diameters=diameters)
+
+
+def logits(B, C, S, seed=99, scale=2.0, smooth=True):
+    """Continuous random logits (ties have measure zero -> selection ops are well defined)."""
+    g = rng(seed)
+    x = g.standard_normal((B, C, S, S, S)).astype(np.float32) * np.float32(scale)
+    if smooth:
+        # a bump near the centre so the ball search has a clear optimum
+        z = (np.arange(S, dtype=np.float32) - S / 2.0) / (S / 6.0)
+        bump = np.exp(-0.5 * (z[:, None, None] ** 2 + z[None, :, None] ** 2 + z[None, None, :] ** 2))
+        x += 3.0 * bump[None, None]
+    return x.astype(np.float32)
+
+
+def subsample(a, n=4096):
+    """Deterministic strided subsample of a flattened array (for compact fixtures)."""
+    f = np.asarray(a).reshape(-1)
+    step = max(1, f.size // n)
+    return f[::step][:n].copy(), step
+
+
+def summary(a):
+    f = np.asarray(a, dtype=np.float64).reshape(-1)
+    return np.array([f.sum(), (f * f).sum(), np.abs(f).max(), f.size], np.float64)
