@@ -1,0 +1,237 @@
+"""CPU: pin the oracle against every golden fixture generated from the reference
+(tests/golden/gen_golden.py).  Tolerances: bit-exact for binary masks / integers,
+1e-4 (BASELINE.json north_star) or tighter for floats."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import morph, losses_oracle as lo, unet_oracle as uo, train_oracle as to
+
+
+def unpack(bits, shape):
+    n = int(np.prod(shape))
+    return np.unpackbits(bits)[:n].reshape(shape)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def make_args(**kw):
+    d = dict(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1,
+             volume_loss_tolerance=0.2, ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2,
+             multi_ch_tumor=False, stardard_ce_ball=False, classification_branch=False)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+# ------------------------------------------------------------------ primitives
+def test_ball_kernels(golden):
+    p = golden['primitives']
+    for d in [1, 3, 5, 7, 8, 10, 15, 31, 40]:
+        k = lo.create_ball_kernel(d)
+        assert [k.shape[0], int((k > 0).sum())] == list(p[f'ball_{d}_edge_nnz'])
+    for d in [3, 5, 9]:
+        np.testing.assert_allclose(lo.create_ball_kernel(d, True, 1.5).numpy(), p[f'gball_{d}'], rtol=1e-6, atol=1e-9)
+    assert np.array_equal(lo.create_ball_kernel(6.0).numpy().astype(np.uint8), p['ball_6p0'])
+    # the C ball used for dilation has the same support as the reference's binary kernel
+    for d in [1, 3, 5, 7, 9]:
+        assert morph.ball_nnz(d) == int(p[f'ball_{d}_edge_nnz'][1]) if f'ball_{d}_edge_nnz' in p.files else True
+
+
+def test_dilate_volume(golden):
+    p = golden['primitives']
+    shape = (2, 3, 20, 20, 20)
+    vol = unpack(p['dil_in'], shape)
+    for ks in [1, 2, 3, 5, 7, 9, 13, 31]:
+        got = morph.dilate_volume(vol, ks)
+        assert np.array_equal(got, unpack(p[f'dil_{ks}'], shape)), ks
+    single = np.zeros((40, 40, 40), np.uint8)
+    single[20, 20, 20] = 1
+    assert morph.dilate_volume(single, 31).sum() == p['dil_single31_sum'][0] == 16251
+
+
+def test_known_voxels(golden):
+    p = golden['primitives']
+    shape = (2, 3, 16, 16, 16)
+    unk = unpack(p['known_in'], shape)
+    kv = lo.known_voxels(T(unk.astype(np.float32)), 5).numpy()
+    assert np.array_equal(kv.astype(np.uint8), unpack(p['known_out'], shape))
+
+
+def test_dice_based_volume_loss(golden):
+    p = golden['primitives']
+    for tol in (0.1, 0.2):
+        got = lo.dice_based_volume_loss(T(p['dvl_x']), T(p['dvl_y']), tolerance=tol).numpy()
+        np.testing.assert_allclose(got, p[f'dvl_tol{tol}'], rtol=0, atol=1e-6)
+
+
+def test_dice_loss_multiclass(golden):
+    p = golden['primitives']
+    x = T(p['dice_p']).requires_grad_(True)
+    l = lo.dice_loss_multiclass(x, T(p['dice_t']), T(p['dice_k']))
+    l.backward()
+    np.testing.assert_allclose(l.item(), p['dice_loss'], atol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), p['dice_grad'], atol=1e-8, rtol=1e-4)
+    x = T(p['dice_p']).requires_grad_(True)
+    l = lo.dice_loss_multiclass(x, T(p['dice_t']), T(p['dice_k']), T(p['dice_cw'])[:, :, None, None, None])
+    l.backward()
+    np.testing.assert_allclose(l.item(), p['dice_loss_cw'], atol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), p['dice_grad_cw'], atol=1e-8, rtol=1e-4)
+
+
+def test_gwrp_weights(golden):
+    p = golden['primitives']
+    pm, x = T(p['gwrp_pm']), T(p['gwrp_x'])
+    w = lo.gwrp_weights(x * pm + pm, float(pm.sum()), 0.5).numpy()
+    np.testing.assert_allclose(w, p['gwrp_w'], atol=1e-7, rtol=1e-4)
+    assert (w > 0).sum() == int(pm.sum())
+
+
+@pytest.mark.parametrize('name,dia,vol', [('a', 7.0, 150.0), ('b', 4.6, 40.0), ('c', 9.0, 300.0)])
+def test_isolate_tumor(golden, name, dia, vol):
+    p = golden['primitives']
+    x = T(p['iso_x'])
+    m, ms, mb, _ = lo.isolate_tumor(x, dia, vol, 0.2, 0.2)
+    sh = tuple(x.shape)
+    assert np.array_equal(m.numpy().astype(np.uint8), unpack(p[f'iso_{name}_m'], sh))
+    assert np.array_equal(ms.numpy().astype(np.uint8), unpack(p[f'iso_{name}_s'], sh))
+    assert np.array_equal(mb.numpy().astype(np.uint8), unpack(p[f'iso_{name}_b'], sh))
+    assert [m.sum().item(), ms.sum().item(), mb.sum().item()] == list(p[f'iso_{name}_sums'])
+
+
+def test_isolate_tumor_border_growth(golden):
+    p = golden['primitives']
+    x = T(p['iso_border_x'])
+    m, ms, mb, _ = lo.isolate_tumor(x, 9.0, 380.0, 0.2, 0.2)
+    sh = tuple(x.shape)
+    for got, key in ((m, 'm'), (ms, 's'), (mb, 'b')):
+        assert np.array_equal(got.numpy().astype(np.uint8), unpack(p[f'iso_border_{key}'], sh)), key
+
+
+# ------------------------------------------------------------------ network
+@pytest.mark.parametrize('tag,ci,co,S,seed', [('b8_16', 8, 16, 12, 1), ('b16_16', 16, 16, 10, 2), ('b24_8', 24, 8, 12, 3)])
+def test_basic_block(golden, tag, ci, co, S, seed):
+    g = golden['blocks']
+    shapes = {'conv1.conv.weight': (co, ci, 3, 3, 3), 'conv2.conv.weight': (co, co, 3, 3, 3)}
+    if ci != co:
+        shapes['shortcut.conv.weight'] = (co, ci, 3, 3, 3)
+    sd = {'blk.' + k: T(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes, seed).items()}
+    x = T(synth.rng(40 + ci).standard_normal((2, ci, S, S, S)).astype(np.float32)).requires_grad_(True)
+    go = T(synth.rng(50 + co).standard_normal((2, co, S, S, S)).astype(np.float32))
+    y = uo.basic_block(x, sd, 'blk')
+    y.backward(go)
+    np.testing.assert_allclose(y.detach().numpy(), g[f'{tag}_y'], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(x.grad.numpy(), g[f'{tag}_dx'], atol=1e-4, rtol=1e-3)
+    for k in shapes:
+        np.testing.assert_allclose(sd['blk.' + k].grad.numpy(), g[f'{tag}_dw_{k}'], atol=2e-4, rtol=1e-3)
+
+
+def test_pool_upsample(golden):
+    g = golden['blocks']
+    x = T(synth.rng(63).standard_normal((1, 8, 3, 3, 3)).astype(np.float32)).requires_grad_(True)
+    y = uo.upsample_trilinear_ac(x, (6, 6, 6))
+    y.backward(T(synth.rng(64).standard_normal((1, 8, 6, 6, 6)).astype(np.float32)))
+    np.testing.assert_allclose(y.detach().numpy(), g['up_y'], atol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), g['up_dx'], atol=1e-5)
+
+
+def test_unet_tiny(golden):
+    g = golden['unet_tiny']
+    classes = synth.TINY_CLASSES
+    shapes = uo.unet_param_shapes(1, 8, len(classes))
+    sdn = synth.fill_state_dict(shapes, 3)
+    assert abs(sum(float(np.abs(v).sum()) for v in sdn.values()) - g['param_checksum'][0]) < 1e-6 * g['param_checksum'][0]
+    sd = {k: T(v).requires_grad_(True) for k, v in sdn.items()}
+    y = uo.unet_forward(sd, T(synth.image(1, 48, seed=1234)))
+    go = synth.rng(77).standard_normal(tuple(y.shape)).astype(np.float32) / y.numel()
+    y.backward(T(go))
+    sub, step = synth.subsample(y.detach().numpy(), 8192)
+    assert step == int(g['logits_step'][0])
+    np.testing.assert_allclose(sub, g['logits_sub'], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(synth.summary(y.detach().numpy()), g['logits_summary'], rtol=1e-4)
+    for k in shapes:
+        gr = sd[k].grad.numpy()
+        ref = g[f'g_{k}_summary']
+        scale = max(ref[2], 1e-12)
+        # deep pre-activation chain: fp32 round-off between two valid op orders grows to ~3e-3 of max at the stem
+        np.testing.assert_allclose(gr.reshape(-1)[:64] / scale, g[f"g_{k}_head"] / scale, atol=1e-2, err_msg=k)
+
+
+# ------------------------------------------------------------------ calculate_loss
+CASES = [('single_last', dict(loss='ball_dice_last'), False, 7, None),
+         ('single_both', dict(loss='ball_dice_both'), False, 7, None),
+         ('single_dice', dict(loss='dice'), False, 7, None),
+         ('single_ball', dict(loss='ball'), False, 7, None),
+         ('single_norep', dict(report_volume_loss_basic=0.0), False, 7, None),
+         ('deep_last', dict(loss='ball_dice_last'), True, 7, None),
+         ('deep_dice', dict(loss='dice'), True, 7, None),
+         ('single_both_cw', dict(loss='ball_dice_both'), False, 7, 'cw'),
+         ('single_both_norpt', dict(loss='ball_dice_both'), False, 8, None)]
+
+
+def calc_loss_inputs(seed):
+    classes = synth.TINY_CLASSES
+    kinds = ['mask', 'report'] if seed == 7 else ['healthy', 'mask']
+    kw = dict(diam_range=(5.0, 9.0), max_tumors=2) if seed == 7 else {}
+    bt = synth.batch(2, 32, classes, kinds, seed=seed, **kw)
+    return classes, bt, synth.logits(2, len(classes), 32, seed=99), synth.logits(2, len(classes), 32, seed=100)
+
+
+@pytest.mark.parametrize('tag,akw,deep,seed,cw', CASES)
+def test_calculate_loss(golden, tag, akw, deep, seed, cw):
+    g = golden['calc_loss']
+    classes, bt, lg0, lg1 = calc_loss_inputs(seed)
+    a, b = T(lg0).requires_grad_(True), T(lg1).requires_grad_(True)
+    res = lo.calculate_loss({'segmentation': [a, b] if deep else a}, T(bt['label']), T(bt['unk_channels']),
+                            make_args(**akw), T(bt['mask']), T(bt['volumes']), T(bt['diameters']), classes,
+                            class_weights=None if cw is None else T(g['cw']))
+    res['overall'].backward()
+    assert sorted(res.keys()) == list(g[f'{tag}_keys'])
+    for k, v in res.items():
+        np.testing.assert_allclose(float(v.detach()), float(g[f'{tag}_{k}']), atol=1e-4, err_msg=k)
+    sub, _ = synth.subsample(a.grad.numpy(), 8192)
+    np.testing.assert_allclose(sub, g[f'{tag}_g0_sub'], atol=1e-8, rtol=2e-3)
+    np.testing.assert_allclose(synth.summary(a.grad.numpy())[:2], g[f'{tag}_g0_summary'][:2], rtol=1e-3)
+    if deep:
+        sub, _ = synth.subsample(b.grad.numpy(), 8192)
+        np.testing.assert_allclose(sub, g[f'{tag}_g1_sub'], atol=1e-8, rtol=2e-3)
+
+
+# ------------------------------------------------------------------ train step
+def test_train_steps(golden):
+    g = golden['train_step']
+    classes, bt, _, _ = calc_loss_inputs(7)
+    shapes = uo.unet_param_shapes(1, 8, len(classes))
+    names = list(shapes)   # reference parameter order == module registration order; only used pairwise
+    sd = {k: T(v).clone().requires_grad_(True) for k, v in synth.fill_state_dict(shapes, 3).items()}
+    ema = {k: v.detach().clone() for k, v in sd.items()}
+    opt = to.AdamW([sd[k] for k in names], lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+    img = T(synth.image(2, 32, seed=4321))
+    args = make_args(loss='ball_dice_both')
+    for step in range(2):
+        for v in sd.values():
+            v.grad = None
+        r = uo.unet_forward(sd, img)
+        la = lo.calculate_loss({'segmentation': r}, T(bt['label']), T(bt['unk_channels']), args, T(bt['mask']),
+                               T(bt['volumes']), T(bt['diameters']), classes)
+        la['overall'].backward()
+        grads = [sd[k].grad for k in names]
+        gn = to.clip_grad_norm_(grads, 1.0)
+        with torch.no_grad():
+            opt.step(grads)
+            to.update_ema([sd[k] for k in names], [ema[k] for k in names], 0.99, step)
+        for k, v in la.items():
+            np.testing.assert_allclose(float(v.detach()), float(g[f's{step}_{k}']), atol=1e-4, err_msg=f'{step}:{k}')
+        np.testing.assert_allclose(float(gn), float(g[f's{step}_gradnorm']), rtol=2e-3)
+        for k in ['inc.conv1.weight', 'down2.conv.1.conv1.conv.weight', 'up4.conv.0.shortcut.conv.weight', 'outc.weight', 'outc.bias']:
+            # Adam's first steps are ~lr*sign(g): elements whose gradient is below the fp32 noise of the
+            # deep chain may move by up to ~lr either way, so bound the median tightly and the max by 2*lr.
+            for got, ref in ((sd[k].detach().numpy(), g[f's{step}_p_{k}_head']), (ema[k].numpy(), g[f's{step}_ema_{k}_head'])):
+                d = np.abs(got.reshape(-1)[:64] - ref)
+                assert np.median(d) < 2e-5 and d.max() < 1.2e-3, (k, np.median(d), d.max())
+    lrs = [6e-4 * to.lr_multiplier(e, 5, 100) for e in [0, 1, 3, 5, 6, 50, 99]]
+    np.testing.assert_allclose(lrs, g['lr_sched'], rtol=1e-12)
