@@ -1,0 +1,155 @@
+/* rsuper_hip.h -- C ABI of the MI355X-native (gfx950) kernels behind R-Super's training hot path.
+ *
+ * The reference (MrGiovanni/R-Super) contains no native code and no FFI: every device op of
+ * rsuper_train/train_ddp.py's step is an ATen/cuDNN call made from Python.
+ * Each entry point below therefore cites the reference Python call site whose ATen op it replaces
+ * (paths relative to rsuper_train/).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless named host_*;
+ *   - activations are channels-last: element (n,d,h,w,c) of a view lives at x[(((n*D+d)*H+h)*W+w)*ld + c];
+ *     C and ld are multiples of 8, base pointers 16-byte aligned;
+ *   - dtype: RSUPER_F32 (parity mode, exact-f32 MFMA) or RSUPER_BF16 (bf16 storage, f32 accumulate);
+ *   - logits, masks' companions and all parameter/gradient tensors are f32; masks are uint8 0/1;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous, never own their inputs;
+ *   - return value: 0 = RSUPER_OK, otherwise an RSUPER_ERR_* code (nothing was launched on error).
+ */
+#ifndef RSUPER_HIP_H
+#define RSUPER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSUPER_F32 0
+#define RSUPER_BF16 1
+#define RSUPER_OK 0
+#define RSUPER_ERR_ARG 1
+#define RSUPER_ERR_LAUNCH 2
+#define RSUPER_ERR_UNSUPPORTED 3
+#define RSUPER_ERR_NO_DEVICE 4
+
+const char* rsuper_version(void);
+/* 0 when device 0 is a gfx950 GPU; RSUPER_ERR_NO_DEVICE otherwise.  The host layer refuses to run without it. */
+int rsuper_device_check(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3x3x3 convolution (stride 1, pad 1, no bias) -- nn.Conv3d inside ConvNormAct,
+ * model/dim3/conv_layers.py:29-38,46-51; BasicBlock model/dim3/conv_layers.py:86-94.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Elements (of `dtype`) of the fragment-ordered weight buffer for GEMM-K sources (ka, kb) and n_cols columns. */
+size_t rsuper_conv3_packed_elems(int dtype, int ka, int kb, int n_cols, int bn);
+
+/* Re-order state_dict weights (Cout, Cin, 3,3,3) f32 into MFMA B-fragment order.
+ * mode 0 (forward):  K = forward input channels split as ka|kb (concat sources, model/dim3/unet_utils.py:71),
+ *                    columns [0,na) from wa and [na,na+nb) from wb (conv1 + shortcut fused, conv_layers.py:79,84).
+ * mode 1 (data grad): K = forward output channels (ka rows of wa, kb rows of wb), columns = forward Cin = na;
+ *                    taps flipped. */
+int rsuper_conv3_pack_weights(int dtype, int mode, const float* wa, const float* wb, int ka, int kb, int na, int nb,
+                              int bn, void* packed, void* stream);
+
+/* Number of 4x4x16 output tiles per sample == rows of the per-block partial-sum buffer. */
+int rsuper_conv3_tiles(int D, int H, int W);
+
+/* Implicit-GEMM convolution.  epi 0: forward  y = conv(prologue(x)) [+ res]; part <- per-tile (sum, sumsq) of y.
+ *                             epi 1: data gradient g = conv(dy, flipped w) * [x_hat > 0]; part <- (sum g, sum g*x_n),
+ *                                    where x_hat/x_n come from the forward inputs (ex*, with their mean/rstd emr*).
+ * mra/mrb: [N][C][2] (mean, rstd) -> fused InstanceNorm(eps=1e-4)+ReLU prologue (conv_layers.py:40-43); NULL = raw.
+ * part:    [N][tiles][n_cols][2] f32 or NULL. */
+int rsuper_conv3_igemm(int dtype, int epi,
+                       const void* xa, int lda, int Ca, const float* mra,
+                       const void* xb, int ldb, int Cb, const float* mrb,
+                       const void* packed, int n_cols, int bn, int N, int D, int H, int W,
+                       void* out, int ldo, const void* res, int ldr, float* part,
+                       const void* exa, int elda, int eCa, const float* emra,
+                       const void* exb, int eldb, int eCb, const float* emrb, void* stream);
+
+/* Weight gradient dW[co][ci][tap] += sum_v dy[v][co] * x_hat[v+tap][ci]   (autograd of the same nn.Conv3d under
+ * loss.backward(), train_ddp.py:349).  dy rows [0,Ya) accumulate into dwa (Ya, Ca+Cb, 27), rows [Ya,Ya+Yb) into dwb.
+ * dwa/dwb must be zero-initialised; use_tr selects ds_read_b64_tr_b16 operand fetch (bf16). */
+int rsuper_conv3_wgrad(int dtype, int use_tr,
+                       const void* xa, int lda, int Ca, const float* mra,
+                       const void* xb, int ldb, int Cb, const float* mrb,
+                       const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
+                       float* dwa, float* dwb, int N, int D, int H, int W, int splits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * InstanceNorm3d(eps, affine=False) statistics and backward tail -- conv_layers.py:40-42
+ * ------------------------------------------------------------------------------------------------ */
+/* part [N][nblk][C][2] -> out [N][C][2]: mode 0 (mean, rstd = 1/sqrt(var+eps)), mode 1 (sum0/cnt, sum1/cnt). */
+int rsuper_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, float* out, void* stream);
+/* dx = rstd * (g - gm0 - x_n * gm1) [+ add1] [+ add2] */
+int rsuper_in_bwd_finalize(int dtype, const void* g, int ldg, const void* x, int ldx, const float* mr, const float* gm,
+                           const void* add1, int lda1, const void* add2, int lda2, void* out, int ldo,
+                           int N, int vox, int C, void* stream);
+
+/* nn.MaxPool3d(2) -- model/dim3/unet_utils.py:35-37.  part: [N][blocks][C][2] partial stats of y (or NULL). */
+int rsuper_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, float* part, int blocks,
+                        int N, int D, int H, int W, int C, void* stream);
+int rsuper_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx,
+                        int N, int D, int H, int W, int C, void* stream);
+
+/* F.interpolate(mode='trilinear', align_corners=True) -- model/dim3/unet_utils.py:69 */
+int rsuper_upsample_fwd(int dtype, const void* x, int ldx, void* y, int ldy, float* part, int blocks,
+                        int N, int ID, int IH, int IW, int OD, int OH, int OW, int C, void* stream);
+int rsuper_upsample_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx,
+                        int N, int ID, int IH, int IW, int OD, int OH, int OW, int C, void* stream);
+
+/* inconv.conv1 = nn.Conv3d(1, C, 3, padding=1, bias=False) -- model/dim3/unet_utils.py:14.  x: [N][D][H][W] f32. */
+int rsuper_stem_fwd(int dtype, const float* x, const float* w, void* y, int ldy, float* part,
+                    int N, int D, int H, int W, int C, void* stream);
+int rsuper_stem_wgrad(int dtype, const float* x, const void* dy, int lddy, float* dw, int N, int D, int H, int W, int C, void* stream);
+
+/* outc = nn.Conv3d(C, K, kernel_size=1) with bias -- model/dim3/unet.py:47.  logits: [N][K][vox] f32 (NCDHW). */
+int rsuper_head_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* logits, int N, int vox, int C, int K, void* stream);
+int rsuper_head_bwd_data(int dtype, const float* dlogits, const float* w, void* dx, int lddx, int N, int vox, int C, int K, void* stream);
+int rsuper_head_bwd_weight(int dtype, const void* x, int ldx, const float* dlogits, float* dw, float* db, int N, int vox, int C, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss reductions -- training/losses_foundation.py:945-956 (masked BCE), :541-607 (DiceLossMultiClass),
+ * :329/:367 (soft volume), :1743-1811 (ball loss BCE with GWRP / background weights).
+ * sums[planes][6] f64 (pre-zeroed): S=sum bce*k, A=sum sig*k, B=sum sig*t*k, Cn=sum t*k, F1=sum bce*k*w1, F2=sum bce*k*(1-w2)
+ * ------------------------------------------------------------------------------------------------ */
+int rsuper_plane_partials_fwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
+                              double* sums, int planes, size_t V, void* stream);
+int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
+                              const float* g, float* dx, int accumulate, int planes, size_t V, void* stream);
+int rsuper_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Binary morphology and selection -- training/losses_foundation.py
+ * ------------------------------------------------------------------------------------------------ */
+/* dilate_volume :22-46 (iterated ball dilation).  in/out/tmp: nvol volumes of D*H*W bytes; tmp may be NULL when
+ * kernel_size <= 7. */
+int rsuper_dilate_volume(const uint8_t* in, uint8_t* out, uint8_t* tmp, long nvol, int D, int H, int W, int kernel_size, void* stream);
+/* isolate_tumor :1423-1445: Gaussian-ball correlation (odd diameter d_odd, std) and first-maximum argmax.
+ * best: device u64, pre-zeroed; key = (f32 bits << 32) | (0xFFFFFFFF - linear index). conv_out optional (debug). */
+int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, void* stream);
+/* insert_ball :1336-1385; count (device u32, pre-zeroed) += voxels set. */
+int rsuper_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, void* stream);
+/* exact top-k as radix select over non-negative f32 (torch.topk use at :1483-1492); ties -> lower index first. */
+int rsuper_radix_hist(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist256, void* stream);
+int rsuper_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr_bits, unsigned int need_eq, uint8_t* out, void* stream);
+/* GlobalWeightedRankPooling(return_weights, hard_cutoff) :442-535 restricted to the pseudo mask. */
+int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream);
+int rsuper_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float log2_d, float scale, float* w, void* stream);
+int rsuper_mask_op(uint8_t* a, const uint8_t* b, long V, int op /*0 and, 1 or, 2 andnot*/, void* stream);
+int rsuper_zero_where(float* x, const uint8_t* m, long V, void* stream);
+int rsuper_count(const uint8_t* m, long V, unsigned int* count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser -- train_ddp.py:352-357, training/utils.py:46-51,154-161.  host_* are HOST arrays of device pointers.
+ * ------------------------------------------------------------------------------------------------ */
+int rsuper_grad_sqnorm(int n, void* const* host_g, const size_t* host_numel, double* total_sq, void* stream);
+int rsuper_clip_scale(int n, void* const* host_g, const size_t* host_numel, float max_norm, const double* total_sq, void* stream);
+/* One fused pass: clip (coef from *total_sq, NULL = no clipping) + AdamW + EMA (host_ema NULL = no EMA). */
+int rsuper_adamw_ema_step(int n, void* const* host_p, void* const* host_g, void* const* host_m, void* const* host_v,
+                          void* const* host_ema, const size_t* host_numel, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, float ema_alpha, float max_norm, const double* total_sq, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,277 @@
+// extern "C" entry points declared in include/rsuper_hip.h: argument checking + kernel launches.
+#include <string.h>
+#include <math.h>
+#include "common.hpp"
+#include "kernels.hpp"
+#include "misc.hpp"
+#include "loss.hpp"
+#include "morph.hpp"
+#include "optim.hpp"
+#include "../../include/rsuper_hip.h"
+
+#define ST(s) ((hipStream_t)(s))
+
+static inline bool dt_ok(int dt) { return dt == RS_F32 || dt == RS_BF16; }
+static inline bool ch_ok(int C, int ld) { return C >= 0 && (C % 8) == 0 && (ld % 8) == 0 && ld >= C; }
+static inline int ntiles_for(int n_cols, int bn) { const int per = bn / 32; return ((n_cols + bn - 1) / bn) * per; }
+
+// ---- optimiser: split the tensor list into kernel-argument sized chunks
+template <typename F>
+static int for_chunks(int n, void* const* p, void* const* g, void* const* m, void* const* v, void* const* e, const size_t* numel, F f) {
+    for (int i0 = 0; i0 < n; i0 += RS_MT_MAX) {
+        MTChunk c;
+        memset(&c, 0, sizeof(c));
+        c.n = n - i0 < RS_MT_MAX ? n - i0 : RS_MT_MAX;
+        int blk = 0;
+        for (int i = 0; i < c.n; ++i) {
+            c.p[i] = p ? p[i0 + i] : nullptr; c.g[i] = g ? g[i0 + i] : nullptr; c.m[i] = m ? m[i0 + i] : nullptr;
+            c.v[i] = v ? v[i0 + i] : nullptr; c.ema[i] = e ? e[i0 + i] : nullptr;
+            c.numel[i] = numel[i0 + i];
+            c.blk_start[i] = blk;
+            blk += rs_mt_blocks(numel[i0 + i]);
+        }
+        c.blk_start[c.n] = blk;
+        if (blk == 0) continue;
+        const int rc = f(c);
+        if (rc) return rc;
+    }
+    return RS_OK;
+}
+
+
+extern "C" {
+
+const char* rsuper_version(void) { return "rsuper-hip 0.1 (gfx950)"; }
+
+int rsuper_device_check(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return RSUPER_ERR_NO_DEVICE;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return RSUPER_ERR_NO_DEVICE;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? RSUPER_OK : RSUPER_ERR_NO_DEVICE;
+}
+
+size_t rsuper_conv3_packed_elems(int dtype, int ka, int kb, int n_cols, int bn) {
+    if (!dt_ok(dtype) || (bn != 32 && bn != 64 && bn != 128)) return 0;
+    return rs_packed_elems(dtype, ka, kb, ntiles_for(n_cols, bn));
+}
+
+int rsuper_conv3_pack_weights(int dtype, int mode, const float* wa, const float* wb, int ka, int kb, int na, int nb,
+                              int bn, void* packed, void* stream) {
+    if (!dt_ok(dtype) || !wa || !packed || (mode != 0 && mode != 1) || ka <= 0 || kb < 0 || na <= 0 || nb < 0) return RS_ERR_ARG;
+    if ((kb > 0 || nb > 0) && mode == 1 && kb > 0 && !wb) return RS_ERR_ARG;
+    if (mode == 0 && nb > 0 && !wb) return RS_ERR_ARG;
+    if (bn != 32 && bn != 64 && bn != 128) return RS_ERR_ARG;
+    PackParams q;
+    q.wa = wa; q.wb = wb; q.mode = mode; q.ka = ka; q.kb = kb; q.na = na; q.nb = nb;
+    q.ntiles = ntiles_for(na + nb, bn);
+    return rs_launch_pack(q, dtype, packed, ST(stream));
+}
+
+int rsuper_conv3_tiles(int D, int H, int W) { return ((D + 3) / 4) * ((H + 3) / 4) * ((W + 15) / 16); }
+
+int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, const float* mra,
+                       const void* xb, int ldb, int Cb, const float* mrb,
+                       const void* packed, int n_cols, int bn, int N, int D, int H, int W,
+                       void* out, int ldo, const void* res, int ldr, float* part,
+                       const void* exa, int elda, int eCa, const float* emra,
+                       const void* exb, int eldb, int eCb, const float* emrb, void* stream) {
+    if (!dt_ok(dtype) || (epi != 0 && epi != 1) || !xa || !packed || !out) return RS_ERR_ARG;
+    if (!ch_ok(Ca, lda) || Ca == 0 || (Cb > 0 && (!xb || !ch_ok(Cb, ldb))) || n_cols <= 0 || (n_cols % 8) || (ldo % 8) || ldo < n_cols) return RS_ERR_ARG;
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return RS_ERR_ARG;
+    if (res && ((ldr % 8) || ldr < n_cols)) return RS_ERR_ARG;
+    if (epi == 1 && (!exa || !emra || eCa + eCb != n_cols || (eCb > 0 && (!exb || !emrb)))) return RS_ERR_ARG;
+    if (dtype == RS_F32 && bn == 128) return RS_ERR_UNSUPPORTED;   // register budget: f32 parity mode uses bn <= 64
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.a = {xa, lda, Ca, mra};
+    p.b = {xb, ldb, Cb > 0 ? Cb : 0, Cb > 0 ? mrb : nullptr};
+    p.wp = packed; p.ntiles = ntiles_for(n_cols, bn); p.bn = bn;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = n_cols;
+    p.out = out; p.ldo = ldo; p.res = res; p.ldr = ldr; p.part = part;
+    p.ea = {exa, elda, eCa, emra};
+    p.eb = {exb, eldb, eCb, emrb};
+    return rs_launch_igemm(p, dtype, epi, ST(stream));
+}
+
+int rsuper_conv3_wgrad(int dtype, int use_tr, const void* xa, int lda, int Ca, const float* mra,
+                       const void* xb, int ldb, int Cb, const float* mrb,
+                       const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
+                       float* dwa, float* dwb, int N, int D, int H, int W, int splits, void* stream) {
+    if (!dt_ok(dtype) || !xa || !ya || !dwa || !ch_ok(Ca, lda) || Ca == 0 || !ch_ok(Ya, ldya) || Ya == 0) return RS_ERR_ARG;
+    if (Cb > 0 && (!xb || !ch_ok(Cb, ldb))) return RS_ERR_ARG;
+    if (Yb > 0 && (!yb || !dwb || !ch_ok(Yb, ldyb))) return RS_ERR_ARG;
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || splits <= 0) return RS_ERR_ARG;
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.xa = {xa, lda, Ca, mra};
+    p.xb = {xb, ldb, Cb > 0 ? Cb : 0, Cb > 0 ? mrb : nullptr};
+    p.ya = {ya, ldya, Ya, nullptr};
+    p.yb = {yb, ldyb, Yb > 0 ? Yb : 0, nullptr};
+    p.dwa = dwa; p.dwb = dwb; p.N = N; p.D = D; p.H = H; p.W = W; p.splits = splits;
+    return rs_launch_wgrad(p, dtype, use_tr, ST(stream));
+}
+
+int rsuper_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, float* out, void* stream) {
+    if (!part || !out || N <= 0 || nblk <= 0 || C <= 0 || cnt <= 0) return RS_ERR_ARG;
+    return rs_launch_stats_finalize(part, N, nblk, C, cnt, eps, mode, out, ST(stream));
+}
+
+int rsuper_in_bwd_finalize(int dtype, const void* g, int ldg, const void* x, int ldx, const float* mr, const float* gm,
+                           const void* add1, int lda1, const void* add2, int lda2, void* out, int ldo,
+                           int N, int vox, int C, void* stream) {
+    if (!dt_ok(dtype) || !g || !x || !mr || !gm || !out || !ch_ok(C, ldg) || !ch_ok(C, ldx) || !ch_ok(C, ldo)) return RS_ERR_ARG;
+    InBwdParams p = {g, ldg, x, ldx, mr, gm, add1, lda1, add2, lda2, out, ldo, N, vox, C};
+    return rs_launch_in_bwd(p, dtype, ST(stream));
+}
+
+int rsuper_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, float* part, int blocks,
+                        int N, int D, int H, int W, int C, void* stream) {
+    if (!dt_ok(dtype) || !x || !y || !ch_ok(C, ldx) || !ch_ok(C, ldy) || blocks <= 0 || D < 2 || H < 2 || W < 2) return RS_ERR_ARG;
+    PoolParams p = {x, ldx, y, ldy, nullptr, 0, part, N, D, H, W, C};
+    return rs_launch_pool(p, dtype, 0, blocks, ST(stream));
+}
+int rsuper_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx,
+                        int N, int D, int H, int W, int C, void* stream) {
+    if (!dt_ok(dtype) || !x || !dy || !dx || !ch_ok(C, ldx) || !ch_ok(C, lddy) || !ch_ok(C, lddx)) return RS_ERR_ARG;
+    if ((D & 1) || (H & 1) || (W & 1)) return RS_ERR_UNSUPPORTED;   // odd sizes leave un-pooled voxels (dx must be 0 there)
+    PoolParams p = {x, ldx, (void*)dy, lddy, dx, lddx, nullptr, N, D, H, W, C};
+    return rs_launch_pool(p, dtype, 1, 1, ST(stream));
+}
+
+int rsuper_upsample_fwd(int dtype, const void* x, int ldx, void* y, int ldy, float* part, int blocks,
+                        int N, int ID, int IH, int IW, int OD, int OH, int OW, int C, void* stream) {
+    if (!dt_ok(dtype) || !x || !y || !ch_ok(C, ldx) || !ch_ok(C, ldy) || blocks <= 0) return RS_ERR_ARG;
+    UpParams p = {x, ldx, y, ldy, nullptr, 0, part, N, ID, IH, IW, OD, OH, OW, C};
+    return rs_launch_upsample(p, dtype, 0, blocks, ST(stream));
+}
+int rsuper_upsample_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx,
+                        int N, int ID, int IH, int IW, int OD, int OH, int OW, int C, void* stream) {
+    if (!dt_ok(dtype) || !dy || !dx || !ch_ok(C, lddy) || !ch_ok(C, lddx)) return RS_ERR_ARG;
+    UpParams p = {nullptr, 0, (void*)dy, lddy, dx, lddx, nullptr, N, ID, IH, IW, OD, OH, OW, C};
+    return rs_launch_upsample(p, dtype, 1, 1, ST(stream));
+}
+
+int rsuper_stem_fwd(int dtype, const float* x, const float* w, void* y, int ldy, float* part,
+                    int N, int D, int H, int W, int C, void* stream) {
+    if (!dt_ok(dtype) || !x || !w || !y || !part || !ch_ok(C, ldy)) return RS_ERR_ARG;
+    StemParams p = {x, w, y, ldy, part, nullptr, N, D, H, W, C};
+    return rs_launch_stem(p, dtype, 0, ST(stream));
+}
+int rsuper_stem_wgrad(int dtype, const float* x, const void* dy, int lddy, float* dw, int N, int D, int H, int W, int C, void* stream) {
+    if (!dt_ok(dtype) || !x || !dy || !dw || !ch_ok(C, lddy)) return RS_ERR_ARG;
+    StemParams p = {x, nullptr, (void*)dy, lddy, nullptr, dw, N, D, H, W, C};
+    return rs_launch_stem(p, dtype, 1, ST(stream));
+}
+
+int rsuper_head_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* logits, int N, int vox, int C, int K, void* stream) {
+    if (!dt_ok(dtype) || !x || !w || !b || !logits || !ch_ok(C, ldx) || K <= 0) return RS_ERR_ARG;
+    HeadParams p = {x, ldx, w, b, logits, nullptr, 0, nullptr, nullptr, N, vox, C, K};
+    return rs_launch_head(p, dtype, 0, ST(stream));
+}
+int rsuper_head_bwd_data(int dtype, const float* dlogits, const float* w, void* dx, int lddx, int N, int vox, int C, int K, void* stream) {
+    if (!dt_ok(dtype) || !dlogits || !w || !dx || !ch_ok(C, lddx) || K <= 0) return RS_ERR_ARG;
+    HeadParams p = {nullptr, 0, w, nullptr, (float*)dlogits, dx, lddx, nullptr, nullptr, N, vox, C, K};
+    return rs_launch_head(p, dtype, 1, ST(stream));
+}
+int rsuper_head_bwd_weight(int dtype, const void* x, int ldx, const float* dlogits, float* dw, float* db, int N, int vox, int C, int K, void* stream) {
+    if (!dt_ok(dtype) || !x || !dlogits || !dw || !db || !ch_ok(C, ldx) || K <= 0) return RS_ERR_ARG;
+    HeadParams p = {x, ldx, nullptr, nullptr, (float*)dlogits, nullptr, 0, dw, db, N, vox, C, K};
+    return rs_launch_head(p, dtype, 2, ST(stream));
+}
+
+int rsuper_plane_partials_fwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
+                              double* sums, int planes, size_t V, void* stream) {
+    if (!x || !sums || planes <= 0 || V == 0) return RS_ERR_ARG;
+    PlaneParams p = {x, xstride, t, k, w1, w2, sums, nullptr, nullptr, 0, V};
+    return rs_launch_plane_partials(p, planes, 0, ST(stream));
+}
+int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
+                              const float* g, float* dx, int accumulate, int planes, size_t V, void* stream) {
+    if (!x || !g || !dx || planes <= 0 || V == 0) return RS_ERR_ARG;
+    PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, accumulate, V};
+    return rs_launch_plane_partials(p, planes, 1, ST(stream));
+}
+int rsuper_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, void* stream) {
+    if (!x || !out || V == 0) return RS_ERR_ARG;
+    return rs_launch_sigmoid_mask(x, m, out, V, ST(stream));
+}
+
+int rsuper_dilate_volume(const uint8_t* in, uint8_t* out, uint8_t* tmp, long nvol, int D, int H, int W, int kernel_size, void* stream) {
+    if (!in || !out || nvol <= 0 || kernel_size < 1) return RS_ERR_ARG;
+    if (kernel_size % 2 == 0) kernel_size += 1;                  // losses_foundation.py:24-25
+    const int full = 3;
+    if (kernel_size <= 2 * full + 1) return rs_launch_dilate_pass(in, out, nvol, D, H, W, kernel_size, ST(stream));
+    if (!tmp) return RS_ERR_ARG;
+    const int radius = (kernel_size - 1) / 2, num_full = radius / full, rem = radius % full;   // :31-44
+    const int passes = num_full + (rem > 0 ? 1 : 0);
+    const uint8_t* src = in;
+    for (int i = 0; i < passes; ++i) {
+        uint8_t* dst = ((passes - i) & 1) ? out : tmp;           // last pass lands in `out`
+        const int k = i < num_full ? 2 * full + 1 : 2 * rem + 1;
+        const int rc = rs_launch_dilate_pass(src, dst, nvol, D, H, W, k, ST(stream));
+        if (rc) return rc;
+        src = dst;
+    }
+    return RS_OK;
+}
+
+int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, void* stream) {
+    if (!x || !best || d_odd < 1 || !(d_odd & 1) || std <= 0) return RS_ERR_ARG;
+    return rs_launch_ball_conv_argmax(x, D, H, W, d_odd, std, best, conv_out, ST(stream));
+}
+int rsuper_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, void* stream) {
+    if (!out || !count) return RS_ERR_ARG;
+    return rs_launch_insert_ball(out, D, H, W, cz, cy, cx, d_odd, half, count, ST(stream));
+}
+int rsuper_radix_hist(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist256, void* stream) {
+    if (!x || !hist256 || (shift != 24 && shift != 16 && shift != 8 && shift != 0)) return RS_ERR_ARG;
+    return rs_launch_radix_hist(x, m, V, prefix, shift, hist256, ST(stream));
+}
+int rsuper_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr_bits, unsigned int need_eq, uint8_t* out, void* stream) {
+    if (!x || !out) return RS_ERR_ARG;
+    return rs_launch_topk_mark(x, m, V, thr_bits, need_eq, out, ST(stream));
+}
+int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream) {
+    if (!x || !pm || !vals || !idx || !n) return RS_ERR_ARG;
+    return rs_launch_compact(x, pm, V, vals, idx, n, ST(stream));
+}
+int rsuper_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float log2_d, float scale, float* w, void* stream) {
+    if (!vals || !idx || !w) return RS_ERR_ARG;
+    return rs_launch_rank_weights(vals, idx, n, log2_d, scale, w, ST(stream));
+}
+int rsuper_mask_op(uint8_t* a, const uint8_t* b, long V, int op, void* stream) {
+    if (!a || !b || op < 0 || op > 2) return RS_ERR_ARG;
+    return rs_launch_mask_op(a, b, V, op, ST(stream));
+}
+int rsuper_zero_where(float* x, const uint8_t* m, long V, void* stream) {
+    if (!x || !m) return RS_ERR_ARG;
+    return rs_launch_zero_where(x, m, V, ST(stream));
+}
+int rsuper_count(const uint8_t* m, long V, unsigned int* count, void* stream) {
+    if (!m || !count) return RS_ERR_ARG;
+    return rs_launch_count(m, V, count, ST(stream));
+}
+
+int rsuper_grad_sqnorm(int n, void* const* host_g, const size_t* host_numel, double* total_sq, void* stream) {
+    if (n <= 0 || !host_g || !host_numel || !total_sq) return RS_ERR_ARG;
+    if (hipMemsetAsync(total_sq, 0, sizeof(double), ST(stream)) != hipSuccess) return RS_ERR_LAUNCH;
+    return for_chunks(n, nullptr, host_g, nullptr, nullptr, nullptr, host_numel, [&](const MTChunk& c) { return rs_launch_sqnorm(c, total_sq, ST(stream)); });
+}
+int rsuper_clip_scale(int n, void* const* host_g, const size_t* host_numel, float max_norm, const double* total_sq, void* stream) {
+    if (n <= 0 || !host_g || !host_numel || !total_sq) return RS_ERR_ARG;
+    return for_chunks(n, nullptr, host_g, nullptr, nullptr, nullptr, host_numel, [&](const MTChunk& c) { return rs_launch_scale(c, max_norm, total_sq, ST(stream)); });
+}
+int rsuper_adamw_ema_step(int n, void* const* host_p, void* const* host_g, void* const* host_m, void* const* host_v,
+                          void* const* host_ema, const size_t* host_numel, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, float ema_alpha, float max_norm, const double* total_sq, void* stream) {
+    if (n <= 0 || !host_p || !host_g || !host_m || !host_v || !host_numel || step < 1) return RS_ERR_ARG;
+    AdamParams a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+    a.sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.ema_alpha = ema_alpha; a.max_norm = max_norm;
+    return for_chunks(n, host_p, host_g, host_m, host_v, host_ema, host_numel, [&](const MTChunk& c) { return rs_launch_adamw_ema(c, a, total_sq, ST(stream)); });
+}
+
+}  // extern "C"

@@ -1,0 +1,320 @@
+// 3x3x3 / stride 1 / pad 1 convolution as an implicit GEMM on MFMA (gfx950), channels-last (NDHWC).
+//
+//   M = voxels (block tile 4x4x16 = 256), N = output channels (32/64/128 per block), K = 27 taps x Cin.
+//
+// Replaces, on the hot path, every nn.Conv3d(k=3, bias=False) forward and its autograd data-gradient
+// launched by rsuper_train/model/dim3/conv_layers.py:29-38,46-51 (ConvNormAct, preact) inside BasicBlock
+// (conv_layers.py:86-94).  Fused into this kernel:
+//   * prologue: x_hat = relu((x - mean) * rstd) applied while the haloed input tile is staged into LDS
+//     (InstanceNorm3d eps=1e-4 + ReLU of ConvNormAct, conv_layers.py:40-43) -- x_hat is never materialised;
+//     zero padding is applied AFTER the activation, as the reference's conv does;
+//   * two input sources (channel concat of up_block, unet_utils.py:71, or the [dY1 | dOut] pair of the
+//     fused conv1+shortcut data-gradient) without a concat copy;
+//   * epilogue FWD  : + residual (BasicBlock `out += shortcut`, conv_layers.py:92), per-block partial
+//                     sum / sum-of-squares of the stored output for the NEXT InstanceNorm;
+//   * epilogue DGRAD: g = acc * [x_hat > 0] (ReLU backward) and partial sums of g and g*x_n for the
+//                     InstanceNorm backward reductions.
+//
+// Data flow per K chunk (64 bytes of channels: 32 bf16 / 16 f32):
+//   global --(16-B loads, norm+relu in registers)--> LDS halo tile [6][6][18] rows x 80-B pitch
+//   LDS --ds_read_b128--> A fragments;  packed weights (fragment order, L1/L2 resident) --> B fragments
+//   v_mfma_f32_32x32x16_bf16 (or 4x v_mfma_f32_32x32x2_f32 in the f32 parity mode), f32 accumulate.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+constexpr int TD = 4, TH = 4, TW = 16;          // output tile (voxels)
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+constexpr int HROWS = HD * HH * HW;             // 648 halo rows
+constexpr int PITCH = 80;                       // bytes per LDS row: 64 data + 16 pad (conflict-free b128)
+constexpr int HALO_BYTES = HROWS * PITCH;       // 51840
+
+template <typename T>
+__device__ __forceinline__ void stage_vec(char* halo, int r, int s, const ConvSrc& src, const float* mr_lds, int mr_off,
+                                          int c0, int n, int d0, int h0, int w0, int D, int H, int W, bool norm) {
+    constexpr int KP = Elem<T>::KP;
+    const int hd = r / (HH * HW);
+    const int rem = r - hd * (HH * HW);
+    const int hh = rem / HW;
+    const int hw = rem - hh * HW;
+    const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+    const int c = c0 + s * KP;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W && c < src.C) {
+        const T* px = (const T*)src.x + ((((size_t)n * D + d) * H + h) * W + w) * (size_t)src.ld + c;
+        v = *(const uint4*)px;
+        if (norm) {
+            float f[KP];
+            unpack16<T>(v, f);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const float mu = mr_lds[2 * (mr_off + c + j)], rs = mr_lds[2 * (mr_off + c + j) + 1];
+                f[j] = fmaxf((f[j] - mu) * rs, 0.f);
+            }
+            v = pack16<T>(f);
+        }
+    }
+    *(uint4*)(halo + r * PITCH + s * 16) = v;
+}
+
+// EPI: 0 = forward (residual + stats of output), 1 = dgrad (relu mask + IN-backward sums)
+template <typename T, int WM, int MF, int WN, int NF, int EPI>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    float* mr_lds = (float*)(smem + HALO_BYTES);      // [Ca + Cb][2]
+    constexpr int KC = Elem<T>::KC;
+    constexpr int BN32 = WN * NF;                     // 32-column tiles per block
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tw = t % tiles_w; t /= tiles_w;
+    const int th = t % tiles_h; t /= tiles_h;
+    const int td = t;
+    const int n = blockIdx.z;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+    const int nchA = (p.a.C + KC - 1) / KC, nchB = (p.b.C + KC - 1) / KC;
+    const bool normA = p.a.mr != nullptr, normB = p.b.mr != nullptr;
+
+    // per-sample mean/rstd of every input channel -> LDS
+    if (normA) for (int i = tid; i < 2 * p.a.C; i += 256) mr_lds[i] = p.a.mr[(size_t)n * 2 * p.a.C + i];
+    if (normB) for (int i = tid; i < 2 * p.b.C; i += 256) mr_lds[2 * p.a.C + i] = p.b.mr[(size_t)n * 2 * p.b.C + i];
+
+    // per-lane LDS byte offset of the A-fragment row for each m-fragment (tap (0,0,0), k-step 0)
+    int hs, wl;
+    row_to_hw(lane & 31, hs, wl);
+    int a_off[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int f = wm * MF + mf;                   // fragment 0..7 in the block: d = f/2, h pair = f%2
+        const int fd = f >> 1, fh = (f & 1) * 2 + hs;
+        a_off[mf] = ((fd * HH + fh) * HW + wl) * PITCH + (lane >> 5) * 16;
+    }
+
+    f32x16_t acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+    const uint4* wp = (const uint4*)p.wp;
+    const int ntile0 = blockIdx.y * BN32 + wn * NF;
+    const size_t wstep = (size_t)p.ntiles * 64;       // uint4 per (chunk, tap, kstep)
+
+    for (int ch = 0; ch < nchA + nchB; ++ch) {
+        const bool isB = ch >= nchA;
+        const ConvSrc& src = isB ? p.b : p.a;
+        const int c0 = (isB ? ch - nchA : ch) * KC;
+        const bool norm = isB ? normB : normA;
+        const int mr_off = isB ? p.a.C : 0;
+        __syncthreads();                              // previous chunk fully consumed (and mr_lds visible)
+#pragma unroll 4
+        for (int v = tid; v < HROWS * 4; v += 256)
+            stage_vec<T>(halo, v >> 2, v & 3, src, mr_lds, mr_off, c0, n, d0, h0, w0, p.D, p.H, p.W, norm);
+        __syncthreads();
+
+        const uint4* wch = wp + (size_t)ch * 27 * 2 * wstep + (size_t)ntile0 * 64 + lane;
+        uint4 bq[2][NF];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) bq[ks][nf] = wch[ks * wstep + nf * 64];
+        int tap = 0;
+        for (int kd = 0; kd < 3; ++kd)
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw, ++tap) {
+                    const int toff = ((kd * HH + kh) * HW + kw) * PITCH;
+                    uint4 bn[2][NF];
+                    const int tnext = tap < 26 ? tap + 1 : 26;           // prefetch next tap's B fragments
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf) bn[ks][nf] = wch[(size_t)(tnext * 2 + ks) * wstep + nf * 64];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        uint4 aq[MF];
+#pragma unroll
+                        for (int mf = 0; mf < MF; ++mf) aq[mf] = *(const uint4*)(halo + a_off[mf] + toff + ks * 32);
+#pragma unroll
+                        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < NF; ++nf) mma32<T>(acc[mf][nf], aq[mf], bq[ks][nf]);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf) bq[ks][nf] = bn[ks][nf];
+                }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    __syncthreads();                                  // halo region is reused as reduction scratch
+    float* red = (float*)smem;                        // [WM][BN32*32][2]
+    const int col_l = lane & 31;
+    float s1[NF], s2[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) { s1[nf] = 0.f; s2[nf] = 0.f; }
+
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const int col = (ntile0 + nf) * 32 + col_l;
+        const bool cok = col < p.Cout;
+        // dgrad epilogue: which forward-input source does this column belong to?
+        const ConvSrc& es = (EPI == 1 && col >= p.ea.C) ? p.eb : p.ea;
+        const int ecol = (EPI == 1 && col >= p.ea.C) ? col - p.ea.C : col;
+        float mu = 0.f, rs = 1.f;
+        if (EPI == 1 && cok) { mu = es.mr[((size_t)n * es.C + ecol) * 2]; rs = es.mr[((size_t)n * es.C + ecol) * 2 + 1]; }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int f = wm * MF + mf;
+            const int d = d0 + (f >> 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int rhs, rw;
+                row_to_hw(cd_row32(r, lane), rhs, rw);
+                const int h = h0 + (f & 1) * 2 + rhs, w = w0 + rw;
+                if (!(cok && d < p.D && h < p.H && w < p.W)) continue;
+                const size_t vox = (((size_t)n * p.D + d) * p.H + h) * p.W + w;
+                float v = acc[mf][nf][r];
+                if (EPI == 0) {
+                    if (p.res) v += Elem<T>::ld((const T*)p.res + vox * p.ldr + col);
+                    v = Elem<T>::rnd(v);
+                    s1[nf] += v; s2[nf] += v * v;
+                } else {
+                    const float xn = (Elem<T>::ld((const T*)es.x + vox * es.ld + ecol) - mu) * rs;
+                    v = xn > 0.f ? v : 0.f;
+                    v = Elem<T>::rnd(v);
+                    s1[nf] += v; s2[nf] += v * xn;
+                }
+                Elem<T>::st((T*)p.out + vox * p.ldo + col, v);
+            }
+        }
+    }
+    if (p.part) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            s1[nf] += __shfl_xor(s1[nf], 32, 64);
+            s2[nf] += __shfl_xor(s2[nf], 32, 64);
+            if (lane < 32) {
+                const int cl = (wn * NF + nf) * 32 + col_l;
+                red[(wm * BN32 * 32 + cl) * 2] = s1[nf];
+                red[(wm * BN32 * 32 + cl) * 2 + 1] = s2[nf];
+            }
+        }
+        __syncthreads();
+        for (int cl = tid; cl < BN32 * 32; cl += 256) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) { a += red[(m * BN32 * 32 + cl) * 2]; b += red[(m * BN32 * 32 + cl) * 2 + 1]; }
+            const int col = blockIdx.y * BN32 * 32 + cl;
+            if (col < p.Cout) {
+                float* pp = p.part + (((size_t)n * gridDim.x + blockIdx.x) * p.Cout + col) * 2;
+                pp[0] = a; pp[1] = b;
+            }
+        }
+    }
+}
+
+template <typename T, int WM, int MF, int WN, int NF>
+int launch_cfg(const IgemmParams& p, int epi, hipStream_t st) {
+    const int tiles = ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    dim3 grid(tiles, p.ntiles / (WN * NF), p.N), block(256);
+    const size_t smem = HALO_BYTES + (size_t)(p.a.C + p.b.C) * 2 * sizeof(float);
+    if (smem > 160 * 1024) return RS_ERR_UNSUPPORTED;
+    if (epi == 0) {
+        auto k = igemm_kernel<T, WM, MF, WN, NF, 0>;
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    } else {
+        auto k = igemm_kernel<T, WM, MF, WN, NF, 1>;
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    }
+    return rs_check_launch();
+}
+
+template <typename T>
+int launch_dt(const IgemmParams& p, int epi, hipStream_t st) {
+    const int bn32 = p.bn / 32;
+    if (p.ntiles % bn32) return RS_ERR_ARG;
+    switch (p.bn) {
+        case 32: return launch_cfg<T, 4, 2, 1, 1>(p, epi, st);
+        case 64: return launch_cfg<T, 2, 4, 2, 1>(p, epi, st);
+        case 128: return launch_cfg<T, 2, 4, 2, 2>(p, epi, st);
+    }
+    return RS_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight packing into B-fragment order:  wp[chunk][tap][kstep][ntile][lane] (16 B each)
+//   lane l of (chunk, tap, kstep, ntile) holds B[k .. k+KP-1][n] with n = ntile*32 + (l & 31),
+//   k = kbase(chunk) + kstep*(KC/2) + (l >> 5)*KP.
+// mode 0 (forward):  GEMM-K = forward Cin (two sources ka|kb => chunks are padded per source),
+//                    GEMM-N = forward Cout, columns [0,na) from wa, [na,na+nb) from wb (fused conv1+shortcut);
+//                    value = w[n][k][tap]                (weights are (Cout, Cin, 27) as in the state_dict)
+// mode 1 (dgrad):    GEMM-K = forward Cout, source A = wa's rows (ka), source B = wb's rows (kb),
+//                    GEMM-N = forward Cin (na);  value = w[k][n][26 - tap]   (flipped taps)
+template <typename T>
+__global__ void pack_kernel(PackParams q, T* out) {
+    constexpr int KC = Elem<T>::KC, KP = Elem<T>::KP;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nchA = (q.ka + KC - 1) / KC, nchB = (q.kb + KC - 1) / KC;
+    const size_t total = (size_t)(nchA + nchB) * 27 * 2 * q.ntiles * 64;
+    if (idx >= total) return;
+    const int lane = idx & 63;
+    size_t r = idx >> 6;
+    const int ntile = r % q.ntiles; r /= q.ntiles;
+    const int ks = r & 1; r >>= 1;
+    const int tap = r % 27; r /= 27;
+    const int ch = (int)r;
+    const bool isB = ch >= nchA;
+    const int kloc = (isB ? ch - nchA : ch) * KC + ks * (KC / 2) + (lane >> 5) * KP;
+    const int klim = isB ? q.kb : q.ka;
+    const int n = ntile * 32 + (lane & 31);
+    float f[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int k = kloc + j;
+        float v = 0.f;
+        if (k < klim && n < q.na + q.nb) {
+            if (q.mode == 0) {
+                const int kin = (isB ? q.ka : 0) + k;                    // forward input channel
+                const int cin = q.ka + q.kb;
+                v = n < q.na ? q.wa[((size_t)n * cin + kin) * 27 + tap] : q.wb[((size_t)(n - q.na) * cin + kin) * 27 + tap];
+            } else {
+                const float* w = isB ? q.wb : q.wa;                      // rows = forward couts of that conv
+                v = w[((size_t)k * q.na + n) * 27 + (26 - tap)];
+            }
+        }
+        f[j] = v;
+    }
+    *(uint4*)(out + idx * KP) = pack16<T>(f);
+}
+
+}  // namespace
+
+int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st) {
+    if (dtype == RS_F32) return launch_dt<float>(p, epi, st);
+    if (dtype == RS_BF16) return launch_dt<bf16_t>(p, epi, st);
+    return RS_ERR_ARG;
+}
+
+size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles) {
+    const int KC = dtype == RS_F32 ? 16 : 32, KP = dtype == RS_F32 ? 4 : 8;
+    const size_t nch = (size_t)((ka + KC - 1) / KC + (kb + KC - 1) / KC);
+    return nch * 27 * 2 * ntiles * 64 * KP;
+}
+
+int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st) {
+    const size_t vecs = rs_packed_elems(dtype, q.ka, q.kb, q.ntiles) / (dtype == RS_F32 ? 4 : 8);
+    const int blocks = (int)((vecs + 255) / 256);
+    if (dtype == RS_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, q, (float*)out);
+    else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, q, (bf16_t*)out);
+    return rs_check_launch();
+}

@@ -1,0 +1,48 @@
+// Internal launch interfaces shared between the kernel translation units and the C-ABI (api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// One channels-last activation source: element (n,d,h,w,c) at x[(((n*D+d)*H+h)*W+w)*ld + c].
+struct ConvSrc {
+    const void* x;     // base pointer (already offset to the first channel of the view)
+    int ld;            // channel stride of a voxel (elements)
+    int C;             // channels in this source (multiple of 8)
+    const float* mr;   // [N][C][2] (mean, rstd) -> fused InstanceNorm+ReLU prologue; nullptr -> raw
+};
+
+struct IgemmParams {
+    ConvSrc a, b;          // GEMM-K sources (b.C == 0 when unused)
+    const void* wp;        // packed B fragments (rs_launch_pack)
+    int ntiles;            // 32-column tiles in the packed weights (multiple of bn/32)
+    int bn;                // block N tile: 32, 64 or 128
+    int N, D, H, W;
+    int Cout;              // valid GEMM-N columns
+    void* out; int ldo;
+    const void* res; int ldr;   // EPI 0: optional residual added before store
+    float* part;           // per-block partial sums [N][tiles][Cout][2] or nullptr
+    ConvSrc ea, eb;        // EPI 1: forward inputs (with mr) whose relu mask / x_n the data-gradient needs
+};
+
+struct PackParams {
+    const float* wa; const float* wb;
+    int mode;              // 0 forward, 1 dgrad
+    int ka, kb;            // GEMM-K channels per source
+    int na, nb;            // GEMM-N columns from wa / wb (mode 0); na = forward Cin (mode 1)
+    int ntiles;
+};
+
+struct WgradParams {
+    ConvSrc xa, xb;        // forward inputs (x_hat recomputed from mr when non-null)
+    ConvSrc ya, yb;        // output-gradient sources: rows [0,ya.C) -> dwa, [ya.C, ya.C+yb.C) -> dwb
+    float* dwa; float* dwb;   // (Cout_a, Cin, 27), (Cout_b, Cin, 27) f32, accumulated with atomics (pre-zeroed)
+    int N, D, H, W;
+    int splits;            // spatial split factor (grid.z)
+};
+
+int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st);
+size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
+int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
+int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st);
+int rs_wgrad_grid_y(int Mtot);

@@ -1,0 +1,131 @@
+// Loss reductions of the R-Super step (gfx950, HBM-bound): one pass over logits + byte masks producing the
+// per-(sample, class) partial sums every loss term needs, with wave-shuffle + LDS block reductions, and the
+// matching one-pass backward that writes / accumulates d(loss)/d(logits).
+//
+// Restates, for planes of V voxels (rsuper_train/training/losses_foundation.py):
+//   masked BCE-with-logits          :945-956   S  = sum bce(x,t) * k
+//   DiceLossMultiClass              :541-607   A  = sum sig(x)*k ; B = sum sig(x)*t*k ; Cn = sum t*k
+//                                              (TP = B, FP = A - B, FN = Cn - B because k is binary)
+//   soft volume of volume_loss_basic:329,:367  A with k = dilated segment mask
+//   ball_loss weighted BCE          :1793-1811 F1 = sum bce*k*w1 (GWRP foreground weights)
+//                                              F2 = sum bce*k*(1-w2) (background = outside dilated pseudo mask)
+// The tiny (B,C) algebra on these sums (adaptive alpha, clamps, means) stays in autograd on the host side so
+// d(alpha) flows exactly as in the reference; this file supplies d(sum)/d(x) per voxel.
+#include "common.hpp"
+#include "misc.hpp"
+#include "loss.hpp"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float bce_logits(float x, float t) {
+    // max(x,0) - x*t + log1p(exp(-|x|))   (ATen binary_cross_entropy_with_logits)
+    return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+// grid: (blocks, planes).  sums: [planes][6] doubles, pre-zeroed, accumulated with f64 atomics.
+__global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) {
+    const int plane = blockIdx.y;
+    const size_t base = (size_t)plane * p.V;
+    const float* x = p.x + (size_t)plane * p.xstride;
+    const uint8_t* t = p.t ? p.t + base : nullptr;
+    const uint8_t* k = p.k ? p.k + base : nullptr;
+    const float* w1 = p.w1 ? p.w1 + base : nullptr;
+    const uint8_t* w2 = p.w2 ? p.w2 + base : nullptr;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool vec_ok = (p.V & 3) == 0 && (p.xstride & 3) == 0;   // 16-byte alignment of every plane
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < (size_t)p.V; i += (size_t)gridDim.x * 256 * 4) {
+        float xv[4]; uint8_t tv[4] = {0, 0, 0, 0}, kv[4] = {1, 1, 1, 1}, w2v[4] = {0, 0, 0, 0}; float w1v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool full = vec_ok && i + 4 <= (size_t)p.V;
+        if (full) {
+            const float4 q = *(const float4*)(x + i);
+            xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+            if (t) { const uchar4 u = *(const uchar4*)(t + i); tv[0] = u.x; tv[1] = u.y; tv[2] = u.z; tv[3] = u.w; }
+            if (k) { const uchar4 u = *(const uchar4*)(k + i); kv[0] = u.x; kv[1] = u.y; kv[2] = u.z; kv[3] = u.w; }
+            if (w2) { const uchar4 u = *(const uchar4*)(w2 + i); w2v[0] = u.x; w2v[1] = u.y; w2v[2] = u.z; w2v[3] = u.w; }
+            if (w1) { const float4 u = *(const float4*)(w1 + i); w1v[0] = u.x; w1v[1] = u.y; w1v[2] = u.z; w1v[3] = u.w; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!full) {
+                if (i + j >= (size_t)p.V) break;
+                xv[j] = x[i + j];
+                if (t) tv[j] = t[i + j];
+                if (k) kv[j] = k[i + j];
+                if (w2) w2v[j] = w2[i + j];
+                if (w1) w1v[j] = w1[i + j];
+            }
+            const float tt = tv[j] ? 1.f : 0.f, kk = kv[j] ? 1.f : 0.f;
+            const float sg = sigmoidf(xv[j]);
+            const float b = bce_logits(xv[j], tt) * kk;
+            s[0] += b;
+            s[1] += sg * kk;
+            s[2] += sg * tt * kk;
+            s[3] += tt * kk;
+            s[4] += b * w1v[j];
+            s[5] += b * (w2v[j] ? 0.f : 1.f);
+        }
+    }
+    __shared__ float red[4][6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const float v = wave_sum(s[q]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double v = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
+        atomicAdd(p.sums + (size_t)plane * 6 + threadIdx.x, v);
+    }
+}
+
+// dx = k * ( (gS + gF1*w1 + gF2*(1-w2)) * (sig - t) + sig*(1-sig) * (gA + gB*t) ),  g: [planes][6] floats
+__global__ __launch_bounds__(256) void plane_partials_bwd_kernel(PlaneParams p) {
+    const int plane = blockIdx.y;
+    const size_t base = (size_t)plane * p.V;
+    const float* x = p.x + (size_t)plane * p.xstride;
+    float* dx = p.dx + (size_t)plane * p.xstride;
+    const uint8_t* t = p.t ? p.t + base : nullptr;
+    const uint8_t* k = p.k ? p.k + base : nullptr;
+    const float* w1 = p.w1 ? p.w1 + base : nullptr;
+    const uint8_t* w2 = p.w2 ? p.w2 + base : nullptr;
+    const float gS = p.g[plane * 6], gA = p.g[plane * 6 + 1], gB = p.g[plane * 6 + 2], gF1 = p.g[plane * 6 + 4], gF2 = p.g[plane * 6 + 5];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)p.V; i += (size_t)gridDim.x * 256) {
+        const float xv = x[i];
+        const float tt = (t && t[i]) ? 1.f : 0.f;
+        const float kk = (!k || k[i]) ? 1.f : 0.f;
+        const float sg = sigmoidf(xv);
+        float gb = gS;
+        if (w1) gb += gF1 * w1[i];
+        gb += gF2 * ((w2 && w2[i]) ? 0.f : 1.f);
+        const float v = kk * (gb * (sg - tt) + sg * (1.f - sg) * (gA + gB * tt));
+        dx[i] = p.accumulate ? dx[i] + v : v;
+    }
+}
+
+// out[i] = sigmoid(x[i]) * (m ? m[i] : 1)      (x_iter of ball_loss, :1691-1694)
+__global__ void sigmoid_mask_kernel(const float* x, const uint8_t* m, float* out, size_t V) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (1.f / (1.f + expf(-x[i]))) * ((!m || m[i]) ? 1.f : 0.f);   // accurate exp: feeds argmax / top-k selection
+}
+
+}  // namespace
+
+int rs_launch_plane_partials(const PlaneParams& p, int planes, int bwd, hipStream_t st) {
+    int blocks = (int)((p.V + 4095) / 4096);
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    if (!bwd) {
+        hipLaunchKernelGGL(plane_partials_fwd_kernel, dim3(blocks, planes), dim3(256), 0, st, p);
+    } else {
+        int b2 = (int)((p.V + 1023) / 1024);
+        if (b2 > 256) b2 = 256;
+        hipLaunchKernelGGL(plane_partials_bwd_kernel, dim3(b2, planes), dim3(256), 0, st, p);
+    }
+    return rs_check_launch();
+}
+
+int rs_launch_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, hipStream_t st) {
+    hipLaunchKernelGGL(sigmoid_mask_kernel, dim3(rs_elem_blocks(V)), dim3(256), 0, st, x, m, out, V);
+    return rs_check_launch();
+}

@@ -1,0 +1,59 @@
+// Launch interfaces of the HBM-bound UNet kernels (unet_misc.hip), the loss kernels (loss.hip),
+// the morphology kernels (morph.hip) and the optimiser kernels (optim.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+struct InBwdParams {
+    const void* g; int ldg;        // masked upstream gradient g = dX_hat * [x_hat > 0]
+    const void* x; int ldx;        // forward input of the norm
+    const float* mr;               // [N][C][2] mean, rstd
+    const float* gm;               // [N][C][2] mean(g), mean(g * x_n)
+    const void* add1; int lda1;    // optional extra gradient terms (residual / skip paths)
+    const void* add2; int lda2;
+    void* out; int ldo;
+    int N, vox, C;
+};
+
+struct PoolParams {
+    const void* x; int ldx;        // forward input
+    void* y; int ldy;              // forward: pooled output; backward: pooled gradient (read)
+    void* dx; int lddx;            // backward output
+    float* part;                   // forward: partial stats [N][blocks][C][2] or nullptr
+    int N, D, H, W, C;             // input dims
+};
+
+struct UpParams {
+    const void* x; int ldx;        // forward input (low resolution)
+    void* y; int ldy;              // forward: output; backward: output gradient (read)
+    void* dx; int lddx;
+    float* part;
+    int N, ID, IH, IW, OD, OH, OW, C;
+};
+
+struct StemParams {
+    const float* x;                // [N][D][H][W] f32 (single input channel)
+    const float* w;                // (C,1,3,3,3)
+    void* y; int ldy;              // forward: output; wgrad: dY (read)
+    float* part;                   // forward partial stats [N][blocks][C][2]
+    float* dw;                     // wgrad output (C,27) f32, pre-zeroed
+    int N, D, H, W, C;
+};
+
+struct HeadParams {
+    const void* x; int ldx;        // features, channels-last
+    const float* w; const float* b;   // (K,C), (K)
+    float* logits;                 // forward: out [N][K][vox] f32; backward: d logits (read)
+    void* dx; int lddx;
+    float* dw; float* db;          // pre-zeroed
+    int N, vox, C, K;
+};
+
+int rs_launch_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, float* out, hipStream_t st);
+int rs_elem_blocks(size_t items);
+int rs_launch_in_bwd(const InBwdParams& p, int dtype, hipStream_t st);
+int rs_launch_pool(const PoolParams& p, int dtype, int bwd, int blocks, hipStream_t st);
+int rs_launch_upsample(const UpParams& p, int dtype, int bwd, int blocks, hipStream_t st);
+int rs_launch_stem(const StemParams& p, int dtype, int wgrad, hipStream_t st);
+int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st);

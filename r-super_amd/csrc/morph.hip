@@ -1,0 +1,295 @@
+// Byte/integer kernels of the report-supervision losses (gfx950, HBM/LDS-bound; no float conv):
+//   dilate_pass      one ball-dilation pass (k <= 7) on 0/1 byte volumes, 4 voxels per lane as one u32
+//                    (dilate_volume_conv, training/losses_foundation.py:50-99; ball of create_ball_kernel :1161)
+//   ball_conv_argmax Gaussian-ball correlation + first-maximum argmax   (isolate_tumor :1423-1445)
+//   insert_ball      binary ball pasted at a centre, clipped          (insert_ball :1336-1385)
+//   radix histogram / select   exact top-k mask, ties by lower index  (torch.topk use at :1483-1492)
+//   rank weights     GWRP rank weights on the pseudo mask              (GlobalWeightedRankPooling :442-535)
+#include "common.hpp"
+#include "misc.hpp"
+#include "morph.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ dilation
+// 4*(dz^2+dy^2+dx^2) <= k^2  <=>  inside the ball of diameter k (k odd).  For a (dz,dy) row the half width is
+// L = floor(sqrt(k^2/4 - dz^2 - dy^2)).
+__device__ __forceinline__ int row_halfwidth(int k, int dz, int dy) {
+    const int rem4 = k * k - 4 * (dz * dz + dy * dy);
+    if (rem4 < 0) return -1;
+    int L = 0;
+    while (4 * (L + 1) * (L + 1) <= rem4) ++L;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void dilate_pass_kernel(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k) {
+    const int W4 = W >> 2;                                       // W % 4 == 0 (checked on the host)
+    const long words = (long)nvol * D * H * W4;
+    const int r = k >> 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (long)gridDim.x * blockDim.x) {
+        const int x4 = (int)(i % W4);
+        long t = i / W4;
+        const int y = (int)(t % H); t /= H;
+        const int z = (int)(t % D);
+        const long v = t / D;
+        const uint32_t* vol = (const uint32_t*)(in + v * (long)D * H * W);
+        uint32_t acc = 0;
+        for (int dz = -r; dz <= r; ++dz) {
+            const int zz = z + dz;
+            if (zz < 0 || zz >= D) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                const int L = row_halfwidth(k, dz, dy);
+                if (L < 0) continue;
+                const uint32_t* row = vol + ((long)zz * H + yy) * W4;
+                const uint32_t cur = row[x4];
+                uint32_t o = cur;
+                if (L > 0) {
+                    const uint32_t prev = x4 > 0 ? row[x4 - 1] : 0u, next = x4 + 1 < W4 ? row[x4 + 1] : 0u;
+                    for (int s = 1; s <= L; ++s) {
+                        o |= __builtin_amdgcn_alignbyte(cur, prev, 4 - s);    // bytes x-s .. x-s+3
+                        o |= __builtin_amdgcn_alignbyte(next, cur, s);        // bytes x+s .. x+s+3
+                    }
+                }
+                acc |= o;
+            }
+        }
+        ((uint32_t*)out)[i] = acc;
+    }
+}
+
+// generic-width fallback (one voxel per lane)
+__global__ __launch_bounds__(256) void dilate_pass_scalar_kernel(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k) {
+    const long total = (long)nvol * D * H * W;
+    const int r = k >> 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        long t = i / W;
+        const int y = (int)(t % H); t /= H;
+        const int z = (int)(t % D);
+        const uint8_t* vol = in + (t / D) * (long)D * H * W;
+        uint8_t acc = 0;
+        for (int dz = -r; dz <= r && !acc; ++dz)
+            for (int dy = -r; dy <= r && !acc; ++dy) {
+                const int L = row_halfwidth(k, dz, dy);
+                const int zz = z + dz, yy = y + dy;
+                if (L < 0 || zz < 0 || zz >= D || yy < 0 || yy >= H) continue;
+                for (int dx = -L; dx <= L; ++dx) {
+                    const int xx = x + dx;
+                    if (xx >= 0 && xx < W && vol[((long)zz * H + yy) * W + xx]) { acc = 1; break; }
+                }
+            }
+        out[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ball correlation + argmax
+// out(z,y,x) = sum over the ball of diameter d of exp(-|o|^2/(2 std^2)) * x(z+oz, y+oy, x+ox); the reference
+// normalises the kernel to sum 1, a positive scale that does not move the argmax.  key = (value bits << 32) |
+// ~index so a 64-bit atomicMax keeps the FIRST maximum (torch.argmax), values are >= 0.
+__global__ __launch_bounds__(256) void ball_conv_argmax_kernel(const float* x, int D, int H, int W, int d_odd, float inv2s2,
+                                                               unsigned long long* best, float* conv_out) {
+    __shared__ float g1[64];
+    __shared__ unsigned long long wbest[4];
+    const int R = d_odd >> 1;                                    // integer offsets with |o| <= d/2
+    for (int i = threadIdx.x; i <= R && i < 64; i += 256) g1[i] = expf(-(float)(i * i) * inv2s2);
+    __syncthreads();
+    const long V = (long)D * H * W;
+    unsigned long long mine = 0ull;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long)gridDim.x * 256) {
+        const int xx = (int)(i % W), yy = (int)((i / W) % H), zz = (int)(i / ((long)W * H));
+        float acc = 0.f;
+        for (int dz = -R; dz <= R; ++dz) {
+            const int z = zz + dz;
+            if (z < 0 || z >= D) continue;
+            for (int dy = -R; dy <= R; ++dy) {
+                const int y = yy + dy;
+                if (y < 0 || y >= H) continue;
+                const int L = row_halfwidth(d_odd, dz, dy);
+                if (L < 0) continue;
+                const float gzy = g1[dz < 0 ? -dz : dz] * g1[dy < 0 ? -dy : dy];
+                const float* row = x + ((long)z * H + y) * W;
+                const int lo = max(-L, -xx), hi = min(L, W - 1 - xx);
+                float rs = 0.f;
+                for (int dx = lo; dx <= hi; ++dx) rs += g1[dx < 0 ? -dx : dx] * row[xx + dx];
+                acc += gzy * rs;
+            }
+        }
+        if (conv_out) conv_out[i] = acc;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+        mine = key > mine ? key : mine;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(mine, o, 64);
+        mine = other > mine ? other : mine;
+    }
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = wbest[0];
+        for (int i = 1; i < 4; ++i) b = wbest[i] > b ? wbest[i] : b;
+        atomicMax(best, b);
+    }
+}
+
+// binary ball of (odd) diameter d_odd centred at (cz,cy,cx); count of set voxels accumulated into *count
+__global__ void insert_ball_kernel(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count) {
+    const long V = (long)D * H * W;
+    unsigned int c = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W) - cx, y = (int)((i / W) % H) - cy, z = (int)(i / ((long)W * H)) - cz;
+        // inside the pasted kernel cube (edge 2*half+1) and inside the ball (4*|o|^2 <= d^2)
+        const bool in = abs(x) <= half && abs(y) <= half && abs(z) <= half && 4 * (x * x + y * y + z * z) <= d_odd * d_odd;
+        out[i] = in ? 1 : 0;
+        c += in;
+    }
+    c = (unsigned int)wave_sum((float)c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+// ------------------------------------------------------------------------------------------------ exact top-k (radix select)
+// values are non-negative floats (bit pattern order == value order), optionally masked by m.
+// pass `shift` in {24,16,8,0}: histogram of byte (bits >> shift) & 255 over elements whose higher bits == prefix.
+__global__ __launch_bounds__(256) void radix_hist_kernel(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t hmask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long)gridDim.x * 256) {
+        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
+        if ((b & hmask) == (prefix & hmask)) atomicAdd(&h[(b >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// mask = (bits > thr) | first `need_eq` elements (index order) with bits == thr.  Single block, ordered scan.
+__global__ __launch_bounds__(1024) void topk_mark_kernel(const float* x, const uint8_t* m, long V, uint32_t thr, unsigned int need_eq, uint8_t* out) {
+    __shared__ unsigned int cnt[1024];
+    const long per = (V + 1023) / 1024;
+    const long b0 = (long)threadIdx.x * per, b1 = min(V, b0 + per);
+    unsigned int c = 0;
+    for (long i = b0; i < b1; ++i) {
+        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
+        c += (b == thr);
+    }
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    // exclusive prefix (Hillis-Steele on 1024 entries)
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned int v = threadIdx.x >= o ? cnt[threadIdx.x - o] : 0u;
+        __syncthreads();
+        cnt[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned int before = cnt[threadIdx.x] - c;
+    for (long i = b0; i < b1; ++i) {
+        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
+        uint8_t o = b > thr;
+        if (b == thr) { o = before < need_eq; ++before; }
+        out[i] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GWRP rank weights
+// compact the voxels of the pseudo mask, then rank each by value (desc) / index (asc) against all others.
+__global__ void compact_kernel(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x)
+        if (pm[i]) { const unsigned int p = atomicAdd(n, 1u); vals[p] = x[i]; idx[p] = (uint32_t)i; }
+}
+
+__global__ __launch_bounds__(256) void rank_weight_kernel(const float* vals, const uint32_t* idx, unsigned int n, float dlog2, float scale, float* w) {
+    __shared__ float sv[256];
+    __shared__ uint32_t si[256];
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    const float v = i < n ? vals[i] : 0.f;
+    const uint32_t id = i < n ? idx[i] : 0u;
+    unsigned int rank = 0;
+    for (unsigned int j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        if (j0 + threadIdx.x < n) { sv[threadIdx.x] = vals[j0 + threadIdx.x]; si[threadIdx.x] = idx[j0 + threadIdx.x]; }
+        __syncthreads();
+        const unsigned int lim = min(256u, n - j0);
+        for (unsigned int j = 0; j < lim; ++j) rank += (sv[j] > v) || (sv[j] == v && si[j] < id);
+    }
+    if (i < n) w[id] = exp2f((float)rank * dlog2) * scale;       // d^rank * N / sum_{r<N} d^r
+}
+
+__global__ void mask_op_kernel(uint8_t* a, const uint8_t* b, long V, int op) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) {
+        const uint8_t x = a[i], y = b[i];
+        a[i] = op == 0 ? (x & y) : op == 1 ? (x | y) : (uint8_t)(x & (y ? 0 : 1));
+    }
+}
+__global__ void zero_where_kernel(float* x, const uint8_t* m, long V) {     // x *= (1 - m)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x)
+        if (m[i]) x[i] = 0.f;
+}
+__global__ void count_kernel(const uint8_t* m, long V, unsigned int* count) {
+    unsigned int c = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) c += m[i] != 0;
+    c = (unsigned int)wave_sum((float)c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+}  // namespace
+
+int rs_launch_dilate_pass(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k, hipStream_t st) {
+    if (k < 1 || k > 7 || !(k & 1)) return RS_ERR_ARG;
+    if ((W & 3) == 0) {
+        const long words = nvol * D * H * (W >> 2);
+        hipLaunchKernelGGL(dilate_pass_kernel, dim3(rs_elem_blocks((size_t)words)), dim3(256), 0, st, in, out, nvol, D, H, W, k);
+    } else {
+        hipLaunchKernelGGL(dilate_pass_scalar_kernel, dim3(rs_elem_blocks((size_t)(nvol * D * H * W))), dim3(256), 0, st, in, out, nvol, D, H, W, k);
+    }
+    return rs_check_launch();
+}
+
+int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, hipStream_t st) {
+    if ((d_odd >> 1) >= 64) return RS_ERR_UNSUPPORTED;
+    const long V = (long)D * H * W;
+    int blocks = (int)((V + 255) / 256);
+    hipLaunchKernelGGL(ball_conv_argmax_kernel, dim3(blocks), dim3(256), 0, st, x, D, H, W, d_odd, 1.f / (2.f * std * std), best, conv_out);
+    return rs_check_launch();
+}
+
+int rs_launch_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, hipStream_t st) {
+    hipLaunchKernelGGL(insert_ball_kernel, dim3(rs_elem_blocks((size_t)D * H * W)), dim3(256), 0, st, out, D, H, W, cz, cy, cx, d_odd, half, count);
+    return rs_check_launch();
+}
+
+int rs_launch_radix_hist(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist, hipStream_t st) {
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(rs_elem_blocks((size_t)V) > 512 ? 512 : rs_elem_blocks((size_t)V)), dim3(256), 0, st, x, m, V, prefix, shift, hist);
+    return rs_check_launch();
+}
+
+int rs_launch_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr, unsigned int need_eq, uint8_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(topk_mark_kernel, dim3(1), dim3(1024), 0, st, x, m, V, thr, need_eq, out);
+    return rs_check_launch();
+}
+
+int rs_launch_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, hipStream_t st) {
+    hipLaunchKernelGGL(compact_kernel, dim3(rs_elem_blocks((size_t)V)), dim3(256), 0, st, x, pm, V, vals, idx, n);
+    return rs_check_launch();
+}
+
+int rs_launch_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float dlog2, float scale, float* w, hipStream_t st) {
+    if (!n) return RS_OK;
+    hipLaunchKernelGGL(rank_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, st, vals, idx, n, dlog2, scale, w);
+    return rs_check_launch();
+}
+
+int rs_launch_mask_op(uint8_t* a, const uint8_t* b, long V, int op, hipStream_t st) {
+    hipLaunchKernelGGL(mask_op_kernel, dim3(rs_elem_blocks((size_t)V)), dim3(256), 0, st, a, b, V, op);
+    return rs_check_launch();
+}
+int rs_launch_zero_where(float* x, const uint8_t* m, long V, hipStream_t st) {
+    hipLaunchKernelGGL(zero_where_kernel, dim3(rs_elem_blocks((size_t)V)), dim3(256), 0, st, x, m, V);
+    return rs_check_launch();
+}
+int rs_launch_count(const uint8_t* m, long V, unsigned int* count, hipStream_t st) {
+    hipLaunchKernelGGL(count_kernel, dim3(rs_elem_blocks((size_t)V)), dim3(256), 0, st, m, V, count);
+    return rs_check_launch();
+}

@@ -1,0 +1,79 @@
+// Optimiser side of the training step (gfx950, HBM-bound), multi-tensor:
+//   global grad L2 norm  -> clip coefficient (torch.nn.utils.clip_grad_norm_(params, 1.0), train_ddp.py:352)
+//   AdamW(eps=1e-5) step (training/utils.py:46-51)  fused with
+//   EMA update ema = a*ema + (1-a)*p               (update_ema_variables, training/utils.py:154-161)
+// One pass reads g, p, m, v, ema and writes p, m, v, ema; the clip coefficient is read from device memory so
+// the host never synchronises on the norm.
+#include "common.hpp"
+#include "optim.hpp"
+
+namespace {
+
+__device__ __forceinline__ int find_tensor(const MTChunk& c, int blk, int& local) {
+    int lo = 0, hi = c.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c.blk_start[mid] <= blk) lo = mid; else hi = mid; }
+    local = blk - c.blk_start[lo];
+    return lo;
+}
+
+constexpr int MT_ELEMS = 256 * 4 * 4;   // elements per block
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(MTChunk c, double* total) {
+    int local; const int ti = find_tensor(c, blockIdx.x, local);
+    const float* g = (const float*)c.g[ti];
+    const size_t n = c.numel[ti], base = (size_t)local * MT_ELEMS;
+    float s = 0.f;
+    for (size_t i = base + threadIdx.x; i < base + MT_ELEMS && i < n; i += 256) { const float v = g[i]; s += v * v; }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(total, (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(MTChunk c, AdamParams a, const double* total_sq) {
+    int local; const int ti = find_tensor(c, blockIdx.x, local);
+    float* p = (float*)c.p[ti]; const float* g = (const float*)c.g[ti];
+    float* m = (float*)c.m[ti]; float* v = (float*)c.v[ti]; float* e = (float*)c.ema[ti];
+    const size_t n = c.numel[ti], base = (size_t)local * MT_ELEMS;
+    float coef = 1.f;
+    if (total_sq) {                                              // clip_grad_norm_: max_norm / (norm + 1e-6), clamped to 1
+        const float norm = (float)sqrt(*total_sq);
+        coef = fminf(a.max_norm / (norm + 1e-6f), 1.f);
+    }
+    for (size_t i = base + threadIdx.x; i < base + MT_ELEMS && i < n; i += 256) {
+        const float gi = g[i] * coef;
+        float pi = p[i] * (1.f - a.lr * a.wd);                   // decoupled weight decay
+        const float mi = a.beta1 * m[i] + (1.f - a.beta1) * gi;
+        const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gi * gi;
+        const float denom = sqrtf(vi) / a.sqrt_bc2 + a.eps;
+        pi -= a.step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (e) e[i] = a.ema_alpha * e[i] + (1.f - a.ema_alpha) * pi;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(MTChunk c, float max_norm, const double* total_sq) {
+    int local; const int ti = find_tensor(c, blockIdx.x, local);
+    float* g = (float*)c.g[ti];
+    const size_t n = c.numel[ti], base = (size_t)local * MT_ELEMS;
+    const float coef = fminf(max_norm / ((float)sqrt(*total_sq) + 1e-6f), 1.f);
+    for (size_t i = base + threadIdx.x; i < base + MT_ELEMS && i < n; i += 256) g[i] *= coef;
+}
+
+}  // namespace
+
+int rs_mt_blocks(size_t numel) { return (int)((numel + MT_ELEMS - 1) / MT_ELEMS); }
+
+int rs_launch_sqnorm(const MTChunk& c, double* total, hipStream_t st) {
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(c.blk_start[c.n]), dim3(256), 0, st, c, total);
+    return rs_check_launch();
+}
+int rs_launch_adamw_ema(const MTChunk& c, const AdamParams& a, const double* total_sq, hipStream_t st) {
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(c.blk_start[c.n]), dim3(256), 0, st, c, a, total_sq);
+    return rs_check_launch();
+}
+int rs_launch_scale(const MTChunk& c, float max_norm, const double* total_sq, hipStream_t st) {
+    hipLaunchKernelGGL(scale_kernel, dim3(c.blk_start[c.n]), dim3(256), 0, st, c, max_norm, total_sq);
+    return rs_check_launch();
+}

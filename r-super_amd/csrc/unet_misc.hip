@@ -1,0 +1,576 @@
+// HBM-bound kernels of the UNet path (gfx950): everything around the MFMA convolutions.
+// Activations are channels-last [N][D][H][W][C] (views with channel stride ld), 16-byte vector accesses.
+//
+//   stats_finalize        per-block partial sums -> per-(n,c) (mean, rstd) / backward means
+//                         (nn.InstanceNorm3d(eps=1e-4, affine=False), model/dim3/conv_layers.py:40-42)
+//   in_bwd_finalize       InstanceNorm backward tail: dx = rstd*(g - mean(g) - x_n*mean(g*x_n)) [+ adds]
+//   maxpool2 fwd/bwd      nn.MaxPool3d(2)                       (model/dim3/unet_utils.py:35-37)
+//   upsample fwd/bwd      F.interpolate(trilinear, align_corners=True)   (unet_utils.py:69)
+//   stem fwd/wgrad        inconv.conv1: Conv3d(1 -> C, k=3, bias=False)  (unet_utils.py:14)
+//   head fwd/bwd          outc: Conv3d(C -> K, k=1) + bias               (unet.py:47)
+#include "common.hpp"
+#include "kernels.hpp"
+#include "misc.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ stats
+// part: [N][nblk][C][2] floats.  mode 0: out = (mean, rstd);  mode 1: out = (sum0/cnt, sum1/cnt).
+__global__ void stats_finalize_kernel(const float* part, int nblk, int C, double cnt, float eps, int mode, float* out) {
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per channel
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        const float* p = part + (((size_t)n * nblk + b) * C + c) * 2;
+        s0 += (double)p[0]; s1 += (double)p[1];
+    }
+    s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+    if (lane == 0) {
+        float* o = out + ((size_t)n * C + c) * 2;
+        if (mode == 0) {
+            const double mean = s0 / cnt;
+            double var = s1 / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            o[0] = (float)mean;
+            o[1] = (float)(1.0 / sqrt(var + (double)eps));
+        } else {
+            o[0] = (float)(s0 / cnt); o[1] = (float)(s1 / cnt);
+        }
+    }
+}
+
+// Block-level per-channel partial sums for the elementwise kernels.
+// Thread layout: CV = C/KP channel vectors, VL = 256/CV voxel lanes; thread (vl, s) owns KP channels.
+template <int KP>
+__device__ __forceinline__ void block_channel_sums(const float* s1, const float* s2, int C, int CV, int VL, int vl, int s,
+                                                   bool active, float* part_blk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;                                  // [VL][C][2]
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            red[((vl * C) + s * KP + j) * 2] = s1[j];
+            red[((vl * C) + s * KP + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int v = 0; v < VL; ++v) { a += red[(v * C + c) * 2]; b += red[(v * C + c) * 2 + 1]; }
+        part_blk[c * 2] = a; part_blk[c * 2 + 1] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ IN backward tail
+template <typename T>
+__global__ void in_bwd_finalize_kernel(InBwdParams p) {
+    constexpr int KP = Elem<T>::KP;
+    const int CV = p.C / KP;
+    const size_t total = (size_t)p.vox * CV;                    // per sample
+    const int n = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t v = i / CV; const int s = (int)(i % CV);
+        const size_t vox = (size_t)n * p.vox + v;
+        const int c = s * KP;
+        float g[KP], x[KP], o[KP];
+        unpack16<T>(*(const uint4*)((const T*)p.g + vox * p.ldg + c), g);
+        unpack16<T>(*(const uint4*)((const T*)p.x + vox * p.ldx + c), x);
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const float mu = p.mr[((size_t)n * p.C + c + j) * 2], rs = p.mr[((size_t)n * p.C + c + j) * 2 + 1];
+            const float m1 = p.gm[((size_t)n * p.C + c + j) * 2], m2 = p.gm[((size_t)n * p.C + c + j) * 2 + 1];
+            const float xn = (x[j] - mu) * rs;
+            o[j] = rs * (g[j] - m1 - xn * m2);
+        }
+        if (p.add1) {
+            float a[KP];
+            unpack16<T>(*(const uint4*)((const T*)p.add1 + vox * p.lda1 + c), a);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) o[j] += a[j];
+        }
+        if (p.add2) {
+            float a[KP];
+            unpack16<T>(*(const uint4*)((const T*)p.add2 + vox * p.lda2 + c), a);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) o[j] += a[j];
+        }
+        *(uint4*)((T*)p.out + vox * p.ldo + c) = pack16<T>(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ max pool 2x2x2
+// grid: (blocks over output voxels of one sample, N).  Output partial stats for the next InstanceNorm.
+template <typename T>
+__global__ void maxpool_fwd_kernel(PoolParams p) {
+    constexpr int KP = Elem<T>::KP;
+    const int CV = p.C / KP, VL = 256 / CV;
+    const int vl = threadIdx.x / CV, s = threadIdx.x % CV;
+    const bool active = vl < VL;
+    const int n = blockIdx.y;
+    const int OD = p.D / 2, OH = p.H / 2, OW = p.W / 2;
+    const int ovox = OD * OH * OW;
+    const int per_blk = (ovox + gridDim.x - 1) / gridDim.x;
+    const int v0 = blockIdx.x * per_blk, v1 = min(ovox, v0 + per_blk);
+    float s1[KP], s2[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (active)
+        for (int v = v0 + vl; v < v1; v += VL) {
+            const int ow = v % OW, oh = (v / OW) % OH, od = v / (OW * OH);
+            float m[KP];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) m[j] = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int d = od * 2 + (k >> 2), h = oh * 2 + ((k >> 1) & 1), w = ow * 2 + (k & 1);
+                float x[KP];
+                unpack16<T>(*(const uint4*)((const T*)p.x + ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (size_t)p.ldx + s * KP), x);
+#pragma unroll
+                for (int j = 0; j < KP; ++j) m[j] = fmaxf(m[j], x[j]);
+            }
+            *(uint4*)((T*)p.y + ((size_t)n * ovox + v) * p.ldy + s * KP) = pack16<T>(m);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) { s1[j] += m[j]; s2[j] += m[j] * m[j]; }
+        }
+    if (p.part) block_channel_sums<KP>(s1, s2, p.C, CV, VL, vl, s, active, p.part + ((size_t)n * gridDim.x + blockIdx.x) * p.C * 2);
+}
+
+// dx = dy routed to the FIRST maximum in (d,h,w) scan order (ATen max_pool3d keeps the first `>`), else 0.
+template <typename T>
+__global__ void maxpool_bwd_kernel(PoolParams p) {
+    constexpr int KP = Elem<T>::KP;
+    const int CV = p.C / KP;
+    const int n = blockIdx.y;
+    const int OD = p.D / 2, OH = p.H / 2, OW = p.W / 2;
+    const size_t total = (size_t)OD * OH * OW * CV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % CV); const int v = (int)(i / CV);
+        const int ow = v % OW, oh = (v / OW) % OH, od = v / (OW * OH);
+        float x[8][KP], m[KP], dy[KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) m[j] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = od * 2 + (k >> 2), h = oh * 2 + ((k >> 1) & 1), w = ow * 2 + (k & 1);
+            unpack16<T>(*(const uint4*)((const T*)p.x + ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (size_t)p.ldx + s * KP), x[k]);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) m[j] = fmaxf(m[j], x[k][j]);
+        }
+        unpack16<T>(*(const uint4*)((const T*)p.y + ((size_t)n * OD * OH * OW + v) * p.ldy + s * KP), dy);
+        bool done[KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) done[j] = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = od * 2 + (k >> 2), h = oh * 2 + ((k >> 1) & 1), w = ow * 2 + (k & 1);
+            float o[KP];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const bool hit = !done[j] && x[k][j] == m[j];
+                o[j] = hit ? dy[j] : 0.f;
+                done[j] = done[j] || hit;
+            }
+            *(uint4*)((T*)p.dx + ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (size_t)p.lddx + s * KP) = pack16<T>(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ trilinear, align_corners
+__device__ __forceinline__ void lin_coord(int o, float scale, int I, int& i0, int& i1, float& l1) {
+    // ATen area_pixel_compute_source_index(align_corners=True): src = scale * dst (float32)
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    if (i0 > I - 1) i0 = I - 1;
+    i1 = i0 + (i0 < I - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+template <typename T>
+__global__ void upsample_fwd_kernel(UpParams p) {
+    constexpr int KP = Elem<T>::KP;
+    const int CV = p.C / KP, VL = 256 / CV;
+    const int vl = threadIdx.x / CV, s = threadIdx.x % CV;
+    const bool active = vl < VL;
+    const int n = blockIdx.y;
+    const int ovox = p.OD * p.OH * p.OW;
+    const int per_blk = (ovox + gridDim.x - 1) / gridDim.x;
+    const int v0 = blockIdx.x * per_blk, v1 = min(ovox, v0 + per_blk);
+    const float sd = p.OD > 1 ? (float)(p.ID - 1) / (float)(p.OD - 1) : 0.f;
+    const float sh = p.OH > 1 ? (float)(p.IH - 1) / (float)(p.OH - 1) : 0.f;
+    const float sw = p.OW > 1 ? (float)(p.IW - 1) / (float)(p.OW - 1) : 0.f;
+    float s1[KP], s2[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (active)
+        for (int v = v0 + vl; v < v1; v += VL) {
+            const int ow = v % p.OW, oh = (v / p.OW) % p.OH, od = v / (p.OW * p.OH);
+            int d0, d1, h0, h1, w0, w1; float ld, lh, lw;
+            lin_coord(od, sd, p.ID, d0, d1, ld);
+            lin_coord(oh, sh, p.IH, h0, h1, lh);
+            lin_coord(ow, sw, p.IW, w0, w1, lw);
+            float acc[KP];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int d = (k & 4) ? d1 : d0, h = (k & 2) ? h1 : h0, w = (k & 1) ? w1 : w0;
+                const float wt = ((k & 4) ? ld : 1.f - ld) * ((k & 2) ? lh : 1.f - lh) * ((k & 1) ? lw : 1.f - lw);
+                float x[KP];
+                unpack16<T>(*(const uint4*)((const T*)p.x + ((((size_t)n * p.ID + d) * p.IH + h) * p.IW + w) * (size_t)p.ldx + s * KP), x);
+#pragma unroll
+                for (int j = 0; j < KP; ++j) acc[j] += wt * x[j];
+            }
+#pragma unroll
+            for (int j = 0; j < KP; ++j) acc[j] = Elem<T>::rnd(acc[j]);
+            *(uint4*)((T*)p.y + ((size_t)n * ovox + v) * p.ldy + s * KP) = pack16<T>(acc);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
+        }
+    if (p.part) block_channel_sums<KP>(s1, s2, p.C, CV, VL, vl, s, active, p.part + ((size_t)n * gridDim.x + blockIdx.x) * p.C * 2);
+}
+
+// contribution range of input index i along one axis: outputs o whose i0(o)==i or i1(o)==i
+__device__ __forceinline__ void up_range(int i, float scale, int O, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = O - 1; return; }
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > O - 1) hi = O - 1;
+}
+__device__ __forceinline__ float up_weight(int o, int i, float scale, int I) {
+    int i0, i1; float l1;
+    lin_coord(o, scale, I, i0, i1, l1);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i1 == i) w += l1;
+    return w;
+}
+
+template <typename T>
+__global__ void upsample_bwd_kernel(UpParams p) {
+    constexpr int KP = Elem<T>::KP;
+    const int CV = p.C / KP;
+    const int n = blockIdx.y;
+    const size_t total = (size_t)p.ID * p.IH * p.IW * CV;
+    const int ovox = p.OD * p.OH * p.OW;
+    const float sd = p.OD > 1 ? (float)(p.ID - 1) / (float)(p.OD - 1) : 0.f;
+    const float sh = p.OH > 1 ? (float)(p.IH - 1) / (float)(p.OH - 1) : 0.f;
+    const float sw = p.OW > 1 ? (float)(p.IW - 1) / (float)(p.OW - 1) : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % CV); const int v = (int)(i / CV);
+        const int iw = v % p.IW, ih = (v / p.IW) % p.IH, id = v / (p.IW * p.IH);
+        int dl, dh, hl, hh, wl, wh;
+        up_range(id, sd, p.OD, dl, dh); up_range(ih, sh, p.OH, hl, hh); up_range(iw, sw, p.OW, wl, wh);
+        float acc[KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) acc[j] = 0.f;
+        for (int od = dl; od <= dh; ++od) {
+            const float wd = up_weight(od, id, sd, p.ID);
+            if (wd == 0.f) continue;
+            for (int oh = hl; oh <= hh; ++oh) {
+                const float whh = up_weight(oh, ih, sh, p.IH);
+                if (whh == 0.f) continue;
+                for (int ow = wl; ow <= wh; ++ow) {
+                    const float ww = up_weight(ow, iw, sw, p.IW);
+                    if (ww == 0.f) continue;
+                    float g[KP];
+                    unpack16<T>(*(const uint4*)((const T*)p.y + ((size_t)n * ovox + ((size_t)od * p.OH + oh) * p.OW + ow) * p.ldy + s * KP), g);
+                    const float wt = wd * whh * ww;
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) acc[j] += wt * g[j];
+                }
+            }
+        }
+        *(uint4*)((T*)p.dx + ((size_t)n * p.ID * p.IH * p.IW + v) * p.lddx + s * KP) = pack16<T>(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stem: Conv3d(1 -> C, 3x3x3)
+// thread = one voxel, all C outputs; weights (C,1,27) f32 broadcast from LDS.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* w = (float*)smem;                                    // [27][C]
+    float* tile = w + 27 * C;                                   // [256][C+1] for the stats transpose
+    for (int i = threadIdx.x; i < 27 * C; i += 256) w[(i % 27) * C + i / 27] = p.w[i];
+    __syncthreads();
+    const int n = blockIdx.y;
+    const int vox = p.D * p.H * p.W;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    const bool ok = v < vox;
+    if (ok) {
+        const int x0 = v % p.W, y0 = (v / p.W) % p.H, z0 = v / (p.W * p.H);
+        const float* xin = p.x + (size_t)n * vox;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int z = z0 + tap / 9 - 1, y = y0 + (tap % 9) / 3 - 1, x = x0 + tap % 3 - 1;
+            float xv = 0.f;
+            if (z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) xv = xin[((size_t)z * p.H + y) * p.W + x];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] += xv * w[tap * C + c];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = Elem<T>::rnd(acc[c]);
+        T* o = (T*)p.y + ((size_t)n * vox + v) * p.ldy;
+        constexpr int KP = Elem<T>::KP;
+#pragma unroll
+        for (int c = 0; c < C; c += KP) *(uint4*)(o + c) = pack16<T>(acc + c);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) tile[threadIdx.x * (C + 1) + c] = ok ? acc[c] : 0.f;
+    __syncthreads();
+    // channel-major reduction: thread (g, c) sums 256/G voxels
+    constexpr int G = 256 / C;
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    float a = 0.f, b = 0.f;
+    for (int r = g; r < 256; r += G) { const float t = tile[r * (C + 1) + c]; a += t; b += t * t; }
+    __syncthreads();
+    float* red = tile;                                          // [G][C][2]
+    red[(g * C + c) * 2] = a; red[(g * C + c) * 2 + 1] = b;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float sa = 0.f, sb = 0.f;
+        for (int k = 0; k < G; ++k) { sa += red[(k * C + threadIdx.x) * 2]; sb += red[(k * C + threadIdx.x) * 2 + 1]; }
+        float* pp = p.part + (((size_t)n * gridDim.x + blockIdx.x) * C + threadIdx.x) * 2;
+        pp[0] = sa; pp[1] = sb;
+    }
+}
+
+// dW[c][tap] += sum_v dY[v][c] * x[v + off(tap)]; block loops over 256-voxel runs, thread = (channel, tap group).
+template <typename T, int C>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* dyt = (float*)smem;                                  // [256][C+1]
+    float* xt = dyt + 256 * (C + 1);                            // [256][27] gathered neighbourhood
+    constexpr int G = 256 / C;                                  // tap groups
+    constexpr int TPT = (27 + G - 1) / G;
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    const int vox = p.D * p.H * p.W;
+    const int runs = (vox + 255) / 256;
+    float acc[TPT];
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) acc[j] = 0.f;
+    for (int run = blockIdx.x; run < runs * p.N; run += gridDim.x) {
+        const int n = run / runs, v = (run % runs) * 256 + threadIdx.x;
+        __syncthreads();
+        const bool ok = v < vox;
+        const int x0 = v % p.W, y0 = (v / p.W) % p.H, z0 = v / (p.W * p.H);
+        for (int tap = 0; tap < 27; ++tap) {
+            const int z = z0 + tap / 9 - 1, y = y0 + (tap % 9) / 3 - 1, x = x0 + tap % 3 - 1;
+            float xv = 0.f;
+            if (ok && z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) xv = p.x[(size_t)n * vox + ((size_t)z * p.H + y) * p.W + x];
+            xt[threadIdx.x * 27 + tap] = xv;
+        }
+        for (int cc = 0; cc < C; ++cc) dyt[threadIdx.x * (C + 1) + cc] = ok ? Elem<T>::ld((const T*)p.y + ((size_t)n * vox + v) * p.ldy + cc) : 0.f;
+        __syncthreads();
+        for (int r = 0; r < 256; ++r) {
+            const float dy = dyt[r * (C + 1) + c];
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) {
+                const int tap = g + j * G;
+                if (tap < 27) acc[j] += dy * xt[r * 27 + tap];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) {
+        const int tap = g + j * G;
+        if (tap < 27) atomicAdd(p.dw + c * 27 + tap, acc[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ head: Conv3d(C -> K, 1x1x1) + bias
+// logits are NCDHW f32 (the loss kernels reduce per (b, class) plane; the reference returns (B,C,D,H,W)).
+template <typename T, int C>
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* w = (float*)smem;                                    // [K][C] + bias[K]
+    for (int i = threadIdx.x; i < p.K * C; i += 256) w[i] = p.w[i];
+    for (int i = threadIdx.x; i < p.K; i += 256) w[p.K * C + i] = p.b[i];
+    __syncthreads();
+    const int n = blockIdx.y;
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= (size_t)p.vox) return;
+    constexpr int KP = Elem<T>::KP;
+    float f[C];
+    const T* x = (const T*)p.x + ((size_t)n * p.vox + v) * p.ldx;
+#pragma unroll
+    for (int c = 0; c < C; c += KP) unpack16<T>(*(const uint4*)(x + c), f + c);
+    for (int k = 0; k < p.K; ++k) {
+        float a = w[p.K * C + k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) a += f[c] * w[k * C + c];
+        p.logits[((size_t)n * p.K + k) * p.vox + v] = a;
+    }
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void head_bwd_data_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* w = (float*)smem;
+    for (int i = threadIdx.x; i < p.K * C; i += 256) w[i] = p.w[i];
+    __syncthreads();
+    const int n = blockIdx.y;
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= (size_t)p.vox) return;
+    constexpr int KP = Elem<T>::KP;
+    float f[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) f[c] = 0.f;
+    for (int k = 0; k < p.K; ++k) {
+        const float g = p.logits[((size_t)n * p.K + k) * p.vox + v];
+#pragma unroll
+        for (int c = 0; c < C; ++c) f[c] += g * w[k * C + c];
+    }
+    T* dx = (T*)p.dx + ((size_t)n * p.vox + v) * p.lddx;
+#pragma unroll
+    for (int c = 0; c < C; c += KP) *(uint4*)(dx + c) = pack16<T>(f + c);
+}
+
+// dW[k][c] += sum_v g[k][v]*x[v][c]; db[k] += sum_v g[k][v].  thread = (c, k group).
+template <typename T, int C>
+__global__ __launch_bounds__(256) void head_bwd_weight_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xt = (float*)smem;                                   // [256][C+1]
+    float* gt = xt + 256 * (C + 1);                             // [K][256]
+    constexpr int G = 256 / C;
+    constexpr int KPT = 64 / G > 0 ? (64 + G - 1) / G : 64;     // classes per thread (K <= 64)
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    float acc[KPT], accb[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) { acc[j] = 0.f; accb[j] = 0.f; }
+    const int runs = (p.vox + 255) / 256;
+    for (int run = blockIdx.x; run < runs * p.N; run += gridDim.x) {
+        const int n = run / runs;
+        const size_t v = (size_t)(run % runs) * 256 + threadIdx.x;
+        const bool ok = v < (size_t)p.vox;
+        __syncthreads();
+        for (int cc = 0; cc < C; ++cc) xt[threadIdx.x * (C + 1) + cc] = ok ? Elem<T>::ld((const T*)p.x + ((size_t)n * p.vox + v) * p.ldx + cc) : 0.f;
+        for (int k = 0; k < p.K; ++k) gt[k * 256 + threadIdx.x] = ok ? p.logits[((size_t)n * p.K + k) * p.vox + v] : 0.f;
+        __syncthreads();
+        for (int r = 0; r < 256; ++r) {
+            const float xv = xt[r * (C + 1) + c];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const int k = g + j * G;
+                if (k < p.K) { const float gv = gt[k * 256 + r]; acc[j] += gv * xv; accb[j] += gv; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int k = g + j * G;
+        if (k < p.K) {
+            atomicAdd(p.dw + k * C + c, acc[j]);
+            if (c == 0) atomicAdd(p.db + k, accb[j]);
+        }
+    }
+}
+
+template <typename F> void set_smem(F k, size_t smem) {
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+}
+
+}  // namespace
+
+int rs_launch_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, N), dim3(256), 0, st, part, nblk, C, cnt, eps, mode, out);
+    return rs_check_launch();
+}
+
+int rs_elem_blocks(size_t items) {
+    size_t b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+int rs_launch_in_bwd(const InBwdParams& p, int dtype, hipStream_t st) {
+    const int KP = dtype == RS_F32 ? 4 : 8;
+    const int blocks = rs_elem_blocks((size_t)p.vox * (p.C / KP));
+    if (dtype == RS_F32) hipLaunchKernelGGL(in_bwd_finalize_kernel<float>, dim3(blocks, p.N), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(in_bwd_finalize_kernel<bf16_t>, dim3(blocks, p.N), dim3(256), 0, st, p);
+    return rs_check_launch();
+}
+
+int rs_launch_pool(const PoolParams& p, int dtype, int bwd, int blocks, hipStream_t st) {
+    const int KP = dtype == RS_F32 ? 4 : 8;
+    const int CV = p.C / KP;
+    if (CV > 256) return RS_ERR_UNSUPPORTED;
+    if (!bwd) {
+        const size_t smem = (size_t)(256 / CV) * p.C * 2 * sizeof(float);
+        if (dtype == RS_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(blocks, p.N), dim3(256), smem, st, p);
+        else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(blocks, p.N), dim3(256), smem, st, p);
+    } else {
+        const int b = rs_elem_blocks((size_t)(p.D / 2) * (p.H / 2) * (p.W / 2) * CV);
+        if (dtype == RS_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(b, p.N), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(b, p.N), dim3(256), 0, st, p);
+    }
+    return rs_check_launch();
+}
+
+int rs_launch_upsample(const UpParams& p, int dtype, int bwd, int blocks, hipStream_t st) {
+    const int KP = dtype == RS_F32 ? 4 : 8;
+    const int CV = p.C / KP;
+    if (CV > 256) return RS_ERR_UNSUPPORTED;
+    if (!bwd) {
+        const size_t smem = (size_t)(256 / CV) * p.C * 2 * sizeof(float);
+        if (dtype == RS_F32) hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(blocks, p.N), dim3(256), smem, st, p);
+        else hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(blocks, p.N), dim3(256), smem, st, p);
+    } else {
+        const int b = rs_elem_blocks((size_t)p.ID * p.IH * p.IW * CV);
+        if (dtype == RS_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(b, p.N), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(b, p.N), dim3(256), 0, st, p);
+    }
+    return rs_check_launch();
+}
+
+#define RS_DISPATCH_C(KERNEL, T, C, ...)                                                        \
+    switch (C) {                                                                                \
+        case 8: { auto k = KERNEL<T, 8>; set_smem(k, smem); hipLaunchKernelGGL(k, __VA_ARGS__); break; }   \
+        case 16: { auto k = KERNEL<T, 16>; set_smem(k, smem); hipLaunchKernelGGL(k, __VA_ARGS__); break; } \
+        case 32: { auto k = KERNEL<T, 32>; set_smem(k, smem); hipLaunchKernelGGL(k, __VA_ARGS__); break; } \
+        case 64: { auto k = KERNEL<T, 64>; set_smem(k, smem); hipLaunchKernelGGL(k, __VA_ARGS__); break; } \
+        default: return RS_ERR_UNSUPPORTED;                                                     \
+    }
+
+int rs_launch_stem(const StemParams& p, int dtype, int wgrad, hipStream_t st) {
+    const int vox = p.D * p.H * p.W;
+    if (!wgrad) {
+        const size_t smem = (size_t)(27 * p.C + 256 * (p.C + 1)) * sizeof(float);
+        dim3 grid((vox + 255) / 256, p.N);
+        if (dtype == RS_F32) { RS_DISPATCH_C(stem_fwd_kernel, float, p.C, grid, dim3(256), smem, st, p) }
+        else { RS_DISPATCH_C(stem_fwd_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
+    } else {
+        const size_t smem = (size_t)(256 * (p.C + 1) + 256 * 27) * sizeof(float);
+        int runs = ((vox + 255) / 256) * p.N;
+        dim3 grid(runs < 1024 ? runs : 1024);
+        if (dtype == RS_F32) { RS_DISPATCH_C(stem_wgrad_kernel, float, p.C, grid, dim3(256), smem, st, p) }
+        else { RS_DISPATCH_C(stem_wgrad_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
+    }
+    return rs_check_launch();
+}
+
+int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st) {
+    if (p.K > 64) return RS_ERR_UNSUPPORTED;
+    dim3 grid((p.vox + 255) / 256, p.N);
+    if (which == 0) {
+        const size_t smem = (size_t)(p.K * p.C + p.K) * sizeof(float);
+        if (dtype == RS_F32) { RS_DISPATCH_C(head_fwd_kernel, float, p.C, grid, dim3(256), smem, st, p) }
+        else { RS_DISPATCH_C(head_fwd_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
+    } else if (which == 1) {
+        const size_t smem = (size_t)(p.K * p.C) * sizeof(float);
+        if (dtype == RS_F32) { RS_DISPATCH_C(head_bwd_data_kernel, float, p.C, grid, dim3(256), smem, st, p) }
+        else { RS_DISPATCH_C(head_bwd_data_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
+    } else {
+        const size_t smem = (size_t)(256 * (p.C + 1) + p.K * 256) * sizeof(float);
+        int runs = ((p.vox + 255) / 256) * p.N;
+        dim3 g2(runs < 1024 ? runs : 1024);
+        if (dtype == RS_F32) { RS_DISPATCH_C(head_bwd_weight_kernel, float, p.C, g2, dim3(256), smem, st, p) }
+        else { RS_DISPATCH_C(head_bwd_weight_kernel, bf16_t, p.C, g2, dim3(256), smem, st, p) }
+    }
+    return rs_check_launch();
+}

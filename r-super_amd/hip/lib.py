@@ -1,0 +1,88 @@
+"""ctypes binding of csrc/librsuper_hip.so (C ABI declared in include/rsuper_hip.h).
+
+The product path has no CPU fallback: `lib()` raises if the shared library is missing and
+`require_device()` raises if device 0 is not a gfx950 GPU.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_long, c_size_t, c_float, c_double, c_void_p, c_uint32, c_uint
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'librsuper_hip.so')
+
+F32, BF16 = 0, 1
+_LIB = None
+
+P = c_void_p
+_SIGS = {
+    'rsuper_version': (ctypes.c_char_p, []),
+    'rsuper_device_check': (c_int, []),
+    'rsuper_conv3_packed_elems': (c_size_t, [c_int] * 5),
+    'rsuper_conv3_pack_weights': (c_int, [c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    'rsuper_conv3_tiles': (c_int, [c_int] * 3),
+    'rsuper_conv3_igemm': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   P, c_int, P, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, P]),
+    'rsuper_conv3_wgrad': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int,
+                                   P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'rsuper_stats_finalize': (c_int, [P, c_int, c_int, c_int, c_double, c_float, c_int, P, P]),
+    'rsuper_in_bwd_finalize': (c_int, [c_int, P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    'rsuper_maxpool2_fwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'rsuper_maxpool2_bwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'rsuper_upsample_fwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int] + [c_int] * 8 + [P]),
+    'rsuper_upsample_bwd': (c_int, [c_int, P, c_int, P, c_int] + [c_int] * 8 + [P]),
+    'rsuper_stem_fwd': (c_int, [c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'rsuper_stem_wgrad': (c_int, [c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'rsuper_head_fwd': (c_int, [c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'rsuper_head_bwd_data': (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'rsuper_head_bwd_weight': (c_int, [c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'rsuper_plane_partials_fwd': (c_int, [P, c_size_t, P, P, P, P, P, c_int, c_size_t, P]),
+    'rsuper_plane_partials_bwd': (c_int, [P, c_size_t, P, P, P, P, P, P, c_int, c_int, c_size_t, P]),
+    'rsuper_sigmoid_mask': (c_int, [P, P, P, c_size_t, P]),
+    'rsuper_dilate_volume': (c_int, [P, P, P, c_long, c_int, c_int, c_int, c_int, P]),
+    'rsuper_ball_conv_argmax': (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, P, P]),
+    'rsuper_insert_ball': (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    'rsuper_radix_hist': (c_int, [P, P, c_long, c_uint32, c_int, P, P]),
+    'rsuper_topk_mark': (c_int, [P, P, c_long, c_uint32, c_uint, P, P]),
+    'rsuper_compact': (c_int, [P, P, c_long, P, P, P, P]),
+    'rsuper_rank_weights': (c_int, [P, P, c_uint, c_float, c_float, P, P]),
+    'rsuper_mask_op': (c_int, [P, P, c_long, c_int, P]),
+    'rsuper_zero_where': (c_int, [P, P, c_long, P]),
+    'rsuper_count': (c_int, [P, c_long, P, P]),
+    'rsuper_grad_sqnorm': (c_int, [c_int, P, P, P, P]),
+    'rsuper_clip_scale': (c_int, [c_int, P, P, c_float, P, P]),
+    'rsuper_adamw_ema_step': (c_int, [c_int, P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_float, P, P]),
+}
+
+ERR = {1: 'RSUPER_ERR_ARG', 2: 'RSUPER_ERR_LAUNCH', 3: 'RSUPER_ERR_UNSUPPORTED', 4: 'RSUPER_ERR_NO_DEVICE'}
+
+
+class RSuperHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librsuper_hip.so; no fallback -- a missing library is a hard error."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise RSuperHipError(f'{SO_PATH} not found: build it with `make -C r-super_amd/csrc` '
+                                 f'(or python -c "import __graft_entry__ as g; g.build()"). There is no CPU fallback.')
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)      # AttributeError here == header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RSuperHipError(f'{what} failed: {ERR.get(rc, rc)}')
+
+
+def require_device():
+    check(lib().rsuper_device_check(), 'rsuper_device_check (MI355X / gfx950 required)')

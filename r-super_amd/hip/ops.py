@@ -1,0 +1,377 @@
+"""Autograd functions over the C ABI (include/rsuper_hip.h).  PyTorch supplies device memory, the current HIP
+stream and the autograd graph; every device op below is a hand-written gfx950 kernel in csrc/.
+
+Activation convention between functions: a contiguous tensor of shape (N, D, H, W, C) (channels-last storage,
+bf16 or f32) plus its InstanceNorm statistics `mr` of shape (N, C, 2) = (mean, rstd), f32, computed by the
+producing kernel's epilogue (model/dim3/conv_layers.py:40-42: eps=1e-4, affine=False, biased variance).
+"""
+import os
+
+import torch
+
+from . import lib as _l
+
+EPS = 1e-4
+_DT = {torch.float32: _l.F32, torch.bfloat16: _l.BF16}
+
+
+def use_tr():
+    """bf16 weight-gradient operand fetch via ds_read_b64_tr_b16 (1, default) or 16-bit LDS reads (0)."""
+    return int(os.environ.get('RSUPER_WGRAD_TR', '1'))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, off_elems=0):
+    if t is None:
+        return None
+    return t.data_ptr() + off_elems * t.element_size()
+
+
+def _L():
+    return _l.lib()
+
+
+def pick_bn(n_cols, dtype):
+    """Block N tile of the implicit GEMM (32/64/128 output columns); f32 parity mode is limited to 64."""
+    cands = (32, 64) if dtype == torch.float32 else (32, 64, 128)
+    if n_cols <= 32:
+        return 32
+    best = None
+    for bn in cands:
+        padded = -(-n_cols // bn) * bn
+        key = (padded, -bn)
+        if best is None or key < best[0]:
+            best = (key, bn)
+    return best[1]
+
+
+def _chk_act(x):
+    assert x.dim() == 5 and x.is_contiguous() and x.dtype in _DT and x.shape[-1] % 8 == 0, (x.shape, x.dtype, x.is_contiguous())
+
+
+def stats_finalize(part, cnt, mode=0):
+    """part (N, nblk, C, 2) f32 -> (N, C, 2)."""
+    N, nblk, C, _ = part.shape
+    out = torch.empty((N, C, 2), device=part.device, dtype=torch.float32)
+    _l.check(_L().rsuper_stats_finalize(_ptr(part), N, nblk, C, float(cnt), EPS, mode, _ptr(out), _stream()), 'stats_finalize')
+    return out
+
+
+def pack_weights(dtype, mode, wa, wb, ka, kb, na, nb, bn):
+    dt = _DT[dtype]
+    n = _L().rsuper_conv3_packed_elems(dt, ka, kb, na + nb, bn)
+    out = torch.empty((n,), device=wa.device, dtype=dtype)
+    _l.check(_L().rsuper_conv3_pack_weights(dt, mode, _ptr(wa), _ptr(wb), ka, kb, na, nb, bn, _ptr(out), _stream()), 'pack_weights')
+    return out
+
+
+class Src:
+    """A channels-last source view: tensor (N,D,H,W,ld) + channel offset/count + optional (N,C,2) stats."""
+
+    def __init__(self, t, C=None, off=0, mr=None):
+        self.t, self.off, self.mr = t, off, mr
+        self.ld = t.shape[-1]
+        self.C = self.ld - off if C is None else C
+
+    def args(self):
+        return (_ptr(self.t, self.off), self.ld, self.C, _ptr(self.mr))
+
+
+_NONE = (None, 0, 0, None)
+
+
+class KernelTimer:
+    """Optional HIP-event timing of the MFMA conv launches on the launch stream (used by bench.py's roofline leg).
+    Records (kind, algorithmic FLOPs, start event, end event) per launch; `summary()` synchronises."""
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, kind, flops, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.append((kind, flops, s, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, s, e in self.records:
+            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
+            d['launches'] += 1
+            d['flops'] += flops
+            d['ms'] += s.elapsed_time(e)
+        return out
+
+
+TIMER = None   # set to a KernelTimer to time conv launches
+
+
+def igemm(epi, a, b, packed, n_cols, bn, dims, out, out_ld=None, res=None, part=None, ea=None, eb=None):
+    """a, b, ea, eb: Src (b/eb may be None).  res: Src or None.  dims = (N, D, H, W)."""
+    dt = _DT[a.t.dtype]
+    N, D, H, W = dims
+    ra = (None, 0) if res is None else (_ptr(res.t, res.off), res.ld)
+
+    def run():
+        _l.check(_L().rsuper_conv3_igemm(dt, epi, *a.args(), *(b.args() if b is not None else _NONE), _ptr(packed), n_cols, bn,
+                                         N, D, H, W, _ptr(out), out.shape[-1] if out_ld is None else out_ld, ra[0], ra[1], _ptr(part),
+                                         *(ea.args() if ea is not None else _NONE), *(eb.args() if eb is not None else _NONE),
+                                         _stream()), 'conv3_igemm')
+    if TIMER is not None:
+        K = a.C + (b.C if b is not None else 0)
+        TIMER.launch('conv3d_igemm_fwd' if epi == 0 else 'conv3d_igemm_dgrad', 2.0 * N * D * H * W * n_cols * K * 27, run)
+    else:
+        run()
+
+
+def wgrad(xa, xb, ya, yb, dwa, dwb, dims):
+    dt = _DT[xa.t.dtype]
+    N, D, H, W = dims
+    tiles = _L().rsuper_conv3_tiles(D, H, W) * N
+    Mtot = ya.C + (yb.C if yb is not None else 0)
+    nch = -(-xa.C // 32) + (-(-xb.C // 32) if xb is not None else 0)
+    gy = 1 if Mtot <= 32 else 3 * (-(-Mtot // 64))
+    splits = max(1, min(tiles, 512 // max(1, nch * gy)))   # ~2 blocks per CU; bounds the dW atomics
+    yb_args = (None, 0, 0) if yb is None else (_ptr(yb.t, yb.off), yb.ld, yb.C)
+
+    def run():
+        _l.check(_L().rsuper_conv3_wgrad(dt, use_tr(), *xa.args(), *(xb.args() if xb is not None else _NONE),
+                                         _ptr(ya.t, ya.off), ya.ld, ya.C, *yb_args, _ptr(dwa), _ptr(dwb), N, D, H, W, splits, _stream()),
+                  'conv3_wgrad')
+    if TIMER is not None:
+        Cin = xa.C + (xb.C if xb is not None else 0)
+        TIMER.launch('conv3d_wgrad', 2.0 * N * D * H * W * Mtot * Cin * 27, run)
+    else:
+        run()
+
+
+def in_bwd_finalize(g, x, gm, out_C, add1=None):
+    """g, x: Src (x carries mr).  gm: (N, C, 2) contiguous.  Returns new tensor (N,D,H,W,out_C)."""
+    N, D, H, W = g.t.shape[:4]
+    out = torch.empty((N, D, H, W, out_C), device=g.t.device, dtype=g.t.dtype)
+    a1 = (None, 0) if add1 is None else (_ptr(add1), add1.shape[-1])
+    _l.check(_L().rsuper_in_bwd_finalize(_DT[g.t.dtype], _ptr(g.t, g.off), g.ld, _ptr(x.t, x.off), x.ld, _ptr(x.mr), _ptr(gm),
+                                         a1[0], a1[1], None, 0, _ptr(out), out_C, N, D * H * W, out_C, _stream()), 'in_bwd_finalize')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ BasicBlock
+class BasicBlockFn(torch.autograd.Function):
+    """BasicBlock.forward (model/dim3/conv_layers.py:86-94) with pre-activation ConvNormAct members:
+        out = conv2(relu(IN(conv1(relu(IN(x)))))) + [convS(relu(IN(x))) | x]
+    conv1 and the shortcut conv read the same normalised input and run as ONE GEMM with N = 2*Cout."""
+
+    @staticmethod
+    def forward(ctx, xa, mra, xb, mrb, w1, w2, ws):
+        _chk_act(xa)
+        N, D, H, W, Ca = xa.shape
+        Cb = 0 if xb is None else xb.shape[-1]
+        Cout = w1.shape[0]
+        has_sc = ws is not None
+        assert w1.shape[1] == Ca + Cb and (has_sc or (Cb == 0 and Ca == Cout))
+        dims = (N, D, H, W)
+        dev, dt = xa.device, xa.dtype
+        tiles = _L().rsuper_conv3_tiles(D, H, W)
+        cnt = D * H * W
+        sa = Src(xa, mr=mra)
+        sb = None if xb is None else Src(xb, mr=mrb)
+        # conv1 (+ shortcut): one GEMM
+        nc1 = Cout * (2 if has_sc else 1)
+        bn1 = pick_bn(nc1, dt)
+        wp1 = pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if has_sc else 0, bn1)
+        ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
+        part = torch.empty((N, tiles, nc1, 2), device=dev, dtype=torch.float32)
+        igemm(0, sa, sb, wp1, nc1, bn1, dims, ys, part=part)
+        mr_ys = stats_finalize(part, cnt)
+        mr_y1 = mr_ys[:, :Cout].contiguous() if has_sc else mr_ys
+        # conv2 + residual
+        bn2 = pick_bn(Cout, dt)
+        wp2 = pack_weights(dt, 0, w2, None, Cout, 0, Cout, 0, bn2)
+        out = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
+        part2 = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
+        res = Src(ys, C=Cout, off=Cout) if has_sc else Src(xa)
+        igemm(0, Src(ys, C=Cout, mr=mr_y1), None, wp2, Cout, bn2, dims, out, res=res, part=part2)
+        mr_out = stats_finalize(part2, cnt)
+        ctx.save_for_backward(xa, mra, xb, mrb, ys, mr_y1, w1, w2, ws)
+        ctx.mark_non_differentiable(mr_out)
+        return out, mr_out
+
+    @staticmethod
+    def backward(ctx, dout, _unused):
+        xa, mra, xb, mrb, ys, mr_y1, w1, w2, ws = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, D, H, W, Ca = xa.shape
+        Cb = 0 if xb is None else xb.shape[-1]
+        Cin, Cout = Ca + Cb, w1.shape[0]
+        has_sc = ws is not None
+        dims = (N, D, H, W)
+        dev, dt = xa.device, xa.dtype
+        tiles = _L().rsuper_conv3_tiles(D, H, W)
+        cnt = D * H * W
+        y1 = Src(ys, C=Cout, mr=mr_y1)
+        sdo = Src(dout)
+        # conv2: data gradient (ReLU mask + IN sums fused), weight gradient
+        bn = pick_bn(Cout, dt)
+        wpd2 = pack_weights(dt, 1, w2, None, Cout, 0, Cout, 0, bn)
+        g1 = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
+        part = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
+        igemm(1, sdo, None, wpd2, Cout, bn, dims, g1, part=part, ea=y1)
+        gm1 = stats_finalize(part, cnt, mode=1)
+        dw2 = torch.zeros_like(w2)
+        wgrad(y1, None, sdo, None, dw2, None, dims)
+        dy1 = in_bwd_finalize(Src(g1), y1, gm1, Cout)
+        # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
+        sa = Src(xa, mr=mra)
+        sb = None if xb is None else Src(xb, mr=mrb)
+        bn = pick_bn(Cin, dt)
+        wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bn)
+        g0 = torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
+        part0 = torch.empty((N, tiles, Cin, 2), device=dev, dtype=torch.float32)
+        igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
+        gm0 = stats_finalize(part0, cnt, mode=1)
+        dw1 = torch.zeros_like(w1)
+        dws = torch.zeros_like(ws) if has_sc else None
+        wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims)
+        if xb is None:
+            dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca, add1=None if has_sc else dout)
+            dxb = None
+        else:
+            dxa = in_bwd_finalize(Src(g0, C=Ca), sa, gm0[:, :Ca].contiguous(), Ca)
+            dxb = in_bwd_finalize(Src(g0, C=Cb, off=Ca), sb, gm0[:, Ca:].contiguous(), Cb)
+        return dxa, None, dxb, None, dw1, dw2, dws
+
+
+# ------------------------------------------------------------------------------------------------ pool / upsample
+def _stat_blocks(ovox):
+    return max(1, min(1024, ovox // 64))
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool3d(2) (model/dim3/unet_utils.py:35-37) + statistics of the pooled tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk_act(x)
+        N, D, H, W, C = x.shape
+        OD, OH, OW = D // 2, H // 2, W // 2
+        y = torch.empty((N, OD, OH, OW, C), device=x.device, dtype=x.dtype)
+        blocks = _stat_blocks(OD * OH * OW)
+        part = torch.empty((N, blocks, C, 2), device=x.device, dtype=torch.float32)
+        _l.check(_L().rsuper_maxpool2_fwd(_DT[x.dtype], _ptr(x), C, _ptr(y), C, _ptr(part), blocks, N, D, H, W, C, _stream()), 'maxpool2_fwd')
+        mr = stats_finalize(part, OD * OH * OW)
+        ctx.save_for_backward(x)
+        ctx.mark_non_differentiable(mr)
+        return y, mr
+
+    @staticmethod
+    def backward(ctx, dy, _unused):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, D, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        _l.check(_L().rsuper_maxpool2_bwd(_DT[x.dtype], _ptr(x), C, _ptr(dy), C, _ptr(dx), C, N, D, H, W, C, _stream()), 'maxpool2_bwd')
+        return dx
+
+
+class UpsampleFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='trilinear', align_corners=True) (model/dim3/unet_utils.py:69)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        _chk_act(x)
+        N, ID, IH, IW, C = x.shape
+        OD, OH, OW = size
+        y = torch.empty((N, OD, OH, OW, C), device=x.device, dtype=x.dtype)
+        blocks = _stat_blocks(OD * OH * OW)
+        part = torch.empty((N, blocks, C, 2), device=x.device, dtype=torch.float32)
+        _l.check(_L().rsuper_upsample_fwd(_DT[x.dtype], _ptr(x), C, _ptr(y), C, _ptr(part), blocks, N, ID, IH, IW, OD, OH, OW, C, _stream()),
+                  'upsample_fwd')
+        mr = stats_finalize(part, OD * OH * OW)
+        ctx.in_shape = tuple(x.shape)
+        ctx.mark_non_differentiable(mr)
+        return y, mr
+
+    @staticmethod
+    def backward(ctx, dy, _unused):
+        dy = dy.contiguous()
+        N, ID, IH, IW, C = ctx.in_shape
+        OD, OH, OW = dy.shape[1:4]
+        dx = torch.empty(ctx.in_shape, device=dy.device, dtype=dy.dtype)
+        _l.check(_L().rsuper_upsample_bwd(_DT[dy.dtype], _ptr(dy), C, _ptr(dx), C, N, ID, IH, IW, OD, OH, OW, C, _stream()), 'upsample_bwd')
+        return dx, None
+
+
+# ------------------------------------------------------------------------------------------------ stem / head
+class StemFn(torch.autograd.Function):
+    """inconv.conv1 = nn.Conv3d(1, C, 3, padding=1, bias=False) (model/dim3/unet_utils.py:14): raw conv, no norm/act."""
+
+    @staticmethod
+    def forward(ctx, img, w, dtype):
+        assert img.dim() == 5 and img.shape[1] == 1, 'hot path supports in_chan == 1 (reference configs use 1)'
+        img = img.contiguous().float()
+        N, _, D, H, W = img.shape
+        C = w.shape[0]
+        y = torch.empty((N, D, H, W, C), device=img.device, dtype=dtype)
+        blocks = -(-(D * H * W) // 256)
+        part = torch.empty((N, blocks, C, 2), device=img.device, dtype=torch.float32)
+        _l.check(_L().rsuper_stem_fwd(_DT[dtype], _ptr(img), _ptr(w), _ptr(y), C, _ptr(part), N, D, H, W, C, _stream()), 'stem_fwd')
+        mr = stats_finalize(part, D * H * W)
+        ctx.save_for_backward(img, w)
+        ctx.mark_non_differentiable(mr)
+        return y, mr
+
+    @staticmethod
+    def backward(ctx, dy, _unused):
+        img, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, _, D, H, W = img.shape
+        C = w.shape[0]
+        dw = torch.zeros_like(w)
+        _l.check(_L().rsuper_stem_wgrad(_DT[dy.dtype], _ptr(img), _ptr(dy), C, _ptr(dw), N, D, H, W, C, _stream()), 'stem_wgrad')
+        return None, dw, None
+
+
+class HeadFn(torch.autograd.Function):
+    """outc = nn.Conv3d(C, K, kernel_size=1) with bias (model/dim3/unet.py:47) -> logits (N, K, D, H, W) f32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _chk_act(x)
+        N, D, H, W, C = x.shape
+        K = w.shape[0]
+        logits = torch.empty((N, K, D, H, W), device=x.device, dtype=torch.float32)
+        _l.check(_L().rsuper_head_fwd(_DT[x.dtype], _ptr(x), C, _ptr(w), _ptr(b), _ptr(logits), N, D * H * W, C, K, _stream()), 'head_fwd')
+        ctx.save_for_backward(x, w)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, w = ctx.saved_tensors
+        dl = dl.contiguous().float()
+        N, D, H, W, C = x.shape
+        K = w.shape[0]
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros((K,), device=x.device, dtype=torch.float32)
+        st = _stream()
+        _l.check(_L().rsuper_head_bwd_data(_DT[x.dtype], _ptr(dl), _ptr(w), _ptr(dx), C, N, D * H * W, C, K, st), 'head_bwd_data')
+        _l.check(_L().rsuper_head_bwd_weight(_DT[x.dtype], _ptr(x), C, _ptr(dl), _ptr(dw), _ptr(db), N, D * H * W, C, K, st), 'head_bwd_weight')
+        return dx, dw, db
+
+
+def dilate_volume(vol_u8, kernel_size):
+    """dilate_volume (training/losses_foundation.py:22-46) on a uint8 0/1 tensor (..., D, H, W)."""
+    v = vol_u8.contiguous()
+    assert v.dtype == torch.uint8 and v.dim() >= 3
+    D, H, W = v.shape[-3:]
+    nvol = v.numel() // (D * H * W)
+    out = torch.empty_like(v)
+    ks = kernel_size + 1 if kernel_size % 2 == 0 else kernel_size
+    tmp = torch.empty_like(v) if ks > 7 else None
+    _l.check(_L().rsuper_dilate_volume(_ptr(v), _ptr(out), _ptr(tmp), nvol, D, H, W, kernel_size, _stream()), 'dilate_volume')
+    return out

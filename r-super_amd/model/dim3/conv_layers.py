@@ -1,0 +1,35 @@
+"""Modules mirroring rsuper_train/model/dim3/conv_layers.py (ConvNormAct :16-53, BasicBlock :71-94) so that
+parameter names/shapes match the reference state_dict; the math runs in fused gfx950 kernels
+(rsuper_amd.hip.ops.BasicBlockFn) instead of module-by-module ATen calls."""
+import torch.nn as nn
+
+from ...hip import ops
+
+
+class ConvNormAct(nn.Module):
+    """Parameter holder for conv(act(norm(x))) with preact=True, norm=InstanceNorm3d(eps=1e-4, affine=False),
+    act=ReLU, conv bias=False (conv_layers.py:22-43).  InstanceNorm has no state, so only `conv.weight` exists."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, padding=1, norm='in', act='relu', preact=True):
+        super().__init__()
+        ks = tuple(kernel_size) if isinstance(kernel_size, (list, tuple)) else (kernel_size,) * 3
+        st = tuple(stride) if isinstance(stride, (list, tuple)) else (stride,) * 3
+        if ks != (3, 3, 3) or st != (1, 1, 1) or not preact or norm != 'in' or act != 'relu':
+            raise NotImplementedError('gfx950 hot path implements the shipped configuration: 3x3x3, stride 1, '
+                                      'pre-activation InstanceNorm+ReLU (conv_layers.py:46-51)')
+        self.conv = nn.Conv3d(in_ch, out_ch, kernel_size=3, stride=1, padding=1, bias=False)   # holder: weight + default init
+        self.preact = True
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, in_ch, out_ch, kernel_size=(3, 3, 3), stride=1, norm='in', act='relu', preact=True):
+        super().__init__()
+        self.conv1 = ConvNormAct(in_ch, out_ch, kernel_size, stride, 1, norm, act, preact)
+        self.conv2 = ConvNormAct(out_ch, out_ch, kernel_size, 1, 1, norm, act, preact)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_ch != out_ch:
+            self.shortcut = ConvNormAct(in_ch, out_ch, kernel_size, stride, 1, norm, act, preact)
+
+    def forward(self, xa, mra, xb=None, mrb=None):
+        ws = self.shortcut.conv.weight if isinstance(self.shortcut, ConvNormAct) else None
+        return ops.BasicBlockFn.apply(xa, mra, xb, mrb, self.conv1.conv.weight, self.conv2.conv.weight, ws)

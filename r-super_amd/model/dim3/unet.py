@@ -1,0 +1,67 @@
+"""3D UNet / ResUNet with the constructor of rsuper_train/model/dim3/unet.py:12-47, running on gfx950 kernels.
+
+Differences from the reference class, both required by the drop-in boundary:
+  * forward returns {'segmentation': logits} -- the contract calculate_loss reads
+    (training/losses_foundation.py:859; the reference UNet returns a bare tensor and cannot be trained by
+    train_ddp.py as shipped);
+  * `compute_dtype`: 'bf16' (default; bf16 activations, f32 accumulate, f32 logits) or 'f32' (parity mode).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .conv_layers import BasicBlock
+from .unet_utils import inconv, down_block, up_block
+from ...hip import ops, lib as _lib
+
+
+def _get_block(name):
+    if name != 'BasicBlock':
+        raise NotImplementedError(f"block={name!r}: the gfx950 hot path implements 'BasicBlock' (config/abdomenatlas/resunet_3d.yaml:13)")
+    return BasicBlock
+
+
+class UNet(nn.Module):
+    def __init__(self, in_ch, base_ch, scale=[2, 2, 2, 2], kernel_size=[3, 3, 3, 3, 3], num_classes=1, block='BasicBlock',
+                 pool=True, norm='in', compute_dtype=None):
+        super().__init__()
+        if norm != 'in':
+            raise NotImplementedError("norm must be 'in' (InstanceNorm3d) on the gfx950 hot path")
+        if in_ch != 1 or base_ch % 8:
+            raise NotImplementedError('in_ch must be 1 and base_ch a multiple of 8')
+        blk = _get_block(block)
+        num_block = 2
+        ks = [k if isinstance(k, (list, tuple)) else [k] * 3 for k in kernel_size]
+        b = base_ch
+        self.inc = inconv(in_ch, b, block=blk, kernel_size=ks[0], norm=norm)
+        self.down1 = down_block(b, 2 * b, num_block, blk, ks[1], scale[0], pool, norm)
+        self.down2 = down_block(2 * b, 4 * b, num_block, blk, ks[2], scale[1], pool, norm)
+        self.down3 = down_block(4 * b, 8 * b, num_block, blk, ks[3], scale[2], pool, norm)
+        self.down4 = down_block(8 * b, 10 * b, num_block, blk, ks[4], scale[3], pool, norm)
+        self.up1 = up_block(10 * b, 8 * b, num_block, blk, ks[3], scale[3], norm)
+        self.up2 = up_block(8 * b, 4 * b, num_block, blk, ks[2], scale[2], norm)
+        self.up3 = up_block(4 * b, 2 * b, num_block, blk, ks[1], scale[1], norm)
+        self.up4 = up_block(2 * b, b, num_block, blk, ks[0], scale[0], norm)
+        self.outc = nn.Conv3d(b, num_classes, kernel_size=1)          # holder: weight (K,C,1,1,1) + bias
+        self.compute_dtype = compute_dtype or os.environ.get('RSUPER_DTYPE', 'bf16')
+
+    def _dtype(self):
+        return {'bf16': torch.bfloat16, 'f32': torch.float32}[self.compute_dtype]
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.RSuperHipError('rsuper_amd UNet runs on MI355X only (no CPU fallback); move the input to cuda')
+        _lib.require_device()
+        dt = self._dtype()
+        x1, m1 = self.inc(x, dt)
+        x2, m2 = self.down1(x1, m1)
+        x3, m3 = self.down2(x2, m2)
+        x4, m4 = self.down3(x3, m3)
+        x5, m5 = self.down4(x4, m4)
+        o, mo = self.up1(x5, m5, x4, m4)
+        o, mo = self.up2(o, mo, x3, m3)
+        o, mo = self.up3(o, mo, x2, m2)
+        o, mo = self.up4(o, mo, x1, m1)
+        logits = ops.HeadFn.apply(o, self.outc.weight, self.outc.bias)
+        return {'segmentation': logits}

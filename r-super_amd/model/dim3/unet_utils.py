@@ -1,0 +1,61 @@
+"""inconv / down_block / up_block mirroring rsuper_train/model/dim3/unet_utils.py:7-75 (same module tree, so
+state_dict keys are identical: inc.conv1.weight, down1.conv.1.conv1.conv.weight, up4.conv.0.shortcut.conv.weight...)."""
+import torch.nn as nn
+
+from .conv_layers import BasicBlock
+from ...hip import ops
+
+
+class _Pool(nn.Module):
+    """Occupies index 0 of down_block.conv like nn.MaxPool3d does in the reference (unet_utils.py:36)."""
+
+    def forward(self, x):
+        return ops.MaxPoolFn.apply(x)
+
+
+class inconv(nn.Module):
+    def __init__(self, in_ch, out_ch, kernel_size=(3, 3, 3), block=BasicBlock, norm='in'):
+        super().__init__()
+        self.conv1 = nn.Conv3d(in_ch, out_ch, kernel_size=3, padding=1, bias=False)   # holder (unet_utils.py:14)
+        self.conv2 = block(out_ch, out_ch, kernel_size=kernel_size, norm=norm)
+
+    def forward(self, img, dtype):
+        x, mr = ops.StemFn.apply(img, self.conv1.weight, dtype)
+        return self.conv2(x, mr)
+
+
+class down_block(nn.Module):
+    def __init__(self, in_ch, out_ch, num_block, block=BasicBlock, kernel_size=(3, 3, 3), down_scale=(2, 2, 2), pool=True, norm='in'):
+        super().__init__()
+        ds = tuple(down_scale) if isinstance(down_scale, (list, tuple)) else (down_scale,) * 3
+        if not pool or ds != (2, 2, 2):
+            raise NotImplementedError('gfx950 hot path implements MaxPool3d(2) down-sampling (get_model never passes pool=False, '
+                                      'model/utils.py:87-89)')
+        layers = [_Pool(), block(in_ch, out_ch, kernel_size=kernel_size, norm=norm)]
+        for _ in range(num_block - 1):
+            layers.append(block(out_ch, out_ch, kernel_size=kernel_size, norm=norm))
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x, mr):
+        x, mr = self.conv[0](x)
+        for blk in list(self.conv)[1:]:
+            x, mr = blk(x, mr)
+        return x, mr
+
+
+class up_block(nn.Module):
+    def __init__(self, in_ch, out_ch, num_block, block=BasicBlock, kernel_size=(3, 3, 3), up_scale=(2, 2, 2), norm='in'):
+        super().__init__()
+        layers = [block(in_ch + out_ch, out_ch, kernel_size=kernel_size, norm=norm)]
+        for _ in range(num_block - 1):
+            layers.append(block(out_ch, out_ch, kernel_size=kernel_size, norm=norm))
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x1, mr1, x2, mr2):
+        """x1: coarse map, x2: skip.  cat([x2, x1]) (unet_utils.py:71) is never materialised: the first block
+        reads both sources."""
+        up, mru = ops.UpsampleFn.apply(x1, tuple(x2.shape[1:4]))
+        x, mr = self.conv[0](x2, mr2, up, mru)
+        for blk in list(self.conv)[1:]:
+            x, mr = blk(x, mr)
+        return x, mr

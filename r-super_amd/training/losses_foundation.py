@@ -1,0 +1,477 @@
+"""R-Super losses on gfx950 kernels, behind the interface of rsuper_train/training/losses_foundation.py
+(line numbers below refer to that file).
+
+    calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segment_mask, tumor_volumes_report,
+                   tumor_diameters, classes, input_tensor=None, class_weights=None, ...) -> dict with 'overall'
+
+Structure: every per-voxel pass (masked BCE, Dice partial sums, soft volumes, ball-loss weighted BCE, ball
+dilation, ball correlation + argmax, top-k selection, rank weights) is a HIP kernel called through the C ABI;
+one fused autograd node per network head produces all partial sums and, in backward, writes d(logits) in one
+pass.  The tiny (B,C) algebra (adaptive Tversky alpha :581-586 -- NOT detached, clamps, means, weights) stays
+in torch autograd so gradients flow exactly as in the reference.
+Host-synchronous control flow of ball_loss (argmax -> centre, growth / dilation loops, :1444-1461,:1513-1522)
+is kept host-synchronous, as in the reference.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from ..hip import lib as _l
+from ..hip import ops
+from ..hip.ops import _ptr, _stream, _L
+
+SANITY_CHECKS = os.environ.get('RSUPER_SANITY', '1') != '0'   # reference-style input checks / NaN guard (host syncs)
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _u8(t):
+    if t.dtype == torch.uint8:
+        return t.contiguous()
+    return (t != 0).to(torch.uint8).contiguous()
+
+
+def lesion_groups(classes):
+    """get_lesion_channels (:204-221): lesion/cyst/pdac/pnet channels grouped per organ, in class order."""
+    groups = {}
+    for i, c in enumerate(classes):
+        for suffix in ['lesion', 'cyst', 'pdac', 'pnet']:
+            if suffix in c:
+                name = c[:c.index('_' + suffix) + len('_' + suffix)].replace('pancreatic', 'pancreas')
+                groups.setdefault(name, []).append(i)
+    for k, v in groups.items():
+        if len(set(v)) != 1:
+            raise NotImplementedError(f'lesion group {k!r} spans several channels {v}: multi-channel tumour merging '
+                                      '(--multi_ch_tumor, unused in the paper) is not on the gfx950 hot path')
+    return {k: v[0] for k, v in groups.items()}
+
+
+def dilate_volume(volume, kernel_size, full_pass_radius=3):
+    """dilate_volume (:22-46); accepts float/bool/uint8 0-1 tensors, returns the input dtype."""
+    assert full_pass_radius == 3
+    out = ops.dilate_volume(_u8(volume), int(kernel_size))
+    return out if volume.dtype == torch.uint8 else out.to(volume.dtype)
+
+
+def get_known_voxels(y, unk_voxels, dilation=5, sanity=False, classes=None):
+    """(:150-165) 1 - dilate(unk, dilation), float like the reference."""
+    u = _u8(unk_voxels)
+    if dilation > 0:
+        u = ops.dilate_volume(u, dilation)
+    return (1 - u).to(torch.float32)
+
+
+def dice_based_volume_loss(x, y, tolerance=0.1, E=500, cross_entropy=False):
+    """(:352-395) on (B,L) predicted / report volumes."""
+    loss = torch.abs(x - y) / (x + y + E)
+    v = torch.max((1 - tolerance) * y, y.clamp(max=100))
+    loss = loss - torch.abs(v - y) / (v + y + E)
+    loss = torch.clamp(loss, min=0, max=1)
+    if cross_entropy:
+        loss = -torch.log(torch.ones_like(loss) - loss + 1e-5)
+    return loss
+
+
+# ------------------------------------------------------------------------------------------------ fused partial sums
+class _Term:
+    """One family of planes of the logits tensor: plane p lives at element offset x_off + p * xstride."""
+    __slots__ = ('x_off', 'xstride', 'planes', 't', 'k', 'w1', 'w2')
+
+    def __init__(self, x_off, xstride, planes, t=None, k=None, w1=None, w2=None):
+        self.x_off, self.xstride, self.planes, self.t, self.k, self.w1, self.w2 = x_off, xstride, planes, t, k, w1, w2
+
+
+class _PartialsFn(torch.autograd.Function):
+    """sums[planes, 6] = (S, A, B, Cn, F1, F2) per term (csrc/loss.hip); backward writes d(logits) once:
+    term 0 must cover every plane (segmentation term), later terms accumulate on their planes."""
+
+    @staticmethod
+    def forward(ctx, logits, terms):
+        assert logits.is_contiguous() and logits.dtype == torch.float32
+        V = logits[0, 0].numel()
+        outs = []
+        for tm in terms:
+            sums = torch.zeros((tm.planes, 6), device=logits.device, dtype=torch.float64)
+            _l.check(_L().rsuper_plane_partials_fwd(_ptr(logits, tm.x_off), tm.xstride, _ptr(tm.t), _ptr(tm.k), _ptr(tm.w1), _ptr(tm.w2),
+                                                    _ptr(sums), tm.planes, V, _stream()), 'plane_partials_fwd')
+            outs.append(sums.to(torch.float32))
+        ctx.terms = terms
+        ctx.save_for_backward(logits)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        (logits,) = ctx.saved_tensors
+        V = logits[0, 0].numel()
+        B, C = logits.shape[:2]
+        assert ctx.terms[0].planes == B * C and ctx.terms[0].x_off == 0
+        dl = torch.empty_like(logits)
+        for i, (tm, g) in enumerate(zip(ctx.terms, gs)):
+            if g is None:
+                if i == 0:
+                    dl.zero_()
+                continue
+            g = g.contiguous().float()
+            _l.check(_L().rsuper_plane_partials_bwd(_ptr(logits, tm.x_off), tm.xstride, _ptr(tm.t), _ptr(tm.k), _ptr(tm.w1), _ptr(tm.w2),
+                                                    _ptr(g), _ptr(dl, tm.x_off), 0 if i == 0 else 1, tm.planes, V, _stream()),
+                      'plane_partials_bwd')
+        return dl, None
+
+
+def _dice_from_sums(A, Bs, Cn, w=None):
+    """DiceLossMultiClass (:541-607) from per-(n,c) sums A=sum P, Bs=sum P*T, Cn=sum T (P,T already masked)."""
+    TP, FP, FN = Bs, A - Bs, Cn - Bs
+    alpha = (FP.sum(0) / (FP.sum(0) + FN.sum(0) + 1e-5)).unsqueeze(0).expand_as(TP).clamp(0.2, 0.8)
+    dice = TP / (TP + alpha * FP + (1 - alpha) * FN + 1e-5)
+    loss = 1 - dice
+    if w is not None:
+        loss = loss * w
+    return loss.mean()
+
+
+# ------------------------------------------------------------------------------------------------ ball machinery (host-synchronous control)
+def _odd_ceil(v):
+    c = math.ceil(v)
+    return c + 1 if c % 2 == 0 else c
+
+
+def ball_kernel_geometry(diameter):
+    """create_ball_kernel (:1192-1207): (odd diameter, kernel edge)."""
+    d_odd = _odd_ceil(diameter)
+    return d_odd, _odd_ceil(1.2 * d_odd)
+
+
+def ball_nnz(d_odd):
+    """Voxels of the ball 4*|o|^2 <= d_odd^2 (support of create_ball_kernel)."""
+    r = d_odd // 2
+    a = np.arange(-r, r + 1)
+    d2 = a[:, None, None] ** 2 + a[None, :, None] ** 2 + a[None, None, :] ** 2
+    return int((4 * d2 <= d_odd * d_odd).sum())
+
+
+def _insert_ball(shape, center, diameter, margin, device):
+    """insert_ball (:1336-1385) -> (uint8 mask, voxel count)."""
+    d_odd, ks = ball_kernel_geometry(diameter * (1 + margin))
+    D, H, W = shape
+    out = torch.empty(shape, device=device, dtype=torch.uint8)
+    cnt = torch.zeros(1, device=device, dtype=torch.int32)
+    _l.check(_L().rsuper_insert_ball(_ptr(out), D, H, W, int(center[0]), int(center[1]), int(center[2]), d_odd, ks // 2, _ptr(cnt), _stream()),
+              'insert_ball')
+    return out, int(cnt.item())
+
+
+def _topk_mask(x, ball, k):
+    """Exact top-k of x*ball (x >= 0) as a uint8 mask; ties -> lower linear index (radix select on the f32 bits)."""
+    V = x.numel()
+    k = int(min(k, V))
+    out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    if k <= 0:
+        return out.zero_()
+    prefix, remaining = 0, k
+    hist = torch.empty(256, device=x.device, dtype=torch.int32)
+    for shift in (24, 16, 8, 0):
+        hist.zero_()
+        _l.check(_L().rsuper_radix_hist(_ptr(x), _ptr(ball), V, prefix, shift, _ptr(hist), _stream()), 'radix_hist')
+        h = hist.cpu().numpy().astype(np.int64)
+        acc = 0
+        for digit in range(255, -1, -1):       # largest values first
+            if acc + h[digit] >= remaining:
+                prefix |= digit << shift
+                remaining -= acc
+                break
+            acc += h[digit]
+    # `prefix` = bit pattern of the k-th largest value; `remaining` = how many elements equal to it are still needed
+    _l.check(_L().rsuper_topk_mark(_ptr(x), _ptr(ball), V, prefix, remaining, _ptr(out), _stream()), 'topk_mark')
+    return out
+
+
+def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_margin=0.5, volume_margin=0.5):
+    """(:1387-1532) x: (D,H,W) f32 >= 0 on device.  Returns three uint8 masks (tumor, small, big)."""
+    assert gaussian, 'the reference always calls isolate_tumor with gaussian=True (:1713)'
+    D, H, W = x.shape
+    V = x.numel()
+    diameter = int(np.round(diameter).astype(int))
+    vol = int(np.round(tumor_volume).astype(int))
+    if diameter % 2 == 0:
+        diameter += 1
+    nnz = ball_nnz(diameter)
+    f32 = False
+    if nnz > vol:                         # :1431-1433 (vol becomes a 0-dim tensor there -> float32 products below)
+        vol, f32 = nnz - 1, True
+    best = torch.zeros(1, device=x.device, dtype=torch.int64)
+    _l.check(_L().rsuper_ball_conv_argmax(_ptr(x), D, H, W, diameter, float(gaussian_std * (diameter / 2.0)), _ptr(best), None, _stream()),
+              'ball_conv_argmax')
+    key = int(best.item()) & 0xFFFFFFFFFFFFFFFF
+    idx = 0xFFFFFFFF - (key & 0xFFFFFFFF)
+    center = np.unravel_index(idx, (D, H, W))
+    ball, bsum = _insert_ball((D, H, W), center, diameter, diameter_margin, x.device)
+    new_dim = diameter
+    while bsum < vol:                     # :1450-1461
+        old = new_dim
+        new_dim = int(np.round(new_dim * 1.1))
+        if old == new_dim:
+            new_dim += 1
+        if new_dim % 2 == 0:
+            new_dim += 1
+        if new_dim >= max(D, H, W):
+            break
+        ball, bsum = _insert_ball((D, H, W), center, new_dim, diameter_margin, x.device)
+    t = min(V - 1, vol)
+    ms = min(0.5, volume_margin)
+    t_small = int(np.float32(t) * np.float32(1 - ms)) if f32 else int(t * (1 - ms))
+    t_small = max(t_small, min(100, vol))
+    t_big = min(V - 1, int(np.float32(vol) * np.float32(1 + volume_margin)) if f32 else int(vol * (1 + volume_margin)))
+    masks = [_topk_mask(x, ball, k) for k in (t, t_small, t_big)]
+    for m in masks:                       # "ensure no tumor_mask value is outside the ball" (:1504-1507)
+        _l.check(_L().rsuper_mask_op(_ptr(m), _ptr(ball), V, 0, _stream()), 'mask_and')
+    iters = 0
+    while vol < 50 ** 3 and _count(masks[0]) < vol * 0.7:     # :1513-1522
+        if iters > 5:
+            break
+        nm = []
+        for m in masks:
+            dm = ops.dilate_volume(m, 7)
+            _l.check(_L().rsuper_mask_op(_ptr(dm), _ptr(ball), V, 0, _stream()), 'mask_and')
+            nm.append(dm)
+        masks = nm
+        iters += 1
+    return masks[0], masks[1], masks[2]
+
+
+def _count(m):
+    c = torch.zeros(1, device=m.device, dtype=torch.int32)
+    _l.check(_L().rsuper_count(_ptr(m), m.numel(), _ptr(c), _stream()), 'count')
+    return int(c.item())
+
+
+def gwrp_foreground_weights(x_plane, pm, c=0.5):
+    """GlobalWeightedRankPooling(sig(x)*pm + pm, N=|pm|, c, return_weights=True, hard_cutoff=True) * |pm| * pm
+    (:1780-1791): rank the pseudo-mask voxels by sig(x) (desc, ties by index), weight d^rank, renormalise."""
+    V = x_plane.numel()
+    N = _count(pm)
+    w = torch.zeros(x_plane.shape, device=x_plane.device, dtype=torch.float32)
+    if N == 0:
+        return w, 0
+    sig = torch.empty(x_plane.shape, device=x_plane.device, dtype=torch.float32)
+    _l.check(_L().rsuper_sigmoid_mask(_ptr(x_plane), _ptr(pm), _ptr(sig), V, _stream()), 'sigmoid_mask')
+    vals = torch.empty(N, device=w.device, dtype=torch.float32)
+    idx = torch.empty(N, device=w.device, dtype=torch.int32)
+    n = torch.zeros(1, device=w.device, dtype=torch.int32)
+    _l.check(_L().rsuper_compact(_ptr(sig), _ptr(pm), V, _ptr(vals), _ptr(idx), _ptr(n), _stream()), 'compact')
+    d = float(np.float32(1 - c) ** (np.float32(1.0) / np.float32(max(N, 1))))      # d = (1-c)^(1/N)  (:482)
+    s_n = (1.0 - d ** N) / (1.0 - d) if d < 1.0 else float(N)                       # sum_{r<N} d^r
+    _l.check(_L().rsuper_rank_weights(_ptr(vals), _ptr(idx), N, math.log2(d), float(N / s_n), _ptr(w), _stream()), 'rank_weights')
+    return w, N
+
+
+class _BallPlan:
+    """Masks for one batch item of ball_loss, built without gradient from the current logits."""
+    __slots__ = ('kind', 'b', 'c', 'pm', 'penal', 'fw', 'big', 'pens', 'chs')
+
+
+def _ball_plans(out, label_u8, unk_u8, mask_u8, volumes, diameters, groups, margin):
+    """The data-dependent, non-differentiable part of ball_loss (:1587-1737): returns one plan per sample."""
+    B, C, D, H, W = out.shape
+    chs = list(groups.values())
+    L = len(chs)
+    V = D * H * W
+    m_l = mask_u8[:, chs].contiguous()
+    u_l = unk_u8[:, chs].contiguous()
+    t_l = label_u8[:, chs].contiguous()
+    mseg = ops.dilate_volume(m_l, 31)                                   # :1593
+    # to_penalize = ((1 - unk)*(1 - labels) + segment) > 0   (:1597-1605); unk dilation 1 is the identity
+    pen = (((1 - u_l) * (1 - t_l)) + mseg > 0).to(torch.uint8)
+    vols_h = volumes.detach().float().cpu().numpy()
+    dias_h = diameters.detach().float().cpu().numpy()
+    seg_any = mseg.flatten(2).any(2).cpu().numpy()                      # (B, L)
+    plans = []
+    for b in range(B):
+        p = _BallPlan()
+        p.b, p.chs = b, chs
+        if SANITY_CHECKS:
+            assert np.array_equal(dias_h[b].sum(-1) > 0, vols_h[b] > 0), 'Tumor diameters and volumes should be consistent'
+            assert seg_any[b].sum() <= 1, 'Only one channel should be non-zero'
+        if not seg_any[b].any() or vols_h[b].sum() == 0:               # :1625
+            p.kind, p.pens = 'none', pen[b].contiguous()
+            plans.append(p)
+            continue
+        li = int(np.nonzero(seg_any[b])[0][0])
+        c = chs[li]
+        penal = pen[b, li].contiguous()
+        tumor_seg = mseg[b].sum(0).clamp(max=1).to(torch.uint8).contiguous()       # one channel active -> 0/1
+        order = [int(i) for i in np.argsort(-vols_h[b], kind='stable') if vols_h[b][int(i)] > 0]
+        x_it = torch.empty((D, H, W), device=out.device, dtype=torch.float32)
+        _l.check(_L().rsuper_sigmoid_mask(_ptr(out, (b * C + c) * V), _ptr(tumor_seg), _ptr(x_it), V, _stream()), 'sigmoid_mask')
+        pm_small, pm_big = None, None
+        for ti in order:                                                # :1695-1719
+            vol, dmax = float(vols_h[b][ti]), float(dias_h[b][ti].max())
+            if dmax <= 1:
+                dmax = 3
+            if vol <= 1:
+                vol = 9
+            pm, pms, pmb = isolate_tumor(x_it, dmax, True, 1.5, vol, margin, margin)
+            _l.check(_L().rsuper_zero_where(_ptr(x_it), _ptr(pm), V, _stream()), 'zero_where')    # x_iter *= (1 - pseudo_mask)
+            if pm_small is None:
+                pm_small, pm_big = pms, pmb
+            else:
+                _l.check(_L().rsuper_mask_op(_ptr(pm_small), _ptr(pms), V, 1, _stream()), 'mask_or')
+                _l.check(_L().rsuper_mask_op(_ptr(pm_big), _ptr(pmb), V, 1, _stream()), 'mask_or')
+        big = ops.dilate_volume(pm_big, 7)                              # :1727-1731
+        # border = (BIG - PM) > 0 ; penalize *= (1 - border)  ==  penal &= ~(BIG & ~PM)
+        border = big.clone()
+        _l.check(_L().rsuper_mask_op(_ptr(border), _ptr(pm_small), V, 2, _stream()), 'mask_andnot')
+        _l.check(_L().rsuper_mask_op(_ptr(penal), _ptr(border), V, 2, _stream()), 'mask_andnot')
+        fw, npm = gwrp_foreground_weights(out[b, c], pm_small)
+        if SANITY_CHECKS:
+            assert npm > 0, 'Pseudo mask should have at least one voxel'
+        p.kind, p.c, p.pm, p.penal, p.fw, p.big = 'tumor', c, pm_small, penal, fw, big
+        plans.append(p)
+    return plans
+
+
+# ------------------------------------------------------------------------------------------------ calculate_loss
+def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segment_mask,
+                   tumor_volumes_report, tumor_diameters, classes, input_tensor=None, class_weights=None,
+                   model_genesis=False, clip_only=False, report_embeddings=None, dist=None):
+    """Same contract as the reference (:685-1076): returns {'segmentation', report keys..., 'overall'}."""
+    if model_genesis or clip_only or getattr(args, 'classification_branch', False) or getattr(args, 'multi_ch_tumor', False):
+        raise NotImplementedError('model_genesis / clip_only / classification_branch / multi_ch_tumor are baselines outside '
+                                  'the accelerated R-Super path (SURVEY.md section 2.1)')
+    _l.require_device()
+    result = model_output['segmentation']
+    deep = isinstance(result, (tuple, list))
+    heads = list(result) if deep else [result]
+    B, C = label.shape[:2]
+    assert len(classes) == C, f'Number of classes in classes: {len(classes)} does not match the number of channels in label: {C}'
+    assert len(classes) == heads[0].shape[1], 'Number of classes in result does not match the number of channels in label'
+    label_u8 = _u8(label)
+    unk_u8 = _u8(unk_voxels) if unk_voxels is not None else torch.zeros_like(label_u8)
+    mask_u8 = _u8(chosen_segment_mask) if chosen_segment_mask is not None else torch.zeros_like(label_u8)
+    D, H, W = label.shape[2:]
+    V = D * H * W
+
+    if SANITY_CHECKS and chosen_segment_mask is not None:                # :864-869
+        m_any = mask_u8.flatten(1).any(1).cpu()
+        if bool(m_any.any()):
+            u_any = unk_u8.flatten(1).any(1).cpu()
+            v_any = (tumor_volumes_report.sum(1) != 0).cpu()
+            for b in range(B):
+                if m_any[b] and not u_any[b]:
+                    raise ValueError('unk_voxels should not be all zeros if chosen_segment_mask is not all zeros')
+                if m_any[b] and not v_any[b]:
+                    raise ValueError('tumor_volumes_report should not be all zeros if chosen_segment_mask is not all zeros')
+
+    if class_weights is not None and torch.equal(class_weights, torch.ones_like(class_weights)):     # :876-877
+        class_weights = None
+    cw = None
+    if class_weights is not None:
+        cw = class_weights.to(label.device).float()
+        assert cw.shape == (B, C), f'Class weights should be (B, C), got {tuple(cw.shape)}'
+
+    known = (1 - ops.dilate_volume(unk_u8, 5)) if unk_voxels is not None else None      # :899 / get_known_voxels :150
+    groups = lesion_groups(classes)
+    chs = list(groups.values())
+    L = len(chs)
+    rw = float(args.report_volume_loss_basic)
+
+    loss_seg_total = 0
+    rep = {}
+    rep_scalar = 0
+    mseg31 = None
+    for j, r in enumerate(heads):
+        r = r.contiguous().float() if (not r.is_contiguous() or r.dtype != torch.float32) else r
+        aw = args.aux_weight[j] if deep else 1.0
+        use_ball = use_vol = False
+        if rw > 0:
+            use_ball = ('ball' in args.loss or 'dynamic' in args.loss or 'dll' in args.loss)
+            if deep:
+                use_ball = use_ball and not (j != 0 and 'last' in args.loss)        # :924
+            use_vol = (not use_ball) or ('both' in args.loss)
+        terms = [_Term(0, V, B * C, t=label_u8, k=known)]
+        if use_vol and L > 0:
+            if mseg31 is None:
+                mseg31 = [ops.dilate_volume(mask_u8[:, c].contiguous(), 31) for c in chs]   # :308
+            for li, c in enumerate(chs):
+                terms.append(_Term(c * V, C * V, B, k=mseg31[li]))
+        plans = []
+        if use_ball and L > 0:
+            with torch.no_grad():
+                plans = _ball_plans(r.detach(), label_u8, unk_u8, mask_u8, tumor_volumes_report, tumor_diameters, groups,
+                                    float(args.ball_volume_margin))
+            for p in plans:
+                if p.kind == 'none':
+                    for li, c in enumerate(p.chs):
+                        terms.append(_Term((p.b * C + c) * V, 0, 1, k=p.pens[li].contiguous()))
+                else:
+                    terms.append(_Term((p.b * C + p.c) * V, 0, 1, t=p.pm, k=p.penal, w1=p.fw, w2=p.big))
+        sums = _PartialsFn.apply(r, terms)
+        ti = 0
+        # ---- segmentation: masked BCE mean + adaptive-Tversky Dice (:945-956)
+        s = sums[ti].view(B, C, 6); ti += 1
+        S, A, Bs, Cn = s[..., 0], s[..., 1], s[..., 2], s[..., 3]
+        bce = ((S * cw) if cw is not None else S).sum() / float(B * C * V)
+        seg = bce + _dice_from_sums(A, Bs, Cn, cw)
+        loss_seg_total = loss_seg_total + aw * args.seg_loss * seg
+        loss_r = {}
+        # ---- volume loss (:250-349)
+        if use_vol and L > 0:
+            vhat = torch.stack([sums[ti + li][:, 1] for li in range(L)], dim=1)          # (B, L) sum sig * M
+            ti += L
+            lab_any = torch.stack([label_u8[:, c].flatten(1).any(1) for c in chs], 1).float()     # per-voxel annotated tumour (:313)
+            gate = torch.stack([m.flatten(1).any(1) for m in mseg31], 1).float()                   # :335
+            vhat = vhat * (1 - lab_any)
+            rv = tumor_volumes_report.float().sum(-1, keepdim=True).expand(B, L) * gate
+            lv = dice_based_volume_loss(vhat, rv, tolerance=args.volume_loss_tolerance, E=500)
+            if cw is not None:
+                lv = lv * cw[:, chs]
+            loss_r['dice_volume_loss'] = lv.mean()
+        # ---- ball loss (:1537-1864)
+        if use_ball and L > 0:
+            apply_dice = 'dice' in args.loss
+            l_bce, l_dice = [], []
+            for p in plans:
+                if p.kind == 'none':                                      # :1625-1661
+                    ss = torch.stack([sums[ti + li][0] for li in range(L)], 0)   # (L, 6)
+                    ti += L
+                    wl = cw[p.b, chs] if cw is not None else None
+                    Sb = ss[:, 0] * wl if wl is not None else ss[:, 0]
+                    l_bce.append(Sb.sum() / float(L * V))
+                    if apply_dice:
+                        l_dice.append(_dice_from_sums(ss[None, :, 1], ss[None, :, 2], ss[None, :, 3], None if wl is None else wl[None]))
+                else:
+                    ss = sums[ti][0]; ti += 1
+                    wc = cw[p.b, p.c] if cw is not None else None
+                    if getattr(args, 'stardard_ce_ball', False):
+                        lb = ss[0] / float(V)
+                    else:
+                        lb = ss[4] / float(V) + ss[5] / float(V)          # mean(BCE*w_fg) + mean(BCE*(1-BIG))  (:1793-1811)
+                    l_bce.append(lb * wc if wc is not None else lb)
+                    if apply_dice:
+                        l_dice.append(_dice_from_sums(ss[1].view(1, 1), ss[2].view(1, 1), ss[3].view(1, 1),
+                                                      None if wc is None else wc.view(1, 1)))
+            loss_r['ball_loss_bce'] = torch.stack(l_bce).mean()
+            loss_r['ball_loss_dice'] = torch.stack(l_dice).mean() if apply_dice else torch.zeros_like(loss_r['ball_loss_bce'])
+        if not loss_r:
+            rep_scalar = rep_scalar + aw * rw * torch.zeros((), device=r.device)
+        for k, v in loss_r.items():
+            wk = {'ball_loss_bce': args.ball_bce_weight, 'ball_loss_dice': args.ball_dice_weight}.get(k, 1)
+            term = aw * rw * wk * v
+            rep[k] = rep[k] + term if k in rep else term
+
+    loss = {'segmentation': loss_seg_total}
+    if rep:
+        # key order of the reference: ball keys first, then volume
+        for k in ('ball_loss_bce', 'ball_loss_dice', 'dice_volume_loss'):
+            if k in rep:
+                loss[k] = rep[k]
+    else:
+        loss['report'] = rep_scalar
+    overall = 0
+    for k in list(loss.keys()):
+        overall = overall + loss[k]
+    loss['overall'] = overall
+    if SANITY_CHECKS and bool(torch.isnan(overall).any()):                 # :1070-1071
+        raise ValueError('loss is nan, propagating this can destroy the network weights, STOP!')
+    assert overall.requires_grad, 'Loss overall should require grad'
+    return loss

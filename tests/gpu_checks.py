@@ -1,0 +1,562 @@
+"""GPU parity checks shared by tests/test_gpu_*.py (pytest, -m gpu) and tests/gpu_diag.py (run-everything report).
+
+Every check compares the HIP path (called through the C ABI via rsuper_amd.hip) with the oracle / a plain torch
+fp32 CPU reference on the same seeded inputs and returns a dict(name, ok, err, tol, note).
+Tolerances: f32 mode 1e-4 (BASELINE.json north_star) relative to the output scale; bf16 mode is judged against the
+same fp32 oracle with a stated looser tolerance (the reference is fp32-only).
+"""
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import synth  # noqa: E402
+from oracle import unet_oracle as uo, losses_oracle as lo, train_oracle as to, morph as omorph  # noqa: E402
+
+DEV = 'cuda'
+DT = {'f32': torch.float32, 'bf16': torch.bfloat16}
+TOL = {'f32': 1e-4, 'bf16': 3e-2}
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def to_cl(x, dt):
+    """(N,C,D,H,W) fp32 cpu -> (N,D,H,W,C) device tensor of dtype dt."""
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(DEV).to(dt)
+
+
+def from_cl(x):
+    return x.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def rnd(x, mode):
+    return x.bfloat16().float() if mode == 'bf16' else x.clone()
+
+
+def relerr(got, ref):
+    got, ref = got.double(), ref.double()
+    scale = max(ref.abs().max().item(), 1e-12)
+    return (got - ref).abs().max().item() / scale
+
+
+def result(name, err, tol, note=''):
+    return dict(name=name, ok=bool(err <= tol) and math.isfinite(err), err=float(err), tol=float(tol), note=note)
+
+
+def stats_ref(x, eps=1e-4):
+    """(N,C,D,H,W) -> mean, rstd as (N,C,2) like the kernels' (mean, rstd)."""
+    m = x.mean(dim=(2, 3, 4))
+    v = ((x - m[:, :, None, None, None]) ** 2).mean(dim=(2, 3, 4))
+    return torch.stack([m, 1.0 / torch.sqrt(v + eps)], dim=-1)
+
+
+def _rng_t(seed, shape, scale=1.0):
+    return T(synth.rng(seed).standard_normal(shape).astype(np.float32) * np.float32(scale))
+
+
+# ================================================================================================ conv kernels
+def check_conv_fwd(mode, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, norm=True, seed=0):
+    from rsuper_amd.hip import ops
+    dt = DT[mode]
+    D, H, W = S
+    xa = rnd(_rng_t(seed + 1, (N, Ca, D, H, W)) + 0.3, mode)
+    xb = rnd(_rng_t(seed + 2, (N, Cb, D, H, W)) * 1.5 - 0.2, mode) if Cb else None
+    Cin = Ca + Cb
+    w1 = _rng_t(seed + 3, (Cout, Cin, 3, 3, 3), 1.0 / math.sqrt(27 * Cin))
+    ws = _rng_t(seed + 4, (Cout, Cin, 3, 3, 3), 1.0 / math.sqrt(27 * Cin)) if fused_sc else None
+    res = rnd(_rng_t(seed + 5, (N, Cout, D, H, W)), mode) if residual else None
+    x = xa if xb is None else torch.cat([xa, xb], 1)
+    xh = F.relu(uo.instance_norm(x)) if norm else x
+    if mode == 'bf16':
+        xh = xh.bfloat16().float()
+    wr1 = rnd(w1, mode)
+    ref = F.conv3d(xh, wr1, padding=1)
+    if fused_sc:
+        ref = torch.cat([ref, F.conv3d(xh, rnd(ws, mode), padding=1)], 1)
+    if residual:
+        ref = ref + res
+    # device
+    mra = stats_ref(xa).to(DEV) if norm else None
+    mrb = stats_ref(xb).to(DEV) if (norm and xb is not None) else None
+    nc = Cout * (2 if fused_sc else 1)
+    bn = ops.pick_bn(nc, dt)
+    wp = ops.pack_weights(dt, 0, w1.to(DEV), ws.to(DEV) if ws is not None else None, Ca, Cb, Cout, Cout if fused_sc else 0, bn)
+    out = torch.empty((N, D, H, W, nc), device=DEV, dtype=dt)
+    tiles = ops._L().rsuper_conv3_tiles(D, H, W)
+    part = torch.full((N, tiles, nc, 2), float('nan'), device=DEV)
+    a = ops.Src(to_cl(xa, dt), mr=mra)
+    b = ops.Src(to_cl(xb, dt), mr=mrb) if xb is not None else None
+    r = ops.Src(to_cl(res, dt)) if residual else None
+    ops.igemm(0, a, b, wp, nc, bn, (N, D, H, W), out, res=r, part=part)
+    mr = ops.stats_finalize(part, D * H * W)
+    torch.cuda.synchronize()
+    got = from_cl(out)
+    e1 = relerr(got, ref)
+    mr_ref = stats_ref(rnd(ref, mode))
+    e2 = relerr(mr.cpu()[..., 0], mr_ref[..., 0]) + relerr(mr.cpu()[..., 1], mr_ref[..., 1])
+    tol = TOL[mode]
+    return result(f'conv_fwd[{mode} N{N} S{S} {Ca}+{Cb}->{Cout} sc{int(fused_sc)} res{int(residual)} norm{int(norm)}]',
+                  max(e1, e2 * (0.1 if mode == 'bf16' else 1.0)), tol, f'out {e1:.2e} stats {e2:.2e}')
+
+
+def _block_ref(mode, xa, xb, w1, ws, dy1, dys):
+    """Reference for the fused conv1(+shortcut) data/weight gradients on x_hat = relu(IN(x))."""
+    x = (xa if xb is None else torch.cat([xa, xb], 1)).clone().requires_grad_(True)
+    xh = F.relu(uo.instance_norm(x))
+    w1r = rnd(w1, mode).requires_grad_(True)
+    wsr = rnd(ws, mode).requires_grad_(True) if ws is not None else None
+    y = F.conv3d(xh, w1r, padding=1)
+    loss = (y * dy1).sum()
+    if ws is not None:
+        loss = loss + (F.conv3d(xh, wsr, padding=1) * dys).sum()
+    gx, = torch.autograd.grad(loss, x, retain_graph=True)
+    gxh, = torch.autograd.grad(loss, xh, retain_graph=True)
+    gw = torch.autograd.grad(loss, [w1r] + ([wsr] if ws is not None else []))
+    return gx, gxh, gw, xh.detach()
+
+
+def check_conv_bwd(mode, N, S, Ca, Cb, Cout, fused_sc, seed=0, tr=None):
+    """dgrad (epi 1, relu mask + IN sums) + in_bwd_finalize + wgrad against autograd."""
+    from rsuper_amd.hip import ops
+    dt = DT[mode]
+    D, H, W = S
+    xa = rnd(_rng_t(seed + 1, (N, Ca, D, H, W)) + 0.3, mode)
+    xb = rnd(_rng_t(seed + 2, (N, Cb, D, H, W)) * 1.5 - 0.2, mode) if Cb else None
+    Cin = Ca + Cb
+    w1 = _rng_t(seed + 3, (Cout, Cin, 3, 3, 3), 1.0 / math.sqrt(27 * Cin))
+    ws = _rng_t(seed + 4, (Cout, Cin, 3, 3, 3), 1.0 / math.sqrt(27 * Cin)) if fused_sc else None
+    dy1 = rnd(_rng_t(seed + 6, (N, Cout, D, H, W)), mode)
+    dys = rnd(_rng_t(seed + 7, (N, Cout, D, H, W)), mode) if fused_sc else None
+    gx, gxh, gw, xh = _block_ref(mode, xa, xb, w1, ws, dy1, dys)
+    # device
+    mra = stats_ref(xa).to(DEV)
+    mrb = stats_ref(xb).to(DEV) if xb is not None else None
+    sa = ops.Src(to_cl(xa, dt), mr=mra)
+    sb = ops.Src(to_cl(xb, dt), mr=mrb) if xb is not None else None
+    y1 = ops.Src(to_cl(dy1, dt))
+    y2 = ops.Src(to_cl(dys, dt)) if fused_sc else None
+    bn = ops.pick_bn(Cin, dt)
+    wp = ops.pack_weights(dt, 1, w1.to(DEV), ws.to(DEV) if ws is not None else None, Cout, Cout if fused_sc else 0, Cin, 0, bn)
+    g0 = torch.empty((N, D, H, W, Cin), device=DEV, dtype=dt)
+    tiles = ops._L().rsuper_conv3_tiles(D, H, W)
+    part = torch.full((N, tiles, Cin, 2), float('nan'), device=DEV)
+    ops.igemm(1, y1, y2, wp, Cin, bn, (N, D, H, W), g0, part=part, ea=sa, eb=sb)
+    gm = ops.stats_finalize(part, D * H * W, mode=1)
+    if xb is None:
+        dxa = ops.in_bwd_finalize(ops.Src(g0), sa, gm, Ca)
+        dx = from_cl(dxa)
+    else:
+        dxa = ops.in_bwd_finalize(ops.Src(g0, C=Ca), sa, gm[:, :Ca].contiguous(), Ca)
+        dxb = ops.in_bwd_finalize(ops.Src(g0, C=Cb, off=Ca), sb, gm[:, Ca:].contiguous(), Cb)
+        dx = torch.cat([from_cl(dxa), from_cl(dxb)], 1)
+    dw1 = torch.zeros((Cout, Cin, 3, 3, 3), device=DEV)
+    dws = torch.zeros_like(dw1) if fused_sc else None
+    old = os.environ.get('RSUPER_WGRAD_TR')
+    if tr is not None:
+        os.environ['RSUPER_WGRAD_TR'] = str(tr)
+    try:
+        ops.wgrad(sa, sb, y1, y2, dw1, dws, (N, D, H, W))
+    finally:
+        if tr is not None:
+            if old is None:
+                os.environ.pop('RSUPER_WGRAD_TR')
+            else:
+                os.environ['RSUPER_WGRAD_TR'] = old
+    torch.cuda.synchronize()
+    e_g = relerr(from_cl(g0), gxh * (xh > 0))
+    e_dx = relerr(dx, gx)
+    e_w = relerr(dw1.cpu(), gw[0])
+    if fused_sc:
+        e_w = max(e_w, relerr(dws.cpu(), gw[1]))
+    tol = TOL[mode]
+    return result(f'conv_bwd[{mode} tr{tr} N{N} S{S} {Ca}+{Cb}->{Cout} sc{int(fused_sc)}]', max(e_g, e_dx, e_w), tol,
+                  f'g {e_g:.2e} dx {e_dx:.2e} dw {e_w:.2e}')
+
+
+def check_tr16_probe():
+    """Raw ds_read_b64_tr_b16 behaviour is exercised through wgrad with tr=1 vs tr=0 (bit-identical operands ->
+    identical MFMA results up to atomic order)."""
+    r0 = check_conv_bwd('bf16', 1, (4, 4, 16), 32, 0, 32, False, seed=11, tr=0)
+    r1 = check_conv_bwd('bf16', 1, (4, 4, 16), 32, 0, 32, False, seed=11, tr=1)
+    return result('wgrad_tr16_vs_u16', abs(r1['err'] - r0['err']) + (0 if r1['ok'] else 1), 1e-3, f"tr0 {r0['note']} | tr1 {r1['note']}")
+
+
+# ================================================================================================ pool / upsample / stem / head
+def check_pool(mode):
+    from rsuper_amd.hip import ops
+    dt = DT[mode]
+    g = golden('blocks')
+    x = rnd(T(synth.rng(61).standard_normal((1, 8, 8, 8, 8)).astype(np.float32)), mode).requires_grad_(True)
+    y_ref = F.max_pool3d(x, 2)
+    go = rnd(T(synth.rng(62).standard_normal(tuple(y_ref.shape)).astype(np.float32)), mode)
+    y_ref.backward(go)
+    xc = to_cl(x.detach(), dt).requires_grad_(True)
+    y, mr = ops.MaxPoolFn.apply(xc)
+    y.backward(to_cl(go, dt))
+    torch.cuda.synchronize()
+    e = max(relerr(from_cl(y.detach()), y_ref.detach()), relerr(from_cl(xc.grad), x.grad),
+            relerr(mr.cpu()[..., 0], stats_ref(y_ref.detach())[..., 0]))
+    if mode == 'f32':
+        e = max(e, relerr(from_cl(y.detach()), T(g['pool_y'])), relerr(from_cl(xc.grad), T(g['pool_dx'])))
+    return result(f'maxpool[{mode}]', e, 1e-6 if mode == 'f32' else 1e-2)
+
+
+def check_upsample(mode, Cin=8, I=3, O=6, seed=63):
+    from rsuper_amd.hip import ops
+    dt = DT[mode]
+    x = rnd(T(synth.rng(seed).standard_normal((1, Cin, I, I, I)).astype(np.float32)), mode).requires_grad_(True)
+    y_ref = F.interpolate(x, size=(O, O, O), mode='trilinear', align_corners=True)
+    go = rnd(T(synth.rng(seed + 1).standard_normal(tuple(y_ref.shape)).astype(np.float32)), mode)
+    y_ref.backward(go)
+    xc = to_cl(x.detach(), dt).requires_grad_(True)
+    y, mr = ops.UpsampleFn.apply(xc, (O, O, O))
+    y.backward(to_cl(go, dt))
+    torch.cuda.synchronize()
+    e = max(relerr(from_cl(y.detach()), y_ref.detach()), relerr(from_cl(xc.grad), x.grad))
+    e2 = relerr(mr.cpu()[..., 1], stats_ref(rnd(y_ref.detach(), mode))[..., 1])
+    return result(f'upsample[{mode} {I}->{O} C{Cin}]', max(e, e2 * 0.1), 2e-5 if mode == 'f32' else 2e-2, f'val/grad {e:.2e} rstd {e2:.2e}')
+
+
+def check_stem(mode, C=8, S=12):
+    from rsuper_amd.hip import ops
+    dt = DT[mode]
+    img = T(synth.image(2, S, seed=5))
+    w = _rng_t(21, (C, 1, 3, 3, 3), 0.2).requires_grad_(True)
+    y_ref = F.conv3d(img, w, padding=1)
+    go = rnd(_rng_t(22, tuple(y_ref.shape)), mode)
+    y_ref.backward(go)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    y, mr = ops.StemFn.apply(img.to(DEV), wd, dt)
+    y.backward(to_cl(go, dt))
+    torch.cuda.synchronize()
+    e = max(relerr(from_cl(y.detach()), y_ref.detach()), relerr(wd.grad.cpu(), w.grad),
+            relerr(mr.cpu()[..., 1], stats_ref(rnd(y_ref.detach(), mode))[..., 1]) * 0.1)
+    return result(f'stem[{mode} C{C}]', e, 1e-5 if mode == 'f32' else 1e-2)
+
+
+def check_head(mode, C=8, K=5, S=10):
+    from rsuper_amd.hip import ops
+    dt = DT[mode]
+    x = rnd(_rng_t(31, (2, C, S, S, S)), mode).requires_grad_(True)
+    w = _rng_t(32, (K, C, 1, 1, 1), 0.3).requires_grad_(True)
+    b = _rng_t(33, (K,), 0.1).requires_grad_(True)
+    y_ref = F.conv3d(x, w, b)
+    go = _rng_t(34, tuple(y_ref.shape))
+    y_ref.backward(go)
+    xc = to_cl(x.detach(), dt).requires_grad_(True)
+    wd, bd = w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    y = ops.HeadFn.apply(xc, wd, bd)
+    y.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    e = max(relerr(y.detach().cpu(), y_ref.detach()), relerr(from_cl(xc.grad), x.grad), relerr(wd.grad.cpu(), w.grad),
+            relerr(bd.grad.cpu(), b.grad))
+    return result(f'head[{mode} C{C} K{K}]', e, 1e-5 if mode == 'f32' else 1e-2)
+
+
+# ================================================================================================ blocks / UNet vs golden
+def _load_block(tag, ci, co, seed, mode):
+    from rsuper_amd.model.dim3.conv_layers import BasicBlock
+    blk = BasicBlock(ci, co)
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    blk.load_state_dict({k: T(v) for k, v in synth.fill_state_dict(shapes, seed).items()})
+    return blk.to(DEV)
+
+
+def check_basic_block(mode, tag, ci, co, S, seed):
+    g = golden('blocks')
+    dt = DT[mode]
+    blk = _load_block(tag, ci, co, seed, mode)
+    x = T(synth.rng(40 + ci).standard_normal((2, ci, S, S, S)).astype(np.float32))
+    go = T(synth.rng(50 + co).standard_normal((2, co, S, S, S)).astype(np.float32))
+    from rsuper_amd.hip import ops
+    xc = to_cl(x, dt).requires_grad_(True)
+    mr = stats_ref(rnd(x, mode)).to(DEV)
+    y, _ = blk(xc, mr)
+    y.backward(to_cl(go, dt))
+    torch.cuda.synchronize()
+    e_y = relerr(from_cl(y.detach()), T(g[f'{tag}_y']))
+    e_dx = relerr(from_cl(xc.grad), T(g[f'{tag}_dx']))
+    e_w = max(relerr(p.grad.cpu(), T(g[f'{tag}_dw_{k}'])) for k, p in blk.named_parameters())
+    tol = 2e-4 if mode == 'f32' else 5e-2
+    return result(f'basic_block_golden[{mode} {tag}]', max(e_y, e_dx, e_w), tol, f'y {e_y:.2e} dx {e_dx:.2e} dw {e_w:.2e}')
+
+
+def make_tiny_unet(mode, seed=3, classes=None):
+    from rsuper_amd.model.dim3.unet import UNet
+    classes = classes or synth.TINY_CLASSES
+    net = UNet(1, 8, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype=mode)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: T(v) for k, v in synth.fill_state_dict(shapes, seed).items()})
+    return net.to(DEV)
+
+
+def check_unet_tiny(mode):
+    g = golden('unet_tiny')
+    net = make_tiny_unet(mode)
+    img = T(synth.image(1, 48, seed=1234)).to(DEV)
+    y = net(img)['segmentation']
+    go = synth.rng(77).standard_normal(tuple(y.shape)).astype(np.float32) / y.numel()
+    y.backward(T(go).to(DEV))
+    torch.cuda.synchronize()
+    sub, step = synth.subsample(y.detach().cpu().numpy(), 8192)
+    ref = g['logits_sub']
+    e_y = float(np.abs(sub - ref).max() / max(np.abs(ref).max(), 1e-12))
+    e_abs = float(np.abs(sub - ref).max())
+    worst, wk = 0.0, ''
+    for k, p in net.named_parameters():
+        r = g[f'g_{k}_summary']
+        sc = max(r[2], 1e-12)
+        e = float(np.abs(p.grad.cpu().numpy().reshape(-1)[:64] - g[f'g_{k}_head']).max() / sc)
+        if e > worst:
+            worst, wk = e, k
+    tol_y = 1e-4 if mode == 'f32' else 5e-2
+    tol_g = 1e-2 if mode == 'f32' else 0.25      # deep-chain fp32 noise already ~3e-3 CPU-vs-CPU (test_oracle_vs_golden)
+    ok_err = max(e_y / tol_y, worst / tol_g)
+    return result(f'unet_tiny_golden[{mode}]', ok_err, 1.0, f'logits rel {e_y:.2e} abs {e_abs:.2e} (tol {tol_y}); worst grad {worst:.2e} @ {wk} (tol {tol_g})')
+
+
+# ================================================================================================ losses
+def check_plane_partials():
+    from rsuper_amd.training import losses_foundation as lf
+    B, C, S = 2, 3, 12
+    V = S ** 3
+    g = synth.rng(3)
+    x = T(g.standard_normal((B, C, S, S, S)).astype(np.float32) * 3)
+    t = T((g.random((B, C, S, S, S)) < 0.3).astype(np.uint8))
+    k = T((g.random((B, C, S, S, S)) < 0.8).astype(np.uint8))
+    w1 = T(g.random((B, C, S, S, S)).astype(np.float32))
+    w2 = T((g.random((B, C, S, S, S)) < 0.5).astype(np.uint8))
+    xr = x.clone().requires_grad_(True)
+    tf, kf = t.float(), k.float()
+    bce = F.binary_cross_entropy_with_logits(xr, tf, reduction='none') * kf
+    sg = torch.sigmoid(xr)
+    ref = torch.stack([bce.flatten(2).sum(2), (sg * kf).flatten(2).sum(2), (sg * tf * kf).flatten(2).sum(2), (tf * kf).flatten(2).sum(2),
+                       (bce * w1).flatten(2).sum(2), (bce * (1 - w2.float())).flatten(2).sum(2)], -1).view(B * C, 6)
+    gs = T(g.standard_normal((B * C, 6)).astype(np.float32))
+    (ref * gs).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    term = lf._Term(0, V, B * C, t=t.to(DEV), k=k.to(DEV), w1=w1.to(DEV), w2=w2.to(DEV))
+    (sums,) = lf._PartialsFn.apply(xd, [term])
+    (sums * gs.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    e1 = relerr(sums.detach().cpu(), ref.detach())
+    e2 = relerr(xd.grad.cpu(), xr.grad)
+    return result('plane_partials', max(e1, e2), 2e-5, f'sums {e1:.2e} grad {e2:.2e}')
+
+
+def check_dilate():
+    from rsuper_amd.hip import ops
+    g = synth.rng(11)
+    worst = 0
+    for shape in [(2, 3, 20, 20, 20), (1, 2, 9, 10, 11)]:
+        vol = (g.random(shape) < 0.004).astype(np.uint8)
+        for ks in [1, 2, 3, 5, 7, 9, 13, 31]:
+            got = ops.dilate_volume(T(vol).to(DEV), ks).cpu().numpy()
+            ref = omorph.dilate_volume(vol, ks)
+            worst = max(worst, int((got != ref).sum()))
+    p = golden('primitives')
+    vol = np.unpackbits(p['dil_in'])[:2 * 3 * 8000].reshape(2, 3, 20, 20, 20)
+    for ks in [5, 7, 31]:
+        got = ops.dilate_volume(T(vol).to(DEV), ks).cpu().numpy()
+        worst = max(worst, int((got != np.unpackbits(p[f'dil_{ks}'])[:vol.size].reshape(vol.shape)).sum()))
+    return result('dilate_volume (bit-exact vs oracle C and reference golden)', worst, 0)
+
+
+def check_isolate_tumor():
+    from rsuper_amd.training import losses_foundation as lf
+    p = golden('primitives')
+    x = T(p['iso_x'])
+    sh = tuple(x.shape)
+    bad, notes = 0, []
+    for name, dia, vol in [('a', 7.0, 150.0), ('b', 4.6, 40.0), ('c', 9.0, 300.0)]:
+        m, ms, mb = lf.isolate_tumor(x.to(DEV), dia, True, 1.5, vol, 0.2, 0.2)
+        for got, key in ((m, 'm'), (ms, 's'), (mb, 'b')):
+            ref = np.unpackbits(p[f'iso_{name}_{key}'])[:x.numel()].reshape(sh)
+            d = int((got.cpu().numpy() != ref).sum())
+            bad += d
+            notes.append(f'{name}{key}:{d}')
+    xb = T(p['iso_border_x'])
+    m, ms, mb = lf.isolate_tumor(xb.to(DEV), 9.0, True, 1.5, 380.0, 0.2, 0.2)
+    for got, key in ((m, 'm'), (ms, 's'), (mb, 'b')):
+        ref = np.unpackbits(p[f'iso_border_{key}'])[:xb.numel()].reshape(tuple(xb.shape))
+        d = int((got.cpu().numpy() != ref).sum())
+        bad += d
+        notes.append(f'border{key}:{d}')
+    return result('isolate_tumor masks (bit-exact vs reference golden)', bad, 0, ' '.join(notes))
+
+
+def check_gwrp():
+    from rsuper_amd.training import losses_foundation as lf
+    p = golden('primitives')
+    pm = T(p['gwrp_pm'])
+    xsig = T(p['gwrp_x']).clamp(1e-6, 1 - 1e-6)
+    logit = torch.log(xsig / (1 - xsig))
+    w, n = lf.gwrp_foreground_weights(logit.to(DEV), pm.to(torch.uint8).to(DEV))
+    ref = T(p['gwrp_w']) * pm.sum() * pm
+    return result('gwrp_weights', relerr(w.cpu(), ref), 1e-4, f'N {n}')
+
+
+def make_args(**kw):
+    d = dict(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1,
+             volume_loss_tolerance=0.2, ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2,
+             multi_ch_tumor=False, stardard_ce_ball=False, classification_branch=False, ema=True, ema_alpha=0.99)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+LOSS_CASES = [('single_last', dict(loss='ball_dice_last'), False, 7, None),
+              ('single_both', dict(loss='ball_dice_both'), False, 7, None),
+              ('single_dice', dict(loss='dice'), False, 7, None),
+              ('single_ball', dict(loss='ball'), False, 7, None),
+              ('single_norep', dict(report_volume_loss_basic=0.0), False, 7, None),
+              ('deep_last', dict(loss='ball_dice_last'), True, 7, None),
+              ('deep_dice', dict(loss='dice'), True, 7, None),
+              ('single_both_cw', dict(loss='ball_dice_both'), False, 7, 'cw'),
+              ('single_both_norpt', dict(loss='ball_dice_both'), False, 8, None)]
+
+
+def loss_inputs(seed):
+    classes = synth.TINY_CLASSES
+    kinds = ['mask', 'report'] if seed == 7 else ['healthy', 'mask']
+    kw = dict(diam_range=(5.0, 9.0), max_tumors=2) if seed == 7 else {}
+    bt = synth.batch(2, 32, classes, kinds, seed=seed, **kw)
+    return classes, bt, synth.logits(2, len(classes), 32, seed=99), synth.logits(2, len(classes), 32, seed=100)
+
+
+def check_calculate_loss(tag, akw, deep, seed, cw):
+    from rsuper_amd.training import losses_foundation as lf
+    g = golden('calc_loss')
+    classes, bt, lg0, lg1 = loss_inputs(seed)
+    a, b = T(lg0).to(DEV).requires_grad_(True), T(lg1).to(DEV).requires_grad_(True)
+    res = lf.calculate_loss({'segmentation': [a, b] if deep else a}, T(bt['label']).to(DEV), T(bt['unk_channels']).to(DEV), make_args(**akw),
+                            None, T(bt['mask']).to(DEV), T(bt['volumes']).to(DEV), T(bt['diameters']).to(DEV), classes,
+                            class_weights=None if cw is None else T(g['cw']).to(DEV))
+    res['overall'].backward()
+    torch.cuda.synchronize()
+    notes, worst = [], 0.0
+    if sorted(res.keys()) != list(g[f'{tag}_keys']):
+        return result(f'calculate_loss[{tag}]', float('inf'), 1e-4, f'keys {sorted(res.keys())} vs {list(g[tag + "_keys"])}')
+    for k, v in res.items():
+        d = abs(float(v.detach()) - float(g[f'{tag}_{k}']))
+        worst = max(worst, d)
+        notes.append(f'{k}:{d:.1e}')
+    sub, _ = synth.subsample(a.grad.cpu().numpy(), 8192)
+    ref = g[f'{tag}_g0_sub']
+    eg = float(np.abs(sub - ref).max() / max(np.abs(ref).max(), 1e-12))
+    notes.append(f'grad:{eg:.1e}')
+    return result(f'calculate_loss[{tag}]', max(worst, eg * 0.1), 1e-4, ' '.join(notes))
+
+
+def check_optimizer():
+    from rsuper_amd.training.utils import FusedAdamWEMA, clip_grad_norm_
+    g = synth.rng(9)
+    shapes = [(33,), (8, 4, 3, 3, 3), (1, 7), (100000,)]
+    ps = [T(g.standard_normal(s).astype(np.float32)) for s in shapes]
+    gs = [[T(g.standard_normal(s).astype(np.float32) * 0.7) for s in shapes] for _ in range(3)]
+    ref_p = [p.clone() for p in ps]
+    ref_e = [p.clone() for p in ps]
+    opt_ref = to.AdamW(ref_p, lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+    dp = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    de = [p.clone().to(DEV) for p in ps]
+    opt = FusedAdamWEMA(dp, lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+    worst = 0.0
+    for step in range(3):
+        gr = [x.clone() for x in gs[step]]
+        n_ref = to.clip_grad_norm_(gr, 1.0)
+        opt_ref.step(gr)
+        to.update_ema(ref_p, ref_e, 0.99, step)
+        for p, gg in zip(dp, gs[step]):
+            p.grad = gg.clone().to(DEV)
+        n = opt.fused_step(max_norm=1.0, ema_params=de, ema_alpha=min(1 - 1 / (step + 1), 0.99))
+        torch.cuda.synchronize()
+        worst = max(worst, abs(float(n) - float(n_ref)) / float(n_ref))
+        for a, b in zip(dp, ref_p):
+            worst = max(worst, (a.detach().cpu() - b).abs().max().item())
+        for a, b in zip(de, ref_e):
+            worst = max(worst, (a.cpu() - b).abs().max().item())
+    # stand-alone clip
+    for p, gg in zip(dp, gs[0]):
+        p.grad = gg.clone().to(DEV)
+    clip_grad_norm_(dp, 1.0)
+    gr = [x.clone() for x in gs[0]]
+    to.clip_grad_norm_(gr, 1.0)
+    worst = max(worst, max((a.grad.cpu() - b).abs().max().item() for a, b in zip(dp, gr)))
+    return result('fused clip+AdamW+EMA', worst, 2e-6)
+
+
+def check_train_steps(mode='f32'):
+    from rsuper_amd.train_ddp import train_step, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    g = golden('train_step')
+    classes, bt, _, _ = loss_inputs(7)
+    net = make_tiny_unet(mode)
+    ema = make_ema(net)
+    opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+    args = make_args(loss='ball_dice_both')
+    batch = dict(image=T(synth.image(2, 32, seed=4321)).to(DEV), label=T(bt['label']).to(DEV), unk_channels=T(bt['unk_channels']).to(DEV),
+                 mask=T(bt['mask']).to(DEV), volumes=T(bt['volumes']).to(DEV), diameters=T(bt['diameters']).to(DEV))
+    notes, worst = [], 0.0
+    tol = 1e-4 if mode == 'f32' else 3e-2
+    for step in range(2):
+        la, gn = train_step(net, ema, opt, batch, args, classes, step)
+        torch.cuda.synchronize()
+        for k, v in la.items():
+            d = abs(float(v.detach()) - float(g[f's{step}_{k}']))
+            worst = max(worst, d)
+            notes.append(f's{step}.{k}:{d:.1e}')
+        dgn = abs(float(gn) - float(g[f's{step}_gradnorm'])) / float(g[f's{step}_gradnorm'])
+        notes.append(f's{step}.gnorm:{dgn:.1e}')
+        worst = max(worst, dgn * tol / (5e-3 if mode == 'f32' else 0.2))
+        for k in ['inc.conv1.weight', 'outc.weight', 'outc.bias']:
+            p = dict(net.named_parameters())[k].detach().cpu().numpy().reshape(-1)[:64]
+            d = np.abs(p - g[f's{step}_p_{k}_head'])
+            notes.append(f's{step}.{k}:med{np.median(d):.1e}/max{d.max():.1e}')
+            if mode == 'f32':
+                worst = max(worst, (np.median(d) / 2e-5) * tol, (d.max() / 1.2e-3) * tol)
+    return result(f'train_steps_golden[{mode}]', worst, tol, ' '.join(notes))
+
+
+# ================================================================================================ registry
+def all_checks(quick=False):
+    cs = []
+    for mode in ('f32', 'bf16'):
+        cs += [
+            (check_conv_fwd, (mode, 1, (4, 4, 16), 32, 0, 32)),
+            (check_conv_fwd, (mode, 2, (8, 8, 16), 32, 0, 32, False, True)),
+            (check_conv_fwd, (mode, 1, (5, 6, 7), 8, 16, 8, True, False)),
+            (check_conv_fwd, (mode, 1, (8, 12, 20), 64, 32, 64, True, False)),
+            (check_conv_fwd, (mode, 1, (4, 8, 16), 64, 0, 64, False, False, False)),
+            (check_conv_fwd, (mode, 1, (6, 6, 6), 80, 0, 80, False, True)),
+            (check_conv_bwd, (mode, 1, (4, 4, 16), 32, 0, 32, False)),
+            (check_conv_bwd, (mode, 2, (8, 8, 16), 32, 0, 32, False)),
+            (check_conv_bwd, (mode, 1, (5, 6, 7), 8, 16, 8, True)),
+            (check_conv_bwd, (mode, 1, (8, 12, 20), 64, 32, 64, True)),
+            (check_conv_bwd, (mode, 1, (6, 6, 6), 80, 0, 80, False)),
+            (check_pool, (mode,)), (check_upsample, (mode,)), (check_upsample, (mode, 16, 6, 12, 70)),
+            (check_stem, (mode,)), (check_head, (mode,)),
+            (check_basic_block, (mode, 'b8_16', 8, 16, 12, 1)), (check_basic_block, (mode, 'b16_16', 16, 16, 10, 2)),
+            (check_basic_block, (mode, 'b24_8', 24, 8, 12, 3)),
+            (check_unet_tiny, (mode,)),
+        ]
+    cs += [(check_conv_bwd, ('bf16', 1, (4, 4, 16), 32, 0, 32, False, 0, 0)), (check_conv_bwd, ('bf16', 1, (8, 12, 20), 64, 32, 64, True, 0, 0)),
+           (check_tr16_probe, ()),
+           (check_plane_partials, ()), (check_dilate, ()), (check_isolate_tumor, ()), (check_gwrp, ()), (check_optimizer, ())]
+    cs += [(check_calculate_loss, c) for c in LOSS_CASES]
+    cs += [(check_train_steps, ('f32',)), (check_train_steps, ('bf16',))]
+    return cs

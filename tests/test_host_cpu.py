@@ -1,0 +1,120 @@
+"""CPU tests of the host logic and of the C-ABI library surface (no compute calls without a GPU)."""
+import argparse
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from rsuper_amd.hip import lib
+    so = lib.SO_PATH
+    if not os.path.exists(so):
+        import __graft_entry__ as ge
+        ge.build()
+    L = ctypes.CDLL(so)
+    hdr = open(os.path.join(ROOT, 'include', 'rsuper_hip.h')).read()
+    declared = set(re.findall(r'\b(rsuper_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), f'{name} declared in include/rsuper_hip.h but not exported'
+    assert set(lib.exported_symbols()) == declared, set(lib.exported_symbols()) ^ declared
+    assert b'gfx950' in lib.lib().rsuper_version()
+
+
+def test_no_cpu_fallback():
+    from rsuper_amd.hip import lib
+    from rsuper_amd.model.dim3.unet import UNet
+    net = UNet(1, 8, num_classes=3)
+    with pytest.raises(lib.RSuperHipError):
+        net(torch.zeros(1, 1, 16, 16, 16))
+    if not torch.cuda.is_available():
+        with pytest.raises(lib.RSuperHipError):
+            lib.require_device()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'r-super_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                src = open(os.path.join(dp, f)).read()
+                assert 'oracle' not in src.replace('the oracle', ''), f'{f} references oracle/'
+
+
+def test_state_dict_matches_reference_layout():
+    from rsuper_amd.model.dim3.unet import UNet
+    from oracle.unet_oracle import unet_param_shapes
+    for b, k in ((8, 5), (32, 26)):
+        sd = UNet(1, b, num_classes=k).state_dict()
+        sh = unet_param_shapes(1, b, k)
+        assert set(sd) == set(sh)
+        assert all(tuple(sd[n].shape) == sh[n] for n in sh)
+    assert sum(v.numel() for v in UNet(1, 32, num_classes=26).state_dict().values()) == 40561338
+
+
+def test_get_model_and_yaml_keys():
+    import yaml
+    from rsuper_amd.model.utils import get_model
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'r-super_amd', 'config', 'abdomenatlas_ufo', 'unet_3d.yaml')))
+    args = argparse.Namespace(model='unet', dimension='3d', **cfg)
+    net = get_model(args)
+    assert net.outc.weight.shape == (26, 32, 1, 1, 1)
+    with pytest.raises(NotImplementedError):
+        get_model(argparse.Namespace(model='medformer', dimension='3d', **cfg))
+
+
+def test_lr_schedule_and_ema_alpha(golden):
+    from rsuper_amd.training.utils import exp_lr_scheduler_with_warmup, ema_alpha_for_step
+
+    class O:
+        param_groups = [{'lr': 6e-4}]
+    lrs = []
+    for e in [0, 1, 3, 5, 6, 50, 99]:
+        o = O()
+        o.param_groups = [{'lr': 6e-4}]
+        lrs.append(exp_lr_scheduler_with_warmup(o, e, 5, 100))
+    np.testing.assert_allclose(lrs, golden['train_step']['lr_sched'], rtol=1e-12)
+    assert ema_alpha_for_step(0.99, 0) == 0 and ema_alpha_for_step(0.99, 1) == 0.5 and ema_alpha_for_step(0.99, 1000) == 0.99
+
+
+def test_lesion_groups_and_ball_geometry(golden):
+    from rsuper_amd.training import losses_foundation as lf
+    import synth
+    assert lf.lesion_groups(synth.TINY_CLASSES) == {'kidney_lesion': 1, 'pancreas_lesion': 4}
+    assert lf.lesion_groups(synth.PANTS_CLASSES) == {'pancreas_lesion': 19}
+    p = golden['primitives']
+    for d in [1, 3, 5, 7, 8, 10, 15, 31, 40]:
+        d_odd, ks = lf.ball_kernel_geometry(d)
+        assert [ks, lf.ball_nnz(d_odd)] == list(p[f'ball_{d}_edge_nnz'])
+    with pytest.raises(NotImplementedError):
+        lf.lesion_groups(['kidney_lesion_1', 'kidney_lesion_2'])
+
+
+def test_pick_bn():
+    from rsuper_amd.hip.ops import pick_bn
+    assert pick_bn(32, torch.bfloat16) == 32 and pick_bn(64, torch.bfloat16) == 64 and pick_bn(128, torch.bfloat16) == 128
+    assert pick_bn(96, torch.bfloat16) == 32 and pick_bn(320, torch.bfloat16) == 64 and pick_bn(128, torch.float32) == 64
+
+
+def test_shard_indices_round_robin():
+    from rsuper_amd.train_ddp import shard_indices
+    chunk = list(range(10))
+    assert shard_indices(chunk, 0, 4) == [0, 4, 8] and shard_indices(chunk, 3, 4) == [3, 7]
+
+
+def test_ddp_world2_gloo_cpu():
+    """N>1 path on CPU: two gloo ranks average gradients of a host-side module through wrap_ddp and agree."""
+    script = os.path.join(ROOT, 'tests', 'ddp_gloo_worker.py')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29533', script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'DDP_OK' in r.stdout
