@@ -68,12 +68,13 @@ int rsuper_conv3_igemm(int dtype, int epi,
 
 /* Weight gradient dW[co][ci][tap] += sum_v dy[v][co] * x_hat[v+tap][ci]   (autograd of the same nn.Conv3d under
  * loss.backward(), train_ddp.py:349).  dy rows [0,Ya) accumulate into dwa (Ya, Ca+Cb, 27), rows [Ya,Ya+Yb) into dwb.
- * dwa/dwb must be zero-initialised; use_tr selects ds_read_b64_tr_b16 operand fetch (bf16). */
+ * dwa/dwb are overwritten.  workspace: splits * 27 * (Ya+Yb) * (Ca+Cb) floats (per-split partial slabs, summed by a
+ * reduce kernel -- deterministic, no atomics).  use_tr selects ds_read_b64_tr_b16 operand fetch (bf16). */
 int rsuper_conv3_wgrad(int dtype, int use_tr,
                        const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,
                        const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
-                       float* dwa, float* dwb, int N, int D, int H, int W, int splits, void* stream);
+                       float* dwa, float* dwb, float* workspace, int N, int D, int H, int W, int splits, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine=False) statistics and backward tail -- conv_layers.py:40-42

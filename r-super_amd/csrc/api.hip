@@ -97,8 +97,8 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
 int rsuper_conv3_wgrad(int dtype, int use_tr, const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,
                        const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
-                       float* dwa, float* dwb, int N, int D, int H, int W, int splits, void* stream) {
-    if (!dt_ok(dtype) || !xa || !ya || !dwa || !ch_ok(Ca, lda) || Ca == 0 || !ch_ok(Ya, ldya) || Ya == 0) return RS_ERR_ARG;
+                       float* dwa, float* dwb, float* workspace, int N, int D, int H, int W, int splits, void* stream) {
+    if (!dt_ok(dtype) || !xa || !ya || !dwa || !workspace || !ch_ok(Ca, lda) || Ca == 0 || !ch_ok(Ya, ldya) || Ya == 0) return RS_ERR_ARG;
     if (Cb > 0 && (!xb || !ch_ok(Cb, ldb))) return RS_ERR_ARG;
     if (Yb > 0 && (!yb || !dwb || !ch_ok(Yb, ldyb))) return RS_ERR_ARG;
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || splits <= 0) return RS_ERR_ARG;
@@ -108,7 +108,7 @@ int rsuper_conv3_wgrad(int dtype, int use_tr, const void* xa, int lda, int Ca, c
     p.xb = {xb, ldb, Cb > 0 ? Cb : 0, Cb > 0 ? mrb : nullptr};
     p.ya = {ya, ldya, Ya, nullptr};
     p.yb = {yb, ldyb, Yb > 0 ? Yb : 0, nullptr};
-    p.dwa = dwa; p.dwb = dwb; p.N = N; p.D = D; p.H = H; p.W = W; p.splits = splits;
+    p.dwa = dwa; p.dwb = dwb; p.ws = workspace; p.N = N; p.D = D; p.H = H; p.W = W; p.splits = splits;
     return rs_launch_wgrad(p, dtype, use_tr, ST(stream));
 }
 

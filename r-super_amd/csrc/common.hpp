@@ -93,7 +93,7 @@ __device__ __forceinline__ void row_to_hw(int i, int& hs, int& w) {
     else if (i < 16) { hs = 0; w = i - 8; }
     else if (i < 20) { hs = 1; w = i - 8; }
     else if (i < 28) { hs = 0; w = i - 12; }
-    else { hs = 1; w = i - 12; }
+    else { hs = 1; w = i - 16; }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -30,45 +30,42 @@ constexpr int HROWS = HD * HH * HW;             // 648 halo rows
 constexpr int PITCH = 80;                       // bytes per LDS row: 64 data + 16 pad (conflict-free b128)
 constexpr int HALO_BYTES = HROWS * PITCH;       // 51840
 
+// Staging is split in two (issue-early / write-late): `stage_issue` starts the 16-byte global loads of the NEXT
+// K chunk into registers right before the MFMA phase of the current one, `stage_commit` applies norm+ReLU and
+// writes LDS after the barrier -- HBM/L2 latency hides under the MFMAs.
+constexpr int NVEC = (HROWS * 4 + 255) / 256;   // 16-byte vectors per thread per chunk (11)
+
 template <typename T>
-__device__ __forceinline__ void stage_vec(char* halo, int r, int s, const ConvSrc& src, const float* mr_lds, int mr_off,
-                                          int c0, int n, int d0, int h0, int w0, int D, int H, int W, bool norm) {
+__device__ __forceinline__ bool stage_coords(int v, const ConvSrc& src, int c0, int n, int d0, int h0, int w0, int D, int H, int W,
+                                             size_t& off, int& c) {
     constexpr int KP = Elem<T>::KP;
+    const int r = v >> 2, s = v & 3;
     const int hd = r / (HH * HW);
     const int rem = r - hd * (HH * HW);
     const int hh = rem / HW;
     const int hw = rem - hh * HW;
     const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
-    const int c = c0 + s * KP;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W && c < src.C) {
-        const T* px = (const T*)src.x + ((((size_t)n * D + d) * H + h) * W + w) * (size_t)src.ld + c;
-        v = *(const uint4*)px;
-        if (norm) {
-            float f[KP];
-            unpack16<T>(v, f);
-#pragma unroll
-            for (int j = 0; j < KP; ++j) {
-                const float mu = mr_lds[2 * (mr_off + c + j)], rs = mr_lds[2 * (mr_off + c + j) + 1];
-                f[j] = fmaxf((f[j] - mu) * rs, 0.f);
-            }
-            v = pack16<T>(f);
-        }
-    }
-    *(uint4*)(halo + r * PITCH + s * 16) = v;
+    c = c0 + s * KP;
+    off = ((((size_t)n * D + d) * H + h) * W + w) * (size_t)src.ld + c;
+    return v < HROWS * 4 && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W && c < src.C;
 }
 
 // EPI: 0 = forward (residual + stats of output), 1 = dgrad (relu mask + IN-backward sums)
-template <typename T, int WM, int MF, int WN, int NF, int EPI>
+// KSPLIT: 1 = waves tile M x N;  4 = every wave owns the whole 256 x 32 tile for a quarter of the taps (32-column
+//         layers: weight fragments are then distinct per wave instead of 4x redundant L1 traffic), partial
+//         accumulators are summed through LDS before the epilogue.
+template <typename T, int WM, int MF, int WN, int NF, int EPI, int KSPLIT>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     float* mr_lds = (float*)(smem + HALO_BYTES);      // [Ca + Cb][2]
     constexpr int KC = Elem<T>::KC;
+    constexpr int KP = Elem<T>::KP;
     constexpr int BN32 = WN * NF;                     // 32-column tiles per block
+    static_assert(KSPLIT == 1 || (WM == 1 && WN == 1 && MF == 8 && NF == 1), "tap-split config is 256 x 32 per wave");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = KSPLIT == 1 ? wave / WN : 0, wn = KSPLIT == 1 ? wave % WN : 0;
     const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
     int t = blockIdx.x;
     const int tw = t % tiles_w; t /= tiles_w;
@@ -77,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int n = blockIdx.z;
     const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
     const int nchA = (p.a.C + KC - 1) / KC, nchB = (p.b.C + KC - 1) / KC;
+    const int nch = nchA + nchB;
     const bool normA = p.a.mr != nullptr, normB = p.b.mr != nullptr;
 
     // per-sample mean/rstd of every input channel -> LDS
@@ -84,15 +82,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     if (normB) for (int i = tid; i < 2 * p.b.C; i += 256) mr_lds[2 * p.a.C + i] = p.b.mr[(size_t)n * 2 * p.b.C + i];
 
     // per-lane LDS byte offset of the A-fragment row for each m-fragment (tap (0,0,0), k-step 0)
+    // fragment f = wm*MF + mf (0..7 in the block) covers d = f/2, h pair = f%2; MF is even, so the per-fragment
+    // part ((mf/2)*HH + (mf%2)*2)*HW*PITCH is a compile-time constant folded into the ds_read offset.
     int hs, wl;
     row_to_hw(lane & 31, hs, wl);
-    int a_off[MF];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-        const int f = wm * MF + mf;                   // fragment 0..7 in the block: d = f/2, h pair = f%2
-        const int fd = f >> 1, fh = (f & 1) * 2 + hs;
-        a_off[mf] = ((fd * HH + fh) * HW + wl) * PITCH + (lane >> 5) * 16;
-    }
+    const int a_base = (((wm * MF / 2) * HH + hs) * HW + wl) * PITCH + (lane >> 5) * 16;
+    auto a_const = [](int mf) { return (((mf >> 1) * HH + (mf & 1) * 2) * HW) * PITCH; };
 
     f32x16_t acc[MF][NF];
 #pragma unroll
@@ -106,56 +101,135 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int ntile0 = blockIdx.y * BN32 + wn * NF;
     const size_t wstep = (size_t)p.ntiles * 64;       // uint4 per (chunk, tap, kstep)
 
-    for (int ch = 0; ch < nchA + nchB; ++ch) {
+    uint4 pre[NVEC];
+    auto issue = [&](int ch) {
+        const bool isB = ch >= nchA;
+        const ConvSrc& src = isB ? p.b : p.a;
+        const int c0 = (isB ? ch - nchA : ch) * KC;
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+            size_t off; int c;
+            const bool ok = stage_coords<T>(tid + i * 256, src, c0, n, d0, h0, w0, p.D, p.H, p.W, off, c);
+            pre[i] = ok ? *(const uint4*)((const T*)src.x + off) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit = [&](int ch) {
         const bool isB = ch >= nchA;
         const ConvSrc& src = isB ? p.b : p.a;
         const int c0 = (isB ? ch - nchA : ch) * KC;
         const bool norm = isB ? normB : normA;
         const int mr_off = isB ? p.a.C : 0;
-        __syncthreads();                              // previous chunk fully consumed (and mr_lds visible)
-#pragma unroll 4
-        for (int v = tid; v < HROWS * 4; v += 256)
-            stage_vec<T>(halo, v >> 2, v & 3, src, mr_lds, mr_off, c0, n, d0, h0, w0, p.D, p.H, p.W, norm);
-        __syncthreads();
-
-        const uint4* wch = wp + (size_t)ch * 27 * 2 * wstep + (size_t)ntile0 * 64 + lane;
-        uint4 bq[2][NF];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int i = 0; i < NVEC; ++i) {
+            const int v = tid + i * 256;
+            size_t off; int c;
+            const bool ok = stage_coords<T>(v, src, c0, n, d0, h0, w0, p.D, p.H, p.W, off, c);
+            uint4 q = pre[i];
+            if (ok && norm) {
+                float f[KP];
+                unpack16<T>(q, f);
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) bq[ks][nf] = wch[ks * wstep + nf * 64];
-        int tap = 0;
-        for (int kd = 0; kd < 3; ++kd)
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw, ++tap) {
-                    const int toff = ((kd * HH + kh) * HW + kw) * PITCH;
-                    uint4 bn[2][NF];
-                    const int tnext = tap < 26 ? tap + 1 : 26;           // prefetch next tap's B fragments
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int nf = 0; nf < NF; ++nf) bn[ks][nf] = wch[(size_t)(tnext * 2 + ks) * wstep + nf * 64];
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        uint4 aq[MF];
-#pragma unroll
-                        for (int mf = 0; mf < MF; ++mf) aq[mf] = *(const uint4*)(halo + a_off[mf] + toff + ks * 32);
-#pragma unroll
-                        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                            for (int nf = 0; nf < NF; ++nf) mma32<T>(acc[mf][nf], aq[mf], bq[ks][nf]);
-                    }
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int nf = 0; nf < NF; ++nf) bq[ks][nf] = bn[ks][nf];
+                for (int j = 0; j < KP; ++j) {
+                    const float mu = mr_lds[2 * (mr_off + c + j)], rs = mr_lds[2 * (mr_off + c + j) + 1];
+                    f[j] = fmaxf((f[j] - mu) * rs, 0.f);
                 }
+                q = pack16<T>(f);
+            }
+            if (v < HROWS * 4) *(uint4*)(halo + (v >> 2) * PITCH + (v & 3) * 16) = q;
+        }
+    };
+
+    // configs whose accumulators already take 128 VGPRs stage synchronously (the co-resident block covers the
+    // latency); the others keep the next chunk's loads in flight during the MFMA phase.
+    constexpr bool PF = MF * NF <= 4;
+    if (PF) issue(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();                              // previous chunk fully consumed (and mr_lds visible)
+        if (!PF) issue(ch);
+        commit(ch);
+        __syncthreads();
+        if (PF && ch + 1 < nch) issue(ch + 1);        // loads fly during the MFMA phase below
+
+        // ---- MFMA phase, software pipelined with static register indices:
+        //   unit u = (step, group of AU m-fragments); A fragments of unit u+1 are read from LDS while unit u's MFMAs
+        //   issue; B fragments (weights, L1/L2 resident) run RB steps ahead in a register ring.
+        const uint4* wch = wp + (size_t)ch * 27 * 2 * wstep + (size_t)ntile0 * 64 + lane;
+        constexpr int AU = (NF == 2 || KSPLIT == 4) ? 2 : 4;      // A fragments per pipeline unit (register budget)
+        constexpr int G = MF / AU;                                // units per step
+        constexpr int NSTEP = KSPLIT == 1 ? 54 : 14;              // (tap, k-step) pairs handled by this wave
+        constexpr int RB = NF == 1 ? 4 : 2;                       // B ring depth (steps)
+        const int wv = KSPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(wave);
+        auto step_tap = [&](int st) { return KSPLIT == 1 ? st >> 1 : wv + 4 * (st >> 1); };
+        auto tap_off = [&](int tap) {
+            const int tc = tap < 27 ? tap : 26;
+            const int kd = tc / 9, kh = (tc - kd * 9) / 3, kw = tc - kd * 9 - kh * 3;
+            return ((kd * HH + kh) * HW + kw) * PITCH;
+        };
+        auto load_b = [&](int st, uint4* dst) {
+            const int tap = step_tap(st);
+            const bool ok = tap < 27;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+                dst[nf] = ok ? wch[(size_t)(tap * 2 + (st & 1)) * wstep + nf * 64] : make_uint4(0, 0, 0, 0);
+        };
+        auto load_a = [&](int u, uint4* dst) {
+            const int st = u / G, g = u % G;
+            const int off = tap_off(step_tap(st)) + (st & 1) * 32;
+#pragma unroll
+            for (int i = 0; i < AU; ++i) dst[i] = *(const uint4*)(halo + a_base + a_const(g * AU + i) + off);
+        };
+        uint4 bq[RB][NF];
+        uint4 aq[2][AU];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) load_b(r, bq[r]);
+        load_a(0, aq[0]);
+#pragma unroll
+        for (int u = 0; u < NSTEP * G; ++u) {
+            const int st = u / G, g = u % G;
+            if (u + 1 < NSTEP * G) load_a(u + 1, aq[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);                    // keep the prefetch ahead of this unit's MFMAs
+#pragma unroll
+            for (int i = 0; i < AU; ++i)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) mma32<T>(acc[g * AU + i][nf], aq[u & 1][i], bq[st % RB][nf]);
+            if (g == G - 1 && st + RB < NSTEP) load_b(st + RB, bq[st % RB]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ------------------------------------------------------------------ epilogue
     __syncthreads();                                  // halo region is reused as reduction scratch
-    float* red = (float*)smem;                        // [WM][BN32*32][2]
+    constexpr int MFE = KSPLIT == 1 ? MF : 2;         // m-fragments per wave in the epilogue
+    constexpr int WME = KSPLIT == 1 ? WM : 4;
+    const int wme = KSPLIT == 1 ? wm : wave;
+    f32x16_t eacc[MFE][NF];
+    if constexpr (KSPLIT == 1) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) eacc[mf][nf] = acc[mf][nf];
+    } else {
+        // sum the four tap-partial accumulators through LDS: element (mf, r, lane) at ((mf*16 + r)*64 + lane)
+        float* sc = (float*)smem;                     // 8 * 16 * 64 floats = 32 KB
+        for (int round = 0; round < 4; ++round) {
+            if (wave == round) {
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* q = sc + ((mf * 16 + r) * 64 + lane);
+                        *q = round == 0 ? acc[mf][0][r] : *q + acc[mf][0][r];
+                    }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int mf = 0; mf < MFE; ++mf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) eacc[mf][0][r] = sc[(((wave * 2 + mf) * 16 + r) * 64 + lane)];
+        __syncthreads();
+    }
+    float* red = (float*)smem;                        // [WME][BN32*32][2]
     const int col_l = lane & 31;
     float s1[NF], s2[NF];
 #pragma unroll
@@ -171,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         float mu = 0.f, rs = 1.f;
         if (EPI == 1 && cok) { mu = es.mr[((size_t)n * es.C + ecol) * 2]; rs = es.mr[((size_t)n * es.C + ecol) * 2 + 1]; }
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-            const int f = wm * MF + mf;
+        for (int mf = 0; mf < MFE; ++mf) {
+            const int f = wme * MFE + mf;
             const int d = d0 + (f >> 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -181,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
                 const int h = h0 + (f & 1) * 2 + rhs, w = w0 + rw;
                 if (!(cok && d < p.D && h < p.H && w < p.W)) continue;
                 const size_t vox = (((size_t)n * p.D + d) * p.H + h) * p.W + w;
-                float v = acc[mf][nf][r];
+                float v = eacc[mf][nf][r];
                 if (EPI == 0) {
                     if (p.res) v += Elem<T>::ld((const T*)p.res + vox * p.ldr + col);
                     v = Elem<T>::rnd(v);
@@ -203,15 +277,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
             s2[nf] += __shfl_xor(s2[nf], 32, 64);
             if (lane < 32) {
                 const int cl = (wn * NF + nf) * 32 + col_l;
-                red[(wm * BN32 * 32 + cl) * 2] = s1[nf];
-                red[(wm * BN32 * 32 + cl) * 2 + 1] = s2[nf];
+                red[(wme * BN32 * 32 + cl) * 2] = s1[nf];
+                red[(wme * BN32 * 32 + cl) * 2 + 1] = s2[nf];
             }
         }
         __syncthreads();
         for (int cl = tid; cl < BN32 * 32; cl += 256) {
             float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int m = 0; m < WM; ++m) { a += red[(m * BN32 * 32 + cl) * 2]; b += red[(m * BN32 * 32 + cl) * 2 + 1]; }
+            for (int m = 0; m < WME; ++m) { a += red[(m * BN32 * 32 + cl) * 2]; b += red[(m * BN32 * 32 + cl) * 2 + 1]; }
             const int col = blockIdx.y * BN32 * 32 + cl;
             if (col < p.Cout) {
                 float* pp = p.part + (((size_t)n * gridDim.x + blockIdx.x) * p.Cout + col) * 2;
@@ -221,18 +295,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     }
 }
 
-template <typename T, int WM, int MF, int WN, int NF>
+template <typename T, int WM, int MF, int WN, int NF, int KSPLIT = 1>
 int launch_cfg(const IgemmParams& p, int epi, hipStream_t st) {
     const int tiles = ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     dim3 grid(tiles, p.ntiles / (WN * NF), p.N), block(256);
     const size_t smem = HALO_BYTES + (size_t)(p.a.C + p.b.C) * 2 * sizeof(float);
     if (smem > 160 * 1024) return RS_ERR_UNSUPPORTED;
     if (epi == 0) {
-        auto k = igemm_kernel<T, WM, MF, WN, NF, 0>;
+        auto k = igemm_kernel<T, WM, MF, WN, NF, 0, KSPLIT>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, block, smem, st, p);
     } else {
-        auto k = igemm_kernel<T, WM, MF, WN, NF, 1>;
+        auto k = igemm_kernel<T, WM, MF, WN, NF, 1, KSPLIT>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, block, smem, st, p);
     }
@@ -244,7 +318,7 @@ int launch_dt(const IgemmParams& p, int epi, hipStream_t st) {
     const int bn32 = p.bn / 32;
     if (p.ntiles % bn32) return RS_ERR_ARG;
     switch (p.bn) {
-        case 32: return launch_cfg<T, 4, 2, 1, 1>(p, epi, st);
+        case 32: return launch_cfg<T, 1, 8, 1, 1, 4>(p, epi, st);
         case 64: return launch_cfg<T, 2, 4, 2, 1>(p, epi, st);
         case 128: return launch_cfg<T, 2, 4, 2, 2>(p, epi, st);
     }

@@ -10,7 +10,8 @@
 // f32 MFMA (32x32x2) holds one k per lane and needs no transpose.
 //
 // Block = 4 waves, output tile = MT*32 output channels x NTAPS taps x 32 input channels, looping over the
-// spatial tiles of its split; result accumulated into the f32 dW with atomics (dW pre-zeroed).
+// spatial tiles of its split; each split writes its partial dW slab with coalesced plain stores and a small
+// reduce kernel sums the slabs into the f32 dW (deterministic; f32 atomics measured ~14 G/s were the bottleneck).
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -89,92 +90,149 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    int cur_n = -1;
-    for (int tile = blockIdx.z; tile < tiles; tile += p.splits) {
+    // LDS offset of each of this wave's taps (wave-uniform -> SGPRs); taps past NTAPS are clamped (their
+    // accumulator slot is never stored).
+    int xoff[TPW];
+    {
+        const int wts = __builtin_amdgcn_readfirstlane(wt);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            int tl = wts + i * WT;
+            if (tl >= NTAPS) tl = NTAPS - 1;
+            const int kd = NTAPS == 27 ? tl / 9 : 0, kh = (tl % 9) / 3, kw = tl % 3;
+            xoff[i] = ((kd * HH + kh) * HW + kw) * XP;
+        }
+    }
+
+    // Issue-early / write-late staging: the 16-byte global loads of the NEXT tile are started right before the MFMA
+    // phase of the current one and land in LDS (after norm+ReLU) once the barrier says the tile has been consumed.
+    constexpr int NXV = (XROWS * XV + 255) / 256, NYV = (256 * YV + 255) / 256;
+    uint4 px[NXV], py[NYV];
+    auto tile_coords = [&](int tile, int& n, int& d0, int& h0, int& w0) {
         int t = tile;
         const int tw = t % tiles_w; t /= tiles_w;
         const int th = t % tiles_h; t /= tiles_h;
         const int td = t % tiles_d; t /= tiles_d;
-        const int n = t;
-        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+        n = t; d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+    };
+    auto x_coords = [&](int v, int n, int d0, int h0, int w0, size_t& off, int& s) -> bool {
+        const int r = v / XV; s = v % XV;
+        const int hd = r / (HH * HW);
+        const int rem = r - hd * (HH * HW);
+        const int hh = rem / HW, hw = rem - hh * HW;
+        const int d = d0 + hd + (NTAPS == 27 ? -1 : kdg - 1), h = h0 - 1 + hh, w = w0 - 1 + hw;
+        const int c = c0 + s * KP;
+        off = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (size_t)xs.ld + c;
+        return v < XROWS * XV && d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W && c < xs.C;
+    };
+    auto issue = [&](int tile) {
+        int n, d0, h0, w0;
+        tile_coords(tile, n, d0, h0, w0);
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) {
+            size_t off; int s_;
+            const bool ok = x_coords(tid + i * 256, n, d0, h0, w0, off, s_);
+            px[i] = ok ? *(const uint4*)((const T*)xs.x + off) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NYV; ++i) {
+            const int v = tid + i * 256;
+            const int r = v / YV, s_ = v % YV;
+            const int dd = r / (TH * TW), hh = (r / TW) % TH, ww = r % TW;
+            const int d = d0 + dd, h = h0 + hh, w = w0 + ww;
+            const int m = m0 + s_ * KP;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (v < 256 * YV && d < p.D && h < p.H && w < p.W && m < Mtot) {
+                const size_t vox = (((size_t)n * p.D + d) * p.H + h) * p.W + w;
+                if (m < p.ya.C) q = *(const uint4*)((const T*)p.ya.x + vox * p.ya.ld + m);
+                else q = *(const uint4*)((const T*)p.yb.x + vox * p.yb.ld + (m - p.ya.C));
+            }
+            py[i] = q;
+        }
+    };
+    auto commit = [&](int tile) {
+        int n, d0, h0, w0;
+        tile_coords(tile, n, d0, h0, w0);
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) {
+            const int v = tid + i * 256;
+            size_t off; int s_;
+            const bool ok = x_coords(v, n, d0, h0, w0, off, s_);
+            uint4 q = px[i];
+            if (ok && norm) {
+                float f[KP];
+                unpack16<T>(q, f);
+#pragma unroll
+                for (int j = 0; j < KP; ++j) f[j] = fmaxf((f[j] - mr_lds[2 * (s_ * KP + j)]) * mr_lds[2 * (s_ * KP + j) + 1], 0.f);
+                q = pack16<T>(f);
+            }
+            if (v < XROWS * XV) *(uint4*)(xh + (v / XV) * XP + s_ * 16) = q;
+        }
+#pragma unroll
+        for (int i = 0; i < NYV; ++i) {
+            const int v = tid + i * 256;
+            if (v < 256 * YV) *(uint4*)(yt + (v / YV) * YP + (v % YV) * 16) = py[i];
+        }
+    };
+
+    int cur_n = -1;
+    if ((int)blockIdx.z < tiles) issue(blockIdx.z);
+    for (int tile = blockIdx.z; tile < tiles; tile += p.splits) {
+        int n, d0_, h0_, w0_;
+        tile_coords(tile, n, d0_, h0_, w0_);
         __syncthreads();                                         // previous tile consumed
         if (norm && n != cur_n) {
             if (tid < 64) mr_lds[tid] = (c0 + (tid >> 1)) < xs.C ? xs.mr[((size_t)n * xs.C + c0) * 2 + tid] : 0.f;
             cur_n = n;
             __syncthreads();
         }
-        // ---- stage x_hat halo (norm + relu, zero padded)
-        for (int v = tid; v < XROWS * XV; v += 256) {
-            const int r = v / XV, s = v % XV;
-            const int hd = r / (HH * HW);
-            const int rem = r - hd * (HH * HW);
-            const int hh = rem / HW, hw = rem - hh * HW;
-            const int d = d0 + hd + (NTAPS == 27 ? -1 : kdg - 1), h = h0 - 1 + hh, w = w0 - 1 + hw;
-            const int c = c0 + s * KP;
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W && c < xs.C) {
-                q = *(const uint4*)((const T*)xs.x + ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (size_t)xs.ld + c);
-                if (norm) {
-                    float f[KP];
-                    unpack16<T>(q, f);
-#pragma unroll
-                    for (int j = 0; j < KP; ++j) f[j] = fmaxf((f[j] - mr_lds[2 * (s * KP + j)]) * mr_lds[2 * (s * KP + j) + 1], 0.f);
-                    q = pack16<T>(f);
-                }
-            }
-            *(uint4*)(xh + r * XP + s * 16) = q;
-        }
-        // ---- stage dY tile [256 voxels][MT*32]
-        for (int v = tid; v < 256 * YV; v += 256) {
-            const int r = v / YV, s = v % YV;
-            const int dd = r / (TH * TW), hh = (r / TW) % TH, ww = r % TW;
-            const int d = d0 + dd, h = h0 + hh, w = w0 + ww;
-            const int m = m0 + s * KP;
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (d < p.D && h < p.H && w < p.W && m < Mtot) {
-                const size_t vox = (((size_t)n * p.D + d) * p.H + h) * p.W + w;
-                if (m < p.ya.C) q = *(const uint4*)((const T*)p.ya.x + vox * p.ya.ld + m);
-                else q = *(const uint4*)((const T*)p.yb.x + vox * p.yb.ld + (m - p.ya.C));
-            }
-            *(uint4*)(yt + r * YP + s * 16) = q;
-        }
+        commit(tile);
         __syncthreads();
-        // ---- MFMA over the 16 (d,h) rows of the tile; k = 16 voxels along w
-        for (int row = 0; row < TD * TH; ++row) {
-            const int dd = row / TH, hh = row % TH;
-            const char* ybase = yt + (row * TW) * YP + wm * 32 * (int)sizeof(T);
-            if constexpr (sizeof(T) == 2) {
-                const uint4 afr = frag_bf16<TR>(ybase, YP, lane);
+        if (tile + p.splits < tiles) issue(tile + p.splits);     // loads fly during the MFMA phase
+        // ---- MFMA over the 16 (d,h) rows of the tile; k = 16 voxels along w.  Software pipelined with static
+        //      indices: the operand fragments of unit (row, tap i)+1 are fetched from LDS while unit (row, i) issues.
+        if constexpr (sizeof(T) == 2) {
+            auto fetch_a = [&](int row) { return frag_bf16<TR>(yt + (row * TW) * YP + wm * 64, YP, lane); };
+            auto fetch_b = [&](int row, int i) {
+                const int dd = row / TH, hh = row % TH;
+                return frag_bf16<TR>(xh + ((dd * HH + hh) * HW) * XP + xoff[i], XP, lane);
+            };
+            uint4 a_cur = fetch_a(0), a_nxt = a_cur;
+            uint4 b_cur = fetch_b(0, 0), b_nxt = b_cur;
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    const int tl = wt + i * WT;                 // tap index within this block's tap set
-                    if (tl < NTAPS) {
-                        const int kd = NTAPS == 27 ? tl / 9 : 0, kh = (tl % 9) / 3, kw = tl % 3;
-                        const char* xb = xh + (((dd + kd) * HH + hh + kh) * HW + kw) * XP;
-                        const uint4 bfr = frag_bf16<TR>(xb, XP, lane);
-                        mma32<bf16_t>(acc[i], afr, bfr);
-                    }
+            for (int u = 0; u < TD * TH * TPW; ++u) {
+                const int row = u / TPW, i = u % TPW;
+                if (u + 1 < TD * TH * TPW) {
+                    const int r2 = (u + 1) / TPW, i2 = (u + 1) % TPW;
+                    if (i2 == 0) a_nxt = fetch_a(r2);
+                    b_nxt = fetch_b(r2, i2);
                 }
-            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                mma32<bf16_t>(acc[i], a_cur, b_cur);               // invalid taps multiply by a zeroed accumulator slot (never stored)
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == TPW - 1) a_cur = a_nxt;
+                b_cur = b_nxt;
+            }
+        } else {
+            for (int row = 0; row < TD * TH; ++row) {
+                const int dd = row / TH, hh = row % TH;
+                const char* ybase = yt + (row * TW) * YP + wm * 32 * (int)sizeof(T);
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {                // 8 MFMAs of K=2 voxels
                     const int wv = k2 * 2 + (lane >> 5);
                     const float a = *(const float*)(ybase + wv * YP + (lane & 31) * 4);
 #pragma unroll
                     for (int i = 0; i < TPW; ++i) {
-                        const int tl = wt + i * WT;
-                        if (tl < NTAPS) {
-                            const int kd = NTAPS == 27 ? tl / 9 : 0, kh = (tl % 9) / 3, kw = tl % 3;
-                            const float b = *(const float*)(xh + (((dd + kd) * HH + hh + kh) * HW + kw + wv) * XP + (lane & 31) * 4);
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-                        }
+                        const float b = *(const float*)(xh + ((dd * HH + hh) * HW + wv) * XP + xoff[i] + (lane & 31) * 4);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
                     }
                 }
             }
         }
     }
-    // ---- accumulate into dW
+    // ---- write this split's partial dW slab: ws[split][tap][m][cin]  (coalesced along cin)
     const int ci = c0 + (lane & 31);
+    float* slab = p.ws + (size_t)blockIdx.z * 27 * Mtot * cin_total;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int tl = wt + i * WT;
@@ -183,13 +241,30 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + cd_row32(r, lane);
-            if (m < Mtot && ci < xs.C) {
-                float* dst = m < p.ya.C ? p.dwa + ((size_t)m * cin_total + cin_base + (lane & 31)) * 27 + tap
-                                        : p.dwb + ((size_t)(m - p.ya.C) * cin_total + cin_base + (lane & 31)) * 27 + tap;
-                atomicAdd(dst, acc[i][r]);
-            }
+            if (m < Mtot && ci < xs.C) slab[((size_t)tap * Mtot + m) * cin_total + cin_base + (lane & 31)] = acc[i][r];
         }
     }
+}
+
+// dW[m][cin][tap] = sum_s ws[s][tap][m][cin]; rows [0,Ya) -> dwa, [Ya, Ya+Yb) -> dwb.
+// thread = one slab element e = (tap*Mtot + m)*Cin + cin: reads are coalesced across threads for every split.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Mtot, int Ya, int Cin,
+                                                           float* dwa, float* dwb) {
+    const size_t E = (size_t)27 * Mtot * Cin;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+        a0 += ws[(size_t)s * E + e]; a1 += ws[(size_t)(s + 1) * E + e];
+        a2 += ws[(size_t)(s + 2) * E + e]; a3 += ws[(size_t)(s + 3) * E + e];
+    }
+    for (; s < splits; ++s) a0 += ws[(size_t)s * E + e];
+    const int c = (int)(e % Cin);
+    const size_t r = e / Cin;
+    const int m = (int)(r % Mtot), tap = (int)(r / Mtot);
+    float* dst = m < Ya ? dwa + ((size_t)m * Cin + c) * 27 : dwb + ((size_t)(m - Ya) * Cin + c) * 27;
+    dst[tap] = (a0 + a1) + (a2 + a3);
 }
 
 template <typename T, int MT, int NTAPS, int TR>
@@ -205,6 +280,9 @@ int launch(const WgradParams& p, hipStream_t st) {
     auto k = wgrad_kernel<T, MT, NTAPS, TR>;
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    const size_t elems = (size_t)27 * Mtot * (p.xa.C + p.xb.C);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C,
+                       p.xa.C + p.xb.C, p.dwa, p.dwb);
     return rs_check_launch();
 }
 

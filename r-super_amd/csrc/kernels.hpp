@@ -36,7 +36,8 @@ struct PackParams {
 struct WgradParams {
     ConvSrc xa, xb;        // forward inputs (x_hat recomputed from mr when non-null)
     ConvSrc ya, yb;        // output-gradient sources: rows [0,ya.C) -> dwa, [ya.C, ya.C+yb.C) -> dwb
-    float* dwa; float* dwb;   // (Cout_a, Cin, 27), (Cout_b, Cin, 27) f32, accumulated with atomics (pre-zeroed)
+    float* dwa; float* dwb;   // (Cout_a, Cin, 27), (Cout_b, Cin, 27) f32, overwritten
+    float* ws;                // workspace: splits * 27 * (Ya+Yb) * Cin f32
     int N, D, H, W;
     int splits;            // spatial split factor (grid.z)
 };

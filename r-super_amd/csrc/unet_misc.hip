@@ -288,41 +288,42 @@ __global__ void upsample_bwd_kernel(UpParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ stem: Conv3d(1 -> C, 3x3x3)
-// thread = one voxel, all C outputs; weights (C,1,27) f32 broadcast from LDS.
+// thread = one voxel: its 27 neighbours live in registers, the (C,1,27) f32 weights are read through the scalar
+// cache (uniform addresses -> s_load), so the inner loop is pure v_fmac with SGPR operands.
 template <typename T, int C>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* w = (float*)smem;                                    // [27][C]
-    float* tile = w + 27 * C;                                   // [256][C+1] for the stats transpose
-    for (int i = threadIdx.x; i < 27 * C; i += 256) w[(i % 27) * C + i / 27] = p.w[i];
-    __syncthreads();
+    float* tile = (float*)smem;                                 // [256][C+1] for the stats transpose
+    const float* __restrict__ w = p.w;
     const int n = blockIdx.y;
     const int vox = p.D * p.H * p.W;
     const int v = blockIdx.x * 256 + threadIdx.x;
-    float acc[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = 0.f;
     const bool ok = v < vox;
-    if (ok) {
+    float xv[27];
+    {
         const int x0 = v % p.W, y0 = (v / p.W) % p.H, z0 = v / (p.W * p.H);
         const float* xin = p.x + (size_t)n * vox;
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int z = z0 + tap / 9 - 1, y = y0 + (tap % 9) / 3 - 1, x = x0 + tap % 3 - 1;
-            float xv = 0.f;
-            if (z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) xv = xin[((size_t)z * p.H + y) * p.W + x];
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] += xv * w[tap * C + c];
+            xv[tap] = (ok && z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) ? xin[((size_t)z * p.H + y) * p.W + x] : 0.f;
         }
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = Elem<T>::rnd(acc[c]);
-        T* o = (T*)p.y + ((size_t)n * vox + v) * p.ldy;
-        constexpr int KP = Elem<T>::KP;
-#pragma unroll
-        for (int c = 0; c < C; c += KP) *(uint4*)(o + c) = pack16<T>(acc + c);
     }
+    constexpr int KP = Elem<T>::KP;
+    T* o = (T*)p.y + ((size_t)n * vox + (ok ? v : 0)) * p.ldy;
+#pragma unroll 1
+    for (int c8 = 0; c8 < C; c8 += KP) {
+        float acc[KP];
 #pragma unroll
-    for (int c = 0; c < C; ++c) tile[threadIdx.x * (C + 1) + c] = ok ? acc[c] : 0.f;
+        for (int j = 0; j < KP; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) a += xv[tap] * w[(c8 + j) * 27 + tap];
+            acc[j] = Elem<T>::rnd(a);
+            tile[threadIdx.x * (C + 1) + c8 + j] = ok ? acc[j] : 0.f;
+        }
+        if (ok) *(uint4*)(o + c8) = pack16<T>(acc);
+    }
     __syncthreads();
     // channel-major reduction: thread (g, c) sums 256/G voxels
     constexpr int G = 256 / C;
@@ -540,7 +541,7 @@ int rs_launch_upsample(const UpParams& p, int dtype, int bwd, int blocks, hipStr
 int rs_launch_stem(const StemParams& p, int dtype, int wgrad, hipStream_t st) {
     const int vox = p.D * p.H * p.W;
     if (!wgrad) {
-        const size_t smem = (size_t)(27 * p.C + 256 * (p.C + 1)) * sizeof(float);
+        const size_t smem = (size_t)(256 * (p.C + 1)) * sizeof(float);
         dim3 grid((vox + 255) / 256, p.N);
         if (dtype == RS_F32) { RS_DISPATCH_C(stem_fwd_kernel, float, p.C, grid, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(stem_fwd_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }

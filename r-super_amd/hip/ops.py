@@ -138,11 +138,13 @@ def wgrad(xa, xb, ya, yb, dwa, dwb, dims):
     gy = 1 if Mtot <= 32 else 3 * (-(-Mtot // 64))
     splits = max(1, min(tiles, 512 // max(1, nch * gy)))   # ~2 blocks per CU; bounds the dW atomics
     yb_args = (None, 0, 0) if yb is None else (_ptr(yb.t, yb.off), yb.ld, yb.C)
+    Cin_t = xa.C + (xb.C if xb is not None else 0)
+    ws = torch.empty((splits * 27 * Mtot * Cin_t,), device=dwa.device, dtype=torch.float32)
 
     def run():
         _l.check(_L().rsuper_conv3_wgrad(dt, use_tr(), *xa.args(), *(xb.args() if xb is not None else _NONE),
-                                         _ptr(ya.t, ya.off), ya.ld, ya.C, *yb_args, _ptr(dwa), _ptr(dwb), N, D, H, W, splits, _stream()),
-                  'conv3_wgrad')
+                                         _ptr(ya.t, ya.off), ya.ld, ya.C, *yb_args, _ptr(dwa), _ptr(dwb), _ptr(ws), N, D, H, W, splits,
+                                         _stream()), 'conv3_wgrad')
     if TIMER is not None:
         Cin = xa.C + (xb.C if xb is not None else 0)
         TIMER.launch('conv3d_wgrad', 2.0 * N * D * H * W * Mtot * Cin * 27, run)
@@ -222,7 +224,7 @@ class BasicBlockFn(torch.autograd.Function):
         part = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
         igemm(1, sdo, None, wpd2, Cout, bn, dims, g1, part=part, ea=y1)
         gm1 = stats_finalize(part, cnt, mode=1)
-        dw2 = torch.zeros_like(w2)
+        dw2 = torch.empty_like(w2)
         wgrad(y1, None, sdo, None, dw2, None, dims)
         dy1 = in_bwd_finalize(Src(g1), y1, gm1, Cout)
         # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
@@ -234,8 +236,8 @@ class BasicBlockFn(torch.autograd.Function):
         part0 = torch.empty((N, tiles, Cin, 2), device=dev, dtype=torch.float32)
         igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
         gm0 = stats_finalize(part0, cnt, mode=1)
-        dw1 = torch.zeros_like(w1)
-        dws = torch.zeros_like(ws) if has_sc else None
+        dw1 = torch.empty_like(w1)
+        dws = torch.empty_like(ws) if has_sc else None
         wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims)
         if xb is None:
             dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca, add1=None if has_sc else dout)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the MFMA conv kernels on the layer shapes of the full UNet (B=2, 96^3, base 32).
+Usage: python tests/bench_conv.py [bf16|f32]"""
+import os, sys, math
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rsuper_amd.hip import ops
+
+mode = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+dt = {'bf16': torch.bfloat16, 'f32': torch.float32}[mode]
+dev = 'cuda'
+N = 2
+# (name, S, Ca, Cb, Cout, fused_sc)
+LAYERS = [('inc 32->32', 96, 32, 0, 32, False), ('up4.0 96->32+sc', 96, 32, 64, 32, True), ('down1.0 32->64+sc', 48, 32, 0, 64, True),
+          ('64->64', 48, 64, 0, 64, False), ('up3.0 192->64+sc', 48, 64, 128, 64, True), ('128->128', 24, 128, 0, 128, False),
+          ('up2.0 384->128+sc', 24, 128, 256, 128, True), ('256->256', 12, 256, 0, 256, False), ('320->320', 6, 320, 0, 320, False)]
+
+
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+for name, S, Ca, Cb, Cout, sc in LAYERS:
+    dims = (N, S, S, S)
+    Cin = Ca + Cb
+    xa = torch.randn((N, S, S, S, Ca), device=dev).to(dt)
+    xb = torch.randn((N, S, S, S, Cb), device=dev).to(dt) if Cb else None
+    mra = torch.stack([torch.zeros(N, Ca, device=dev), torch.ones(N, Ca, device=dev)], -1).contiguous()
+    mrb = torch.stack([torch.zeros(N, Cb, device=dev), torch.ones(N, Cb, device=dev)], -1).contiguous() if Cb else None
+    w1 = torch.randn((Cout, Cin, 3, 3, 3), device=dev) / math.sqrt(27 * Cin)
+    ws = torch.randn((Cout, Cin, 3, 3, 3), device=dev) / math.sqrt(27 * Cin) if sc else None
+    nc = Cout * (2 if sc else 1)
+    tiles = ops._L().rsuper_conv3_tiles(S, S, S)
+    sa, sb = ops.Src(xa, mr=mra), (ops.Src(xb, mr=mrb) if Cb else None)
+    # forward
+    bn = ops.pick_bn(nc, dt)
+    wp = ops.pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if sc else 0, bn)
+    out = torch.empty((N, S, S, S, nc), device=dev, dtype=dt)
+    part = torch.empty((N, tiles, nc, 2), device=dev)
+    t_f = timeit(lambda: ops.igemm(0, sa, sb, wp, nc, bn, dims, out, part=part))
+    fl = 2.0 * N * S ** 3 * nc * Cin * 27
+    # dgrad
+    dy1 = torch.randn((N, S, S, S, Cout), device=dev).to(dt)
+    dy2 = torch.randn((N, S, S, S, Cout), device=dev).to(dt) if sc else None
+    bnd = ops.pick_bn(Cin, dt)
+    wpd = ops.pack_weights(dt, 1, w1, ws, Cout, Cout if sc else 0, Cin, 0, bnd)
+    g0 = torch.empty((N, S, S, S, Cin), device=dev, dtype=dt)
+    partd = torch.empty((N, tiles, Cin, 2), device=dev)
+    t_d = timeit(lambda: ops.igemm(1, ops.Src(dy1), ops.Src(dy2) if sc else None, wpd, Cin, bnd, dims, g0, part=partd, ea=sa, eb=sb))
+    # wgrad
+    dw1 = torch.zeros_like(w1); dws = torch.zeros_like(ws) if sc else None
+    t_w = timeit(lambda: ops.wgrad(sa, sb, ops.Src(dy1), ops.Src(dy2) if sc else None, dw1, dws, dims))
+    print(f'{name:20s} S{S:3d} {fl / 1e9:7.1f} GF | fwd bn{bn:3d} {t_f * 1e3:8.1f} us {fl / t_f / 1e9:7.1f} TF | dgrad bn{bnd:3d} {t_d * 1e3:8.1f} us {fl / t_d / 1e9:7.1f} TF | '
+          f'wgrad {t_w * 1e3:8.1f} us {fl / t_w / 1e9:7.1f} TF', flush=True)
