@@ -19,12 +19,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (matches torch)
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// two f32 -> packed bf16 pair, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32; matches torch's RNE)
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    union { bf16x2_t b; uint32_t u; } c;
+    c.b = __builtin_convertvector(v, bf16x2_t);
+    return c.u;
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(f2bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -60,8 +64,7 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
     return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
-    return make_uint4((uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
-                      (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+    return make_uint4(f2bf2(f[0], f[1]), f2bf2(f[2], f[3]), f2bf2(f[4], f[5]), f2bf2(f[6], f[7]));
 }
 
 // One K step of a 32x32 MFMA tile from 16-byte operand vectors.
@@ -87,6 +90,9 @@ __device__ __forceinline__ int cd_row32(int reg, int lane) { return (reg & 3) + 
 // Fragment row (0..31) -> position inside a [2 h][16 w] voxel patch.  ds_read_b128 is serviced in the
 // lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}; mapping each group to one h-row keeps the 16 LDS
 // rows of a group distinct mod 16, so a padded 80-byte row pitch is bank-conflict free.
+__host__ __device__ constexpr int row_hw_packed(int i) {   // hs * 16 + w, usable in constant expressions
+    return i < 4 ? i : i < 12 ? 16 + i - 4 : i < 16 ? i - 8 : i < 20 ? 16 + i - 8 : i < 28 ? i - 12 : 16 + i - 16;
+}
 __device__ __forceinline__ void row_to_hw(int i, int& hs, int& w) {
     if (i < 4) { hs = 0; w = i; }
     else if (i < 12) { hs = 1; w = i - 4; }

@@ -35,25 +35,10 @@ constexpr int HALO_BYTES = HROWS * PITCH;       // 51840
 // writes LDS after the barrier -- HBM/L2 latency hides under the MFMAs.
 constexpr int NVEC = (HROWS * 4 + 255) / 256;   // 16-byte vectors per thread per chunk (11)
 
-template <typename T>
-__device__ __forceinline__ bool stage_coords(int v, const ConvSrc& src, int c0, int n, int d0, int h0, int w0, int D, int H, int W,
-                                             size_t& off, int& c) {
-    constexpr int KP = Elem<T>::KP;
-    const int r = v >> 2, s = v & 3;
-    const int hd = r / (HH * HW);
-    const int rem = r - hd * (HH * HW);
-    const int hh = rem / HW;
-    const int hw = rem - hh * HW;
-    const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
-    c = c0 + s * KP;
-    off = ((((size_t)n * D + d) * H + h) * W + w) * (size_t)src.ld + c;
-    return v < HROWS * 4 && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W && c < src.C;
-}
-
 // EPI: 0 = forward (residual + stats of output), 1 = dgrad (relu mask + IN-backward sums)
-// KSPLIT: 1 = waves tile M x N;  4 = every wave owns the whole 256 x 32 tile for a quarter of the taps (32-column
-//         layers: weight fragments are then distinct per wave instead of 4x redundant L1 traffic), partial
-//         accumulators are summed through LDS before the epilogue.
+// KSPLIT: 1 = waves tile M x N;  2 = 32-column layers: waves = 2 (M halves) x 2 (tap halves), so weight fragments are
+//         only 2x (not 4x) redundant in L1; the two tap-partial accumulators of each M half are exchanged through
+//         LDS (8 KB per wave) before the epilogue.
 template <typename T, int WM, int MF, int WN, int NF, int EPI, int KSPLIT>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,10 +47,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     constexpr int KC = Elem<T>::KC;
     constexpr int KP = Elem<T>::KP;
     constexpr int BN32 = WN * NF;                     // 32-column tiles per block
-    static_assert(KSPLIT == 1 || (WM == 1 && WN == 1 && MF == 8 && NF == 1), "tap-split config is 256 x 32 per wave");
+    static_assert(KSPLIT == 1 || (KSPLIT == 2 && WM == 2 && WN == 1 && MF == 4 && NF == 1), "tap-split config is 2 x (128 x 32) x 2 tap halves");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = KSPLIT == 1 ? wave / WN : 0, wn = KSPLIT == 1 ? wave % WN : 0;
+    const int wm = KSPLIT == 1 ? wave / WN : (wave & 1), wn = KSPLIT == 1 ? wave % WN : 0;
+    const int kt = KSPLIT == 1 ? 0 : (wave >> 1);     // tap half of this wave
     const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
     int t = blockIdx.x;
     const int tw = t % tiles_w; t /= tiles_w;
@@ -101,41 +87,56 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int ntile0 = blockIdx.y * BN32 + wn * NF;
     const size_t wstep = (size_t)p.ntiles * 64;       // uint4 per (chunk, tap, kstep)
 
+    // Staging geometry is per-thread constant: vector i of this thread is halo row (tid>>2) + 64*i, 16-byte slot
+    // tid&3 -> its voxel index (or -1 when outside the volume / tile), its LDS address and its 8 (bf16) / 4 (f32)
+    // channels never change between K chunks, so no coordinate math is left in the chunk loop.
+    const int slot = tid & 3;
+    int vi[NVEC];
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+        const int r = (tid >> 2) + 64 * i;
+        const int hd = r / (HH * HW);
+        const int rem = r - hd * (HH * HW);
+        const int hh = rem / HW, hw = rem - hh * HW;
+        const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+        const bool ok = r < HROWS && d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W;
+        vi[i] = ok ? ((n * p.D + d) * p.H + h) * p.W + w : -1;
+    }
+    char* lds_st = halo + (tid >> 2) * PITCH + slot * 16;
+
     uint4 pre[NVEC];
     auto issue = [&](int ch) {
         const bool isB = ch >= nchA;
         const ConvSrc& src = isB ? p.b : p.a;
-        const int c0 = (isB ? ch - nchA : ch) * KC;
+        const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
+        const bool cok = c < src.C;
+        const T* xs = (const T*)src.x + c;
 #pragma unroll
-        for (int i = 0; i < NVEC; ++i) {
-            size_t off; int c;
-            const bool ok = stage_coords<T>(tid + i * 256, src, c0, n, d0, h0, w0, p.D, p.H, p.W, off, c);
-            pre[i] = ok ? *(const uint4*)((const T*)src.x + off) : make_uint4(0, 0, 0, 0);
-        }
+        for (int i = 0; i < NVEC; ++i)
+            pre[i] = (cok && vi[i] >= 0) ? *(const uint4*)(xs + (size_t)(uint32_t)vi[i] * (uint32_t)src.ld) : make_uint4(0, 0, 0, 0);
     };
     auto commit = [&](int ch) {
         const bool isB = ch >= nchA;
         const ConvSrc& src = isB ? p.b : p.a;
-        const int c0 = (isB ? ch - nchA : ch) * KC;
-        const bool norm = isB ? normB : normA;
-        const int mr_off = isB ? p.a.C : 0;
+        const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
+        const bool norm = (isB ? normB : normA) && c < src.C;
+        float sc_[KP], nb_[KP];                        // x_hat = max(x * rstd - mean * rstd, 0)
+        if (norm) {
+            const float* mr = mr_lds + 2 * ((isB ? p.a.C : 0) + c);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) { sc_[j] = mr[2 * j + 1]; nb_[j] = -mr[2 * j] * mr[2 * j + 1]; }
+        }
 #pragma unroll
         for (int i = 0; i < NVEC; ++i) {
-            const int v = tid + i * 256;
-            size_t off; int c;
-            const bool ok = stage_coords<T>(v, src, c0, n, d0, h0, w0, p.D, p.H, p.W, off, c);
             uint4 q = pre[i];
-            if (ok && norm) {
+            if (norm && vi[i] >= 0) {
                 float f[KP];
                 unpack16<T>(q, f);
 #pragma unroll
-                for (int j = 0; j < KP; ++j) {
-                    const float mu = mr_lds[2 * (mr_off + c + j)], rs = mr_lds[2 * (mr_off + c + j) + 1];
-                    f[j] = fmaxf((f[j] - mu) * rs, 0.f);
-                }
+                for (int j = 0; j < KP; ++j) f[j] = fmaxf(fmaf(f[j], sc_[j], nb_[j]), 0.f);
                 q = pack16<T>(f);
             }
-            if (v < HROWS * 4) *(uint4*)(halo + (v >> 2) * PITCH + (v & 3) * 16) = q;
+            if ((tid >> 2) + 64 * i < HROWS) *(uint4*)(lds_st + i * (64 * PITCH)) = q;
         }
     };
 
@@ -154,12 +155,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         //   unit u = (step, group of AU m-fragments); A fragments of unit u+1 are read from LDS while unit u's MFMAs
         //   issue; B fragments (weights, L1/L2 resident) run RB steps ahead in a register ring.
         const uint4* wch = wp + (size_t)ch * 27 * 2 * wstep + (size_t)ntile0 * 64 + lane;
-        constexpr int AU = (NF == 2 || KSPLIT == 4) ? 2 : 4;      // A fragments per pipeline unit (register budget)
+        constexpr int AU = NF == 2 ? 2 : 4;                       // A fragments per pipeline unit (register budget)
         constexpr int G = MF / AU;                                // units per step
-        constexpr int NSTEP = KSPLIT == 1 ? 54 : 14;              // (tap, k-step) pairs handled by this wave
+        constexpr int NSTEP = KSPLIT == 1 ? 54 : 28;              // (tap, k-step) pairs handled by this wave
         constexpr int RB = NF == 1 ? 4 : 2;                       // B ring depth (steps)
-        const int wv = KSPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(wave);
-        auto step_tap = [&](int st) { return KSPLIT == 1 ? st >> 1 : wv + 4 * (st >> 1); };
+        const int wv = KSPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(kt);
+        auto step_tap = [&](int st) { return KSPLIT == 1 ? st >> 1 : wv + KSPLIT * (st >> 1); };
         auto tap_off = [&](int tap) {
             const int tc = tap < 27 ? tap : 26;
             const int kd = tc / 9, kh = (tc - kd * 9) / 3, kw = tc - kd * 9 - kh * 3;
@@ -199,9 +200,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 
     // ------------------------------------------------------------------ epilogue
     __syncthreads();                                  // halo region is reused as reduction scratch
-    constexpr int MFE = KSPLIT == 1 ? MF : 2;         // m-fragments per wave in the epilogue
-    constexpr int WME = KSPLIT == 1 ? WM : 4;
-    const int wme = KSPLIT == 1 ? wm : wave;
+    constexpr int MFE = MF / KSPLIT;                  // m-fragments per wave in the epilogue
+    constexpr int WME = WM * KSPLIT;
+    const int wme = KSPLIT == 1 ? wm : wm * 2 + kt;
     f32x16_t eacc[MFE][NF];
     if constexpr (KSPLIT == 1) {
 #pragma unroll
@@ -209,24 +210,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) eacc[mf][nf] = acc[mf][nf];
     } else {
-        // sum the four tap-partial accumulators through LDS: element (mf, r, lane) at ((mf*16 + r)*64 + lane)
-        float* sc = (float*)smem;                     // 8 * 16 * 64 floats = 32 KB
-        for (int round = 0; round < 4; ++round) {
-            if (wave == round) {
+        // wave (wm, kt) owns fragments [2*kt, 2*kt+2) of its M half: it publishes the other two fragments' partial
+        // sums (8 KB) and adds the partner's (same wm, other tap half = wave ^ 2) partials for the ones it owns.
+        float* sc = (float*)smem;
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf)
+        for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float* q = sc + ((mf * 16 + r) * 64 + lane);
-                        *q = round == 0 ? acc[mf][0][r] : *q + acc[mf][0][r];
-                    }
-            }
-            __syncthreads();
-        }
+            for (int r = 0; r < 16; ++r)
+                sc[wave * 2048 + (mf * 16 + r) * 64 + lane] = kt ? acc[mf][0][r] : acc[2 + mf][0][r];
+        __syncthreads();
 #pragma unroll
-        for (int mf = 0; mf < MFE; ++mf)
+        for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) eacc[mf][0][r] = sc[(((wave * 2 + mf) * 16 + r) * 64 + lane)];
+            for (int r = 0; r < 16; ++r)
+                eacc[mf][0][r] = (kt ? acc[2 + mf][0][r] : acc[mf][0][r]) + sc[(wave ^ 2) * 2048 + (mf * 16 + r) * 64 + lane];
         __syncthreads();
     }
     float* red = (float*)smem;                        // [WME][BN32*32][2]
@@ -235,6 +232,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) { s1[nf] = 0.f; s2[nf] = 0.f; }
 
+    // tile completely inside the volume (the common case): no per-element bounds checks
+    const bool full = d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;
+    const int hi = lane >> 5;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
         const int col = (ntile0 + nf) * 32 + col_l;
@@ -247,26 +247,28 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int mf = 0; mf < MFE; ++mf) {
             const int f = wme * MFE + mf;
-            const int d = d0 + (f >> 1);
+            const int d = d0 + (f >> 1), hb = h0 + (f & 1) * 2;
+            const uint32_t vbase = (uint32_t)(((n * p.D + d) * p.H + hb) * p.W + w0);     // voxel (d, hb, w0)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int rhs, rw;
-                row_to_hw(cd_row32(r, lane), rhs, rw);
-                const int h = h0 + (f & 1) * 2 + rhs, w = w0 + rw;
-                if (!(cok && d < p.D && h < p.H && w < p.W)) continue;
-                const size_t vox = (((size_t)n * p.D + d) * p.H + h) * p.W + w;
+                constexpr int dummy = 0; (void)dummy;
+                const int hw0 = row_hw_packed((r & 3) + 8 * (r >> 2)), hw1 = row_hw_packed((r & 3) + 8 * (r >> 2) + 4);
+                const int hw = hi ? hw1 : hw0;
+                const int rhs = hw >> 4, rw = hw & 15;
+                if (!(cok && (full || (d < p.D && hb + rhs < p.H && w0 + rw < p.W)))) continue;
+                const uint32_t vox = vbase + (uint32_t)(rhs * p.W + rw);
                 float v = eacc[mf][nf][r];
                 if (EPI == 0) {
-                    if (p.res) v += Elem<T>::ld((const T*)p.res + vox * p.ldr + col);
+                    if (p.res) v += Elem<T>::ld((const T*)p.res + (size_t)(vox * (uint32_t)p.ldr + (uint32_t)col));
                     v = Elem<T>::rnd(v);
                     s1[nf] += v; s2[nf] += v * v;
                 } else {
-                    const float xn = (Elem<T>::ld((const T*)es.x + vox * es.ld + ecol) - mu) * rs;
+                    const float xn = (Elem<T>::ld((const T*)es.x + (size_t)(vox * (uint32_t)es.ld + (uint32_t)ecol)) - mu) * rs;
                     v = xn > 0.f ? v : 0.f;
                     v = Elem<T>::rnd(v);
                     s1[nf] += v; s2[nf] += v * xn;
                 }
-                Elem<T>::st((T*)p.out + vox * p.ldo + col, v);
+                Elem<T>::st((T*)p.out + (size_t)(vox * (uint32_t)p.ldo + (uint32_t)col), v);
             }
         }
     }
@@ -318,7 +320,7 @@ int launch_dt(const IgemmParams& p, int epi, hipStream_t st) {
     const int bn32 = p.bn / 32;
     if (p.ntiles % bn32) return RS_ERR_ARG;
     switch (p.bn) {
-        case 32: return launch_cfg<T, 1, 8, 1, 1, 4>(p, epi, st);
+        case 32: return launch_cfg<T, 2, 4, 1, 1, 2>(p, epi, st);
         case 64: return launch_cfg<T, 2, 4, 2, 1>(p, epi, st);
         case 128: return launch_cfg<T, 2, 4, 2, 2>(p, epi, st);
     }

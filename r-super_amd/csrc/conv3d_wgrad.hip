@@ -107,7 +107,25 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
     // Issue-early / write-late staging: the 16-byte global loads of the NEXT tile are started right before the MFMA
     // phase of the current one and land in LDS (after norm+ReLU) once the barrier says the tile has been consumed.
     constexpr int NXV = (XROWS * XV + 255) / 256, NYV = (256 * YV + 255) / 256;
+    constexpr int XRS = 256 / XV, YRS = 256 / YV;                // rows advanced per vector index
     uint4 px[NXV], py[NYV];
+    uint32_t xmask = 0;                                          // bit i: px[i] is inside the volume (gets norm+ReLU)
+    const int xs_slot = tid % XV, xs_row = tid / XV;             // per-thread constants: 16-byte slot and first row
+    const int ys_slot = tid % YV, ys_row = tid / YV;
+    const bool x_cok = c0 + xs_slot * KP < xs.C;
+    const int ym = m0 + ys_slot * KP;                            // first dY channel of this thread's vectors
+    const T* ysrc = nullptr; int yld = 0;
+    if (ym < Mtot) {
+        if (ym < p.ya.C) { ysrc = (const T*)p.ya.x + ym; yld = p.ya.ld; }
+        else { ysrc = (const T*)p.yb.x + (ym - p.ya.C); yld = p.yb.ld; }
+    }
+    const T* xsrc = (const T*)xs.x + c0 + xs_slot * KP;
+    char* x_lds = xh + xs_row * XP + xs_slot * 16;
+    char* y_lds = yt + ys_row * YP + ys_slot * 16;
+    float sc_[KP], nb_[KP];                                      // x_hat = max(x * rstd - mean * rstd, 0) for this thread's channels
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { sc_[j] = 1.f; nb_[j] = 0.f; }
+
     auto tile_coords = [&](int tile, int& n, int& d0, int& h0, int& w0) {
         int t = tile;
         const int tw = t % tiles_w; t /= tiles_w;
@@ -115,78 +133,64 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
         const int td = t % tiles_d; t /= tiles_d;
         n = t; d0 = td * TD; h0 = th * TH; w0 = tw * TW;
     };
-    auto x_coords = [&](int v, int n, int d0, int h0, int w0, size_t& off, int& s) -> bool {
-        const int r = v / XV; s = v % XV;
-        const int hd = r / (HH * HW);
-        const int rem = r - hd * (HH * HW);
-        const int hh = rem / HW, hw = rem - hh * HW;
-        const int d = d0 + hd + (NTAPS == 27 ? -1 : kdg - 1), h = h0 - 1 + hh, w = w0 - 1 + hw;
-        const int c = c0 + s * KP;
-        off = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (size_t)xs.ld + c;
-        return v < XROWS * XV && d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W && c < xs.C;
-    };
     auto issue = [&](int tile) {
         int n, d0, h0, w0;
         tile_coords(tile, n, d0, h0, w0);
+        xmask = 0;
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
-            size_t off; int s_;
-            const bool ok = x_coords(tid + i * 256, n, d0, h0, w0, off, s_);
-            px[i] = ok ? *(const uint4*)((const T*)xs.x + off) : make_uint4(0, 0, 0, 0);
+            const int r = xs_row + i * XRS;
+            const int hd = r / (HH * HW);
+            const int rem = r - hd * (HH * HW);
+            const int hh = rem / HW, hw = rem - hh * HW;
+            const int d = d0 + hd + (NTAPS == 27 ? -1 : kdg - 1), h = h0 - 1 + hh, w = w0 - 1 + hw;
+            const bool ok = x_cok && r < XROWS && d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W;
+            const uint32_t vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
+            px[i] = ok ? *(const uint4*)(xsrc + (size_t)vox * (uint32_t)xs.ld) : make_uint4(0, 0, 0, 0);
+            xmask |= ok ? (1u << i) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < NYV; ++i) {
-            const int v = tid + i * 256;
-            const int r = v / YV, s_ = v % YV;
-            const int dd = r / (TH * TW), hh = (r / TW) % TH, ww = r % TW;
-            const int d = d0 + dd, h = h0 + hh, w = w0 + ww;
-            const int m = m0 + s_ * KP;
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (v < 256 * YV && d < p.D && h < p.H && w < p.W && m < Mtot) {
-                const size_t vox = (((size_t)n * p.D + d) * p.H + h) * p.W + w;
-                if (m < p.ya.C) q = *(const uint4*)((const T*)p.ya.x + vox * p.ya.ld + m);
-                else q = *(const uint4*)((const T*)p.yb.x + vox * p.yb.ld + (m - p.ya.C));
-            }
-            py[i] = q;
+            const int r = ys_row + i * YRS;                      // voxel of the tile: (r/64, (r/16)%4, r%16)
+            const int d = d0 + (r >> 6), h = h0 + ((r >> 4) & 3), w = w0 + (r & 15);
+            const bool ok = ysrc && r < 256 && d < p.D && h < p.H && w < p.W;
+            const uint32_t vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
+            py[i] = ok ? *(const uint4*)(ysrc + (size_t)vox * (uint32_t)yld) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto commit = [&](int tile) {
-        int n, d0, h0, w0;
-        tile_coords(tile, n, d0, h0, w0);
+    auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
-            const int v = tid + i * 256;
-            size_t off; int s_;
-            const bool ok = x_coords(v, n, d0, h0, w0, off, s_);
             uint4 q = px[i];
-            if (ok && norm) {
+            if (norm && ((xmask >> i) & 1u)) {
                 float f[KP];
                 unpack16<T>(q, f);
 #pragma unroll
-                for (int j = 0; j < KP; ++j) f[j] = fmaxf((f[j] - mr_lds[2 * (s_ * KP + j)]) * mr_lds[2 * (s_ * KP + j) + 1], 0.f);
+                for (int j = 0; j < KP; ++j) f[j] = fmaxf(fmaf(f[j], sc_[j], nb_[j]), 0.f);
                 q = pack16<T>(f);
             }
-            if (v < XROWS * XV) *(uint4*)(xh + (v / XV) * XP + s_ * 16) = q;
+            if (xs_row + i * XRS < XROWS) *(uint4*)(x_lds + i * (XRS * XP)) = q;
         }
 #pragma unroll
-        for (int i = 0; i < NYV; ++i) {
-            const int v = tid + i * 256;
-            if (v < 256 * YV) *(uint4*)(yt + (v / YV) * YP + (v % YV) * 16) = py[i];
-        }
+        for (int i = 0; i < NYV; ++i)
+            if (ys_row + i * YRS < 256) *(uint4*)(y_lds + i * (YRS * YP)) = py[i];
     };
 
     int cur_n = -1;
     if ((int)blockIdx.z < tiles) issue(blockIdx.z);
     for (int tile = blockIdx.z; tile < tiles; tile += p.splits) {
-        int n, d0_, h0_, w0_;
-        tile_coords(tile, n, d0_, h0_, w0_);
+        const int n = tile / (tiles_w * tiles_h * tiles_d);
         __syncthreads();                                         // previous tile consumed
-        if (norm && n != cur_n) {
-            if (tid < 64) mr_lds[tid] = (c0 + (tid >> 1)) < xs.C ? xs.mr[((size_t)n * xs.C + c0) * 2 + tid] : 0.f;
+        if (norm && n != cur_n) {                                // per-sample statistics of this thread's KP channels
             cur_n = n;
-            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const int c = c0 + xs_slot * KP + j;
+                const float mu = c < xs.C ? xs.mr[((size_t)n * xs.C + c) * 2] : 0.f, rs = c < xs.C ? xs.mr[((size_t)n * xs.C + c) * 2 + 1] : 1.f;
+                sc_[j] = rs; nb_[j] = -mu * rs;
+            }
         }
-        commit(tile);
+        commit();
         __syncthreads();
         if (tile + p.splits < tiles) issue(tile + p.splits);     // loads fly during the MFMA phase
         // ---- MFMA over the 16 (d,h) rows of the tile; k = 16 voxels along w.  Software pipelined with static

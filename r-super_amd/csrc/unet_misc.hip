@@ -342,12 +342,16 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     }
 }
 
-// dW[c][tap] += sum_v dY[v][c] * x[v + off(tap)]; block loops over 256-voxel runs, thread = (channel, tap group).
+// dW[c][tap] += sum_v dY[v][c] * x[v + off(tap)].  Block loops over 256-voxel runs; both operands are kept
+// voxel-major in LDS ([row][260], pad keeps ds_read_b128 conflict free) so one 16-byte read feeds 4 FMAs.
+// thread = (channel c, tap group g).
+constexpr int RP = 260;
 template <typename T, int C>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* dyt = (float*)smem;                                  // [256][C+1]
-    float* xt = dyt + 256 * (C + 1);                            // [256][27] gathered neighbourhood
+    float* dyt = (float*)smem;                                  // [C][RP]
+    float* xt = dyt + C * RP;                                   // [27][RP] gathered neighbourhood
+    constexpr int KP = Elem<T>::KP;
     constexpr int G = 256 / C;                                  // tap groups
     constexpr int TPT = (27 + G - 1) / G;
     const int c = threadIdx.x % C, g = threadIdx.x / C;
@@ -361,20 +365,32 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
         __syncthreads();
         const bool ok = v < vox;
         const int x0 = v % p.W, y0 = (v / p.W) % p.H, z0 = v / (p.W * p.H);
+#pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int z = z0 + tap / 9 - 1, y = y0 + (tap % 9) / 3 - 1, x = x0 + tap % 3 - 1;
             float xv = 0.f;
             if (ok && z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) xv = p.x[(size_t)n * vox + ((size_t)z * p.H + y) * p.W + x];
-            xt[threadIdx.x * 27 + tap] = xv;
+            xt[tap * RP + threadIdx.x] = xv;
         }
-        for (int cc = 0; cc < C; ++cc) dyt[threadIdx.x * (C + 1) + cc] = ok ? Elem<T>::ld((const T*)p.y + ((size_t)n * vox + v) * p.ldy + cc) : 0.f;
+        const T* dyp = (const T*)p.y + ((size_t)n * vox + (ok ? v : 0)) * p.ldy;
+#pragma unroll
+        for (int c8 = 0; c8 < C; c8 += KP) {
+            float f[KP];
+            unpack16<T>(*(const uint4*)(dyp + c8), f);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) dyt[(c8 + j) * RP + threadIdx.x] = ok ? f[j] : 0.f;
+        }
         __syncthreads();
-        for (int r = 0; r < 256; ++r) {
-            const float dy = dyt[r * (C + 1) + c];
+#pragma unroll 4
+        for (int v4 = 0; v4 < 64; ++v4) {
+            const float4 d = *(const float4*)(dyt + c * RP + v4 * 4);
 #pragma unroll
             for (int j = 0; j < TPT; ++j) {
                 const int tap = g + j * G;
-                if (tap < 27) acc[j] += dy * xt[r * 27 + tap];
+                if (tap < 27) {
+                    const float4 x = *(const float4*)(xt + tap * RP + v4 * 4);
+                    acc[j] += d.x * x.x + d.y * x.y + d.z * x.z + d.w * x.w;
+                }
             }
         }
     }
@@ -433,14 +449,16 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(HeadParams p) {
     for (int c = 0; c < C; c += KP) *(uint4*)(dx + c) = pack16<T>(f + c);
 }
 
-// dW[k][c] += sum_v g[k][v]*x[v][c]; db[k] += sum_v g[k][v].  thread = (c, k group).
+// dW[k][c] += sum_v g[k][v]*x[v][c]; db[k] += sum_v g[k][v].  thread = (c, k group); LDS tiles voxel-major
+// ([row][260]) so one ds_read_b128 feeds 4 FMAs.
 template <typename T, int C>
 __global__ __launch_bounds__(256) void head_bwd_weight_kernel(HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xt = (float*)smem;                                   // [256][C+1]
-    float* gt = xt + 256 * (C + 1);                             // [K][256]
+    float* xt = (float*)smem;                                   // [C][RP]
+    float* gt = xt + C * RP;                                    // [K][RP]
+    constexpr int KP = Elem<T>::KP;
     constexpr int G = 256 / C;
-    constexpr int KPT = 64 / G > 0 ? (64 + G - 1) / G : 64;     // classes per thread (K <= 64)
+    constexpr int KPT = (64 + G - 1) / G;                       // classes per thread (K <= 64)
     const int c = threadIdx.x % C, g = threadIdx.x / C;
     float acc[KPT], accb[KPT];
 #pragma unroll
@@ -451,15 +469,27 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(HeadParams p) {
         const size_t v = (size_t)(run % runs) * 256 + threadIdx.x;
         const bool ok = v < (size_t)p.vox;
         __syncthreads();
-        for (int cc = 0; cc < C; ++cc) xt[threadIdx.x * (C + 1) + cc] = ok ? Elem<T>::ld((const T*)p.x + ((size_t)n * p.vox + v) * p.ldx + cc) : 0.f;
-        for (int k = 0; k < p.K; ++k) gt[k * 256 + threadIdx.x] = ok ? p.logits[((size_t)n * p.K + k) * p.vox + v] : 0.f;
+        const T* xp = (const T*)p.x + ((size_t)n * p.vox + (ok ? v : 0)) * p.ldx;
+#pragma unroll
+        for (int c8 = 0; c8 < C; c8 += KP) {
+            float f[KP];
+            unpack16<T>(*(const uint4*)(xp + c8), f);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) xt[(c8 + j) * RP + threadIdx.x] = ok ? f[j] : 0.f;
+        }
+        for (int k = 0; k < p.K; ++k) gt[k * RP + threadIdx.x] = ok ? p.logits[((size_t)n * p.K + k) * p.vox + v] : 0.f;
         __syncthreads();
-        for (int r = 0; r < 256; ++r) {
-            const float xv = xt[r * (C + 1) + c];
+#pragma unroll 2
+        for (int v4 = 0; v4 < 64; ++v4) {
+            const float4 x = *(const float4*)(xt + c * RP + v4 * 4);
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const int k = g + j * G;
-                if (k < p.K) { const float gv = gt[k * 256 + r]; acc[j] += gv * xv; accb[j] += gv; }
+                if (k < p.K) {
+                    const float4 q = *(const float4*)(gt + k * RP + v4 * 4);
+                    acc[j] += q.x * x.x + q.y * x.y + q.z * x.z + q.w * x.w;
+                    accb[j] += (q.x + q.y) + (q.z + q.w);
+                }
             }
         }
     }
@@ -546,9 +576,9 @@ int rs_launch_stem(const StemParams& p, int dtype, int wgrad, hipStream_t st) {
         if (dtype == RS_F32) { RS_DISPATCH_C(stem_fwd_kernel, float, p.C, grid, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(stem_fwd_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
     } else {
-        const size_t smem = (size_t)(256 * (p.C + 1) + 256 * 27) * sizeof(float);
+        const size_t smem = (size_t)((p.C + 27) * 260) * sizeof(float);
         int runs = ((vox + 255) / 256) * p.N;
-        dim3 grid(runs < 1024 ? runs : 1024);
+        dim3 grid(runs < 512 ? runs : 512);
         if (dtype == RS_F32) { RS_DISPATCH_C(stem_wgrad_kernel, float, p.C, grid, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(stem_wgrad_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
     }
@@ -567,9 +597,9 @@ int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st) {
         if (dtype == RS_F32) { RS_DISPATCH_C(head_bwd_data_kernel, float, p.C, grid, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(head_bwd_data_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
     } else {
-        const size_t smem = (size_t)(256 * (p.C + 1) + p.K * 256) * sizeof(float);
+        const size_t smem = (size_t)((p.C + p.K) * 260) * sizeof(float);
         int runs = ((p.vox + 255) / 256) * p.N;
-        dim3 g2(runs < 1024 ? runs : 1024);
+        dim3 g2(runs < 512 ? runs : 512);
         if (dtype == RS_F32) { RS_DISPATCH_C(head_bwd_weight_kernel, float, p.C, g2, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(head_bwd_weight_kernel, bf16_t, p.C, g2, dim3(256), smem, st, p) }
     }
