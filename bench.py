@@ -55,9 +55,9 @@ def cpu_baseline(args, classes):
     """Oracle (CPU restatement of the reference, kind='port') timed on the host cores on a bounded sample."""
     from oracle import unet_oracle as uo, losses_oracle as lo
     import synth
-    ncores = os.cpu_count()
+    ncores = min(os.cpu_count(), 32)      # ATen CPU conv3d stops scaling (and thrashes) far below 256 threads
     torch.set_num_threads(ncores)
-    B, S = 1, args.size
+    B, S = 1, args.size                   # bounded sample (one B=1 step): ~10-30 s of CPU work
     shapes = uo.unet_param_shapes(1, args.base, len(classes))
     sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes, 3).items()}
     img = torch.from_numpy(synth.image(B, S, seed=1234))

@@ -12,6 +12,16 @@ import torch.nn.functional as F
 
 EPS = 1e-4  # conv_layers.py:40-42: every norm inside ConvNormAct uses eps=1e-4
 
+# bf16 emulation (ORACLE for the bf16 storage mode of the HIP path; the reference itself is fp32-only,
+# train_ddp.py:315-316).  When `EMULATE_BF16` is set, tensors are rounded to bfloat16 (RNE) exactly where the kernels
+# round: every stored activation, the normalised+activated conv input x_hat, and the conv weights; accumulation stays
+# fp32.  `unet_forward(..., emulate_bf16=True)` toggles it.
+EMULATE_BF16 = False
+
+
+def _r(t):
+    return t.bfloat16().float() if EMULATE_BF16 else t
+
 
 def instance_norm(x, eps=EPS):
     """nn.InstanceNorm3d(affine=False, track_running_stats=False): per-(n,c) mean and
@@ -23,17 +33,17 @@ def instance_norm(x, eps=EPS):
 
 def conv_norm_act(x, w, stride=1):
     """ConvNormAct(preact=True): conv(relu(norm(x))), conv has no bias (conv_layers.py:46-51)."""
-    return F.conv3d(F.relu(instance_norm(x)), w, None, stride=stride, padding=1)
+    return F.conv3d(_r(F.relu(instance_norm(x))), _r(w), None, stride=stride, padding=1)
 
 
 def basic_block(x, p, prefix, stride=1):
     """BasicBlock.forward (conv_layers.py:86-94): conv2(conv1(x)) + shortcut(x); the shortcut
     is a full 3x3x3 ConvNormAct when in_ch != out_ch or stride != 1, identity otherwise."""
-    out = conv_norm_act(x, p[prefix + '.conv1.conv.weight'], stride)
+    out = _r(conv_norm_act(x, p[prefix + '.conv1.conv.weight'], stride))
     out = conv_norm_act(out, p[prefix + '.conv2.conv.weight'])
     ks = prefix + '.shortcut.conv.weight'
-    sc = conv_norm_act(x, p[ks], stride) if ks in p else x
-    return out + sc
+    sc = _r(conv_norm_act(x, p[ks], stride)) if ks in p else x
+    return _r(out + sc)
 
 
 def upsample_trilinear_ac(x, size):
@@ -55,8 +65,17 @@ def upsample_trilinear_ac(x, size):
     return x
 
 
-def unet_forward(p, x, pool=True):
+def unet_forward(p, x, pool=True, emulate_bf16=False):
     """UNet.forward (unet.py:50-64).  p: dict name -> tensor.  Returns logits (B,C,D,H,W)."""
+    global EMULATE_BF16
+    old, EMULATE_BF16 = EMULATE_BF16, emulate_bf16
+    try:
+        return _unet_forward(p, x, pool)
+    finally:
+        EMULATE_BF16 = old
+
+
+def _unet_forward(p, x, pool=True):
     def down(x, name):
         if pool:
             x = F.max_pool3d(x, 2)                         # unet_utils.py:35-37
@@ -66,12 +85,12 @@ def unet_forward(p, x, pool=True):
         return basic_block(x, p, name + '.conv.1')
 
     def up(x1, x2, name):
-        x1 = upsample_trilinear_ac(x1, x2.shape[2:])       # unet_utils.py:69
+        x1 = _r(upsample_trilinear_ac(x1, x2.shape[2:]))   # unet_utils.py:69
         x = torch.cat([x2, x1], dim=1)                     # unet_utils.py:71
         x = basic_block(x, p, name + '.conv.0')
         return basic_block(x, p, name + '.conv.1')
 
-    x1 = F.conv3d(x, p['inc.conv1.weight'], None, padding=1)   # unet_utils.py:14 (no norm/act)
+    x1 = _r(F.conv3d(x, p['inc.conv1.weight'], None, padding=1))   # unet_utils.py:14 (no norm/act; f32 weights in the stem)
     x1 = basic_block(x1, p, 'inc.conv2')
     x2 = down(x1, 'down1')
     x3 = down(x2, 'down2')
@@ -81,7 +100,7 @@ def unet_forward(p, x, pool=True):
     o = up(o, x3, 'up2')
     o = up(o, x2, 'up3')
     o = up(o, x1, 'up4')
-    return F.conv3d(o, p['outc.weight'], p['outc.bias'])       # unet.py:47
+    return F.conv3d(o, p['outc.weight'], p['outc.bias'])       # unet.py:47 (f32 weights, f32 logits)
 
 
 def unet_param_shapes(in_ch, base_ch, num_classes):

@@ -39,7 +39,7 @@ def pick_bn(n_cols, dtype):
     cands = (32, 64) if dtype == torch.float32 else (32, 64, 128)
     if n_cols <= 32:
         return 32
-    if dtype != torch.float32 and n_cols > 64:
+    if dtype != torch.float32 and n_cols > 64 and n_cols % 64:
         return 128        # e.g. 96 columns: one padded 128 tile beats three 32-column tap-split tiles
     best = None
     for bn in cands:

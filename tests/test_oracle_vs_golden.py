@@ -235,3 +235,17 @@ def test_train_steps(golden):
                 assert np.median(d) < 2e-5 and d.max() < 1.2e-3, (k, np.median(d), d.max())
     lrs = [6e-4 * to.lr_multiplier(e, 5, 100) for e in [0, 1, 3, 5, 6, 50, 99]]
     np.testing.assert_allclose(lrs, g['lr_sched'], rtol=1e-12)
+
+
+def test_bf16_emulation_distance_is_inherent(golden):
+    """The bf16-emulating oracle (rounding at the kernels' storage points) deviates from the fp32 reference by ~10 %
+    in relative L2 on the randomly initialised tiny UNet: noise amplification of the network itself (doubles per
+    encoder stage), measured on CPU with no HIP code involved.  This is the yardstick for the bf16 GPU tolerance."""
+    classes = synth.TINY_CLASSES
+    sd = {k: T(v) for k, v in synth.fill_state_dict(uo.unet_param_shapes(1, 8, len(classes)), 3).items()}
+    img = T(synth.image(1, 48, seed=1234))
+    with torch.no_grad():
+        y32 = uo.unet_forward(sd, img)
+        y16 = uo.unet_forward(sd, img, emulate_bf16=True)
+    rel = ((y16 - y32).norm() / y32.norm()).item()
+    assert 0.03 < rel < 0.25, rel
