@@ -53,7 +53,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int wm = KSPLIT == 1 ? wave / WN : (wave & 1), wn = KSPLIT == 1 ? wave % WN : 0;
     const int kt = KSPLIT == 1 ? 0 : (wave >> 1);     // tap half of this wave
     const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
-    int t = blockIdx.x;
+    // XCD-aware tile order: the dispatcher places linear workgroup id b on XCD b % 8 (8 private L2s).  Give every XCD
+    // a contiguous run of spatial tiles so neighbouring tiles (which share halo rows) hit the same L2.  Bijective for any
+    // tile count; a different placement only changes speed.
+    int t;
+    {
+        const int nt = gridDim.x, b = blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = b & 7, k = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int tile_id = t;
     const int tw = t % tiles_w; t /= tiles_w;
     const int th = t % tiles_h; t /= tiles_h;
     const int td = t;
@@ -226,71 +235,102 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
                 eacc[mf][0][r] = (kt ? acc[2 + mf][0][r] : acc[mf][0][r]) + sc[(wave ^ 2) * 2048 + (mf * 16 + r) * 64 + lane];
         __syncthreads();
     }
-    float* red = (float*)smem;                        // [WME][BN32*32][2]
-    const int col_l = lane & 31;
-    float s1[NF], s2[NF];
+    // ---- cooperative epilogue through LDS: accumulators are written voxel-major as f32 ([voxel][BN] + 16 B pad), then
+    //      all 256 threads walk the tile with 16-byte vectors (coalesced residual / forward-input loads and output
+    //      stores) and keep per-column partial sums for the InstanceNorm statistics.  FP fragments (32 voxels each)
+    //      per pass keep the scratch below the halo buffer size.
+    constexpr int BN = BN32 * 32;
+    constexpr int FP = BN == 128 ? 2 : BN == 64 ? 4 : 8;
+    constexpr int NPASS = 8 / FP;
+    constexpr int EPF = BN + 4;                       // scratch row pitch in floats
+    constexpr int CG = BN / KP;                       // 16-byte column groups per voxel
+    constexpr int RPT = 256 / CG;                     // voxel stride between a thread's vectors
+    constexpr int NV = FP * 32 / RPT;                 // vectors per thread per pass
+    static_assert(FP * 32 * EPF * 4 <= HALO_BYTES, "epilogue scratch must fit in the halo buffer");
+    float* sc2 = (float*)smem;
+    const int col_l = lane & 31, hi = lane >> 5;
+    const int cg = tid % CG, pr0 = tid / CG;
+    const int col0 = blockIdx.y * BN + cg * KP;       // first output column of this thread's vectors
+    const bool cok = col0 < p.Cout;
+    const bool inb = d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;
+    // dgrad: forward-input source (and its statistics) of this thread's columns
+    const ConvSrc& es = (EPI == 1 && col0 >= p.ea.C) ? p.eb : p.ea;
+    const int ecol0 = (EPI == 1 && col0 >= p.ea.C) ? col0 - p.ea.C : col0;
+    float emu[KP], ers[KP];
+    if (EPI == 1 && cok) {
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) { s1[nf] = 0.f; s2[nf] = 0.f; }
+        for (int j = 0; j < KP; ++j) { emu[j] = es.mr[((size_t)n * es.C + ecol0 + j) * 2]; ers[j] = es.mr[((size_t)n * es.C + ecol0 + j) * 2 + 1]; }
+    }
+    float s1[KP], s2[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 
-    // tile completely inside the volume (the common case): no per-element bounds checks
-    const bool full = d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;
-    const int hi = lane >> 5;
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-        const int col = (ntile0 + nf) * 32 + col_l;
-        const bool cok = col < p.Cout;
-        // dgrad epilogue: which forward-input source does this column belong to?
-        const ConvSrc& es = (EPI == 1 && col >= p.ea.C) ? p.eb : p.ea;
-        const int ecol = (EPI == 1 && col >= p.ea.C) ? col - p.ea.C : col;
-        float mu = 0.f, rs = 1.f;
-        if (EPI == 1 && cok) { mu = es.mr[((size_t)n * es.C + ecol) * 2]; rs = es.mr[((size_t)n * es.C + ecol) * 2 + 1]; }
+    for (int q = 0; q < NPASS; ++q) {
 #pragma unroll
         for (int mf = 0; mf < MFE; ++mf) {
-            const int f = wme * MFE + mf;
-            const int d = d0 + (f >> 1), hb = h0 + (f & 1) * 2;
-            const uint32_t vbase = (uint32_t)(((n * p.D + d) * p.H + hb) * p.W + w0);     // voxel (d, hb, w0)
+            const int f = wme * MFE + mf;             // block fragment: d = f/2, h pair = f%2
+            if (f / FP == q) {
+                const int rowbase = (((f - q * FP) >> 1) * TH + (f & 1) * 2) * TW;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                constexpr int dummy = 0; (void)dummy;
-                const int hw0 = row_hw_packed((r & 3) + 8 * (r >> 2)), hw1 = row_hw_packed((r & 3) + 8 * (r >> 2) + 4);
-                const int hw = hi ? hw1 : hw0;
-                const int rhs = hw >> 4, rw = hw & 15;
-                if (!(cok && (full || (d < p.D && hb + rhs < p.H && w0 + rw < p.W)))) continue;
-                const uint32_t vox = vbase + (uint32_t)(rhs * p.W + rw);
-                float v = eacc[mf][nf][r];
-                if (EPI == 0) {
-                    if (p.res) v += Elem<T>::ld((const T*)p.res + (size_t)(vox * (uint32_t)p.ldr + (uint32_t)col));
-                    v = Elem<T>::rnd(v);
-                    s1[nf] += v; s2[nf] += v * v;
-                } else {
-                    const float xn = (Elem<T>::ld((const T*)es.x + (size_t)(vox * (uint32_t)es.ld + (uint32_t)ecol)) - mu) * rs;
-                    v = xn > 0.f ? v : 0.f;
-                    v = Elem<T>::rnd(v);
-                    s1[nf] += v; s2[nf] += v * xn;
+                for (int r = 0; r < 16; ++r) {
+                    const int hw0 = row_hw_packed((r & 3) + 8 * (r >> 2)), hw1 = row_hw_packed((r & 3) + 8 * (r >> 2) + 4);
+                    const int hw = hi ? hw1 : hw0;
+                    float* dst = sc2 + (rowbase + (hw >> 4) * TW + (hw & 15)) * EPF + wn * NF * 32 + col_l;
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) dst[nf * 32] = eacc[mf][nf][r];
                 }
-                Elem<T>::st((T*)p.out + (size_t)(vox * (uint32_t)p.ldo + (uint32_t)col), v);
-            }
-        }
-    }
-    if (p.part) {
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-            s1[nf] += __shfl_xor(s1[nf], 32, 64);
-            s2[nf] += __shfl_xor(s2[nf], 32, 64);
-            if (lane < 32) {
-                const int cl = (wn * NF + nf) * 32 + col_l;
-                red[(wme * BN32 * 32 + cl) * 2] = s1[nf];
-                red[(wme * BN32 * 32 + cl) * 2 + 1] = s2[nf];
             }
         }
         __syncthreads();
-        for (int cl = tid; cl < BN32 * 32; cl += 256) {
-            float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int m = 0; m < WME; ++m) { a += red[(m * BN32 * 32 + cl) * 2]; b += red[(m * BN32 * 32 + cl) * 2 + 1]; }
-            const int col = blockIdx.y * BN32 * 32 + cl;
+        for (int j = 0; j < NV; ++j) {
+            const int pr = pr0 + j * RPT;             // voxel of this pass: (pr/64, (pr/16)%4, pr%16)
+            const int d = d0 + q * (FP / 2) + (pr >> 6), h = h0 + ((pr >> 4) & 3), w = w0 + (pr & 15);
+            if (cok && (inb || (d < p.D && h < p.H && w < p.W))) {
+                float v[KP];
+                const float4* sp = (const float4*)(sc2 + pr * EPF + cg * KP);
+#pragma unroll
+                for (int k4 = 0; k4 < KP / 4; ++k4) { const float4 t4 = sp[k4]; v[k4 * 4] = t4.x; v[k4 * 4 + 1] = t4.y; v[k4 * 4 + 2] = t4.z; v[k4 * 4 + 3] = t4.w; }
+                const uint32_t vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
+                if (EPI == 0) {
+                    if (p.res) {
+                        float rr[KP];
+                        unpack16<T>(*(const uint4*)((const T*)p.res + (size_t)(vox * (uint32_t)p.ldr + (uint32_t)col0)), rr);
+#pragma unroll
+                        for (int k = 0; k < KP; ++k) v[k] += rr[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) { v[k] = Elem<T>::rnd(v[k]); s1[k] += v[k]; s2[k] += v[k] * v[k]; }
+                } else {
+                    float xx[KP];
+                    unpack16<T>(*(const uint4*)((const T*)es.x + (size_t)(vox * (uint32_t)es.ld + (uint32_t)ecol0)), xx);
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const float xn = (xx[k] - emu[k]) * ers[k];
+                        v[k] = Elem<T>::rnd(xn > 0.f ? v[k] : 0.f);
+                        s1[k] += v[k]; s2[k] += v[k] * xn;
+                    }
+                }
+                *(uint4*)((T*)p.out + (size_t)(vox * (uint32_t)p.ldo + (uint32_t)col0)) = pack16<T>(v);
+            }
+        }
+        __syncthreads();
+    }
+    if (p.part) {
+        float* red = (float*)smem;                    // [RPT][BN][2]
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            red[(pr0 * BN + cg * KP + k) * 2] = s1[k];
+            red[(pr0 * BN + cg * KP + k) * 2 + 1] = s2[k];
+        }
+        __syncthreads();
+        for (int cl = tid; cl < BN; cl += 256) {
+            float a = 0.f, b = 0.f;
+            for (int m = 0; m < RPT; ++m) { a += red[(m * BN + cl) * 2]; b += red[(m * BN + cl) * 2 + 1]; }
+            const int col = blockIdx.y * BN + cl;
             if (col < p.Cout) {
-                float* pp = p.part + (((size_t)n * gridDim.x + blockIdx.x) * p.Cout + col) * 2;
+                float* pp = p.part + (((size_t)n * gridDim.x + tile_id) * p.Cout + col) * 2;
                 pp[0] = a; pp[1] = b;
             }
         }
