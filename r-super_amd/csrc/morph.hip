@@ -59,6 +59,47 @@ __global__ __launch_bounds__(256) void dilate_pass_kernel(const uint8_t* in, uin
     }
 }
 
+// 16 voxels per lane (W % 16 == 0): one 16-byte load per row + the two neighbouring words.
+__global__ __launch_bounds__(256) void dilate_pass16_kernel(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k) {
+    const int W16 = W >> 4;
+    const long items = (long)nvol * D * H * W16;
+    const int r = k >> 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+        const int x16 = (int)(i % W16);
+        long t = i / W16;
+        const int y = (int)(t % H); t /= H;
+        const int z = (int)(t % D);
+        const long v = t / D;
+        const uint8_t* vol = in + v * (long)D * H * W;
+        uint4 acc = make_uint4(0, 0, 0, 0);
+        for (int dz = -r; dz <= r; ++dz) {
+            const int zz = z + dz;
+            if (zz < 0 || zz >= D) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                const int L = row_halfwidth(k, dz, dy);
+                if (L < 0) continue;
+                const uint4* row = (const uint4*)(vol + ((long)zz * H + yy) * W);
+                const uint4 c = row[x16];
+                uint4 o = c;
+                if (L > 0) {
+                    const uint32_t pv = x16 > 0 ? ((const uint32_t*)(row + x16))[-1] : 0u;
+                    const uint32_t nx = x16 + 1 < W16 ? ((const uint32_t*)(row + x16 + 1))[0] : 0u;
+                    for (int s = 1; s <= L; ++s) {
+                        o.x |= __builtin_amdgcn_alignbyte(c.x, pv, 4 - s) | __builtin_amdgcn_alignbyte(c.y, c.x, s);
+                        o.y |= __builtin_amdgcn_alignbyte(c.y, c.x, 4 - s) | __builtin_amdgcn_alignbyte(c.z, c.y, s);
+                        o.z |= __builtin_amdgcn_alignbyte(c.z, c.y, 4 - s) | __builtin_amdgcn_alignbyte(c.w, c.z, s);
+                        o.w |= __builtin_amdgcn_alignbyte(c.w, c.z, 4 - s) | __builtin_amdgcn_alignbyte(nx, c.w, s);
+                    }
+                }
+                acc.x |= o.x; acc.y |= o.y; acc.z |= o.z; acc.w |= o.w;
+            }
+        }
+        ((uint4*)out)[i] = acc;
+    }
+}
+
 // generic-width fallback (one voxel per lane)
 __global__ __launch_bounds__(256) void dilate_pass_scalar_kernel(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k) {
     const long total = (long)nvol * D * H * W;
@@ -238,7 +279,10 @@ __global__ void count_kernel(const uint8_t* m, long V, unsigned int* count) {
 
 int rs_launch_dilate_pass(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k, hipStream_t st) {
     if (k < 1 || k > 7 || !(k & 1)) return RS_ERR_ARG;
-    if ((W & 3) == 0) {
+    if ((W & 15) == 0) {
+        const long items = nvol * D * H * (W >> 4);
+        hipLaunchKernelGGL(dilate_pass16_kernel, dim3(rs_elem_blocks((size_t)items)), dim3(256), 0, st, in, out, nvol, D, H, W, k);
+    } else if ((W & 3) == 0) {
         const long words = nvol * D * H * (W >> 2);
         hipLaunchKernelGGL(dilate_pass_kernel, dim3(rs_elem_blocks((size_t)words)), dim3(256), 0, st, in, out, nvol, D, H, W, k);
     } else {

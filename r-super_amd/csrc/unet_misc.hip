@@ -16,18 +16,32 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ stats
 // part: [N][nblk][C][2] floats.  mode 0: out = (mean, rstd);  mode 1: out = (sum0/cnt, sum1/cnt).
-__global__ void stats_finalize_kernel(const float* part, int nblk, int C, double cnt, float eps, int mode, float* out) {
+// 1024 threads = 32 channels x 32 row groups: every row read is 32 channels x 8 B contiguous, four independent loads
+// in flight per thread; f64 accumulation.
+__global__ __launch_bounds__(1024) void stats_finalize_kernel(const float* part, int nblk, int C, double cnt, float eps, int mode, float* out) {
+    __shared__ double red[32][32][2];
     const int n = blockIdx.y;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per channel
-    const int lane = threadIdx.x & 63;
-    if (c >= C) return;
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s0 = 0.0, s1 = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        const float* p = part + (((size_t)n * nblk + b) * C + c) * 2;
-        s0 += (double)p[0]; s1 += (double)p[1];
+    if (c < C) {
+        const float* base = part + ((size_t)n * nblk * C + c) * 2;
+        int b = g;
+        for (; b + 96 < nblk; b += 128) {
+            const float2 v0 = *(const float2*)(base + (size_t)b * C * 2), v1 = *(const float2*)(base + (size_t)(b + 32) * C * 2);
+            const float2 v2 = *(const float2*)(base + (size_t)(b + 64) * C * 2), v3 = *(const float2*)(base + (size_t)(b + 96) * C * 2);
+            s0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+            s1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+        }
+        for (; b < nblk; b += 32) {
+            const float2 v = *(const float2*)(base + (size_t)b * C * 2);
+            s0 += (double)v.x; s1 += (double)v.y;
+        }
     }
-    s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
-    if (lane == 0) {
+    red[g][cl][0] = s0; red[g][cl][1] = s1;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        for (int k = 1; k < 32; ++k) { s0 += red[k][cl][0]; s1 += red[k][cl][1]; }
         float* o = out + ((size_t)n * C + c) * 2;
         if (mode == 0) {
             const double mean = s0 / cnt;
@@ -248,6 +262,19 @@ __device__ __forceinline__ float up_weight(int o, int i, float scale, int I) {
     return w;
 }
 
+// per-axis candidate outputs of one input index and their interpolation weights (at most 6 for any scale >= 1/4)
+struct UpAxis { int lo, n; float w[6]; };
+__device__ __forceinline__ UpAxis up_axis(int i, float scale, int I, int O) {
+    UpAxis a;
+    int hi;
+    up_range(i, scale, O, a.lo, hi);
+    a.n = hi - a.lo + 1;
+    if (a.n > 6) a.n = 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.w[k] = k < a.n ? up_weight(a.lo + k, i, scale, I) : 0.f;
+    return a;
+}
+
 template <typename T>
 __global__ void upsample_bwd_kernel(UpParams p) {
     constexpr int KP = Elem<T>::KP;
@@ -261,23 +288,24 @@ __global__ void upsample_bwd_kernel(UpParams p) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int s = (int)(i % CV); const int v = (int)(i / CV);
         const int iw = v % p.IW, ih = (v / p.IW) % p.IH, id = v / (p.IW * p.IH);
-        int dl, dh, hl, hh, wl, wh;
-        up_range(id, sd, p.OD, dl, dh); up_range(ih, sh, p.OH, hl, hh); up_range(iw, sw, p.OW, wl, wh);
+        const UpAxis ad = up_axis(id, sd, p.ID, p.OD), ah = up_axis(ih, sh, p.IH, p.OH), aw = up_axis(iw, sw, p.IW, p.OW);
         float acc[KP];
 #pragma unroll
         for (int j = 0; j < KP; ++j) acc[j] = 0.f;
-        for (int od = dl; od <= dh; ++od) {
-            const float wd = up_weight(od, id, sd, p.ID);
-            if (wd == 0.f) continue;
-            for (int oh = hl; oh <= hh; ++oh) {
-                const float whh = up_weight(oh, ih, sh, p.IH);
-                if (whh == 0.f) continue;
-                for (int ow = wl; ow <= wh; ++ow) {
-                    const float ww = up_weight(ow, iw, sw, p.IW);
-                    if (ww == 0.f) continue;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            if (ad.w[a] == 0.f) continue;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                if (ah.w[b] == 0.f) continue;
+                const float wdh = ad.w[a] * ah.w[b];
+                const size_t rowo = (size_t)n * ovox + ((size_t)(ad.lo + a) * p.OH + (ah.lo + b)) * p.OW;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    if (aw.w[c] == 0.f) continue;
                     float g[KP];
-                    unpack16<T>(*(const uint4*)((const T*)p.y + ((size_t)n * ovox + ((size_t)od * p.OH + oh) * p.OW + ow) * p.ldy + s * KP), g);
-                    const float wt = wd * whh * ww;
+                    unpack16<T>(*(const uint4*)((const T*)p.y + (rowo + aw.lo + c) * p.ldy + s * KP), g);
+                    const float wt = wdh * aw.w[c];
 #pragma unroll
                     for (int j = 0; j < KP; ++j) acc[j] += wt * g[j];
                 }
@@ -510,7 +538,7 @@ template <typename F> void set_smem(F k, size_t smem) {
 }  // namespace
 
 int rs_launch_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, N), dim3(256), 0, st, part, nblk, C, cnt, eps, mode, out);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 31) / 32, N), dim3(1024), 0, st, part, nblk, C, cnt, eps, mode, out);
     return rs_check_launch();
 }
 

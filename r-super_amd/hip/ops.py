@@ -34,10 +34,17 @@ def _L():
     return _l.lib()
 
 
-def pick_bn(n_cols, dtype):
-    """Block N tile of the implicit GEMM (32/64/128 output columns); f32 parity mode is limited to 64."""
+def pick_bn(n_cols, dtype, tiles_total=None):
+    """Block N tile of the implicit GEMM (32/64/128 output columns); f32 parity mode is limited to 64.
+    tiles_total (spatial tiles x batch): on small volumes prefer the largest tile that still yields >= 128 workgroups
+    (12^3 and 6^3 levels would otherwise run on 36 / 12 of the 256 CUs)."""
     cands = (32, 64) if dtype == torch.float32 else (32, 64, 128)
     if n_cols <= 32:
+        return 32
+    if tiles_total is not None and tiles_total * -(-n_cols // 128) < 128:
+        for bn in reversed(cands):
+            if tiles_total * -(-n_cols // bn) >= 128:
+                return bn
         return 32
     if dtype != torch.float32 and n_cols > 64 and n_cols % 64:
         return 128        # e.g. 96 columns: one padded 128 tile beats three 32-column tap-split tiles
@@ -186,7 +193,7 @@ class BasicBlockFn(torch.autograd.Function):
         sb = None if xb is None else Src(xb, mr=mrb)
         # conv1 (+ shortcut): one GEMM
         nc1 = Cout * (2 if has_sc else 1)
-        bn1 = pick_bn(nc1, dt)
+        bn1 = pick_bn(nc1, dt, tiles * N)
         wp1 = pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if has_sc else 0, bn1)
         ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
         part = torch.empty((N, tiles, nc1, 2), device=dev, dtype=torch.float32)
@@ -194,7 +201,7 @@ class BasicBlockFn(torch.autograd.Function):
         mr_ys = stats_finalize(part, cnt)
         mr_y1 = mr_ys[:, :Cout].contiguous() if has_sc else mr_ys
         # conv2 + residual
-        bn2 = pick_bn(Cout, dt)
+        bn2 = pick_bn(Cout, dt, tiles * N)
         wp2 = pack_weights(dt, 0, w2, None, Cout, 0, Cout, 0, bn2)
         out = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
         part2 = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
@@ -220,7 +227,7 @@ class BasicBlockFn(torch.autograd.Function):
         y1 = Src(ys, C=Cout, mr=mr_y1)
         sdo = Src(dout)
         # conv2: data gradient (ReLU mask + IN sums fused), weight gradient
-        bn = pick_bn(Cout, dt)
+        bn = pick_bn(Cout, dt, tiles * N)
         wpd2 = pack_weights(dt, 1, w2, None, Cout, 0, Cout, 0, bn)
         g1 = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
         part = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
@@ -232,7 +239,7 @@ class BasicBlockFn(torch.autograd.Function):
         # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
         sa = Src(xa, mr=mra)
         sb = None if xb is None else Src(xb, mr=mrb)
-        bn = pick_bn(Cin, dt)
+        bn = pick_bn(Cin, dt, tiles * N)
         wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bn)
         g0 = torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
         part0 = torch.empty((N, tiles, Cin, 2), device=dev, dtype=torch.float32)

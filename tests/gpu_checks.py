@@ -390,7 +390,7 @@ def check_dilate():
     from rsuper_amd.hip import ops
     g = synth.rng(11)
     worst = 0
-    for shape in [(2, 3, 20, 20, 20), (1, 2, 9, 10, 11)]:
+    for shape in [(2, 3, 20, 20, 20), (1, 2, 9, 10, 11), (1, 2, 12, 12, 32), (2, 1, 8, 8, 48)]:
         vol = (g.random(shape) < 0.004).astype(np.uint8)
         for ks in [1, 2, 3, 5, 7, 9, 13, 31]:
             got = ops.dilate_volume(T(vol).to(DEV), ks).cpu().numpy()
