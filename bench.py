@@ -87,6 +87,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--report', action='store_true', help='config 3: report supervision on (ball_dice_both, 50/50 mask/report batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-ddp', action='store_true', help='wrap in DistributedDataParallel even with one rank (exercises the RCCL reducer path)')
     args = ap.parse_args()
 
     import synth
@@ -96,6 +97,9 @@ def main():
     from rsuper_amd.training.utils import FusedAdamWEMA
     from rsuper_amd.training import losses_foundation as lf
 
+    if args.force_ddp and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group(backend='nccl', rank=0, world_size=1)
     rank, local, world = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local)
@@ -108,7 +112,7 @@ def main():
     torch.manual_seed(0)                 # identical random-init weights on every rank (DDP broadcasts anyway)
     net = UNet(1, args.base, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype=args.dtype).to(dev)
     ema = make_ema(net)
-    model = wrap_ddp(net, local) if world > 1 else net
+    model = wrap_ddp(net, local) if (world > 1 or args.force_ddp) else net
     opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
     kinds = (['mask', 'report'] * B)[:B] if args.report else ['mask'] * B
     bt = synth.batch(B, S, classes, kinds, seed=7 + rank, diam_range=(5.0, 40.0), max_tumors=3)
@@ -174,7 +178,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args, classes)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -40,7 +40,7 @@ constexpr int NVEC = (HROWS * 4 + 255) / 256;   // 16-byte vectors per thread pe
 //         only 2x (not 4x) redundant in L1; the two tap-partial accumulators of each M half are exchanged through
 //         LDS (8 KB per wave) before the epilogue.
 template <typename T, int WM, int MF, int WN, int NF, int EPI, int KSPLIT>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, (MF * NF <= 4 && sizeof(T) == 2) ? 3 : 2) void igemm_kernel(IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     float* mr_lds = (float*)(smem + HALO_BYTES);      // [Ca + Cb][2]
@@ -164,10 +164,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         //   unit u = (step, group of AU m-fragments); A fragments of unit u+1 are read from LDS while unit u's MFMAs
         //   issue; B fragments (weights, L1/L2 resident) run RB steps ahead in a register ring.
         const uint4* wch = wp + (size_t)ch * 27 * 2 * wstep + (size_t)ntile0 * 64 + lane;
-        constexpr int AU = NF == 2 ? 2 : 4;                       // A fragments per pipeline unit (register budget)
+        constexpr int AU = 2;                                     // A fragments per pipeline unit (register budget)
         constexpr int G = MF / AU;                                // units per step
         constexpr int NSTEP = KSPLIT == 1 ? 54 : 28;              // (tap, k-step) pairs handled by this wave
-        constexpr int RB = NF == 1 ? 4 : 2;                       // B ring depth (steps)
+        constexpr int RB = 2;                                     // B ring depth (steps)
         const int wv = KSPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(kt);
         auto step_tap = [&](int st) { return KSPLIT == 1 ? st >> 1 : wv + KSPLIT * (st >> 1); };
         auto tap_off = [&](int tap) {

@@ -23,7 +23,9 @@ constexpr int HH = TH + 2, HW = TW + 2;
 typedef short v4s_t __attribute__((__vector_size__(4 * sizeof(short))));
 
 template <typename T> struct WG;
-template <> struct WG<bf16_t> { static constexpr int XP = 80; };     // x_hat row pitch: 32 ch * 2 B + 16
+// bf16 rows are only read with ds_read_b64_tr_b16 ([4 rows] x [32 B] per 16-lane group, two groups side by side): the
+// four rows must land on disjoint 16-dword bank ranges -> pitch = 16 (mod 64) dwords, or 48 for the 128-byte dY rows.
+template <> struct WG<bf16_t> { static constexpr int XP = 64; };     // x_hat row pitch: 32 ch * 2 B, unpadded
 template <> struct WG<float> { static constexpr int XP = 144; };     // 32 ch * 4 B + 16
 
 // Fragment = 16 bytes/lane for bf16 (8 k), 8 MFMAs worth of scalars for f32 are loaded on the fly.
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KP = Elem<T>::KP;
     constexpr int XP = WG<T>::XP;
-    constexpr int YP = MT * 32 * (int)sizeof(T) + 16;
+    constexpr int YP = sizeof(T) == 2 ? (MT == 2 ? 192 : 64) : MT * 32 * (int)sizeof(T) + 16;
     constexpr int HDN = NTAPS == 27 ? TD + 2 : TD;               // halo depth rows
     constexpr int XROWS = HDN * HH * HW;
     constexpr int XV = 32 / KP;                                  // 16-B vectors per x row
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 template <typename T, int MT, int NTAPS, int TR>
 int launch(const WgradParams& p, hipStream_t st) {
     constexpr int XP = WG<T>::XP;
-    constexpr int YP = MT * 32 * (int)sizeof(T) + 16;
+    constexpr int YP = sizeof(T) == 2 ? (MT == 2 ? 192 : 64) : MT * 32 * (int)sizeof(T) + 16;
     constexpr int HDN = NTAPS == 27 ? TD + 2 : TD;
     const size_t smem = (size_t)HDN * HH * HW * XP + 256 * YP + 64 * sizeof(float);
     const int nch = (p.xa.C + 31) / 32 + (p.xb.C + 31) / 32;

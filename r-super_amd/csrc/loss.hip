@@ -17,11 +17,15 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float bce_logits(float x, float t) {
-    // max(x,0) - x*t + log1p(exp(-|x|))   (ATen binary_cross_entropy_with_logits)
-    return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+// One exp per voxel: e = exp(-|x|) gives both sigmoid(x) = (x >= 0 ? 1 : e) / (1 + e) and the softplus term
+// log1p(e) of ATen's binary_cross_entropy_with_logits: max(x,0) - x*t + log1p(exp(-|x|)).
+__device__ __forceinline__ void sig_bce(float x, float t, float& sg, float& bce) {
+    const float e = __expf(-fabsf(x));
+    const float r = __frcp_rn(1.f + e);
+    sg = x >= 0.f ? r : e * r;
+    bce = fmaxf(x, 0.f) - x * t + log1pf(e);
 }
+__device__ __forceinline__ float sigmoidf(float x) { float s, b; sig_bce(x, 0.f, s, b); return s; }
 
 // grid: (blocks, planes).  sums: [planes][6] doubles, pre-zeroed, accumulated with f64 atomics.
 __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) {
@@ -56,8 +60,9 @@ __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) 
                 if (w1) w1v[j] = w1[i + j];
             }
             const float tt = tv[j] ? 1.f : 0.f, kk = kv[j] ? 1.f : 0.f;
-            const float sg = sigmoidf(xv[j]);
-            const float b = bce_logits(xv[j], tt) * kk;
+            float sg, b;
+            sig_bce(xv[j], tt, sg, b);
+            b *= kk;
             s[0] += b;
             s[1] += sg * kk;
             s[2] += sg * tt * kk;
@@ -94,7 +99,9 @@ __global__ __launch_bounds__(256) void plane_partials_bwd_kernel(PlaneParams p) 
         const float xv = x[i];
         const float tt = (t && t[i]) ? 1.f : 0.f;
         const float kk = (!k || k[i]) ? 1.f : 0.f;
-        const float sg = sigmoidf(xv);
+        const float e = __expf(-fabsf(xv));
+        const float r = __frcp_rn(1.f + e);
+        const float sg = xv >= 0.f ? r : e * r;
         float gb = gS;
         if (w1) gb += gF1 * w1[i];
         gb += gF2 * ((w2 && w2[i]) ? 0.f : 1.f);

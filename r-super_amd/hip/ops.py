@@ -119,6 +119,72 @@ class KernelTimer:
 
 TIMER = None   # set to a KernelTimer to time conv launches
 
+# ------------------------------------------------------------------------------------------------ side stream
+# Weight gradients depend only on (x, dY) and are consumed by the optimiser, so they run on a second HIP stream
+# concurrently with the data-gradient chain of the main stream (they fill CUs left idle by kernel tails and by the
+# small low-resolution layers).  The main stream joins the side stream at the end of backward (autograd callback).
+_SIDE = None
+_PENDING = []
+_CALLBACK_QUEUED = False
+
+
+def overlap_enabled():
+    if os.environ.get('RSUPER_WGRAD_OVERLAP', '0') != '1':
+        return False
+    import torch.distributed as dist
+    # under DDP the reducer's hooks consume gradients as soon as a block's backward returns -> no deferred join
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
+def side_stream():
+    global _SIDE
+    if _SIDE is None:
+        _SIDE = torch.cuda.Stream()
+    return _SIDE
+
+
+def join_side():
+    """Make the current (main) stream wait for all weight-gradient work queued on the side stream."""
+    global _CALLBACK_QUEUED
+    cur = torch.cuda.current_stream()
+    while _PENDING:
+        cur.wait_event(_PENDING.pop())
+    _CALLBACK_QUEUED = False
+
+
+def _queue_join():
+    global _CALLBACK_QUEUED
+    if not _CALLBACK_QUEUED:
+        _CALLBACK_QUEUED = True
+        torch.autograd.Variable._execution_engine.queue_callback(join_side)
+
+
+class _Side:
+    """Context: run the enclosed launches on the side stream after `after` (an event on the main stream)."""
+
+    def __init__(self, enabled, tensors):
+        self.enabled, self.tensors = enabled, [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.ctx = torch.cuda.stream(side_stream())
+            self.ctx.__enter__()
+            side_stream().wait_event(ev)
+        return self
+
+    def __exit__(self, *a):
+        if self.enabled:
+            done = torch.cuda.Event()
+            done.record(side_stream())
+            _PENDING.append(done)
+            self.ctx.__exit__(*a)
+            for t in self.tensors:
+                t.record_stream(side_stream())     # keep inputs alive until the side stream has consumed them
+            _queue_join()
+        return False
+
 
 def igemm(epi, a, b, packed, n_cols, bn, dims, out, out_ld=None, res=None, part=None, ea=None, eb=None):
     """a, b, ea, eb: Src (b/eb may be None).  res: Src or None.  dims = (N, D, H, W)."""
@@ -233,8 +299,10 @@ class BasicBlockFn(torch.autograd.Function):
         part = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
         igemm(1, sdo, None, wpd2, Cout, bn, dims, g1, part=part, ea=y1)
         gm1 = stats_finalize(part, cnt, mode=1)
+        ov = overlap_enabled()
         dw2 = torch.empty_like(w2)
-        wgrad(y1, None, sdo, None, dw2, None, dims)
+        with _Side(ov, (ys, mr_y1, dout, dw2)):
+            wgrad(y1, None, sdo, None, dw2, None, dims)
         dy1 = in_bwd_finalize(Src(g1), y1, gm1, Cout)
         # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
         sa = Src(xa, mr=mra)
@@ -247,7 +315,8 @@ class BasicBlockFn(torch.autograd.Function):
         gm0 = stats_finalize(part0, cnt, mode=1)
         dw1 = torch.empty_like(w1)
         dws = torch.empty_like(ws) if has_sc else None
-        wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims)
+        with _Side(ov, (xa, mra, xb, mrb, dy1, dout, dw1, dws)):
+            wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims)
         if xb is None:
             dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca, add1=None if has_sc else dout)
             dxb = None

@@ -33,6 +33,8 @@ class FusedAdamWEMA(torch.optim.Optimizer):
     @torch.no_grad()
     def grad_sqnorm(self):
         """Device f64 scalar: sum of squared gradient elements over all parameters (no host sync)."""
+        from ..hip import ops as _ops
+        _ops.join_side()      # weight gradients may still be in flight on the side stream
         ps = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
         if self._total_sq is None:
             self._total_sq = torch.zeros(1, device=ps[0].device, dtype=torch.float64)
@@ -45,6 +47,8 @@ class FusedAdamWEMA(torch.optim.Optimizer):
     def fused_step(self, max_norm=None, ema_params=None, ema_alpha=0.0):
         """clip_grad_norm_(max_norm) + AdamW + EMA in one pass.  Returns the pre-clip gradient norm (device tensor)
         when max_norm is given."""
+        from ..hip import ops as _ops
+        _ops.join_side()
         total = self.grad_sqnorm() if max_norm is not None else None
         ema_of = {}
         if ema_params is not None:
