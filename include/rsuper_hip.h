@@ -132,6 +132,7 @@ int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, floa
 int rsuper_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, void* stream);
 /* exact top-k as radix select over non-negative f32 (torch.topk use at :1483-1492); ties -> lower index first. */
 int rsuper_radix_hist(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist256, void* stream);
+/* need_eq = 0xFFFFFFFF: every element equal to the threshold is selected (parallel); otherwise the first need_eq in index order. */
 int rsuper_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr_bits, unsigned int need_eq, uint8_t* out, void* stream);
 /* GlobalWeightedRankPooling(return_weights, hard_cutoff) :442-535 restricted to the pseudo mask. */
 int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream);

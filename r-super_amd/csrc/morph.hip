@@ -234,6 +234,14 @@ __global__ __launch_bounds__(1024) void topk_mark_kernel(const float* x, const u
     }
 }
 
+// all elements equal to the threshold are wanted (the usual case: distinct values) -> no ordering, fully parallel
+__global__ void topk_mark_all_kernel(const float* x, const uint8_t* m, long V, uint32_t thr, uint8_t* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
+        out[i] = b >= thr;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ GWRP rank weights
 // compact the voxels of the pseudo mask, then rank each by value (desc) / index (asc) against all others.
 __global__ void compact_kernel(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n) {
@@ -310,7 +318,8 @@ int rs_launch_radix_hist(const float* x, const uint8_t* m, long V, uint32_t pref
 }
 
 int rs_launch_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr, unsigned int need_eq, uint8_t* out, hipStream_t st) {
-    hipLaunchKernelGGL(topk_mark_kernel, dim3(1), dim3(1024), 0, st, x, m, V, thr, need_eq, out);
+    if (need_eq == 0xFFFFFFFFu) hipLaunchKernelGGL(topk_mark_all_kernel, dim3(rs_elem_blocks((size_t)V)), dim3(256), 0, st, x, m, V, thr, out);
+    else hipLaunchKernelGGL(topk_mark_kernel, dim3(1), dim3(1024), 0, st, x, m, V, thr, need_eq, out);
     return rs_check_launch();
 }
 

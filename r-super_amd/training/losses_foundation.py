@@ -168,7 +168,7 @@ def _topk_mask(x, ball, k):
     out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
     if k <= 0:
         return out.zero_()
-    prefix, remaining = 0, k
+    prefix, remaining, ties = 0, k, 0
     hist = torch.empty(256, device=x.device, dtype=torch.int32)
     for shift in (24, 16, 8, 0):
         hist.zero_()
@@ -179,10 +179,12 @@ def _topk_mask(x, ball, k):
             if acc + h[digit] >= remaining:
                 prefix |= digit << shift
                 remaining -= acc
+                ties = int(h[digit])          # after the last pass: number of elements equal to the threshold
                 break
             acc += h[digit]
     # `prefix` = bit pattern of the k-th largest value; `remaining` = how many elements equal to it are still needed
-    _l.check(_L().rsuper_topk_mark(_ptr(x), _ptr(ball), V, prefix, remaining, _ptr(out), _stream()), 'topk_mark')
+    need = 0xFFFFFFFF if remaining >= ties else remaining      # all ties wanted -> order-free parallel marking
+    _l.check(_L().rsuper_topk_mark(_ptr(x), _ptr(ball), V, prefix, need, _ptr(out), _stream()), 'topk_mark')
     return out
 
 
