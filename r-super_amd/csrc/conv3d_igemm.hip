@@ -114,15 +114,22 @@ __global__ __launch_bounds__(256, (MF * NF <= 4 && sizeof(T) == 2) ? 3 : 2) void
     char* lds_st = halo + (tid >> 2) * PITCH + slot * 16;
 
     uint4 pre[NVEC];
+    // Halo loads go through a buffer descriptor: voxels outside the volume (and channel slots past C) get an offset
+    // beyond num_records, for which the hardware returns zeros -- no exec-mask branches around the 11 loads.
+    const uint32_t nvox_total = (uint32_t)(p.N * p.D * p.H * p.W);
     auto issue = [&](int ch) {
         const bool isB = ch >= nchA;
         const ConvSrc& src = isB ? p.b : p.a;
         const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
-        const bool cok = c < src.C;
-        const T* xs = (const T*)src.x + c;
+        const uint32_t rowb = (uint32_t)src.ld * (uint32_t)sizeof(T);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src.x, 0, nvox_total * rowb, 0x00020000);
+        const uint32_t cb = c < src.C ? (uint32_t)c * (uint32_t)sizeof(T) : 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < NVEC; ++i)
-            pre[i] = (cok && vi[i] >= 0) ? *(const uint4*)(xs + (size_t)(uint32_t)vi[i] * (uint32_t)src.ld) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < NVEC; ++i) {
+            const uint32_t off = (vi[i] >= 0 && cb != 0xFFFFFFFFu) ? (uint32_t)vi[i] * rowb + cb : 0xFFFFFFFFu;
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            pre[i] = make_uint4(q[0], q[1], q[2], q[3]);
+        }
     };
     auto commit = [&](int ch) {
         const bool isB = ch >= nchA;

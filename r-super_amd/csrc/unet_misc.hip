@@ -370,62 +370,66 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     }
 }
 
-// dW[c][tap] += sum_v dY[v][c] * x[v + off(tap)].  Block loops over 256-voxel runs; both operands are kept
-// voxel-major in LDS ([row][260], pad keeps ds_read_b128 conflict free) so one 16-byte read feeds 4 FMAs.
-// thread = (channel c, tap group g).
-constexpr int RP = 260;
-template <typename T, int C>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* dyt = (float*)smem;                                  // [C][RP]
-    float* xt = dyt + C * RP;                                   // [27][RP] gathered neighbourhood
-    constexpr int KP = Elem<T>::KP;
-    constexpr int G = 256 / C;                                  // tap groups
-    constexpr int TPT = (27 + G - 1) / G;
-    const int c = threadIdx.x % C, g = threadIdx.x / C;
-    const int vox = p.D * p.H * p.W;
-    const int runs = (vox + 255) / 256;
-    float acc[TPT];
+// Small weight gradients (stem 1->C conv, 1x1x1 head) as an exact-f32 MFMA reduction over voxels:
+//     out[i][j] += sum_v A[v][i] * B[v][j],  i, j < 32,  v_mfma_f32_32x32x2_f32 (lane l: row/col l&31, voxel parity l>>5).
+// A macro-iteration covers 8 voxels: lane half kk owns voxels v0 + 4*kk .. +3 and MFMA e pairs element e of both
+// operands (any voxel order works as long as A and B agree).  MODE 0 = stem: A = dY[v][c], B = x[v + off(tap)];
+// MODE 1 = head: A = dlogits[k][v] (also summed for the bias gradient), B = features[v][c].
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, HeadParams hp, int k0) {
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = lane & 31, kk = lane >> 5;
+    const int N = MODE == 0 ? sp.N : hp.N;
+    const int V = MODE == 0 ? sp.D * sp.H * sp.W : hp.vox;
+    const int per = (V + 7) / 8;                                 // macro-iterations per sample
+    const long items = (long)N * per;
+    f32x16_t acc;
 #pragma unroll
-    for (int j = 0; j < TPT; ++j) acc[j] = 0.f;
-    for (int run = blockIdx.x; run < runs * p.N; run += gridDim.x) {
-        const int n = run / runs, v = (run % runs) * 256 + threadIdx.x;
-        __syncthreads();
-        const bool ok = v < vox;
-        const int x0 = v % p.W, y0 = (v / p.W) % p.H, z0 = v / (p.W * p.H);
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bias_acc = 0.f;
+    // stem: tap offset of this lane's column
+    int tz = 0, ty = 0, tx = 0;
+    if (MODE == 0) { const int tap = idx < 27 ? idx : 0; tz = tap / 9 - 1; ty = (tap % 9) / 3 - 1; tx = tap % 3 - 1; }
+    for (long it = (long)blockIdx.x * 4 + wave; it < items; it += (long)gridDim.x * 4) {
+        const int n = (int)(it / per);
+        const int v0 = (int)(it % per) * 8 + kk * 4;
+        float a[4], b[4];
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            const int z = z0 + tap / 9 - 1, y = y0 + (tap % 9) / 3 - 1, x = x0 + tap % 3 - 1;
-            float xv = 0.f;
-            if (ok && z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) xv = p.x[(size_t)n * vox + ((size_t)z * p.H + y) * p.W + x];
-            xt[tap * RP + threadIdx.x] = xv;
-        }
-        const T* dyp = (const T*)p.y + ((size_t)n * vox + (ok ? v : 0)) * p.ldy;
-#pragma unroll
-        for (int c8 = 0; c8 < C; c8 += KP) {
-            float f[KP];
-            unpack16<T>(*(const uint4*)(dyp + c8), f);
-#pragma unroll
-            for (int j = 0; j < KP; ++j) dyt[(c8 + j) * RP + threadIdx.x] = ok ? f[j] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int v4 = 0; v4 < 64; ++v4) {
-            const float4 d = *(const float4*)(dyt + c * RP + v4 * 4);
-#pragma unroll
-            for (int j = 0; j < TPT; ++j) {
-                const int tap = g + j * G;
-                if (tap < 27) {
-                    const float4 x = *(const float4*)(xt + tap * RP + v4 * 4);
-                    acc[j] += d.x * x.x + d.y * x.y + d.z * x.z + d.w * x.w;
-                }
+        for (int e = 0; e < 4; ++e) {
+            const int v = v0 + e;
+            const bool ok = v < V;
+            if (MODE == 0) {
+                a[e] = (ok && idx < sp.C) ? Elem<T>::ld((const T*)sp.y + ((size_t)n * V + v) * sp.ldy + idx) : 0.f;
+                const int x0 = v % sp.W, y0 = (v / sp.W) % sp.H, z0 = v / (sp.W * sp.H);
+                const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+                b[e] = (ok && idx < 27 && z >= 0 && z < sp.D && y >= 0 && y < sp.H && x >= 0 && x < sp.W)
+                           ? sp.x[(size_t)n * V + ((size_t)z * sp.H + y) * sp.W + x] : 0.f;
+            } else {
+                a[e] = (ok && k0 + idx < hp.K) ? hp.logits[((size_t)n * hp.K + k0 + idx) * V + v] : 0.f;
+                b[e] = (ok && idx < hp.C) ? Elem<T>::ld((const T*)hp.x + ((size_t)n * V + v) * hp.ldx + idx) : 0.f;
+                bias_acc += a[e];
             }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < TPT; ++j) {
-        const int tap = g + j * G;
-        if (tap < 27) atomicAdd(p.dw + c * 27 + tap, acc[j]);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+    }
+    // block reduction of the four waves' 32x32 partials, then one atomic per element
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+            const int i = cd_row32(r, lane), j = idx;
+            if (MODE == 0) { if (i < sp.C && j < 27) atomicAdd(sp.dw + i * 27 + j, v); }
+            else { if (k0 + i < hp.K && j < hp.C) atomicAdd(hp.dw + (k0 + i) * hp.C + j, v); }
+        }
+    }
+    if (MODE == 1) {
+        bias_acc += __shfl_xor(bias_acc, 32, 64);
+        if (lane < 32 && k0 + idx < hp.K) atomicAdd(hp.db + k0 + idx, bias_acc);
     }
 }
 
@@ -475,60 +479,6 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(HeadParams p) {
     T* dx = (T*)p.dx + ((size_t)n * p.vox + v) * p.lddx;
 #pragma unroll
     for (int c = 0; c < C; c += KP) *(uint4*)(dx + c) = pack16<T>(f + c);
-}
-
-// dW[k][c] += sum_v g[k][v]*x[v][c]; db[k] += sum_v g[k][v].  thread = (c, k group); LDS tiles voxel-major
-// ([row][260]) so one ds_read_b128 feeds 4 FMAs.
-template <typename T, int C>
-__global__ __launch_bounds__(256) void head_bwd_weight_kernel(HeadParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xt = (float*)smem;                                   // [C][RP]
-    float* gt = xt + C * RP;                                    // [K][RP]
-    constexpr int KP = Elem<T>::KP;
-    constexpr int G = 256 / C;
-    constexpr int KPT = (64 + G - 1) / G;                       // classes per thread (K <= 64)
-    const int c = threadIdx.x % C, g = threadIdx.x / C;
-    float acc[KPT], accb[KPT];
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) { acc[j] = 0.f; accb[j] = 0.f; }
-    const int runs = (p.vox + 255) / 256;
-    for (int run = blockIdx.x; run < runs * p.N; run += gridDim.x) {
-        const int n = run / runs;
-        const size_t v = (size_t)(run % runs) * 256 + threadIdx.x;
-        const bool ok = v < (size_t)p.vox;
-        __syncthreads();
-        const T* xp = (const T*)p.x + ((size_t)n * p.vox + (ok ? v : 0)) * p.ldx;
-#pragma unroll
-        for (int c8 = 0; c8 < C; c8 += KP) {
-            float f[KP];
-            unpack16<T>(*(const uint4*)(xp + c8), f);
-#pragma unroll
-            for (int j = 0; j < KP; ++j) xt[(c8 + j) * RP + threadIdx.x] = ok ? f[j] : 0.f;
-        }
-        for (int k = 0; k < p.K; ++k) gt[k * RP + threadIdx.x] = ok ? p.logits[((size_t)n * p.K + k) * p.vox + v] : 0.f;
-        __syncthreads();
-#pragma unroll 2
-        for (int v4 = 0; v4 < 64; ++v4) {
-            const float4 x = *(const float4*)(xt + c * RP + v4 * 4);
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const int k = g + j * G;
-                if (k < p.K) {
-                    const float4 q = *(const float4*)(gt + k * RP + v4 * 4);
-                    acc[j] += q.x * x.x + q.y * x.y + q.z * x.z + q.w * x.w;
-                    accb[j] += (q.x + q.y) + (q.z + q.w);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        const int k = g + j * G;
-        if (k < p.K) {
-            atomicAdd(p.dw + k * C + c, acc[j]);
-            if (c == 0) atomicAdd(p.db + k, accb[j]);
-        }
-    }
 }
 
 template <typename F> void set_smem(F k, size_t smem) {
@@ -604,11 +554,12 @@ int rs_launch_stem(const StemParams& p, int dtype, int wgrad, hipStream_t st) {
         if (dtype == RS_F32) { RS_DISPATCH_C(stem_fwd_kernel, float, p.C, grid, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(stem_fwd_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
     } else {
-        const size_t smem = (size_t)((p.C + 27) * 260) * sizeof(float);
-        int runs = ((vox + 255) / 256) * p.N;
-        dim3 grid(runs < 512 ? runs : 512);
-        if (dtype == RS_F32) { RS_DISPATCH_C(stem_wgrad_kernel, float, p.C, grid, dim3(256), smem, st, p) }
-        else { RS_DISPATCH_C(stem_wgrad_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
+        if (p.C > 32) return RS_ERR_UNSUPPORTED;
+        HeadParams hp{};
+        const long items = (long)p.N * ((vox + 7) / 8);
+        dim3 grid((unsigned)(items / 4 < 512 ? (items + 3) / 4 : 512));
+        if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 0>), grid, dim3(256), 0, st, p, hp, 0);
+        else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 0>), grid, dim3(256), 0, st, p, hp, 0);
     }
     return rs_check_launch();
 }
@@ -625,11 +576,14 @@ int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st) {
         if (dtype == RS_F32) { RS_DISPATCH_C(head_bwd_data_kernel, float, p.C, grid, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(head_bwd_data_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
     } else {
-        const size_t smem = (size_t)((p.C + p.K) * 260) * sizeof(float);
-        int runs = ((p.vox + 255) / 256) * p.N;
-        dim3 g2(runs < 512 ? runs : 512);
-        if (dtype == RS_F32) { RS_DISPATCH_C(head_bwd_weight_kernel, float, p.C, g2, dim3(256), smem, st, p) }
-        else { RS_DISPATCH_C(head_bwd_weight_kernel, bf16_t, p.C, g2, dim3(256), smem, st, p) }
+        if (p.C > 32) return RS_ERR_UNSUPPORTED;
+        StemParams sp{};
+        const long items = (long)p.N * ((p.vox + 7) / 8);
+        dim3 g2((unsigned)(items / 4 < 512 ? (items + 3) / 4 : 512));
+        for (int k0 = 0; k0 < p.K; k0 += 32) {                  // 32 classes per pass (K = 42 in BASELINE config 5 -> 2 passes)
+            if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 1>), g2, dim3(256), 0, st, sp, p, k0);
+            else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 1>), g2, dim3(256), 0, st, sp, p, k0);
+        }
     }
     return rs_check_launch();
 }
