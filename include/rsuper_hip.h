@@ -50,6 +50,12 @@ size_t rsuper_conv3_packed_elems(int dtype, int ka, int kb, int n_cols, int bn);
 int rsuper_conv3_pack_weights(int dtype, int mode, const float* wa, const float* wb, int ka, int kb, int na, int nb,
                               int bn, void* packed, void* stream);
 
+/* Same for n layers in one launch (all convolutions of a UNet forward, or of its backward).  host_desc: n x 6 ints
+ * (mode, ka, kb, na, nb, bn); host_wa/host_wb: n device pointers each (wb may be NULL); host_out_elems: element offset
+ * of every layer's fragment buffer inside `packed`, laid out back to back (each rsuper_conv3_packed_elems long). */
+int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, const float* const* host_wa, const float* const* host_wb,
+                                    const size_t* host_out_elems, void* packed, void* stream);
+
 /* Number of 4x4x16 output tiles per sample == rows of the per-block partial-sum buffer. */
 int rsuper_conv3_tiles(int D, int H, int W);
 

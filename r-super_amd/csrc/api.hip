@@ -68,6 +68,38 @@ int rsuper_conv3_pack_weights(int dtype, int mode, const float* wa, const float*
     return rs_launch_pack(q, dtype, packed, ST(stream));
 }
 
+int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, const float* const* host_wa, const float* const* host_wb,
+                                    const size_t* host_out_elems, void* packed, void* stream) {
+    // host_desc: n x 6 ints (mode, ka, kb, na, nb, bn); host_out_elems: n element offsets into `packed` (multiples of 8)
+    if (!dt_ok(dtype) || n <= 0 || !host_desc || !host_wa || !host_wb || !host_out_elems || !packed) return RS_ERR_ARG;
+    const int KP = dtype == RS_F32 ? 4 : 8;
+    for (int i0 = 0; i0 < n; i0 += RS_PACK_BATCH_MAX) {
+        PackBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n - i0 < RS_PACK_BATCH_MAX ? n - i0 : RS_PACK_BATCH_MAX;
+        const size_t base = host_out_elems[i0];
+        for (int i = 0; i < b.n; ++i) {
+            const int* d = host_desc + (size_t)(i0 + i) * 6;
+            if ((d[0] != 0 && d[0] != 1) || d[1] <= 0 || d[2] < 0 || d[3] <= 0 || d[4] < 0 || (d[5] != 32 && d[5] != 64 && d[5] != 128)) return RS_ERR_ARG;
+            PackParams& q = b.q[i];
+            q.wa = host_wa[i0 + i]; q.wb = host_wb[i0 + i]; q.mode = d[0]; q.ka = d[1]; q.kb = d[2]; q.na = d[3]; q.nb = d[4];
+            q.ntiles = ntiles_for(d[3] + d[4], d[5]);
+            if (!q.wa || ((host_out_elems[i0 + i] - base) % KP)) return RS_ERR_ARG;
+            b.vec_start[i] = (host_out_elems[i0 + i] - base) / KP;
+        }
+        // entries are contiguous: the end of the last one closes the table
+        const int* dl = host_desc + (size_t)(i0 + b.n - 1) * 6;
+        b.vec_start[b.n] = b.vec_start[b.n - 1] + rs_packed_elems(dtype, dl[1], dl[2], ntiles_for(dl[3] + dl[4], dl[5])) / KP;
+        for (int i = 0; i + 1 < b.n; ++i) {   // contiguity check
+            const int* d = host_desc + (size_t)(i0 + i) * 6;
+            if (b.vec_start[i] + rs_packed_elems(dtype, d[1], d[2], ntiles_for(d[3] + d[4], d[5])) / KP != b.vec_start[i + 1]) return RS_ERR_ARG;
+        }
+        const int rc = rs_launch_pack_batch(b, dtype, (char*)packed + base * (dtype == RS_F32 ? 4 : 2), ST(stream));
+        if (rc) return rc;
+    }
+    return RS_OK;
+}
+
 int rsuper_conv3_tiles(int D, int H, int W) { return ((D + 3) / 4) * ((H + 3) / 4) * ((W + 15) / 16); }
 
 int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, const float* mra,

@@ -384,9 +384,26 @@ int launch_dt(const IgemmParams& p, int epi, hipStream_t st) {
 // mode 1 (dgrad):    GEMM-K = forward Cout, source A = wa's rows (ka), source B = wb's rows (kb),
 //                    GEMM-N = forward Cin (na);  value = w[k][n][26 - tap]   (flipped taps)
 template <typename T>
+__device__ __forceinline__ void pack_one(const PackParams& q, T* out, size_t idx);
+
+template <typename T>
 __global__ void pack_kernel(PackParams q, T* out) {
+    pack_one<T>(q, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// all layers of a network in one launch: descriptor table in the kernel argument, vector index -> layer by binary search
+template <typename T>
+__global__ void pack_batch_kernel(PackBatch b, T* out) {
+    const unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= b.vec_start[b.n]) return;
+    int lo = 0, hi = b.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.vec_start[mid] <= v) lo = mid; else hi = mid; }
+    pack_one<T>(b.q[lo], out + b.vec_start[lo] * Elem<T>::KP, (size_t)(v - b.vec_start[lo]));
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_one(const PackParams& q, T* out, size_t idx) {
     constexpr int KC = Elem<T>::KC, KP = Elem<T>::KP;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nchA = (q.ka + KC - 1) / KC, nchB = (q.kb + KC - 1) / KC;
     const size_t total = (size_t)(nchA + nchB) * 27 * 2 * q.ntiles * 64;
     if (idx >= total) return;
@@ -432,6 +449,15 @@ size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles) {
     const int KC = dtype == RS_F32 ? 16 : 32, KP = dtype == RS_F32 ? 4 : 8;
     const size_t nch = (size_t)((ka + KC - 1) / KC + (kb + KC - 1) / KC);
     return nch * 27 * 2 * ntiles * 64 * KP;
+}
+
+int rs_launch_pack_batch(const PackBatch& b, int dtype, void* out, hipStream_t st) {
+    const unsigned long long vecs = b.vec_start[b.n];
+    if (!vecs) return RS_OK;
+    const unsigned blocks = (unsigned)((vecs + 255) / 256);
+    if (dtype == RS_F32) hipLaunchKernelGGL(pack_batch_kernel<float>, dim3(blocks), dim3(256), 0, st, b, (float*)out);
+    else hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, b, (bf16_t*)out);
+    return rs_check_launch();
 }
 
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st) {

@@ -42,6 +42,13 @@ struct WgradParams {
     int splits;            // spatial split factor (grid.z)
 };
 
+#define RS_PACK_BATCH_MAX 40
+struct PackBatch {
+    int n;
+    PackParams q[RS_PACK_BATCH_MAX];
+    unsigned long long vec_start[RS_PACK_BATCH_MAX + 1];   // prefix sum of 16-byte vectors; entry i writes at out + vec_start[i]*16 B
+};
+int rs_launch_pack_batch(const PackBatch& b, int dtype, void* out, hipStream_t st);
 int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);

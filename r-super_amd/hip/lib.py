@@ -19,6 +19,7 @@ _SIGS = {
     'rsuper_device_check': (c_int, []),
     'rsuper_conv3_packed_elems': (c_size_t, [c_int] * 5),
     'rsuper_conv3_pack_weights': (c_int, [c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    'rsuper_conv3_pack_weights_batch': (c_int, [c_int, c_int, P, P, P, P, P, P]),
     'rsuper_conv3_tiles': (c_int, [c_int] * 3),
     'rsuper_conv3_igemm': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                    P, c_int, P, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, P]),

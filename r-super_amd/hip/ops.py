@@ -77,6 +77,40 @@ def pack_weights(dtype, mode, wa, wb, ka, kb, na, nb, bn):
     return out
 
 
+def pack_weights_batch(dtype, specs):
+    """One launch for many layers.  specs: list of (mode, wa, wb, ka, kb, na, nb, bn).  Returns a list of packed views."""
+    import ctypes
+    dt = _DT[dtype]
+    n = len(specs)
+    sizes = [_L().rsuper_conv3_packed_elems(dt, sp[3], sp[4], sp[5] + sp[6], sp[7]) for sp in specs]
+    offs = [0]
+    for z in sizes:
+        offs.append(offs[-1] + z)
+    buf = torch.empty((offs[-1],), device=specs[0][1].device, dtype=dtype)
+    desc = (ctypes.c_int * (6 * n))(*[v for sp in specs for v in (sp[0], sp[3], sp[4], sp[5], sp[6], sp[7])])
+    wa = (ctypes.c_void_p * n)(*[sp[1].data_ptr() for sp in specs])
+    wb = (ctypes.c_void_p * n)(*[(sp[2].data_ptr() if sp[2] is not None else None) for sp in specs])
+    oe = (ctypes.c_size_t * n)(*offs[:-1])
+    _l.check(_L().rsuper_conv3_pack_weights_batch(dt, n, desc, wa, wb, oe, _ptr(buf), _stream()), 'pack_weights_batch')
+    return [buf[offs[i]:offs[i + 1]] for i in range(n)]
+
+
+def block_pack_specs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward):
+    """The (up to) four fragment buffers a BasicBlock needs: forward conv1(+shortcut), forward conv2, data-gradient
+    conv2, data-gradient conv1(+shortcut).  Returns (specs, bns) in that order."""
+    Cout, Cin = w1.shape[0], Ca + Cb
+    has_sc = ws is not None
+    nc1 = Cout * (2 if has_sc else 1)
+    bn1, bn2 = pick_bn(nc1, dtype, tiles_total), pick_bn(Cout, dtype, tiles_total)
+    specs = [(0, w1, ws, Ca, Cb, Cout, Cout if has_sc else 0, bn1), (0, w2, None, Cout, 0, Cout, 0, bn2)]
+    bns = [bn1, bn2]
+    if with_backward:
+        bnd2, bnd1 = pick_bn(Cout, dtype, tiles_total), pick_bn(Cin, dtype, tiles_total)
+        specs += [(1, w2, None, Cout, 0, Cout, 0, bnd2), (1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bnd1)]
+        bns += [bnd2, bnd1]
+    return specs, bns
+
+
 class Src:
     """A channels-last source view: tensor (N,D,H,W,ld) + channel offset/count + optional (N,C,2) stats."""
 
@@ -245,7 +279,8 @@ class BasicBlockFn(torch.autograd.Function):
     conv1 and the shortcut conv read the same normalised input and run as ONE GEMM with N = 2*Cout."""
 
     @staticmethod
-    def forward(ctx, xa, mra, xb, mrb, w1, w2, ws):
+    def forward(ctx, xa, mra, xb, mrb, w1, w2, ws, packs=None):
+        """packs: optional (tensors, bns) from pack_weights_batch / block_pack_specs (whole-network batched packing)."""
         _chk_act(xa)
         N, D, H, W, Ca = xa.shape
         Cb = 0 if xb is None else xb.shape[-1]
@@ -260,22 +295,29 @@ class BasicBlockFn(torch.autograd.Function):
         sb = None if xb is None else Src(xb, mr=mrb)
         # conv1 (+ shortcut): one GEMM
         nc1 = Cout * (2 if has_sc else 1)
-        bn1 = pick_bn(nc1, dt, tiles * N)
-        wp1 = pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if has_sc else 0, bn1)
+        if packs is not None:
+            bn1, wp1 = packs[1][0], packs[0][0]
+        else:
+            bn1 = pick_bn(nc1, dt, tiles * N)
+            wp1 = pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if has_sc else 0, bn1)
         ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
         part = torch.empty((N, tiles, nc1, 2), device=dev, dtype=torch.float32)
         igemm(0, sa, sb, wp1, nc1, bn1, dims, ys, part=part)
         mr_ys = stats_finalize(part, cnt)
         mr_y1 = mr_ys[:, :Cout].contiguous() if has_sc else mr_ys
         # conv2 + residual
-        bn2 = pick_bn(Cout, dt, tiles * N)
-        wp2 = pack_weights(dt, 0, w2, None, Cout, 0, Cout, 0, bn2)
+        if packs is not None:
+            bn2, wp2 = packs[1][1], packs[0][1]
+        else:
+            bn2 = pick_bn(Cout, dt, tiles * N)
+            wp2 = pack_weights(dt, 0, w2, None, Cout, 0, Cout, 0, bn2)
         out = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
         part2 = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
         res = Src(ys, C=Cout, off=Cout) if has_sc else Src(xa)
         igemm(0, Src(ys, C=Cout, mr=mr_y1), None, wp2, Cout, bn2, dims, out, res=res, part=part2)
         mr_out = stats_finalize(part2, cnt)
         ctx.save_for_backward(xa, mra, xb, mrb, ys, mr_y1, w1, w2, ws)
+        ctx.packs = packs if (packs is not None and len(packs[0]) == 4) else None
         ctx.mark_non_differentiable(mr_out)
         return out, mr_out
 
@@ -294,8 +336,11 @@ class BasicBlockFn(torch.autograd.Function):
         y1 = Src(ys, C=Cout, mr=mr_y1)
         sdo = Src(dout)
         # conv2: data gradient (ReLU mask + IN sums fused), weight gradient
-        bn = pick_bn(Cout, dt, tiles * N)
-        wpd2 = pack_weights(dt, 1, w2, None, Cout, 0, Cout, 0, bn)
+        if ctx.packs is not None:
+            bn, wpd2 = ctx.packs[1][2], ctx.packs[0][2]
+        else:
+            bn = pick_bn(Cout, dt, tiles * N)
+            wpd2 = pack_weights(dt, 1, w2, None, Cout, 0, Cout, 0, bn)
         g1 = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
         part = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
         igemm(1, sdo, None, wpd2, Cout, bn, dims, g1, part=part, ea=y1)
@@ -308,8 +353,11 @@ class BasicBlockFn(torch.autograd.Function):
         # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
         sa = Src(xa, mr=mra)
         sb = None if xb is None else Src(xb, mr=mrb)
-        bn = pick_bn(Cin, dt, tiles * N)
-        wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bn)
+        if ctx.packs is not None:
+            bn, wpd1 = ctx.packs[1][3], ctx.packs[0][3]
+        else:
+            bn = pick_bn(Cin, dt, tiles * N)
+            wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bn)
         g0 = torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
         part0 = torch.empty((N, tiles, Cin, 2), device=dev, dtype=torch.float32)
         igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
@@ -324,7 +372,7 @@ class BasicBlockFn(torch.autograd.Function):
         else:
             dxa = in_bwd_finalize(Src(g0, C=Ca), sa, gm0[:, :Ca].contiguous(), Ca)
             dxb = in_bwd_finalize(Src(g0, C=Cb, off=Ca), sb, gm0[:, Ca:].contiguous(), Cb)
-        return dxa, None, dxb, None, dw1, dw2, dws
+        return dxa, None, dxb, None, dw1, dw2, dws, None
 
 
 # ------------------------------------------------------------------------------------------------ pool / upsample

@@ -30,6 +30,11 @@ class BasicBlock(nn.Module):
         if stride != 1 or in_ch != out_ch:
             self.shortcut = ConvNormAct(in_ch, out_ch, kernel_size, stride, 1, norm, act, preact)
 
-    def forward(self, xa, mra, xb=None, mrb=None):
+    def weights(self):
         ws = self.shortcut.conv.weight if isinstance(self.shortcut, ConvNormAct) else None
-        return ops.BasicBlockFn.apply(xa, mra, xb, mrb, self.conv1.conv.weight, self.conv2.conv.weight, ws)
+        return self.conv1.conv.weight, self.conv2.conv.weight, ws
+
+    def forward(self, xa, mra, xb=None, mrb=None):
+        w1, w2, ws = self.weights()
+        packs = getattr(self, '_packs', None)        # set by UNet.forward (whole-network batched weight packing)
+        return ops.BasicBlockFn.apply(xa, mra, xb, mrb, w1, w2, ws, packs)

@@ -49,11 +49,55 @@ class UNet(nn.Module):
     def _dtype(self):
         return {'bf16': torch.bfloat16, 'f32': torch.float32}[self.compute_dtype]
 
+    def _blocks_with_geometry(self, shape):
+        """(block, Ca, Cb, spatial size) for every BasicBlock in execution order."""
+        N, _, D, H, W = shape
+        out = []
+        b = self.inc.conv2.conv1.conv.weight.shape[0]
+        out.append((self.inc.conv2, b, 0, (D, H, W)))
+        size = (D, H, W)
+        sizes = [size]
+        for dn in (self.down1, self.down2, self.down3, self.down4):
+            size = tuple(s // 2 for s in size)
+            sizes.append(size)
+            blks = list(dn.conv)[1:]
+            cin = blks[0].conv1.conv.weight.shape[1]
+            for i, blk in enumerate(blks):
+                out.append((blk, cin if i == 0 else blk.conv1.conv.weight.shape[1], 0, size))
+        for lvl, up in zip((3, 2, 1, 0), (self.up1, self.up2, self.up3, self.up4)):
+            blks = list(up.conv)
+            cout = blks[0].conv1.conv.weight.shape[0]
+            cin_total = blks[0].conv1.conv.weight.shape[1]
+            for i, blk in enumerate(blks):
+                out.append((blk, cout if i == 0 else blk.conv1.conv.weight.shape[1], cin_total - cout if i == 0 else 0, sizes[lvl]))
+        return out
+
+    def _pack_all(self, shape, dt):
+        """Re-order every conv weight into MFMA fragment order with ONE launch (forward + backward buffers)."""
+        N = shape[0]
+        with_bwd = torch.is_grad_enabled()
+        specs, meta = [], []
+        for blk, Ca, Cb, (D, H, W) in self._blocks_with_geometry(shape):
+            tiles_total = ops._L().rsuper_conv3_tiles(D, H, W) * N
+            w1, w2, ws = blk.weights()
+            sp, bns = ops.block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles_total, with_bwd)
+            meta.append((blk, len(specs), len(sp), bns))
+            specs += sp
+        with torch.no_grad():
+            bufs = ops.pack_weights_batch(dt, specs)
+        for blk, i0, k, bns in meta:
+            blk._packs = (bufs[i0:i0 + k], bns)
+
     def forward(self, x):
         if not x.is_cuda:
             raise _lib.RSuperHipError('rsuper_amd UNet runs on MI355X only (no CPU fallback); move the input to cuda')
         _lib.require_device()
         dt = self._dtype()
+        # Batched packing (one launch for all layers) is opt-in: measured SLOWER (+1.2 ms/step) than packing each layer
+        # right before its convolution, because fragments packed up front are cold in L2/MALL when finally used.
+        batch_pack = os.environ.get('RSUPER_BATCH_PACK', '0') == '1'
+        if batch_pack:
+            self._pack_all(tuple(x.shape), dt)
         x1, m1 = self.inc(x, dt)
         x2, m2 = self.down1(x1, m1)
         x3, m3 = self.down2(x2, m2)
@@ -64,4 +108,7 @@ class UNet(nn.Module):
         o, mo = self.up3(o, mo, x2, m2)
         o, mo = self.up4(o, mo, x1, m1)
         logits = ops.HeadFn.apply(o, self.outc.weight, self.outc.bias)
+        if batch_pack:
+            for blk, *_ in self._blocks_with_geometry(tuple(x.shape)):
+                blk._packs = None       # the buffers stay alive in each block's autograd context until backward
         return {'segmentation': logits}
