@@ -166,7 +166,11 @@ int rsuper_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, flo
 int rsuper_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx,
                         int N, int D, int H, int W, int C, void* stream) {
     if (!dt_ok(dtype) || !x || !dy || !dx || !ch_ok(C, ldx) || !ch_ok(C, lddy) || !ch_ok(C, lddx)) return RS_ERR_ARG;
-    if ((D & 1) || (H & 1) || (W & 1)) return RS_ERR_UNSUPPORTED;   // odd sizes leave un-pooled voxels (dx must be 0 there)
+    if ((D & 1) || (H & 1) || (W & 1)) {
+        // MaxPool3d(2) floors odd sizes: the trailing plane/row/column is never pooled and receives zero gradient
+        if (lddx != C) return RS_ERR_UNSUPPORTED;
+        if (hipMemsetAsync(dx, 0, (size_t)N * D * H * W * C * (dtype == RS_F32 ? 4 : 2), ST(stream)) != hipSuccess) return RS_ERR_LAUNCH;
+    }
     PoolParams p = {x, ldx, (void*)dy, lddy, dx, lddx, nullptr, N, D, H, W, C};
     return rs_launch_pool(p, dtype, 1, 1, ST(stream));
 }

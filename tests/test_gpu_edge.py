@@ -1,0 +1,138 @@
+"""GPU edge cases: odd / ragged spatial sizes, batch 1, the 128^3 / 42-class shape of BASELINE config 5, empty report
+information, and the reference's error behaviour (ValueError / AssertionError / NotImplementedError, never a fallback)."""
+import argparse
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import synth  # noqa: E402
+import gpu_checks as gc  # noqa: E402
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def native():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need an MI355X; the product path has no CPU fallback')
+    from rsuper_amd.hip import lib
+    lib.require_device()
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(7, 9, 11), (5, 4, 17), (2, 2, 2), (3, 16, 33)])
+def test_conv_ragged_sizes(mode, shape):
+    """Spatial sizes that are not multiples of the 4x4x16 tile (partial tiles on every axis, single voxel)."""
+    r = gc.check_conv_fwd(mode, 1, shape, 8, 8, 16, True, False, seed=hash(shape) % 97)
+    assert r['ok'], r
+    r = gc.check_conv_bwd(mode, 1, shape, 16, 0, 8, True, seed=hash(shape) % 89)
+    assert r['ok'], r
+
+
+def test_maxpool_odd_sizes_match_torch():
+    from rsuper_amd.hip import ops
+    x = torch.randn((1, 8, 7, 9, 5))
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool3d(xr, 2)
+    go = torch.randn_like(y)
+    y.backward(go)
+    xc = gc.to_cl(x, torch.float32).requires_grad_(True)
+    yo, _ = ops.MaxPoolFn.apply(xc)
+    yo.backward(gc.to_cl(go, torch.float32))
+    assert torch.allclose(gc.from_cl(yo.detach()), y.detach(), atol=1e-6)
+    assert torch.allclose(gc.from_cl(xc.grad), xr.grad, atol=1e-6)
+
+
+def test_unet_batch1_and_config5_shape():
+    """B=1, 128^3, 42 classes (BASELINE config 5 shape) runs forward+backward in bf16 with finite values."""
+    from rsuper_amd.model.dim3.unet import UNet
+    torch.manual_seed(0)
+    net = UNet(1, 32, num_classes=42, compute_dtype='bf16').to(DEV)
+    img = torch.from_numpy(synth.image(1, 128, seed=3)).to(DEV)
+    y = net(img)['segmentation']
+    assert y.shape == (1, 42, 128, 128, 128) and bool(torch.isfinite(y).all())
+    y.square().mean().backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
+def _args(**kw):
+    d = dict(loss='ball_dice_both', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1, volume_loss_tolerance=0.2,
+             ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+             classification_branch=False)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_calculate_loss_error_behaviour():
+    from rsuper_amd.training import losses_foundation as lf
+    classes = synth.TINY_CLASSES
+    S = 16
+    bt = synth.batch(2, S, classes, ['mask', 'report'], seed=7, diam_range=(4.0, 6.0))
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in bt.items()}
+    lg = torch.from_numpy(synth.logits(2, len(classes), S, seed=1)).to(DEV).requires_grad_(True)
+    # inconsistent report sample: segment mask set but unk all zero (losses_foundation.py:866-867)
+    with pytest.raises(ValueError, match='unk_voxels should not be all zeros'):
+        lf.calculate_loss({'segmentation': lg}, t['label'], torch.zeros_like(t['unk_channels']), _args(), None, t['mask'], t['volumes'],
+                          t['diameters'], classes)
+    # ... or no report volume (:868-869)
+    with pytest.raises(ValueError, match='tumor_volumes_report should not be all zeros'):
+        lf.calculate_loss({'segmentation': lg}, t['label'], t['unk_channels'], _args(), None, t['mask'], torch.zeros_like(t['volumes']),
+                          t['diameters'], classes)
+    # wrong class list length (:872)
+    with pytest.raises(AssertionError):
+        lf.calculate_loss({'segmentation': lg}, t['label'], t['unk_channels'], _args(), None, t['mask'], t['volumes'], t['diameters'], classes[:-1])
+    # NaN guard (:1070-1071)
+    bad = lg.detach().clone()
+    bad[0, 0, 0, 0, 0] = float('nan')
+    with pytest.raises(ValueError, match='loss is nan'):
+        lf.calculate_loss({'segmentation': bad.requires_grad_(True)}, t['label'], t['unk_channels'], _args(report_volume_loss_basic=0.0), None,
+                          t['mask'], t['volumes'], t['diameters'], classes)
+    # baselines outside the accelerated path are rejected loudly, not emulated
+    with pytest.raises(NotImplementedError):
+        lf.calculate_loss({'segmentation': lg}, t['label'], t['unk_channels'], _args(), None, t['mask'], t['volumes'], t['diameters'], classes,
+                          model_genesis=True)
+
+
+def test_calculate_loss_without_lesion_classes_and_without_unk():
+    """No lesion channel in the class list -> only the segmentation term ('report' key, as the reference's scalar path);
+    unk_voxels=None -> every voxel known."""
+    from rsuper_amd.training import losses_foundation as lf
+    from oracle import losses_oracle as lo
+    classes = ['kidney_left', 'kidney_right', 'pancreas']
+    S = 16
+    g = synth.rng(5)
+    label = torch.from_numpy((g.random((2, 3, S, S, S)) < 0.2).astype(np.uint8))
+    lg = torch.from_numpy(synth.logits(2, 3, S, seed=2))
+    x = lg.to(DEV).requires_grad_(True)
+    res = lf.calculate_loss({'segmentation': x}, label.to(DEV), None, _args(report_volume_loss_basic=0.0), None, None,
+                            torch.zeros(2, 10, device=DEV), torch.zeros(2, 10, 3, device=DEV), classes)
+    res['overall'].backward()
+    ref = lo.calculate_loss({'segmentation': lg.clone().requires_grad_(True)}, label, torch.zeros_like(label), _args(report_volume_loss_basic=0.0),
+                            torch.zeros_like(label), torch.zeros(2, 10), torch.zeros(2, 10, 3), classes)
+    assert set(res) == {'segmentation', 'report', 'overall'}
+    assert abs(float(res['overall'].detach()) - float(ref['overall'].detach())) < 1e-4
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """Checkpoint dict keys of train_ddp.py:184-189; plain state_dicts that load back (and into a fresh module)."""
+    from rsuper_amd.model.dim3.unet import UNet
+    from rsuper_amd.train_ddp import save_checkpoint, load_checkpoint, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    net = UNet(1, 8, num_classes=5).to(DEV)
+    ema = make_ema(net)
+    opt = FusedAdamWEMA(net.parameters())
+    net(torch.from_numpy(synth.image(1, 32)).to(DEV))['segmentation'].mean().backward()
+    opt.fused_step(max_norm=1.0, ema_params=list(ema.parameters()), ema_alpha=0.0)
+    path = str(tmp_path / 'fold_0_latest.pth')
+    save_checkpoint(path, 3, net, ema, opt)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(ck) == {'epoch', 'model_state_dict', 'ema_model_state_dict', 'optimizer_state_dict'} and ck['epoch'] == 4
+    net2 = UNet(1, 8, num_classes=5).to(DEV)
+    assert load_checkpoint(path, net2, make_ema(net2), FusedAdamWEMA(net2.parameters())) == 4
+    for a, b in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(a, b)
