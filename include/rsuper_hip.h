@@ -59,11 +59,20 @@ int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, cons
 /* Number of 4x4x16 output tiles per sample == rows of the per-block partial-sum buffer. */
 int rsuper_conv3_tiles(int D, int H, int W);
 
+/* Kernel variant of rsuper_conv3_igemm: 0 = classic one-tile-per-block kernel (always used for f32), 1 = wave-specialised
+ * producer/consumer persistent kernel (bf16), 2 (default) = per-launch choice between the two.  v < 0 queries.
+ * Returns the variant in effect. */
+int rsuper_conv3_variant(int v);
+
+/* Rows per sample of the `part` buffer rsuper_conv3_igemm(dtype, epi, ..., bn, N, D, H, W) writes under the current
+ * variant (classic: one row per tile; producer/consumer: one row per (tile, consumer wave row)). */
+int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int bn);
+
 /* Implicit-GEMM convolution.  epi 0: forward  y = conv(prologue(x)) [+ res]; part <- per-tile (sum, sumsq) of y.
  *                             epi 1: data gradient g = conv(dy, flipped w) * [x_hat > 0]; part <- (sum g, sum g*x_n),
  *                                    where x_hat/x_n come from the forward inputs (ex*, with their mean/rstd emr*).
  * mra/mrb: [N][C][2] (mean, rstd) -> fused InstanceNorm(eps=1e-4)+ReLU prologue (conv_layers.py:40-43); NULL = raw.
- * part:    [N][tiles][n_cols][2] f32 or NULL. */
+ * part:    [N][rsuper_conv3_part_rows][n_cols][2] f32 or NULL. */
 int rsuper_conv3_igemm(int dtype, int epi,
                        const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,

@@ -102,6 +102,23 @@ int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, cons
 
 int rsuper_conv3_tiles(int D, int H, int W) { return ((D + 3) / 4) * ((H + 3) / 4) * ((W + 15) / 16); }
 
+static int g_variant = 2;
+int rsuper_conv3_variant(int v) {
+    if (v >= 0 && v <= 2) g_variant = v;
+    return g_variant;
+}
+// variant 2 (auto, default): producer/consumer kernel where it measured faster on MI355X -- data-gradient launches with
+// bn <= 64 (its epilogue operand prefetch) and small grids (persistent blocks fill the chip); classic kernel elsewhere.
+static bool use_pc(int dtype, int epi, int bn, int tiles_total) {
+    if (dtype != RS_BF16) return false;
+    if (g_variant == 2) return bn <= 64 && (epi == 1 || tiles_total <= 1024);
+    return g_variant == 1;
+}
+
+int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int bn) {
+    return rs_igemm_part_rows(bn, use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0, rsuper_conv3_tiles(D, H, W));
+}
+
 int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,
                        const void* packed, int n_cols, int bn, int N, int D, int H, int W,
@@ -123,6 +140,7 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     p.out = out; p.ldo = ldo; p.res = res; p.ldr = ldr; p.part = part;
     p.ea = {exa, elda, eCa, emra};
     p.eb = {exb, eldb, eCb, emrb};
+    p.pc = use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0;
     return rs_launch_igemm(p, dtype, epi, ST(stream));
 }
 

@@ -344,6 +344,381 @@ __global__ __launch_bounds__(256, (MF * NF <= 4 && sizeof(T) == 2) ? 3 : 2) void
     }
 }
 
+// =====================================================================================================================
+// Producer / consumer (wave-specialised) persistent variant.
+//   512 threads: waves 0-3 = consumers (MFMA + wave-private epilogue), waves 4-7 = producers (global loads, norm+ReLU,
+//   LDS writes).  Each SIMD hosts one consumer and one producer wave, so the producers' VALU/VMEM/LDS-write work overlaps
+//   the consumers' MFMAs every cycle instead of alternating with them behind barriers.  Two halo buffers; ONE block
+//   barrier per item (item = K chunk of a tile); blocks are persistent over spatial tiles of one sample so the producer
+//   runs ahead across tile boundaries (its loads for item i+2 are in flight while it commits item i+1).
+//   The epilogue needs no cross-wave exchange: every consumer wave transposes its own fragments through a private LDS
+//   scratch and writes per-(tile, wm) partial statistics.
+// =====================================================================================================================
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int MF, int NF> struct PcCfg {
+    static constexpr int SCR_ROW = 32 * NF + 4;                       // floats per scratch row
+    static constexpr int SCR_BYTES = 32 * SCR_ROW * 4;                // per consumer wave (one fragment row-block)
+};
+
+template <typename T, int WM, int MF, int WN, int NF, int EPI>
+__global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KC = Elem<T>::KC;
+    constexpr int KP = Elem<T>::KP;
+    constexpr int BN32 = WN * NF;
+    static_assert(WM * WN == 4 && WM * MF == 8, "4 consumer waves cover 256 voxels x BN columns");
+    char* bufs = smem;                                                // 2 x HALO_BYTES
+    float* mr_lds = (float*)(smem + 2 * HALO_BYTES);                  // [Ca + Cb][2]
+    char* scr_base = smem + 2 * HALO_BYTES + ((p.a.C + p.b.C) * 8 + 15) / 16 * 16;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int n = blockIdx.z;
+    const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH, tiles_d = (p.D + TD - 1) / TD;
+    const int tiles = tiles_w * tiles_h * tiles_d;
+    const int nchA = (p.a.C + KC - 1) / KC, nchB = (p.b.C + KC - 1) / KC;
+    const int nch = nchA + nchB;
+    const bool normA = p.a.mr != nullptr, normB = p.b.mr != nullptr;
+    const int my_tiles = ((int)blockIdx.x < tiles) ? (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nitems = my_tiles * nch;
+
+    if (normA) for (int i = tid; i < 2 * p.a.C; i += 512) mr_lds[i] = p.a.mr[(size_t)n * 2 * p.a.C + i];
+    if (normB) for (int i = tid; i < 2 * p.b.C; i += 512) mr_lds[2 * p.a.C + i] = p.b.mr[(size_t)n * 2 * p.b.C + i];
+    __syncthreads();
+
+    auto tile_origin = [&](int k, int& d0, int& h0, int& w0) {
+        int t = (int)blockIdx.x + k * (int)gridDim.x;
+        const int tw = t % tiles_w; t /= tiles_w;
+        const int th = t % tiles_h; t /= tiles_h;
+        d0 = t * TD; h0 = th * TH; w0 = tw * TW;
+    };
+
+    if (producer) {
+        // ------------------------------------------------------------------ producer waves
+        const int ptid = tid - 256;
+        const int slot = ptid & 3;
+        const uint32_t nvox_total = (uint32_t)(p.N * p.D * p.H * p.W);
+        int vi[NVEC];
+        uint4 preA[NVEC], preB[NVEC];                                 // two items in flight (global latency >> one item of MFMA work)
+        uint32_t vmA = 0, vmB = 0;                                    // validity of the vectors held in preA / preB
+        int vi_tile = -1;
+        auto setup_tile = [&](int k) {
+            if (k == vi_tile) return;
+            vi_tile = k;
+            int d0, h0, w0;
+            tile_origin(k, d0, h0, w0);
+#pragma unroll
+            for (int i = 0; i < NVEC; ++i) {
+                const int r = (ptid >> 2) + 64 * i;
+                const int hd = r / (HH * HW);
+                const int rem = r - hd * (HH * HW);
+                const int hh = rem / HW, hw = rem - hh * HW;
+                const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+                const bool ok = r < HROWS && d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W;
+                vi[i] = ok ? ((n * p.D + d) * p.H + h) * p.W + w : -1;
+            }
+        };
+        auto issue = [&](int it, uint4* pre, uint32_t& vmask_pre) {
+            setup_tile(it / nch);
+            const int ch = it % nch;
+            const bool isB = ch >= nchA;
+            const ConvSrc& src = isB ? p.b : p.a;
+            const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
+            const uint32_t rowb = (uint32_t)src.ld * (uint32_t)sizeof(T);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src.x, 0, nvox_total * rowb, 0x00020000);
+            const uint32_t cb = c < src.C ? (uint32_t)c * (uint32_t)sizeof(T) : 0xFFFFFFFFu;
+            vmask_pre = 0;
+#pragma unroll
+            for (int i = 0; i < NVEC; ++i) {
+                const bool ok = vi[i] >= 0 && cb != 0xFFFFFFFFu;
+                const uint32_t off = ok ? (uint32_t)vi[i] * rowb + cb : 0xFFFFFFFFu;
+                const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                pre[i] = make_uint4(q[0], q[1], q[2], q[3]);
+                vmask_pre |= ok ? (1u << i) : 0u;
+            }
+        };
+        auto commit = [&](int it, const uint4* pre, const uint32_t vmask_pre) {   // writes item `it` (held in pre) into buffer it & 1
+            const int ch = it % nch;
+            const bool isB = ch >= nchA;
+            const ConvSrc& src = isB ? p.b : p.a;
+            const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
+            const bool norm = (isB ? normB : normA) && c < src.C;
+            float sc_[KP], nb_[KP];
+            if (norm) {
+                const float* mr = mr_lds + 2 * ((isB ? p.a.C : 0) + c);
+#pragma unroll
+                for (int j = 0; j < KP; ++j) { sc_[j] = mr[2 * j + 1]; nb_[j] = -mr[2 * j] * mr[2 * j + 1]; }
+            }
+            char* lds_st = bufs + (it & 1) * HALO_BYTES + (ptid >> 2) * PITCH + slot * 16;
+#pragma unroll
+            for (int i = 0; i < NVEC; ++i) {
+                uint4 q = pre[i];
+                if (norm && ((vmask_pre >> i) & 1u)) {
+                    float f[KP];
+                    unpack16<T>(q, f);
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) f[j] = fmaxf(fmaf(f[j], sc_[j], nb_[j]), 0.f);
+                    q = pack16<T>(f);
+                }
+                if ((ptid >> 2) + 64 * i < HROWS) *(uint4*)(lds_st + i * (64 * PITCH)) = q;
+            }
+        };
+        // items alternate between the register sets: even items in A, odd items in B
+        if (nitems > 0) { issue(0, preA, vmA); commit(0, preA, vmA); }
+        if (nitems > 1) issue(1, preB, vmB);
+        if (nitems > 2) issue(2, preA, vmA);
+        __syncthreads();                                              // item 0 visible
+        for (int it = 0; it < nitems; it += 2) {
+            if (it + 1 < nitems) {
+                commit(it + 1, preB, vmB);                            // loads were issued two items ago
+                if (it + 3 < nitems) issue(it + 3, preB, vmB);
+            }
+            __syncthreads();
+            if (it + 1 < nitems) {
+                if (it + 2 < nitems) {
+                    commit(it + 2, preA, vmA);
+                    if (it + 4 < nitems) issue(it + 4, preA, vmA);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ consumer waves
+        const int wm = wave / WN, wn = wave % WN;
+        int hs, wl;
+        row_to_hw(lane & 31, hs, wl);
+        const int a_base0 = (((wm * MF / 2) * HH + hs) * HW + wl) * PITCH + (lane >> 5) * 16;
+        auto a_const = [](int mf) { return (((mf >> 1) * HH + (mf & 1) * 2) * HW) * PITCH; };
+        const uint4* wp = (const uint4*)p.wp;
+        const int ntile0 = blockIdx.y * BN32 + wn * NF;
+        const size_t wstep = (size_t)p.ntiles * 64;
+        float* scr = (float*)(scr_base + wave * PcCfg<MF, NF>::SCR_BYTES);
+        constexpr int SROW = PcCfg<MF, NF>::SCR_ROW;
+        // epilogue thread mapping inside the wave: 16-byte column groups x rows
+        constexpr int CGW = 32 * NF / KP;                             // column groups of this wave's 32*NF columns
+        constexpr int RPW = 64 / CGW;                                 // rows covered per pass
+        const int cg = lane % CGW, er0 = lane / CGW;
+        const int col0 = (ntile0 * 32) + cg * KP;                     // first output column of this lane's vectors
+        const bool cok = col0 < p.Cout;
+        const uint32_t nvox_total = (uint32_t)(p.N * p.D * p.H * p.W);
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, nvox_total * (uint32_t)p.ldo * (uint32_t)sizeof(T), 0x00020000);
+        const bool useb = EPI == 1 && col0 >= p.ea.C;                  // select VALUES once (a reference into kernarg would be re-read per use)
+        const T* es_x = (const T*)(useb ? p.eb.x : p.ea.x);
+        const uint32_t es_ld = (uint32_t)(useb ? p.eb.ld : p.ea.ld);
+        const int es_C = useb ? p.eb.C : p.ea.C;
+        const float* es_mr = useb ? p.eb.mr : p.ea.mr;
+        const int ecol0 = useb ? col0 - p.ea.C : col0;
+        float emu[KP], ers[KP];
+        if (EPI == 1 && cok) {
+#pragma unroll
+            for (int j = 0; j < KP; ++j) { emu[j] = es_mr[((size_t)n * es_C + ecol0 + j) * 2]; ers[j] = es_mr[((size_t)n * es_C + ecol0 + j) * 2 + 1]; }
+        }
+
+        f32x16_t acc[MF][NF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+        // epilogue operand (residual / forward input of the ReLU mask) is prefetched one fragment ahead; the first
+        // fragment's vectors are requested before the last chunk's MFMA loop so their latency hides behind it
+        constexpr int NPS = 32 / RPW;
+        constexpr bool need_ld = EPI != 0;
+        constexpr bool PRE = NF == 1;                                 // register budget: the 128-column config loads at fragment start instead
+        uint4 ev[PRE ? 2 : 1][NPS];
+        auto epi_vox = [&](int d0, int h0, int w0, bool inb, int mf, int ps, uint32_t& vox) {
+            const int f = wm * MF + mf;
+            int rhs, rw;
+            row_to_hw(er0 + ps * RPW, rhs, rw);
+            const int d = d0 + (f >> 1), h = h0 + (f & 1) * 2 + rhs, w = w0 + rw;
+            vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
+            return cok && (inb || (d < p.D && h < p.H && w < p.W));
+        };
+        auto epi_load = [&](int d0, int h0, int w0, bool inb, int mf, uint4* dst) {
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                uint32_t vox;
+                const bool ok = epi_vox(d0, h0, w0, inb, mf, ps, vox);
+                // branch-free (address select): divergent branches around VMEM make the compiler fall back to vmcnt(0)
+                const T* ptr = EPI == 1 ? (ok ? es_x + (size_t)(vox * es_ld + (uint32_t)ecol0) : (const T*)p.ea.x)
+                                        : (const T*)p.res + (ok ? (size_t)(vox * (uint32_t)p.ldr + (uint32_t)col0) : (size_t)0);
+                dst[ps] = *(const uint4*)ptr;
+            }
+        };
+        constexpr int AU = 2;
+        constexpr int G = MF / AU;
+        constexpr int NSTEP = 54;
+        constexpr int ADIST = NF == 1 ? 3 : 2, AR = ADIST + 1;        // A-operand ring / prefetch distance in units (one MFMA wave per SIMD:
+        constexpr int RB = (NF == 1) ? (G == 1 ? 18 : 9) : 3;  // latency must be covered by distance, not by other waves)
+        static_assert(NSTEP % RB == 0, "the B ring continues across items: its size must divide the steps per item");
+        auto tap_off = [&](int tap) {
+            const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
+            return ((kd * HH + kh) * HW + kw) * PITCH;
+        };
+        // B fragments: buffer loads with a per-lane VGPR offset (lane * 16) and wave-uniform SGPR step offsets -> no VGPR addresses
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7FFFFFFF, 0x00020000);
+        const uint32_t wstep16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wstep * 16));
+        const uint32_t wn_off = (uint32_t)__builtin_amdgcn_readfirstlane(ntile0 * 1024);
+        const uint32_t lane16 = (uint32_t)lane * 16u;
+        auto load_b_at = [&](uint32_t chbase, int st, uint4* dst) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const auto q = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + nf * 1024, chbase + (uint32_t)st * wstep16, 0);
+                dst[nf] = make_uint4(q[0], q[1], q[2], q[3]);
+            }
+        };
+        uint4 bq[RB][NF];
+        uint4 aq[AR][AU];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) load_b_at(wn_off, r, bq[r]);
+        __syncthreads();                                              // item 0 visible
+        for (int it = 0; it < nitems; ++it) {
+            const int ch = it % nch;
+            const char* halo = bufs + (it & 1) * HALO_BYTES;
+            const int a_base = a_base0;
+            const uint32_t cb_cur = wn_off + (uint32_t)__builtin_amdgcn_readfirstlane(ch * 54) * wstep16;
+            const uint32_t cb_nxt = wn_off + (uint32_t)__builtin_amdgcn_readfirstlane((ch + 1 == nch ? 0 : ch + 1) * 54) * wstep16;
+            auto load_b = [&](int st, uint4* dst) {                   // the B stream continues into the next item before the barrier
+                if (st < NSTEP) load_b_at(cb_cur, st, dst); else load_b_at(cb_nxt, st - NSTEP, dst);
+            };
+            auto load_a = [&](int u, uint4* dst) {
+                const int st = u / G, g = u % G;
+                const int off = tap_off(st >> 1) + (st & 1) * 32;
+#pragma unroll
+                for (int i = 0; i < AU; ++i) dst[i] = *(const uint4*)(halo + a_base + a_const(g * AU + i) + off);
+            };
+            int d0 = 0, h0 = 0, w0 = 0;
+            bool inb = false;
+            if (ch == nch - 1) {
+                tile_origin(it / nch, d0, h0, w0);
+                inb = d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;
+                if (need_ld && PRE) epi_load(d0, h0, w0, inb, 0, ev[0]);
+            }
+#pragma unroll
+            for (int u = 0; u < ADIST; ++u) load_a(u, aq[u]);
+#pragma unroll
+            for (int u = 0; u < NSTEP * G; ++u) {
+                const int st = u / G, g = u % G;
+                if (u + ADIST < NSTEP * G) load_a(u + ADIST, aq[(u + ADIST) % AR]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < AU; ++i)
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) mma32<T>(acc[g * AU + i][nf], aq[u % AR][i], bq[st % RB][nf]);
+                if (g == G - 1) load_b(st + RB, bq[st % RB]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            if (ch == nch - 1) {
+                // -------------------------------------------------------------- wave-private epilogue of this tile
+                const int tile_id = (int)blockIdx.x + (it / nch) * (int)gridDim.x;
+                const int hi = lane >> 5, col_l = lane & 31;
+                float s1[KP], s2[KP];
+#pragma unroll
+                for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    if (need_ld && PRE && mf + 1 < MF) epi_load(d0, h0, w0, inb, mf + 1, ev[(mf + 1) & 1]);
+                    if (need_ld && !PRE) epi_load(d0, h0, w0, inb, mf, ev[0]);
+                    // 1) fragment -> scratch, fragment-row major
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf) scr[row * SROW + nf * 32 + col_l] = acc[mf][nf][r];
+                    }
+                    // 2) scratch -> 16-byte vectors (same wave: LDS accesses of one wave are ordered)
+#pragma unroll
+                    for (int ps = 0; ps < NPS; ++ps) {
+                        const int row = er0 + ps * RPW;
+                        float v[KP];
+                        const float4* sp = (const float4*)(scr + row * SROW + cg * KP);
+#pragma unroll
+                        for (int k4 = 0; k4 < KP / 4; ++k4) { const float4 t4 = sp[k4]; v[k4 * 4] = t4.x; v[k4 * 4 + 1] = t4.y; v[k4 * 4 + 2] = t4.z; v[k4 * 4 + 3] = t4.w; }
+                        uint32_t vox;
+                        const bool ok = epi_vox(d0, h0, w0, inb, mf, ps, vox);
+                        {
+                            if (EPI != 1) {
+                                if (EPI == 2) {
+                                    float rr[KP];
+                                    unpack16<T>(ev[PRE ? (mf & 1) : 0][ps], rr);
+#pragma unroll
+                                    for (int q = 0; q < KP; ++q) v[q] += rr[q];
+                                }
+#pragma unroll
+                                for (int q = 0; q < KP; ++q) { v[q] = ok ? Elem<T>::rnd(v[q]) : 0.f; s1[q] += v[q]; s2[q] += v[q] * v[q]; }
+                            } else {
+                                float xx[KP];
+                                unpack16<T>(ev[PRE ? (mf & 1) : 0][ps], xx);
+#pragma unroll
+                                for (int q = 0; q < KP; ++q) {
+                                    const float xn = (xx[q] - emu[q]) * ers[q];
+                                    v[q] = Elem<T>::rnd((ok && xn > 0.f) ? v[q] : 0.f);
+                                    s1[q] += v[q]; s2[q] += v[q] * xn;
+                                }
+                            }
+                            const uint4 pk = pack16<T>(v);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pk), ors,
+                                                                   ok ? (vox * (uint32_t)p.ldo + (uint32_t)col0) * (uint32_t)sizeof(T) : 0xFFFFFFFFu, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);             // keep the scheduler from interleaving all passes (register pressure)
+                    }
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+                }
+                if (p.part) {
+                    // lanes with the same column group hold partial sums: reduce over the RPW row-lanes
+#pragma unroll
+                    for (int q = 0; q < KP; ++q) {
+#pragma unroll
+                        for (int o = CGW; o < 64; o <<= 1) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
+                    }
+                    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, 0x7FFFFFFF, 0x00020000);
+                    const uint32_t poff = (lane < CGW && cok) ? (uint32_t)(((((size_t)n * tiles + tile_id) * WM + wm) * p.Cout + col0) * 8) : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < KP; q += 2) {
+                        u32x4_t pv;
+                        pv[0] = __float_as_uint(s1[q]); pv[1] = __float_as_uint(s2[q]); pv[2] = __float_as_uint(s1[q + 1]); pv[3] = __float_as_uint(s2[q + 1]);
+                        __builtin_amdgcn_raw_buffer_store_b128(pv, prs, poff == 0xFFFFFFFFu ? poff : poff + q * 8, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T, int WM, int MF, int WN, int NF>
+int launch_pc(const IgemmParams& p, int epi, hipStream_t st) {
+    const int tiles = ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    const int gy = p.ntiles / (WN * NF);
+    int gx = 256 / (gy * p.N > 0 ? gy * p.N : 1);                     // ~one persistent block per CU
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    dim3 grid(gx, gy, p.N), block(512);
+    const size_t smem = 2 * (size_t)HALO_BYTES + (((size_t)(p.a.C + p.b.C) * 8 + 15) / 16) * 16 + 4 * (size_t)PcCfg<MF, NF>::SCR_BYTES;
+    if (smem > 160 * 1024) return RS_ERR_UNSUPPORTED;
+    if (epi == 0 && p.res) {
+        auto k = igemm_pc_kernel<T, WM, MF, WN, NF, 2>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    } else if (epi == 0) {
+        auto k = igemm_pc_kernel<T, WM, MF, WN, NF, 0>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    } else {
+        auto k = igemm_pc_kernel<T, WM, MF, WN, NF, 1>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    }
+    return rs_check_launch();
+}
+
 template <typename T, int WM, int MF, int WN, int NF, int KSPLIT = 1>
 int launch_cfg(const IgemmParams& p, int epi, hipStream_t st) {
     const int tiles = ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
@@ -439,7 +814,18 @@ __device__ __forceinline__ void pack_one(const PackParams& q, T* out, size_t idx
 
 }  // namespace
 
+int rs_igemm_part_rows(int bn, int pc, int tiles) { return pc ? tiles * (bn == 32 ? 4 : 2) : tiles; }
+
 int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st) {
+    if (dtype == RS_BF16 && p.pc) {
+        if (p.ntiles % (p.bn / 32)) return RS_ERR_ARG;
+        switch (p.bn) {
+            case 32: return launch_pc<bf16_t, 4, 2, 1, 1>(p, epi, st);
+            case 64: return launch_pc<bf16_t, 2, 4, 2, 1>(p, epi, st);
+            case 128: return launch_pc<bf16_t, 2, 4, 2, 2>(p, epi, st);
+        }
+        return RS_ERR_ARG;
+    }
     if (dtype == RS_F32) return launch_dt<float>(p, epi, st);
     if (dtype == RS_BF16) return launch_dt<bf16_t>(p, epi, st);
     return RS_ERR_ARG;

@@ -21,7 +21,8 @@ struct IgemmParams {
     int Cout;              // valid GEMM-N columns
     void* out; int ldo;
     const void* res; int ldr;   // EPI 0: optional residual added before store
-    float* part;           // per-block partial sums [N][tiles][Cout][2] or nullptr
+    float* part;           // per-block partial sums [N][rows][Cout][2] or nullptr (rows = rs_igemm_part_rows)
+    int pc;                // 1: producer/consumer persistent kernel (bf16)
     ConvSrc ea, eb;        // EPI 1: forward inputs (with mr) whose relu mask / x_n the data-gradient needs
 };
 
@@ -50,6 +51,7 @@ struct PackBatch {
 };
 int rs_launch_pack_batch(const PackBatch& b, int dtype, void* out, hipStream_t st);
 int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st);
+int rs_igemm_part_rows(int bn, int pc, int tiles);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st);

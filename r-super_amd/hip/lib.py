@@ -21,6 +21,8 @@ _SIGS = {
     'rsuper_conv3_pack_weights': (c_int, [c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     'rsuper_conv3_pack_weights_batch': (c_int, [c_int, c_int, P, P, P, P, P, P]),
     'rsuper_conv3_tiles': (c_int, [c_int] * 3),
+    'rsuper_conv3_variant': (c_int, [c_int]),
+    'rsuper_conv3_part_rows': (c_int, [c_int] * 7),
     'rsuper_conv3_igemm': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                    P, c_int, P, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, P]),
     'rsuper_conv3_wgrad': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int,
@@ -72,6 +74,8 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)      # AttributeError here == header/library mismatch
             fn.restype, fn.argtypes = res, args
+        if 'RSUPER_IGEMM_VARIANT' in os.environ:      # 0 = classic kernel, 1 = producer/consumer persistent kernel, 2 = per-launch choice (default)
+            L.rsuper_conv3_variant(int(os.environ['RSUPER_IGEMM_VARIANT']))
         _LIB = L
     return _LIB
 

@@ -61,6 +61,15 @@ def _chk_act(x):
     assert x.dim() == 5 and x.is_contiguous() and x.dtype in _DT and x.shape[-1] % 8 == 0, (x.shape, x.dtype, x.is_contiguous())
 
 
+def part_buffer(dtype, dims, n_cols, bn, device, fill=None, epi=0):
+    """Per-block partial-sum buffer (N, rows, n_cols, 2) in the shape rsuper_conv3_igemm(epi, ...) writes for this dtype/bn."""
+    N, D, H, W = dims
+    rows = _L().rsuper_conv3_part_rows(_DT[dtype], epi, N, D, H, W, bn)
+    if fill is None:
+        return torch.empty((N, rows, n_cols, 2), device=device, dtype=torch.float32)
+    return torch.full((N, rows, n_cols, 2), fill, device=device, dtype=torch.float32)
+
+
 def stats_finalize(part, cnt, mode=0):
     """part (N, nblk, C, 2) f32 -> (N, C, 2)."""
     N, nblk, C, _ = part.shape
@@ -301,7 +310,7 @@ class BasicBlockFn(torch.autograd.Function):
             bn1 = pick_bn(nc1, dt, tiles * N)
             wp1 = pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if has_sc else 0, bn1)
         ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
-        part = torch.empty((N, tiles, nc1, 2), device=dev, dtype=torch.float32)
+        part = part_buffer(dt, dims, nc1, bn1, dev)
         igemm(0, sa, sb, wp1, nc1, bn1, dims, ys, part=part)
         mr_ys = stats_finalize(part, cnt)
         mr_y1 = mr_ys[:, :Cout].contiguous() if has_sc else mr_ys
@@ -312,7 +321,7 @@ class BasicBlockFn(torch.autograd.Function):
             bn2 = pick_bn(Cout, dt, tiles * N)
             wp2 = pack_weights(dt, 0, w2, None, Cout, 0, Cout, 0, bn2)
         out = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
-        part2 = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
+        part2 = part_buffer(dt, dims, Cout, bn2, dev)
         res = Src(ys, C=Cout, off=Cout) if has_sc else Src(xa)
         igemm(0, Src(ys, C=Cout, mr=mr_y1), None, wp2, Cout, bn2, dims, out, res=res, part=part2)
         mr_out = stats_finalize(part2, cnt)
@@ -342,7 +351,7 @@ class BasicBlockFn(torch.autograd.Function):
             bn = pick_bn(Cout, dt, tiles * N)
             wpd2 = pack_weights(dt, 1, w2, None, Cout, 0, Cout, 0, bn)
         g1 = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
-        part = torch.empty((N, tiles, Cout, 2), device=dev, dtype=torch.float32)
+        part = part_buffer(dt, dims, Cout, bn, dev, epi=1)
         igemm(1, sdo, None, wpd2, Cout, bn, dims, g1, part=part, ea=y1)
         gm1 = stats_finalize(part, cnt, mode=1)
         ov = overlap_enabled()
@@ -359,7 +368,7 @@ class BasicBlockFn(torch.autograd.Function):
             bn = pick_bn(Cin, dt, tiles * N)
             wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bn)
         g0 = torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
-        part0 = torch.empty((N, tiles, Cin, 2), device=dev, dtype=torch.float32)
+        part0 = part_buffer(dt, dims, Cin, bn, dev, epi=1)
         igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
         gm0 = stats_finalize(part0, cnt, mode=1)
         dw1 = torch.empty_like(w1)

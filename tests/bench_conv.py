@@ -43,7 +43,7 @@ for name, S, Ca, Cb, Cout, sc in LAYERS:
     bn = ops.pick_bn(nc, dt, tiles * N)
     wp = ops.pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if sc else 0, bn)
     out = torch.empty((N, S, S, S, nc), device=dev, dtype=dt)
-    part = torch.empty((N, tiles, nc, 2), device=dev)
+    part = ops.part_buffer(dt, (N, S, S, S), nc, bn, dev)
     t_f = timeit(lambda: ops.igemm(0, sa, sb, wp, nc, bn, dims, out, part=part))
     fl = 2.0 * N * S ** 3 * nc * Cin * 27
     # dgrad
@@ -52,7 +52,7 @@ for name, S, Ca, Cb, Cout, sc in LAYERS:
     bnd = ops.pick_bn(Cin, dt, tiles * N)
     wpd = ops.pack_weights(dt, 1, w1, ws, Cout, Cout if sc else 0, Cin, 0, bnd)
     g0 = torch.empty((N, S, S, S, Cin), device=dev, dtype=dt)
-    partd = torch.empty((N, tiles, Cin, 2), device=dev)
+    partd = ops.part_buffer(dt, (N, S, S, S), Cin, bnd, dev, epi=1)
     t_d = timeit(lambda: ops.igemm(1, ops.Src(dy1), ops.Src(dy2) if sc else None, wpd, Cin, bnd, dims, g0, part=partd, ea=sa, eb=sb))
     # wgrad
     dw1 = torch.zeros_like(w1); dws = torch.zeros_like(ws) if sc else None

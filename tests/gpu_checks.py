@@ -109,8 +109,7 @@ def check_conv_fwd(mode, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, nor
     bn = ops.pick_bn(nc, dt)
     wp = ops.pack_weights(dt, 0, w1.to(DEV), ws.to(DEV) if ws is not None else None, Ca, Cb, Cout, Cout if fused_sc else 0, bn)
     out = torch.empty((N, D, H, W, nc), device=DEV, dtype=dt)
-    tiles = ops._L().rsuper_conv3_tiles(D, H, W)
-    part = torch.full((N, tiles, nc, 2), float('nan'), device=DEV)
+    part = ops.part_buffer(dt, (N, D, H, W), nc, bn, DEV, fill=float('nan'))
     a = ops.Src(to_cl(xa, dt), mr=mra)
     b = ops.Src(to_cl(xb, dt), mr=mrb) if xb is not None else None
     r = ops.Src(to_cl(res, dt)) if residual else None
@@ -165,8 +164,7 @@ def check_conv_bwd(mode, N, S, Ca, Cb, Cout, fused_sc, seed=0, tr=None):
     bn = ops.pick_bn(Cin, dt)
     wp = ops.pack_weights(dt, 1, w1.to(DEV), ws.to(DEV) if ws is not None else None, Cout, Cout if fused_sc else 0, Cin, 0, bn)
     g0 = torch.empty((N, D, H, W, Cin), device=DEV, dtype=dt)
-    tiles = ops._L().rsuper_conv3_tiles(D, H, W)
-    part = torch.full((N, tiles, Cin, 2), float('nan'), device=DEV)
+    part = ops.part_buffer(dt, (N, D, H, W), Cin, bn, DEV, fill=float('nan'), epi=1)
     ops.igemm(1, y1, y2, wp, Cin, bn, (N, D, H, W), g0, part=part, ea=sa, eb=sb)
     gm = ops.stats_finalize(part, D * H * W, mode=1)
     if xb is None:
@@ -559,6 +557,19 @@ def check_train_steps(mode='f32'):
 
 
 # ================================================================================================ registry
+def with_variant(variant, fn, *a):
+    """Run a conv check under a forced igemm kernel variant (0 classic, 1 producer/consumer); restores the default (2 = auto)."""
+    from rsuper_amd.hip import ops
+    L = ops._L()
+    L.rsuper_conv3_variant(variant)
+    try:
+        r = fn(*a)
+    finally:
+        L.rsuper_conv3_variant(2)
+    r['name'] = f"v{variant}:{r['name']}"
+    return r
+
+
 def all_checks(quick=False):
     cs = []
     for mode in ('f32', 'bf16'):
@@ -580,6 +591,12 @@ def all_checks(quick=False):
             (check_basic_block, (mode, 'b24_8', 24, 8, 12, 3)),
             (check_unet_tiny, (mode,)),
         ]
+    for variant in (0, 1):              # both bf16 igemm kernels on every conv case (the default picks per launch)
+        cs += [(with_variant, (variant, fn) + a) for fn, a in list(cs) if fn in (check_conv_fwd, check_conv_bwd) and a[0] == 'bf16']
+    cs += [(with_variant, (1, check_conv_fwd, 'bf16', 2, (8, 24, 32), 32, 0, 32, False, True)),       # persistent: several tiles per block
+           (with_variant, (1, check_conv_fwd, 'bf16', 1, (12, 20, 48), 64, 64, 128, True, False)),    # 128 columns, 4 chunks, 2 sources
+           (with_variant, (1, check_conv_bwd, 'bf16', 2, (8, 24, 32), 64, 64, 64, True)),
+           (with_variant, (1, check_conv_bwd, 'bf16', 1, (12, 20, 48), 128, 0, 128, False))]
     cs += [(check_conv_bwd, ('bf16', 1, (4, 4, 16), 32, 0, 32, False, 0, 0)), (check_conv_bwd, ('bf16', 1, (8, 12, 20), 64, 32, 64, True, 0, 0)),
            (check_tr16_probe, ()),
            (check_plane_partials, ()), (check_dilate, ()), (check_isolate_tumor, ()), (check_gwrp, ()), (check_optimizer, ())]
