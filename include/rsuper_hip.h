@@ -64,9 +64,9 @@ int rsuper_conv3_tiles(int D, int H, int W);
  * Returns the variant in effect. */
 int rsuper_conv3_variant(int v);
 
-/* Rows per sample of the `part` buffer rsuper_conv3_igemm(dtype, epi, ..., bn, N, D, H, W) writes under the current
- * variant (classic: one row per tile; producer/consumer: one row per (tile, consumer wave row)). */
-int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int bn);
+/* Rows per sample of the `part` buffer rsuper_conv3_igemm(dtype, epi, ..., n_cols, bn, N, D, H, W) writes under the
+ * current variant (classic: one row per tile; producer/consumer: one row per (persistent block, consumer wave row)). */
+int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn);
 
 /* Implicit-GEMM convolution.  epi 0: forward  y = conv(prologue(x)) [+ res]; part <- per-tile (sum, sumsq) of y.
  *                             epi 1: data gradient g = conv(dy, flipped w) * [x_hat > 0]; part <- (sum g, sum g*x_n),
@@ -116,11 +116,13 @@ int rsuper_upsample_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx,
 /* inconv.conv1 = nn.Conv3d(1, C, 3, padding=1, bias=False) -- model/dim3/unet_utils.py:14.  x: [N][D][H][W] f32. */
 int rsuper_stem_fwd(int dtype, const float* x, const float* w, void* y, int ldy, float* part,
                     int N, int D, int H, int W, int C, void* stream);
+/* dw (C,1,3,3,3) f32 is overwritten (per-block partial rows + fixed-order reduce: deterministic, no atomics). */
 int rsuper_stem_wgrad(int dtype, const float* x, const void* dy, int lddy, float* dw, int N, int D, int H, int W, int C, void* stream);
 
 /* outc = nn.Conv3d(C, K, kernel_size=1) with bias -- model/dim3/unet.py:47.  logits: [N][K][vox] f32 (NCDHW). */
 int rsuper_head_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* logits, int N, int vox, int C, int K, void* stream);
 int rsuper_head_bwd_data(int dtype, const float* dlogits, const float* w, void* dx, int lddx, int N, int vox, int C, int K, void* stream);
+/* dw (K,C) and db (K) f32 are overwritten (same reduction scheme as rsuper_stem_wgrad). */
 int rsuper_head_bwd_weight(int dtype, const void* x, int ldx, const float* dlogits, float* dw, float* db, int N, int vox, int C, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

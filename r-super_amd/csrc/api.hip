@@ -115,8 +115,8 @@ static bool use_pc(int dtype, int epi, int bn, int tiles_total) {
     return g_variant == 1;
 }
 
-int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int bn) {
-    return rs_igemm_part_rows(bn, use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0, rsuper_conv3_tiles(D, H, W));
+int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn) {
+    return rs_igemm_part_rows(bn, use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0, rsuper_conv3_tiles(D, H, W), n_cols, N);
 }
 
 int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, const float* mra,

@@ -574,6 +574,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
         uint4 aq[AR][AU];
 #pragma unroll
         for (int r = 0; r < RB; ++r) load_b_at(wn_off, r, bq[r]);
+        float s1[KP], s2[KP];                                         // running statistics over all tiles of this block
+#pragma unroll
+        for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
         __syncthreads();                                              // item 0 visible
         for (int it = 0; it < nitems; ++it) {
             const int ch = it % nch;
@@ -614,11 +617,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
 
             if (ch == nch - 1) {
                 // -------------------------------------------------------------- wave-private epilogue of this tile
-                const int tile_id = (int)blockIdx.x + (it / nch) * (int)gridDim.x;
                 const int hi = lane >> 5, col_l = lane & 31;
-                float s1[KP], s2[KP];
-#pragma unroll
-                for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf) {
                     if (need_ld && PRE && mf + 1 < MF) epi_load(d0, h0, w0, inb, mf + 1, ev[(mf + 1) & 1]);
@@ -671,35 +670,40 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
                 }
-                if (p.part) {
-                    // lanes with the same column group hold partial sums: reduce over the RPW row-lanes
-#pragma unroll
-                    for (int q = 0; q < KP; ++q) {
-#pragma unroll
-                        for (int o = CGW; o < 64; o <<= 1) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
-                    }
-                    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, 0x7FFFFFFF, 0x00020000);
-                    const uint32_t poff = (lane < CGW && cok) ? (uint32_t)(((((size_t)n * tiles + tile_id) * WM + wm) * p.Cout + col0) * 8) : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int q = 0; q < KP; q += 2) {
-                        u32x4_t pv;
-                        pv[0] = __float_as_uint(s1[q]); pv[1] = __float_as_uint(s2[q]); pv[2] = __float_as_uint(s1[q + 1]); pv[3] = __float_as_uint(s2[q + 1]);
-                        __builtin_amdgcn_raw_buffer_store_b128(pv, prs, poff == 0xFFFFFFFFu ? poff : poff + q * 8, 0, 0);
-                    }
-                }
             }
             __syncthreads();
         }
+        // statistics: ONE partial row per (block, wm) -- the block's tiles were accumulated in registers
+        if (p.part) {
+            // lanes with the same column group hold partial sums: reduce over the RPW row-lanes
+#pragma unroll
+            for (int q = 0; q < KP; ++q) {
+#pragma unroll
+                for (int o = CGW; o < 64; o <<= 1) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
+            }
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, 0x7FFFFFFF, 0x00020000);
+            const uint32_t poff = (lane < CGW && cok) ? (uint32_t)(((((size_t)n * gridDim.x + blockIdx.x) * WM + wm) * p.Cout + col0) * 8) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < KP; q += 2) {
+                u32x4_t pv;
+                pv[0] = __float_as_uint(s1[q]); pv[1] = __float_as_uint(s2[q]); pv[2] = __float_as_uint(s1[q + 1]); pv[3] = __float_as_uint(s2[q + 1]);
+                __builtin_amdgcn_raw_buffer_store_b128(pv, prs, poff == 0xFFFFFFFFu ? poff : poff + q * 8, 0, 0);
+            }
+        }
     }
+}
+
+static int pc_grid_x(int tiles, int gy, int N) {                      // ~one persistent block per CU
+    int gx = 256 / (gy * N > 0 ? gy * N : 1);
+    if (gx < 1) gx = 1;
+    return gx > tiles ? tiles : gx;
 }
 
 template <typename T, int WM, int MF, int WN, int NF>
 int launch_pc(const IgemmParams& p, int epi, hipStream_t st) {
     const int tiles = ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const int gy = p.ntiles / (WN * NF);
-    int gx = 256 / (gy * p.N > 0 ? gy * p.N : 1);                     // ~one persistent block per CU
-    if (gx < 1) gx = 1;
-    if (gx > tiles) gx = tiles;
+    const int gx = pc_grid_x(tiles, gy, p.N);
     dim3 grid(gx, gy, p.N), block(512);
     const size_t smem = 2 * (size_t)HALO_BYTES + (((size_t)(p.a.C + p.b.C) * 8 + 15) / 16) * 16 + 4 * (size_t)PcCfg<MF, NF>::SCR_BYTES;
     if (smem > 160 * 1024) return RS_ERR_UNSUPPORTED;
@@ -814,7 +818,11 @@ __device__ __forceinline__ void pack_one(const PackParams& q, T* out, size_t idx
 
 }  // namespace
 
-int rs_igemm_part_rows(int bn, int pc, int tiles) { return pc ? tiles * (bn == 32 ? 4 : 2) : tiles; }
+int rs_igemm_part_rows(int bn, int pc, int tiles, int n_cols, int N) {
+    if (!pc) return tiles;                                            // classic kernel: one row per tile
+    const int gy = (n_cols + bn - 1) / bn;                            // producer/consumer: one row per (persistent block, wm)
+    return pc_grid_x(tiles, gy, N) * (bn == 32 ? 4 : 2);
+}
 
 int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st) {
     if (dtype == RS_BF16 && p.pc) {

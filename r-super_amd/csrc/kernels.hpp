@@ -51,7 +51,7 @@ struct PackBatch {
 };
 int rs_launch_pack_batch(const PackBatch& b, int dtype, void* out, hipStream_t st);
 int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st);
-int rs_igemm_part_rows(int bn, int pc, int tiles);
+int rs_igemm_part_rows(int bn, int pc, int tiles, int n_cols, int N);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st);

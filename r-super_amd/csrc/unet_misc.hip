@@ -370,13 +370,89 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     }
 }
 
+// MFMA variant for C <= 32 (every reference config: base_chan 32): out[c][v] = sum_tap w[c][tap] * x[v + off(tap)] as an
+// exact-f32 v_mfma_f32_32x32x2_f32 chain (14 steps cover the 27 taps + one zero pad).  A = weights (row = channel, held
+// in 14 registers per lane for the whole block), B = gathered input (column = voxel).  A lane ends up with 16 channels
+// of one voxel = four 4-channel groups -> 8-byte (bf16) / 16-byte (f32) stores.  Block = 256 consecutive voxels.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemParams p) {
+    __shared__ float tile[256 * 33];
+    const int C = p.C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = lane & 31, kk = lane >> 5;
+    const int n = blockIdx.y;
+    const int vox = p.D * p.H * p.W;
+    const float* xin = p.x + (size_t)n * vox;
+    float wreg[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int tap = 2 * s + kk;
+        wreg[s] = (idx < C && tap < 27) ? p.w[idx * 27 + tap] : 0.f;
+    }
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int vl = (wave * 2 + gi) * 32 + idx;               // voxel slot inside the block
+        const int v = blockIdx.x * 256 + vl;
+        const bool ok = v < vox;
+        const int x0 = v % p.W, y0 = (v / p.W) % p.H, z0 = v / (p.W * p.H);
+        float xa[14];
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int tap = 2 * s + kk;
+            const int z = z0 + tap / 9 - 1, y = y0 + (tap % 9) / 3 - 1, x = x0 + tap % 3 - 1;
+            xa[s] = (ok && tap < 27 && z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) ? xin[((size_t)z * p.H + y) * p.W + x] : 0.f;
+        }
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[s], xa[s], acc, 0, 0, 0);
+        T* o = (T*)p.y + ((size_t)n * vox + (ok ? v : 0)) * p.ldy;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int c0 = 8 * r4 + 4 * kk;                      // channels c0 .. c0+3 of voxel idx (cd_row32 layout)
+            float q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                q[j] = Elem<T>::rnd(acc[r4 * 4 + j]);
+                tile[vl * 33 + c0 + j] = ok ? q[j] : 0.f;
+            }
+            if (ok && c0 < C) {
+                if (sizeof(T) == 2) {
+                    *(uint2*)(o + c0) = make_uint2(f2bf2(q[0], q[1]), f2bf2(q[2], q[3]));
+                } else {
+                    *(float4*)((float*)o + c0) = make_float4(q[0], q[1], q[2], q[3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // channel-major reduction: thread (g, c) sums 32 voxels; then 8 partials per channel
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    float a = 0.f, b = 0.f;
+    for (int r = g; r < 256; r += 8) { const float t = tile[r * 33 + c]; a += t; b += t * t; }
+    __syncthreads();
+    float* red = tile;                                          // [8][32][2]
+    red[(g * 32 + c) * 2] = a; red[(g * 32 + c) * 2 + 1] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float sa = 0.f, sb = 0.f;
+        for (int k = 0; k < 8; ++k) { sa += red[(k * 32 + threadIdx.x) * 2]; sb += red[(k * 32 + threadIdx.x) * 2 + 1]; }
+        float* pp = p.part + (((size_t)n * gridDim.x + blockIdx.x) * C + threadIdx.x) * 2;
+        pp[0] = sa; pp[1] = sb;
+    }
+}
+
 // Small weight gradients (stem 1->C conv, 1x1x1 head) as an exact-f32 MFMA reduction over voxels:
 //     out[i][j] += sum_v A[v][i] * B[v][j],  i, j < 32,  v_mfma_f32_32x32x2_f32 (lane l: row/col l&31, voxel parity l>>5).
 // A macro-iteration covers 8 voxels: lane half kk owns voxels v0 + 4*kk .. +3 and MFMA e pairs element e of both
 // operands (any voxel order works as long as A and B agree).  MODE 0 = stem: A = dY[v][c], B = x[v + off(tap)];
 // MODE 1 = head: A = dlogits[k][v] (also summed for the bias gradient), B = features[v][c].
+constexpr int SMALL_WS_ROW = 1024 + 32;
+constexpr int SMALL_WS_BLOCKS = 512;
+
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, HeadParams hp, int k0) {
+__global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, HeadParams hp, int k0, float* __restrict__ ws) {
     __shared__ float red[4][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = lane & 31, kk = lane >> 5;
@@ -391,45 +467,85 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
     // stem: tap offset of this lane's column
     int tz = 0, ty = 0, tx = 0;
     if (MODE == 0) { const int tap = idx < 27 ? idx : 0; tz = tap / 9 - 1; ty = (tap % 9) / 3 - 1; tx = tap % 3 - 1; }
-    for (long it = (long)blockIdx.x * 4 + wave; it < items; it += (long)gridDim.x * 4) {
-        const int n = (int)(it / per);
-        const int v0 = (int)(it % per) * 8 + kk * 4;
-        float a[4], b[4];
+    // U macro-iterations are loaded before their MFMAs so U*8 independent loads per lane are in flight (the loop is
+    // latency-bound otherwise: one wave per SIMD-slot, ~100 dependent iterations)
+    constexpr int U = 4;
+    const long stride = (long)gridDim.x * 4;
+    for (long it0 = (long)blockIdx.x * 4 + wave; it0 < items; it0 += stride * U) {
+        float a[U][4], b[U][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int v = v0 + e;
-            const bool ok = v < V;
-            if (MODE == 0) {
-                a[e] = (ok && idx < sp.C) ? Elem<T>::ld((const T*)sp.y + ((size_t)n * V + v) * sp.ldy + idx) : 0.f;
-                const int x0 = v % sp.W, y0 = (v / sp.W) % sp.H, z0 = v / (sp.W * sp.H);
-                const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
-                b[e] = (ok && idx < 27 && z >= 0 && z < sp.D && y >= 0 && y < sp.H && x >= 0 && x < sp.W)
-                           ? sp.x[(size_t)n * V + ((size_t)z * sp.H + y) * sp.W + x] : 0.f;
-            } else {
-                a[e] = (ok && k0 + idx < hp.K) ? hp.logits[((size_t)n * hp.K + k0 + idx) * V + v] : 0.f;
-                b[e] = (ok && idx < hp.C) ? Elem<T>::ld((const T*)hp.x + ((size_t)n * V + v) * hp.ldx + idx) : 0.f;
-                bias_acc += a[e];
+        for (int u = 0; u < U; ++u) {
+            const long it = it0 + u * stride;
+            const bool live = it < items;
+            const int n = live ? (int)(it / per) : 0;
+            const int v0 = live ? (int)(it % per) * 8 + kk * 4 : V;
+            if (MODE == 1 && (V & 3) == 0) {
+                // four consecutive voxels of one class plane: one 16-byte load
+                const bool okp = v0 < V && k0 + idx < hp.K;
+                const float4 q = okp ? *(const float4*)(hp.logits + ((size_t)n * hp.K + k0 + idx) * V + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[u][0] = q.x; a[u][1] = q.y; a[u][2] = q.z; a[u][3] = q.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int v = v0 + e;
+                const bool ok = v < V;
+                if (MODE == 0) {
+                    a[u][e] = (ok && idx < sp.C) ? Elem<T>::ld((const T*)sp.y + ((size_t)n * V + v) * sp.ldy + idx) : 0.f;
+                    const int x0 = v % sp.W, y0 = (v / sp.W) % sp.H, z0 = v / (sp.W * sp.H);
+                    const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+                    b[u][e] = (ok && idx < 27 && z >= 0 && z < sp.D && y >= 0 && y < sp.H && x >= 0 && x < sp.W)
+                                  ? sp.x[(size_t)n * V + ((size_t)z * sp.H + y) * sp.W + x] : 0.f;
+                } else {
+                    if ((V & 3) != 0) a[u][e] = (ok && k0 + idx < hp.K) ? hp.logits[((size_t)n * hp.K + k0 + idx) * V + v] : 0.f;
+                    b[u][e] = (ok && idx < hp.C) ? Elem<T>::ld((const T*)hp.x + ((size_t)n * V + v) * hp.ldx + idx) : 0.f;
+                }
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (MODE == 1) bias_acc += a[u][e];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e], acc, 0, 0, 0);
+            }
     }
-    // block reduction of the four waves' 32x32 partials, then one atomic per element
+    // block reduction of the four waves' 32x32 partials -> one workspace row per block (no atomics: 512 blocks hammering
+    // the same 864 addresses serialised in L2 and dominated the kernel); small_wgrad_reduce_kernel sums the rows.
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
-            const int i = cd_row32(r, lane), j = idx;
-            if (MODE == 0) { if (i < sp.C && j < 27) atomicAdd(sp.dw + i * 27 + j, v); }
-            else { if (k0 + i < hp.K && j < hp.C) atomicAdd(hp.dw + (k0 + i) * hp.C + j, v); }
-        }
-    }
+    __shared__ float bred[4][32];
     if (MODE == 1) {
         bias_acc += __shfl_xor(bias_acc, 32, 64);
-        if (lane < 32 && k0 + idx < hp.K) atomicAdd(hp.db + k0 + idx, bias_acc);
+        if (lane < 32) bred[wave][lane] = bias_acc;
+    }
+    __syncthreads();
+    float* row = ws + (size_t)blockIdx.x * SMALL_WS_ROW;
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) row[r * 64 + lane] = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+    } else if (wave == 1 && lane < 32) {
+        row[1024 + lane] = MODE == 1 ? bred[0][lane] + bred[1][lane] + bred[2][lane] + bred[3][lane] : 0.f;
+    }
+}
+
+// wave per element: sums the per-block rows (fixed order -> deterministic) and scatters into dW / db
+template <int MODE>
+__global__ __launch_bounds__(256) void small_wgrad_reduce_kernel(const float* __restrict__ ws, int nrows, StemParams sp, HeadParams hp, int k0) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= SMALL_WS_ROW) return;
+    float v = 0.f;
+    for (int r = lane; r < nrows; r += 64) v += ws[(size_t)r * SMALL_WS_ROW + e];
+    v = wave_sum(v);
+    if (lane != 0) return;
+    if (e < 1024) {
+        const int rr = e >> 6, ln = e & 63;
+        const int i = cd_row32(rr, ln), j = ln & 31;
+        if (MODE == 0) { if (i < sp.C && j < 27) sp.dw[i * 27 + j] = v; }
+        else { if (k0 + i < hp.K && j < hp.C) hp.dw[(k0 + i) * hp.C + j] = v; }
+    } else if (MODE == 1) {
+        const int i = e - 1024;
+        if (k0 + i < hp.K) hp.db[k0 + i] = v;
     }
 }
 
@@ -546,20 +662,38 @@ int rs_launch_upsample(const UpParams& p, int dtype, int bwd, int blocks, hipStr
         default: return RS_ERR_UNSUPPORTED;                                                     \
     }
 
+// Per-device scratch rows of the small weight-gradient kernels (allocated once, stream-ordered reuse; stem and head have
+// their own so the two may overlap on different streams).
+static float* small_ws(int which) {
+    static float* ws[16][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!ws[dev][which] && hipMalloc((void**)&ws[dev][which], (size_t)SMALL_WS_BLOCKS * SMALL_WS_ROW * sizeof(float)) != hipSuccess) return nullptr;
+    return ws[dev][which];
+}
+
 int rs_launch_stem(const StemParams& p, int dtype, int wgrad, hipStream_t st) {
     const int vox = p.D * p.H * p.W;
     if (!wgrad) {
         const size_t smem = (size_t)(256 * (p.C + 1)) * sizeof(float);
         dim3 grid((vox + 255) / 256, p.N);
+        if (p.C <= 32 && (p.C % 4) == 0) {
+            if (dtype == RS_F32) hipLaunchKernelGGL(stem_fwd_mfma_kernel<float>, grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(stem_fwd_mfma_kernel<bf16_t>, grid, dim3(256), 0, st, p);
+            return rs_check_launch();
+        }
         if (dtype == RS_F32) { RS_DISPATCH_C(stem_fwd_kernel, float, p.C, grid, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(stem_fwd_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
     } else {
         if (p.C > 32) return RS_ERR_UNSUPPORTED;
         HeadParams hp{};
         const long items = (long)p.N * ((vox + 7) / 8);
-        dim3 grid((unsigned)(items / 4 < 512 ? (items + 3) / 4 : 512));
-        if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 0>), grid, dim3(256), 0, st, p, hp, 0);
-        else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 0>), grid, dim3(256), 0, st, p, hp, 0);
+        dim3 grid((unsigned)(items / 4 < SMALL_WS_BLOCKS ? (items + 3) / 4 : SMALL_WS_BLOCKS));
+        float* ws = small_ws(0);
+        if (!ws) return RS_ERR_LAUNCH;
+        if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 0>), grid, dim3(256), 0, st, p, hp, 0, ws);
+        else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 0>), grid, dim3(256), 0, st, p, hp, 0, ws);
+        hipLaunchKernelGGL(small_wgrad_reduce_kernel<0>, dim3((SMALL_WS_ROW + 3) / 4), dim3(256), 0, st, ws, (int)grid.x, p, hp, 0);
     }
     return rs_check_launch();
 }
@@ -579,10 +713,13 @@ int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st) {
         if (p.C > 32) return RS_ERR_UNSUPPORTED;
         StemParams sp{};
         const long items = (long)p.N * ((p.vox + 7) / 8);
-        dim3 g2((unsigned)(items / 4 < 512 ? (items + 3) / 4 : 512));
+        dim3 g2((unsigned)(items / 4 < SMALL_WS_BLOCKS ? (items + 3) / 4 : SMALL_WS_BLOCKS));
+        float* ws = small_ws(1);
+        if (!ws) return RS_ERR_LAUNCH;
         for (int k0 = 0; k0 < p.K; k0 += 32) {                  // 32 classes per pass (K = 42 in BASELINE config 5 -> 2 passes)
-            if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 1>), g2, dim3(256), 0, st, sp, p, k0);
-            else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 1>), g2, dim3(256), 0, st, sp, p, k0);
+            if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 1>), g2, dim3(256), 0, st, sp, p, k0, ws);
+            else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 1>), g2, dim3(256), 0, st, sp, p, k0, ws);
+            hipLaunchKernelGGL(small_wgrad_reduce_kernel<1>, dim3((SMALL_WS_ROW + 3) / 4), dim3(256), 0, st, ws, (int)g2.x, sp, p, k0);
         }
     }
     return rs_check_launch();

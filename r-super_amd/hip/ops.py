@@ -64,7 +64,7 @@ def _chk_act(x):
 def part_buffer(dtype, dims, n_cols, bn, device, fill=None, epi=0):
     """Per-block partial-sum buffer (N, rows, n_cols, 2) in the shape rsuper_conv3_igemm(epi, ...) writes for this dtype/bn."""
     N, D, H, W = dims
-    rows = _L().rsuper_conv3_part_rows(_DT[dtype], epi, N, D, H, W, bn)
+    rows = _L().rsuper_conv3_part_rows(_DT[dtype], epi, N, D, H, W, n_cols, bn)
     if fill is None:
         return torch.empty((N, rows, n_cols, 2), device=device, dtype=torch.float32)
     return torch.full((N, rows, n_cols, 2), fill, device=device, dtype=torch.float32)
@@ -304,22 +304,17 @@ class BasicBlockFn(torch.autograd.Function):
         sb = None if xb is None else Src(xb, mr=mrb)
         # conv1 (+ shortcut): one GEMM
         nc1 = Cout * (2 if has_sc else 1)
-        if packs is not None:
-            bn1, wp1 = packs[1][0], packs[0][0]
-        else:
-            bn1 = pick_bn(nc1, dt, tiles * N)
-            wp1 = pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if has_sc else 0, bn1)
+        if packs is None:                  # one pack launch per block and direction (fragments stay hot in L2 for the convs below)
+            specs, bns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, False)
+            packs = (pack_weights_batch(dt, specs), bns)
+        bn1, wp1 = packs[1][0], packs[0][0]
         ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
         part = part_buffer(dt, dims, nc1, bn1, dev)
         igemm(0, sa, sb, wp1, nc1, bn1, dims, ys, part=part)
         mr_ys = stats_finalize(part, cnt)
         mr_y1 = mr_ys[:, :Cout].contiguous() if has_sc else mr_ys
         # conv2 + residual
-        if packs is not None:
-            bn2, wp2 = packs[1][1], packs[0][1]
-        else:
-            bn2 = pick_bn(Cout, dt, tiles * N)
-            wp2 = pack_weights(dt, 0, w2, None, Cout, 0, Cout, 0, bn2)
+        bn2, wp2 = packs[1][1], packs[0][1]
         out = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
         part2 = part_buffer(dt, dims, Cout, bn2, dev)
         res = Src(ys, C=Cout, off=Cout) if has_sc else Src(xa)
@@ -328,6 +323,7 @@ class BasicBlockFn(torch.autograd.Function):
         ctx.save_for_backward(xa, mra, xb, mrb, ys, mr_y1, w1, w2, ws)
         ctx.packs = packs if (packs is not None and len(packs[0]) == 4) else None
         ctx.mark_non_differentiable(mr_out)
+        ctx.set_materialize_grads(False)        # no zero-fill kernel for the statistics output's (never used) gradient
         return out, mr_out
 
     @staticmethod
@@ -346,10 +342,11 @@ class BasicBlockFn(torch.autograd.Function):
         sdo = Src(dout)
         # conv2: data gradient (ReLU mask + IN sums fused), weight gradient
         if ctx.packs is not None:
-            bn, wpd2 = ctx.packs[1][2], ctx.packs[0][2]
+            bpk = (ctx.packs[0][2:], ctx.packs[1][2:])
         else:
-            bn = pick_bn(Cout, dt, tiles * N)
-            wpd2 = pack_weights(dt, 1, w2, None, Cout, 0, Cout, 0, bn)
+            bspecs, bbns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, True)
+            bpk = (pack_weights_batch(dt, bspecs[2:]), bbns[2:])
+        bn, wpd2 = bpk[1][0], bpk[0][0]
         g1 = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
         part = part_buffer(dt, dims, Cout, bn, dev, epi=1)
         igemm(1, sdo, None, wpd2, Cout, bn, dims, g1, part=part, ea=y1)
@@ -362,11 +359,7 @@ class BasicBlockFn(torch.autograd.Function):
         # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
         sa = Src(xa, mr=mra)
         sb = None if xb is None else Src(xb, mr=mrb)
-        if ctx.packs is not None:
-            bn, wpd1 = ctx.packs[1][3], ctx.packs[0][3]
-        else:
-            bn = pick_bn(Cin, dt, tiles * N)
-            wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bn)
+        bn, wpd1 = bpk[1][1], bpk[0][1]
         g0 = torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
         part0 = part_buffer(dt, dims, Cin, bn, dev, epi=1)
         igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
@@ -404,6 +397,7 @@ class MaxPoolFn(torch.autograd.Function):
         mr = stats_finalize(part, OD * OH * OW)
         ctx.save_for_backward(x)
         ctx.mark_non_differentiable(mr)
+        ctx.set_materialize_grads(False)
         return y, mr
 
     @staticmethod
@@ -432,6 +426,7 @@ class UpsampleFn(torch.autograd.Function):
         mr = stats_finalize(part, OD * OH * OW)
         ctx.in_shape = tuple(x.shape)
         ctx.mark_non_differentiable(mr)
+        ctx.set_materialize_grads(False)
         return y, mr
 
     @staticmethod
@@ -461,6 +456,7 @@ class StemFn(torch.autograd.Function):
         mr = stats_finalize(part, D * H * W)
         ctx.save_for_backward(img, w)
         ctx.mark_non_differentiable(mr)
+        ctx.set_materialize_grads(False)
         return y, mr
 
     @staticmethod
@@ -469,7 +465,7 @@ class StemFn(torch.autograd.Function):
         dy = dy.contiguous()
         N, _, D, H, W = img.shape
         C = w.shape[0]
-        dw = torch.zeros_like(w)
+        dw = torch.empty_like(w)
         _l.check(_L().rsuper_stem_wgrad(_DT[dy.dtype], _ptr(img), _ptr(dy), C, _ptr(dw), N, D, H, W, C, _stream()), 'stem_wgrad')
         return None, dw, None
 
@@ -494,8 +490,8 @@ class HeadFn(torch.autograd.Function):
         N, D, H, W, C = x.shape
         K = w.shape[0]
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
-        db = torch.zeros((K,), device=x.device, dtype=torch.float32)
+        dw = torch.empty_like(w)
+        db = torch.empty((K,), device=x.device, dtype=torch.float32)
         st = _stream()
         _l.check(_L().rsuper_head_bwd_data(_DT[x.dtype], _ptr(dl), _ptr(w), _ptr(dx), C, N, D * H * W, C, K, st), 'head_bwd_data')
         _l.check(_L().rsuper_head_bwd_weight(_DT[x.dtype], _ptr(x), C, _ptr(dl), _ptr(dw), _ptr(db), N, D * H * W, C, K, st), 'head_bwd_weight')
