@@ -445,75 +445,110 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemParams p) {
 
 // Small weight gradients (stem 1->C conv, 1x1x1 head) as an exact-f32 MFMA reduction over voxels:
 //     out[i][j] += sum_v A[v][i] * B[v][j],  i, j < 32,  v_mfma_f32_32x32x2_f32 (lane l: row/col l&31, voxel parity l>>5).
-// A macro-iteration covers 8 voxels: lane half kk owns voxels v0 + 4*kk .. +3 and MFMA e pairs element e of both
-// operands (any voxel order works as long as A and B agree).  MODE 0 = stem: A = dY[v][c], B = x[v + off(tap)];
+// One MFMA consumes two voxels (lane half kk = voxel parity); any voxel order works as long as A and B agree.  MODE 0 = stem: A = dY[v][c], B = x[v + off(tap)];
 // MODE 1 = head: A = dlogits[k][v] (also summed for the bias gradient), B = features[v][c].
 constexpr int SMALL_WS_ROW = 1024 + 32;
 constexpr int SMALL_WS_BLOCKS = 512;
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, HeadParams hp, int k0, float* __restrict__ ws) {
-    __shared__ float red[4][16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Chunks of 256 consecutive voxels are staged block-cooperatively with wide coalesced loads (per-lane 2/4-byte
+    // gathers saturated the address unit): tb = channels-last operand [256][33] as f32; ta = head: dlogits planes
+    // [32][257], stem: im2col of the image [256][29] built from loads that are contiguous across lanes.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tb = (float*)smem;                                    // [256][33]
+    float* ta = tb + 256 * 33;                                   // [32][257] (head only)
+    float (*red)[16][64] = (float (*)[16][64])smem;              // [4][16][64], aliases tb after the last chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = lane & 31, kk = lane >> 5;
     const int N = MODE == 0 ? sp.N : hp.N;
     const int V = MODE == 0 ? sp.D * sp.H * sp.W : hp.vox;
-    const int per = (V + 7) / 8;                                 // macro-iterations per sample
+    const int per = (V + 255) / 256;                             // chunks per sample
     const long items = (long)N * per;
+    constexpr int KP = Elem<T>::KP;
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float bias_acc = 0.f;
-    // stem: tap offset of this lane's column
-    int tz = 0, ty = 0, tx = 0;
-    if (MODE == 0) { const int tap = idx < 27 ? idx : 0; tz = tap / 9 - 1; ty = (tap % 9) / 3 - 1; tx = tap % 3 - 1; }
-    // U macro-iterations are loaded before their MFMAs so U*8 independent loads per lane are in flight (the loop is
-    // latency-bound otherwise: one wave per SIMD-slot, ~100 dependent iterations)
-    constexpr int U = 4;
-    const long stride = (long)gridDim.x * 4;
-    for (long it0 = (long)blockIdx.x * 4 + wave; it0 < items; it0 += stride * U) {
-        float a[U][4], b[U][4];
+    // register-staged, software-pipelined: the next chunk's global loads are in flight during this chunk's MFMAs
+    uint4 rx[32 / KP];                                           // this thread's voxel: 32 channels
+    float4 rl[8];                                                // head: 8 x 4 dlogits of class plane tid>>3
+    float ri[27];                                                // stem: the 27 image taps of this thread's voxel (coalesced over lanes)
+    auto load_chunk = [&](long it) {
+        const int n = (int)(it / per);
+        const int v0 = (int)(it % per) * 256;
+        const int v = v0 + tid;
+        const T* src = MODE == 0 ? (const T*)sp.y + ((size_t)n * V + (v < V ? v : 0)) * sp.ldy : (const T*)hp.x + ((size_t)n * V + (v < V ? v : 0)) * hp.ldx;
+        const int C = MODE == 0 ? sp.C : hp.C;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long it = it0 + u * stride;
-            const bool live = it < items;
-            const int n = live ? (int)(it / per) : 0;
-            const int v0 = live ? (int)(it % per) * 8 + kk * 4 : V;
-            if (MODE == 1 && (V & 3) == 0) {
-                // four consecutive voxels of one class plane: one 16-byte load
-                const bool okp = v0 < V && k0 + idx < hp.K;
-                const float4 q = okp ? *(const float4*)(hp.logits + ((size_t)n * hp.K + k0 + idx) * V + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                a[u][0] = q.x; a[u][1] = q.y; a[u][2] = q.z; a[u][3] = q.w;
-            }
+        for (int c = 0; c < 32; c += KP) rx[c / KP] = (v < V && c < C) ? *(const uint4*)(src + c) : make_uint4(0, 0, 0, 0);
+        if (MODE == 1) {
+            const int k = tid >> 3, seg = tid & 7;
+            const bool kok = k0 + k < hp.K;
+            const float* row = hp.logits + ((size_t)n * hp.K + (kok ? k0 + k : 0)) * V + v0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int v = v0 + e;
-                const bool ok = v < V;
-                if (MODE == 0) {
-                    a[u][e] = (ok && idx < sp.C) ? Elem<T>::ld((const T*)sp.y + ((size_t)n * V + v) * sp.ldy + idx) : 0.f;
-                    const int x0 = v % sp.W, y0 = (v / sp.W) % sp.H, z0 = v / (sp.W * sp.H);
-                    const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
-                    b[u][e] = (ok && idx < 27 && z >= 0 && z < sp.D && y >= 0 && y < sp.H && x >= 0 && x < sp.W)
-                                  ? sp.x[(size_t)n * V + ((size_t)z * sp.H + y) * sp.W + x] : 0.f;
-                } else {
-                    if ((V & 3) != 0) a[u][e] = (ok && k0 + idx < hp.K) ? hp.logits[((size_t)n * hp.K + k0 + idx) * V + v] : 0.f;
-                    b[u][e] = (ok && idx < hp.C) ? Elem<T>::ld((const T*)hp.x + ((size_t)n * V + v) * hp.ldx + idx) : 0.f;
+            for (int i = 0; i < 8; ++i) {
+                const int o = (i * 8 + seg) * 4;                 // 8 lanes cover 128 contiguous bytes of one plane
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kok) {
+                    if ((V & 3) == 0) { if (v0 + o < V) q = *(const float4*)(row + o); }
+                    else {
+                        if (v0 + o < V) q.x = row[o];
+                        if (v0 + o + 1 < V) q.y = row[o + 1];
+                        if (v0 + o + 2 < V) q.z = row[o + 2];
+                        if (v0 + o + 3 < V) q.w = row[o + 3];
+                    }
                 }
+                rl[i] = q;
+            }
+        } else {
+            const int x0 = v % sp.W, y0 = (v / sp.W) % sp.H, z0 = v / (sp.W * sp.H);
+            const float* xin = sp.x + (size_t)n * V;
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) {
+                const int z = z0 + tap / 9 - 1, y = y0 + (tap % 9) / 3 - 1, x = x0 + tap % 3 - 1;
+                ri[tap] = (v < V && z >= 0 && z < sp.D && y >= 0 && y < sp.H && x >= 0 && x < sp.W) ? xin[((size_t)z * sp.H + y) * sp.W + x] : 0.f;
             }
         }
+    };
+    if ((long)blockIdx.x < items) load_chunk(blockIdx.x);
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        // ---- registers -> LDS: tb [256][33] channels-last operand as f32; ta = head [32][257] planes / stem [256][29] taps
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int c = 0; c < 32; c += KP) {
+            float f[KP];
+            unpack16<T>(rx[c / KP], f);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (MODE == 1) bias_acc += a[u][e];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e], acc, 0, 0, 0);
+            for (int j = 0; j < KP; ++j) tb[tid * 33 + c + j] = f[j];
+        }
+        if (MODE == 1) {
+            const int k = tid >> 3, seg = tid & 7;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float* d = ta + k * 257 + (i * 8 + seg) * 4;
+                d[0] = rl[i].x; d[1] = rl[i].y; d[2] = rl[i].z; d[3] = rl[i].w;
             }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) ta[tid * 29 + tap] = ri[tap];
+        }
+        __syncthreads();
+        if (it + gridDim.x < items) load_chunk(it + gridDim.x);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int vl = wave * 64 + 2 * s + kk;
+            float av, bv;
+            if (MODE == 0) { av = tb[vl * 33 + idx]; bv = idx < 27 ? ta[vl * 29 + idx] : 0.f; }
+            else { av = ta[idx * 257 + vl]; bv = tb[vl * 33 + idx]; bias_acc += av; }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
     }
     // block reduction of the four waves' 32x32 partials -> one workspace row per block (no atomics: 512 blocks hammering
     // the same 864 addresses serialised in L2 and dominated the kernel); small_wgrad_reduce_kernel sums the rows.
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    __shared__ float bred[4][32];
+    float (*bred)[32] = (float (*)[32])(smem + 4 * 16 * 64 * sizeof(float));
     if (MODE == 1) {
         bias_acc += __shfl_xor(bias_acc, 32, 64);
         if (lane < 32) bred[wave][lane] = bias_acc;
@@ -687,12 +722,13 @@ int rs_launch_stem(const StemParams& p, int dtype, int wgrad, hipStream_t st) {
     } else {
         if (p.C > 32) return RS_ERR_UNSUPPORTED;
         HeadParams hp{};
-        const long items = (long)p.N * ((vox + 7) / 8);
-        dim3 grid((unsigned)(items / 4 < SMALL_WS_BLOCKS ? (items + 3) / 4 : SMALL_WS_BLOCKS));
+        const long items = (long)p.N * ((vox + 255) / 256);
+        dim3 grid((unsigned)(items < SMALL_WS_BLOCKS ? items : SMALL_WS_BLOCKS));
         float* ws = small_ws(0);
         if (!ws) return RS_ERR_LAUNCH;
-        if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 0>), grid, dim3(256), 0, st, p, hp, 0, ws);
-        else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 0>), grid, dim3(256), 0, st, p, hp, 0, ws);
+        const size_t smem = (size_t)(256 * 33 + 256 * 29) * sizeof(float);
+        if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 0>), grid, dim3(256), smem, st, p, hp, 0, ws);
+        else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 0>), grid, dim3(256), smem, st, p, hp, 0, ws);
         hipLaunchKernelGGL(small_wgrad_reduce_kernel<0>, dim3((SMALL_WS_ROW + 3) / 4), dim3(256), 0, st, ws, (int)grid.x, p, hp, 0);
     }
     return rs_check_launch();
@@ -712,13 +748,21 @@ int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st) {
     } else {
         if (p.C > 32) return RS_ERR_UNSUPPORTED;
         StemParams sp{};
-        const long items = (long)p.N * ((p.vox + 7) / 8);
-        dim3 g2((unsigned)(items / 4 < SMALL_WS_BLOCKS ? (items + 3) / 4 : SMALL_WS_BLOCKS));
+        const long items = (long)p.N * ((p.vox + 255) / 256);
+        dim3 g2((unsigned)(items < SMALL_WS_BLOCKS ? items : SMALL_WS_BLOCKS));
         float* ws = small_ws(1);
         if (!ws) return RS_ERR_LAUNCH;
         for (int k0 = 0; k0 < p.K; k0 += 32) {                  // 32 classes per pass (K = 42 in BASELINE config 5 -> 2 passes)
-            if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 1>), g2, dim3(256), 0, st, sp, p, k0, ws);
-            else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 1>), g2, dim3(256), 0, st, sp, p, k0, ws);
+            const size_t smem = (size_t)(256 * 33 + 32 * 257) * sizeof(float);
+            if (dtype == RS_F32) {
+                auto kf = small_wgrad_mfma_kernel<float, 1>;
+                (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                hipLaunchKernelGGL(kf, g2, dim3(256), smem, st, sp, p, k0, ws);
+            } else {
+                auto kf = small_wgrad_mfma_kernel<bf16_t, 1>;
+                (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                hipLaunchKernelGGL(kf, g2, dim3(256), smem, st, sp, p, k0, ws);
+            }
             hipLaunchKernelGGL(small_wgrad_reduce_kernel<1>, dim3((SMALL_WS_ROW + 3) / 4), dim3(256), 0, st, ws, (int)g2.x, sp, p, k0);
         }
     }
