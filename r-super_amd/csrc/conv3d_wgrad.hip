@@ -29,31 +29,40 @@ template <> struct WG<bf16_t> { static constexpr int XP = 64; };     // x_hat ro
 template <> struct WG<float> { static constexpr int XP = 144; };     // 32 ch * 4 B + 16
 
 // Fragment = 16 bytes/lane for bf16 (8 k), 8 MFMAs worth of scalars for f32 are loaded on the fly.
+// lane part of a fragment address (bytes from the fragment's first row); the rest (tile row, tap) is wave-uniform or static
 template <int TR>
-__device__ __forceinline__ uint4 frag_bf16(const char* base, int pitch, int lane) {
-    // rows = 16 consecutive voxels starting at `base` (row pitch `pitch`), 32 channels (2 B each) at base.
-    // wanted: lane l -> channel l&31, voxels (l>>5)*8 .. +7
-    uint4 r;
+__device__ __forceinline__ int frag_lane_off(int pitch, int lane) {
     if (TR) {
         const int q = lane & 15, g = lane >> 4;
-        const char* a = base + ((g >> 1) * 8 + (q >> 2)) * pitch + ((g & 1) * 16 + (q & 3) * 4) * 2;
+        return ((g >> 1) * 8 + (q >> 2)) * pitch + ((g & 1) * 16 + (q & 3) * 4) * 2;
+    }
+    return ((lane >> 5) * 8) * pitch + (lane & 31) * 2;
+}
+// a = fragment base INCLUDING the lane part: rows = 16 consecutive voxels (row pitch `pitch`), 32 channels (2 B each).
+// result: lane l -> channel l&31, voxels (l>>5)*8 .. +7
+template <int TR>
+__device__ __forceinline__ uint4 frag_bf16(const char* a, int pitch) {
+    uint4 r;
+    if (TR) {
         v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a));
         v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a + 4 * pitch));
         union { v4s_t v; uint2 u; } ul, uh;
         ul.v = lo; uh.v = hi;
         r = make_uint4(ul.u.x, ul.u.y, uh.u.x, uh.u.y);
     } else {
-        const bf16_t* a = (const bf16_t*)(base + ((lane >> 5) * 8) * pitch) + (lane & 31);
         uint32_t e[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = *(const bf16_t*)((const char*)a + j * pitch);
+        for (int j = 0; j < 8; ++j) e[j] = *(const bf16_t*)(a + j * pitch);
         r = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
     return r;
 }
 
-template <typename T, int MT, int NTAPS, int TR>
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
+// NW waves per block: wave -> (wm = wave % MT, wt = wave / MT); a wave owns the taps wt, wt + WT, ... (WT = NW / MT).
+// NW = 4 everywhere: 6 (9 taps) / 9 (27 taps) waves with three taps each measured 1.2-2.4x slower (register cap, spills).
+template <typename T, int MT, int NTAPS, int TR, int NW>
+__global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void wgrad_kernel(WgradParams p) {   // HIP: 2nd = min waves per SIMD
+    constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KP = Elem<T>::KP;
     constexpr int XP = WG<T>::XP;
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
     constexpr int XROWS = HDN * HH * HW;
     constexpr int XV = 32 / KP;                                  // 16-B vectors per x row
     constexpr int YV = MT * 32 / KP;
-    constexpr int WT = 4 / MT;                                   // tap stride between a wave's taps
+    constexpr int WT = NW / MT;                                  // tap stride between a wave's taps
     constexpr int TPW = (NTAPS + WT - 1) / WT;                   // taps per wave (max)
     char* xh = smem;
     char* yt = smem + XROWS * XP;
@@ -105,11 +114,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
             xoff[i] = ((kd * HH + kh) * HW + kw) * XP;
         }
     }
+    // bf16: per-tap fragment bases with the lane part folded in (one VGPR per tap instead of address math per fetch)
+    const char* xb_base[TPW];
+    const char* ya_base = yt + wm * 64 + frag_lane_off<TR>(YP, lane);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) xb_base[i] = xh + xoff[i] + frag_lane_off<TR>(XP, lane);
 
     // Issue-early / write-late staging: the 16-byte global loads of the NEXT tile are started right before the MFMA
     // phase of the current one and land in LDS (after norm+ReLU) once the barrier says the tile has been consumed.
-    constexpr int NXV = (XROWS * XV + 255) / 256, NYV = (256 * YV + 255) / 256;
-    constexpr int XRS = 256 / XV, YRS = 256 / YV;                // rows advanced per vector index
+    constexpr int NXV = (XROWS * XV + NT - 1) / NT, NYV = (256 * YV + NT - 1) / NT;
+    constexpr int XRS = NT / XV, YRS = NT / YV;                  // rows advanced per vector index
+    static_assert(NT % XV == 0 && NT % YV == 0, "staging rows per vector index must be whole");
     uint4 px[NXV], py[NYV];
     uint32_t xmask = 0;                                          // bit i: px[i] is inside the volume (gets norm+ReLU)
     const int xs_slot = tid % XV, xs_row = tid / XV;             // per-thread constants: 16-byte slot and first row
@@ -135,29 +150,74 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
         const int td = t % tiles_d; t /= tiles_d;
         n = t; d0 = td * TD; h0 = th * TH; w0 = tw * TW;
     };
+    // Per-thread constants of the staging vectors: voxel delta of every vector relative to the tile's halo / tile
+    // origin (the (hd, hh, hw) decomposition of its row never changes), so an interior tile costs one add per vector.
+    int xdelta[NXV], ydelta[NYV];
+    uint32_t xrows_ok = 0, yrows_ok = 0;
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+        const int r = xs_row + i * XRS;
+        const int hd = r / (HH * HW);
+        const int rem = r - hd * (HH * HW);
+        const int hh = rem / HW, hw = rem - hh * HW;
+        xdelta[i] = (hd * p.H + hh) * p.W + hw;
+        xrows_ok |= (r < XROWS && x_cok) ? (1u << i) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NYV; ++i) {
+        const int r = ys_row + i * YRS;
+        ydelta[i] = ((r >> 6) * p.H + ((r >> 4) & 3)) * p.W + (r & 15);
+        yrows_ok |= (r < 256 && ysrc != nullptr) ? (1u << i) : 0u;
+    }
+    const uint32_t nvox_total = (uint32_t)(p.N * p.D * p.H * p.W);
+    const uint32_t xrowb = (uint32_t)xs.ld * (uint32_t)sizeof(T);
+    // wave-uniform resource (a per-lane base would make every buffer load a waterfall loop); the thread's channel slot
+    // goes into the offset
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xs.x, 0, nvox_total * xrowb, 0x00020000);
+    const uint32_t xcol = (uint32_t)(c0 + xs_slot * KP) * (uint32_t)sizeof(T);
+    auto ld16 = [&](uint32_t off) {
+        const auto q = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);     // out-of-range offsets return zeros
+        return make_uint4(q[0], q[1], q[2], q[3]);
+    };
     auto issue = [&](int tile) {
         int n, d0, h0, w0;
         tile_coords(tile, n, d0, h0, w0);
-        xmask = 0;
+        const int dlo = d0 + (NTAPS == 27 ? -1 : kdg - 1);
+        const bool x_in = dlo >= 0 && dlo + HDN <= p.D && h0 >= 1 && h0 + TH + 1 <= p.H && w0 >= 1 && w0 + TW + 1 <= p.W;
+        const bool y_in = d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;
+        if (x_in) {                                              // interior halo (wave-uniform): no per-vector bounds checks
+            const int base = ((n * p.D + dlo) * p.H + (h0 - 1)) * p.W + (w0 - 1);
+            xmask = xrows_ok;
 #pragma unroll
-        for (int i = 0; i < NXV; ++i) {
-            const int r = xs_row + i * XRS;
-            const int hd = r / (HH * HW);
-            const int rem = r - hd * (HH * HW);
-            const int hh = rem / HW, hw = rem - hh * HW;
-            const int d = d0 + hd + (NTAPS == 27 ? -1 : kdg - 1), h = h0 - 1 + hh, w = w0 - 1 + hw;
-            const bool ok = x_cok && r < XROWS && d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W;
-            const uint32_t vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
-            px[i] = ok ? *(const uint4*)(xsrc + (size_t)vox * (uint32_t)xs.ld) : make_uint4(0, 0, 0, 0);
-            xmask |= ok ? (1u << i) : 0u;
+            for (int i = 0; i < NXV; ++i) px[i] = ld16(((xrows_ok >> i) & 1u) ? (uint32_t)(base + xdelta[i]) * xrowb + xcol : 0xFFFFFFFFu);
+        } else {
+            xmask = 0;
+#pragma unroll
+            for (int i = 0; i < NXV; ++i) {
+                const int r = xs_row + i * XRS;
+                const int hd = r / (HH * HW);
+                const int rem = r - hd * (HH * HW);
+                const int hh = rem / HW, hw = rem - hh * HW;
+                const int d = dlo + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+                const bool ok = ((xrows_ok >> i) & 1u) && d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W;
+                const uint32_t vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
+                px[i] = ld16(ok ? vox * xrowb + xcol : 0xFFFFFFFFu);
+                xmask |= ok ? (1u << i) : 0u;
+            }
         }
+        const int ybase = ((n * p.D + d0) * p.H + h0) * p.W + w0;
+        if (y_in) {
 #pragma unroll
-        for (int i = 0; i < NYV; ++i) {
-            const int r = ys_row + i * YRS;                      // voxel of the tile: (r/64, (r/16)%4, r%16)
-            const int d = d0 + (r >> 6), h = h0 + ((r >> 4) & 3), w = w0 + (r & 15);
-            const bool ok = ysrc && r < 256 && d < p.D && h < p.H && w < p.W;
-            const uint32_t vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
-            py[i] = ok ? *(const uint4*)(ysrc + (size_t)vox * (uint32_t)yld) : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < NYV; ++i)
+                py[i] = ((yrows_ok >> i) & 1u) ? *(const uint4*)(ysrc + (size_t)(uint32_t)(ybase + ydelta[i]) * (uint32_t)yld) : make_uint4(0, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NYV; ++i) {
+                const int r = ys_row + i * YRS;                  // voxel of the tile: (r/64, (r/16)%4, r%16)
+                const int d = d0 + (r >> 6), h = h0 + ((r >> 4) & 3), w = w0 + (r & 15);
+                const bool ok = ((yrows_ok >> i) & 1u) && d < p.D && h < p.H && w < p.W;
+                py[i] = ok ? *(const uint4*)(ysrc + (size_t)(uint32_t)(ybase + ydelta[i]) * (uint32_t)yld) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
     auto commit = [&]() {
@@ -198,26 +258,25 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradParams p) {
         // ---- MFMA over the 16 (d,h) rows of the tile; k = 16 voxels along w.  Software pipelined with static
         //      indices: the operand fragments of unit (row, tap i)+1 are fetched from LDS while unit (row, i) issues.
         if constexpr (sizeof(T) == 2) {
-            auto fetch_a = [&](int row) { return frag_bf16<TR>(yt + (row * TW) * YP + wm * 64, YP, lane); };
-            auto fetch_b = [&](int row, int i) {
+            auto fetch_a = [&](int row) { return frag_bf16<TR>(ya_base + (row * TW) * YP, YP); };         // static row offsets fold into
+            auto fetch_b = [&](int row, int i) {                                                          // the ds_read offset field
                 const int dd = row / TH, hh = row % TH;
-                return frag_bf16<TR>(xh + ((dd * HH + hh) * HW) * XP + xoff[i], XP, lane);
+                return frag_bf16<TR>(xb_base[i] + ((dd * HH + hh) * HW) * XP, XP);
             };
-            uint4 a_cur = fetch_a(0), a_nxt = a_cur;
-            uint4 b_cur = fetch_b(0, 0), b_nxt = b_cur;
+            // few waves per SIMD: LDS latency (~130+ cycles) must be covered by prefetch distance, one MFMA is only 32 cycles
+            constexpr int NU = TD * TH * TPW, BD = 3, BR = 4;
+            uint4 aq[2], bq[BR];
+            aq[0] = fetch_a(0);
 #pragma unroll
-            for (int u = 0; u < TD * TH * TPW; ++u) {
+            for (int u = 0; u < BD; ++u) bq[u] = fetch_b(u / TPW, u % TPW);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
                 const int row = u / TPW, i = u % TPW;
-                if (u + 1 < TD * TH * TPW) {
-                    const int r2 = (u + 1) / TPW, i2 = (u + 1) % TPW;
-                    if (i2 == 0) a_nxt = fetch_a(r2);
-                    b_nxt = fetch_b(r2, i2);
-                }
+                if (u + BD < NU) bq[(u + BD) % BR] = fetch_b((u + BD) / TPW, (u + BD) % TPW);
+                if (i == 0 && row + 1 < TD * TH) aq[(row + 1) & 1] = fetch_a(row + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                mma32<bf16_t>(acc[i], a_cur, b_cur);               // invalid taps multiply by a zeroed accumulator slot (never stored)
+                mma32<bf16_t>(acc[i], aq[row & 1], bq[u % BR]);    // invalid taps multiply by a zeroed accumulator slot (never stored)
                 __builtin_amdgcn_sched_barrier(0);
-                if (i == TPW - 1) a_cur = a_nxt;
-                b_cur = b_nxt;
             }
         } else {
             for (int row = 0; row < TD * TH; ++row) {
@@ -273,7 +332,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dst[tap] = (a0 + a1) + (a2 + a3);
 }
 
-template <typename T, int MT, int NTAPS, int TR>
+template <typename T, int MT, int NTAPS, int TR, int NW>
 int launch(const WgradParams& p, hipStream_t st) {
     constexpr int XP = WG<T>::XP;
     constexpr int YP = sizeof(T) == 2 ? (MT == 2 ? 192 : 64) : MT * 32 * (int)sizeof(T) + 16;
@@ -282,8 +341,8 @@ int launch(const WgradParams& p, hipStream_t st) {
     const int nch = (p.xa.C + 31) / 32 + (p.xb.C + 31) / 32;
     const int Mtot = p.ya.C + p.yb.C;
     const int mgroups = (Mtot + MT * 32 - 1) / (MT * 32);
-    dim3 grid(nch, mgroups * (NTAPS == 27 ? 1 : 3), p.splits), block(256);
-    auto k = wgrad_kernel<T, MT, NTAPS, TR>;
+    dim3 grid(nch, mgroups * (NTAPS == 27 ? 1 : 3), p.splits), block(64 * NW);
+    auto k = wgrad_kernel<T, MT, NTAPS, TR, NW>;
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
     const size_t elems = (size_t)27 * Mtot * (p.xa.C + p.xb.C);
@@ -298,10 +357,10 @@ int rs_wgrad_grid_y(int Mtot) { return Mtot <= 32 ? 1 : 3 * ((Mtot + 63) / 64); 
 
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st) {
     const int Mtot = p.ya.C + p.yb.C;
-    if (dtype == RS_F32) return Mtot <= 32 ? launch<float, 1, 27, 0>(p, st) : launch<float, 2, 9, 0>(p, st);
+    if (dtype == RS_F32) return Mtot <= 32 ? launch<float, 1, 27, 0, 4>(p, st) : launch<float, 2, 9, 0, 4>(p, st);
     if (dtype == RS_BF16) {
-        if (use_tr) return Mtot <= 32 ? launch<bf16_t, 1, 27, 1>(p, st) : launch<bf16_t, 2, 9, 1>(p, st);
-        return Mtot <= 32 ? launch<bf16_t, 1, 27, 0>(p, st) : launch<bf16_t, 2, 9, 0>(p, st);
+        if (use_tr) return Mtot <= 32 ? launch<bf16_t, 1, 27, 1, 4>(p, st) : launch<bf16_t, 2, 9, 1, 4>(p, st);
+        return Mtot <= 32 ? launch<bf16_t, 1, 27, 0, 4>(p, st) : launch<bf16_t, 2, 9, 0, 4>(p, st);
     }
     return RS_ERR_ARG;
 }

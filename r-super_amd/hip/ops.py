@@ -254,7 +254,7 @@ def wgrad(xa, xb, ya, yb, dwa, dwb, dims):
     Mtot = ya.C + (yb.C if yb is not None else 0)
     nch = -(-xa.C // 32) + (-(-xb.C // 32) if xb is not None else 0)
     gy = 1 if Mtot <= 32 else 3 * (-(-Mtot // 64))
-    target = 256 if Mtot <= 32 else 512                    # measured optimum: 27-tap config 1 block/CU, 9-tap config 2
+    target = 256 if Mtot <= 32 else 512                    # measured optimum: 27-tap config 1 block/CU, 9-tap config 2                    # measured optimum: 27-tap config 1 block/CU, 9-tap config 2
     splits = max(1, min(tiles, target // max(1, nch * gy)))
     yb_args = (None, 0, 0) if yb is None else (_ptr(yb.t, yb.off), yb.ld, yb.C)
     Cin_t = xa.C + (xb.C if xb is not None else 0)
