@@ -25,6 +25,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+# Fabric-side bytes (FETCH_SIZE x2 + WRITE_SIZE) of all conv MFMA launches of ONE default step, from the rocprofv3 PMC
+# passes in profiles/r01_pmc_step.md (bf16, base 32, B=2, 96^3, report losses off); other workloads report null.
+CONV_TRAFFIC_BYTES_PER_STEP = 22.6e9
 
 
 def conv_stack_flops(base, S, B):
@@ -167,7 +170,10 @@ def main():
                                    f'(fwd + {"seg+Volume+Ball" if args.report else "masked BCE + Dice"} loss + bwd + clip + AdamW + EMA), '
                                    f'{S}^3 patches, batch {B}/GPU (BASELINE.json configs[{2 if args.report else 1}])',
                        'global_batch': world * B, 'patch': S, 'parallelism': f'dp{world}', 'final_loss': loss_val},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                         'traffic': (CONV_TRAFFIC_BYTES_PER_STEP if (args.dtype == 'bf16' and args.base == 32 and B == 2 and S == 96 and not args.report) else None),
+                         'traffic_unit': 'bytes per step over all conv MFMA launches (rocprofv3 PMC, profiles/r01_pmc_step.md)',
+                         'sustained_mfma_peak_measured': 2110.0,
                          'kernel': 'conv3d MFMA kernels (igemm fwd + dgrad, wgrad): 3x the 43 3x3x3 convs',
                          'algorithmic_gflop_per_step': conv_fl / args.steps / 1e9, 'expected_gflop_per_step': 3 * fwd_fl / 1e9,
                          'conv_ms_per_step': conv_ms / args.steps,
