@@ -85,6 +85,10 @@ int rsuper_conv3_igemm(int dtype, int epi,
  * loss.backward(), train_ddp.py:349).  dy rows [0,Ya) accumulate into dwa (Ya, Ca+Cb, 27), rows [Ya,Ya+Yb) into dwb.
  * dwa/dwb are overwritten.  workspace: splits * 27 * (Ya+Yb) * (Ca+Cb) floats (per-split partial slabs, summed by a
  * reduce kernel -- deterministic, no atomics).  use_tr selects ds_read_b64_tr_b16 operand fetch (bf16). */
+/* Number of voxel-tile splits (= partial slabs in `workspace`) rsuper_conv3_wgrad should be called with for this shape:
+ * fills the chip with resident blocks for the kernel configuration the launch will pick.  Returns <= 0 on bad arguments. */
+int rsuper_conv3_wgrad_splits(int dtype, int Ca, int Cb, int Mtot, int N, int D, int H, int W);
+
 int rsuper_conv3_wgrad(int dtype, int use_tr,
                        const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,

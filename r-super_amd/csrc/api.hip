@@ -144,6 +144,11 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     return rs_launch_igemm(p, dtype, epi, ST(stream));
 }
 
+int rsuper_conv3_wgrad_splits(int dtype, int Ca, int Cb, int Mtot, int N, int D, int H, int W) {
+    if (!dt_ok(dtype) || Ca <= 0 || Cb < 0 || Mtot <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return -1;
+    return rs_wgrad_splits(dtype, Mtot, (Ca + 31) / 32 + (Cb + 31) / 32, N * rsuper_conv3_tiles(D, H, W));
+}
+
 int rsuper_conv3_wgrad(int dtype, int use_tr, const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,
                        const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,

@@ -353,14 +353,33 @@ int launch(const WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
-int rs_wgrad_grid_y(int Mtot) { return Mtot <= 32 ? 1 : 3 * ((Mtot + 63) / 64); }
+// Configuration per launch (measured on MI355X, tests/bench_conv.py):
+//   0: M <= 32           -> 32 rows x 27 taps, 4 waves, one block per CU
+//   1: M > 32, few tiles -> 64 rows x 9 taps (kd split over blocks), 4 waves, two blocks per CU
+//   2: M > 32, >= 128 tiles (bf16) -> 64 rows x 27 taps, 8 waves, one block per CU: the x halo and the dY tile are staged
+//      once for all 27 taps (2.4x less operand traffic than config 1), seven taps per A fragment
+int rs_wgrad_config(int dtype, int Mtot, int tiles_total) {
+    if (Mtot <= 32) return 0;
+    return (dtype == RS_BF16 && tiles_total >= 128) ? 2 : 1;
+}
+
+int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total) {
+    const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);
+    const int gy = cfg == 0 ? 1 : (cfg == 1 ? 3 : 1) * ((Mtot + 63) / 64);
+    const int target = cfg == 1 ? 512 : 256;                     // resident blocks on 256 CUs
+    int s = target / (nch * gy > 0 ? nch * gy : 1);
+    if (s > tiles_total) s = tiles_total;
+    return s < 1 ? 1 : s;
+}
 
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st) {
     const int Mtot = p.ya.C + p.yb.C;
-    if (dtype == RS_F32) return Mtot <= 32 ? launch<float, 1, 27, 0, 4>(p, st) : launch<float, 2, 9, 0, 4>(p, st);
+    const int tiles_total = p.N * ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);
+    if (dtype == RS_F32) return cfg == 0 ? launch<float, 1, 27, 0, 4>(p, st) : launch<float, 2, 9, 0, 4>(p, st);
     if (dtype == RS_BF16) {
-        if (use_tr) return Mtot <= 32 ? launch<bf16_t, 1, 27, 1, 4>(p, st) : launch<bf16_t, 2, 9, 1, 4>(p, st);
-        return Mtot <= 32 ? launch<bf16_t, 1, 27, 0, 4>(p, st) : launch<bf16_t, 2, 9, 0, 4>(p, st);
+        if (use_tr) return cfg == 0 ? launch<bf16_t, 1, 27, 1, 4>(p, st) : cfg == 1 ? launch<bf16_t, 2, 9, 1, 4>(p, st) : launch<bf16_t, 2, 27, 1, 8>(p, st);
+        return cfg == 0 ? launch<bf16_t, 1, 27, 0, 4>(p, st) : cfg == 1 ? launch<bf16_t, 2, 9, 0, 4>(p, st) : launch<bf16_t, 2, 27, 0, 8>(p, st);
     }
     return RS_ERR_ARG;
 }

@@ -55,4 +55,4 @@ int rs_igemm_part_rows(int bn, int pc, int tiles, int n_cols, int N);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st);
-int rs_wgrad_grid_y(int Mtot);
+int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);

@@ -250,12 +250,9 @@ def igemm(epi, a, b, packed, n_cols, bn, dims, out, out_ld=None, res=None, part=
 def wgrad(xa, xb, ya, yb, dwa, dwb, dims):
     dt = _DT[xa.t.dtype]
     N, D, H, W = dims
-    tiles = _L().rsuper_conv3_tiles(D, H, W) * N
     Mtot = ya.C + (yb.C if yb is not None else 0)
-    nch = -(-xa.C // 32) + (-(-xb.C // 32) if xb is not None else 0)
-    gy = 1 if Mtot <= 32 else 3 * (-(-Mtot // 64))
-    target = 256 if Mtot <= 32 else 512                    # measured optimum: 27-tap config 1 block/CU, 9-tap config 2                    # measured optimum: 27-tap config 1 block/CU, 9-tap config 2
-    splits = max(1, min(tiles, target // max(1, nch * gy)))
+    splits = _L().rsuper_conv3_wgrad_splits(dt, xa.C, xb.C if xb is not None else 0, Mtot, N, D, H, W)
+    assert splits >= 1
     yb_args = (None, 0, 0) if yb is None else (_ptr(yb.t, yb.off), yb.ld, yb.C)
     Cin_t = xa.C + (xb.C if xb is not None else 0)
     ws = torch.empty((splits * 27 * Mtot * Cin_t,), device=dwa.device, dtype=torch.float32)

@@ -597,6 +597,8 @@ def all_checks(quick=False):
            (with_variant, (1, check_conv_fwd, 'bf16', 1, (12, 20, 48), 64, 64, 128, True, False)),    # 128 columns, 4 chunks, 2 sources
            (with_variant, (1, check_conv_bwd, 'bf16', 2, (8, 24, 32), 64, 64, 64, True)),
            (with_variant, (1, check_conv_bwd, 'bf16', 1, (12, 20, 48), 128, 0, 128, False))]
+    cs += [(check_conv_bwd, ('bf16', 2, (16, 16, 64), 32, 32, 64, True)),      # >= 128 tiles, M = 128: 27-tap / 8-wave weight-gradient config
+           (check_conv_bwd, ('bf16', 1, (16, 32, 64), 64, 0, 64, False))]
     cs += [(check_conv_bwd, ('bf16', 1, (4, 4, 16), 32, 0, 32, False, 0, 0)), (check_conv_bwd, ('bf16', 1, (8, 12, 20), 64, 32, 64, True, 0, 0)),
            (check_tr16_probe, ()),
            (check_plane_partials, ()), (check_dilate, ()), (check_isolate_tumor, ()), (check_gwrp, ()), (check_optimizer, ())]
