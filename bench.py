@@ -183,10 +183,16 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args, classes)
-        print(json.dumps(out))
     if world > 1 or args.force_ddp:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: RCCL printf()s a version banner into the C stdio buffer, which would
+        # otherwise be flushed at process exit, after this line
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -93,8 +93,10 @@ def wrap_ddp(net, local_rank, bucket_cap_mb=25):
     gradient_as_bucket_view avoids the extra copy of every gradient into the bucket."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     if next(net.parameters()).is_cuda:
+        bucket_cap_mb = int(os.environ.get('RSUPER_DDP_BUCKET_MB', bucket_cap_mb))
         return DDP(net, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,
-                   bucket_cap_mb=bucket_cap_mb)
+                   bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False,
+                   static_graph=os.environ.get('RSUPER_DDP_STATIC', '0') == '1')
     return DDP(net, find_unused_parameters=False)
 
 
