@@ -159,6 +159,11 @@ int rsuper_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr_bits
 int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream);
 int rsuper_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float log2_d, float scale, float* w, void* stream);
 int rsuper_mask_op(uint8_t* a, const uint8_t* b, long V, int op /*0 and, 1 or, 2 andnot*/, void* stream);
+
+/* Bit-packed label ingestion: device-side np.unpackbits(packed, axis=0)[:C] of the label / unk / chosen-
+ * segment volumes the dataset stores with np.packbits(axis=0) -- training/dataset/dim3/dataset_abdomenatlas_UFO.py:955,
+ * 970,975 (pack), :1031-1034 (unpack).  packed: [B][P = ceil(C/8)][V] bytes (MSB = lowest class), out: [B][C][V] 0/1. */
+int rsuper_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, void* stream);
 int rsuper_zero_where(float* x, const uint8_t* m, long V, void* stream);
 int rsuper_count(const uint8_t* m, long V, unsigned int* count, void* stream);
 

@@ -334,6 +334,47 @@ int rs_launch_rank_weights(const float* vals, const uint32_t* idx, unsigned int 
     return rs_check_launch();
 }
 
+// Bit-packed label ingestion.  The reference stores label / unk / chosen-segment volumes as
+// np.packbits(bool (C, D, H, W), axis=0) (dataset_abdomenatlas_UFO.py:955,970,975) and inflates them on the host with
+// np.unpackbits(...)[:C] (:1031-1034) before a 16x larger H2D copy.  Here the packed bytes travel and are inflated on the
+// device: out[b][c][v] = (packed[b][c >> 3][v] >> (7 - (c & 7))) & 1   (packbits is MSB-first).
+// Thread = 16 voxels of one byte plane: one 16-byte load, up to eight 16-byte stores.
+__global__ __launch_bounds__(256) void unpack_bits_kernel(const uint8_t* __restrict__ packed, uint8_t* __restrict__ out, int P, int C, long V) {
+    const long nvec = (V + 15) / 16;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nvec) return;
+    const int pl = blockIdx.y % P, b = blockIdx.y / P;
+    const uint8_t* src = packed + ((size_t)b * P + pl) * V;
+    const long v0 = t * 16;
+    const bool full = v0 + 16 <= V && (V & 15) == 0;
+    uint8_t in[16];
+    if (full) *(uint4*)in = *(const uint4*)(src + v0);
+    else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) in[j] = v0 + j < V ? src[v0 + j] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = pl * 8 + k;
+        if (c >= C) break;
+        uint8_t o[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = (in[j] >> (7 - k)) & 1;
+        uint8_t* dst = out + ((size_t)b * C + c) * V + v0;
+        if (full) *(uint4*)dst = *(const uint4*)o;
+        else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (v0 + j < V) dst[j] = o[j];
+        }
+    }
+}
+
+int rs_launch_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, hipStream_t st) {
+    const long nvec = (V + 15) / 16;
+    hipLaunchKernelGGL(unpack_bits_kernel, dim3((unsigned)((nvec + 255) / 256), (unsigned)(B * P)), dim3(256), 0, st, packed, out, P, C, V);
+    return rs_check_launch();
+}
+
 int rs_launch_mask_op(uint8_t* a, const uint8_t* b, long V, int op, hipStream_t st) {
     hipLaunchKernelGGL(mask_op_kernel, dim3(rs_elem_blocks((size_t)V)), dim3(256), 0, st, a, b, V, op);
     return rs_check_launch();

@@ -1,0 +1,2 @@
+"""Host-side data formats of the training hot path: bit-packed label ingestion."""
+from .packed import pack_bits, unpack_bits_device, ingest_packed_batch  # noqa: F401

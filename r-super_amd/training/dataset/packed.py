@@ -1,0 +1,53 @@
+"""Bit-packed label ingestion.
+
+The reference dataset stores the label, unknown-channel and chosen-segment volumes of a crop as
+`np.packbits(bool (C, D, H, W), axis=0)` (training/dataset/dim3/dataset_abdomenatlas_UFO.py:955,970,975), inflates them on
+the host with `np.unpackbits(...)[:num_classes]` (:1031-1034) and the training loop then casts them to int64 / float32
+before the H2D copy (train_ddp.py:249-261): 26 x 96^3 x (8 + 4 + 4) bytes per sample.  Here the packed bytes travel
+(ceil(C/8) bytes per voxel and volume: 16x..64x less PCIe traffic) and are inflated on the device by the HIP kernel
+`rsuper_unpack_bits` into the uint8 0/1 masks `calculate_loss` consumes directly.
+"""
+import numpy as np
+import torch
+
+from ...hip import lib as _l
+
+
+def pack_bits(volume):
+    """np.packbits(bool (..., C, D, H, W), axis=-4) as the dataset writer does (:955); accepts numpy or torch (CPU)."""
+    a = volume.cpu().numpy() if isinstance(volume, torch.Tensor) else np.asarray(volume)
+    return np.packbits(a.astype(np.bool_), axis=-4)
+
+
+def unpack_bits_device(packed, num_classes, stream=None):
+    """packed: uint8 CUDA tensor (B, P, D, H, W) or (P, D, H, W), P = ceil(C/8)  ->  uint8 0/1 tensor (B, C, D, H, W).
+    Same result as np.unpackbits(packed, axis=channel)[:num_classes] (:1031-1034); asserts the reference's shape checks."""
+    if packed.dim() == 4:
+        packed = packed.unsqueeze(0)
+    assert packed.dim() == 5 and packed.dtype == torch.uint8, 'packed volume must be uint8 (B, P, D, H, W)'
+    if not packed.is_cuda:
+        raise _l.RSuperHipError('unpack_bits_device needs a device tensor (no CPU fallback)')
+    B, P = packed.shape[:2]
+    assert P * 8 >= num_classes and P * 8 < num_classes + 10, 'packed channel count does not match num_classes (:1032-1033)'
+    packed = packed.contiguous()
+    V = packed[0, 0].numel()
+    out = torch.empty((B, num_classes) + tuple(packed.shape[2:]), device=packed.device, dtype=torch.uint8)
+    st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    _l.check(_l.lib().rsuper_unpack_bits(packed.data_ptr(), out.data_ptr(), B, P, num_classes, V, st), 'unpack_bits')
+    return out
+
+
+def ingest_packed_batch(sample, num_classes, device='cuda'):
+    """sample: dict with 'image' (B,1,D,H,W) f32 and bit-packed uint8 'label', 'unk_channels', 'mask' (B,P,D,H,W), plus
+    'volumes', 'diameters' [, 'weights'] as the dataset yields them.  Returns the device batch `train_step` takes, with the
+    three volumes as uint8 0/1 (B,C,D,H,W)."""
+    out = {}
+    for k, v in sample.items():
+        t = torch.as_tensor(v)
+        if k in ('label', 'unk_channels', 'mask'):
+            out[k] = unpack_bits_device(t.to(device, non_blocking=True), num_classes)
+        else:
+            out[k] = t.to(device, non_blocking=True)
+            if k in ('volumes', 'diameters', 'weights', 'image'):
+                out[k] = out[k].float()
+    return out

@@ -136,3 +136,45 @@ def test_checkpoint_roundtrip(tmp_path):
     assert load_checkpoint(path, net2, make_ema(net2), FusedAdamWEMA(net2.parameters())) == 4
     for a, b in zip(net.parameters(), net2.parameters()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,shape', [(26, (24, 20, 32)), (42, (9, 7, 5)), (5, (16, 16, 16)), (8, (3, 3, 3))])
+def test_unpack_bits_matches_numpy(C, shape):
+    """rsuper_unpack_bits == np.unpackbits(np.packbits(x, axis=0), axis=0)[:C] (dataset_abdomenatlas_UFO.py:955,1031-1034), bit-exact."""
+    import numpy as np
+    from rsuper_amd.training.dataset import pack_bits, unpack_bits_device
+    rng = np.random.default_rng(C)
+    x = rng.random((2, C) + shape) < 0.3
+    packed = pack_bits(x)
+    assert packed.shape == (2, -(-C // 8)) + shape
+    want = np.stack([np.unpackbits(packed[b], axis=0)[:C] for b in range(2)])
+    got = unpack_bits_device(torch.from_numpy(packed).to(DEV), C).cpu().numpy()
+    assert got.dtype == np.uint8 and np.array_equal(got, want) and np.array_equal(got.astype(bool), x)
+
+
+@pytest.mark.gpu
+def test_packed_batch_gives_same_loss():
+    """calculate_loss on a batch ingested from bit-packed volumes == on the plain uint8 batch."""
+    import argparse, sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import synth
+    from rsuper_amd.training import losses_foundation as lf
+    from rsuper_amd.training.dataset import pack_bits, ingest_packed_batch
+    classes = synth.TINY_CLASSES
+    B, S = 2, 32
+    bt = synth.batch(B, S, classes, ['mask', 'report'], seed=11)
+    logits = torch.from_numpy(synth.logits(B, len(classes), S, seed=5)).to(DEV)
+    la = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1, volume_loss_tolerance=0.2,
+                            ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                            classification_branch=False)
+
+    def run(batch):
+        r = lf.calculate_loss({'segmentation': logits.clone().requires_grad_(True)}, batch['label'], batch['unk_channels'], la, None, batch['mask'],
+                              batch['volumes'], batch['diameters'], classes)
+        return {k: float(v) for k, v in r.items()}
+    plain = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in bt.items() if k in ('label', 'unk_channels', 'mask', 'volumes', 'diameters')}
+    packed = ingest_packed_batch({'label': pack_bits(bt['label']), 'unk_channels': pack_bits(bt['unk_channels']), 'mask': pack_bits(bt['mask']),
+                                  'volumes': bt['volumes'], 'diameters': bt['diameters']}, len(classes), DEV)
+    a, b = run(plain), run(packed)
+    assert a.keys() == b.keys() and all(a[k] == b[k] for k in a), (a, b)

@@ -118,3 +118,18 @@ def test_ddp_world2_gloo_cpu():
                         '--master-port', '29533', script], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'DDP_OK' in r.stdout
+
+
+def test_pack_bits_matches_reference_writer_and_needs_device():
+    """pack_bits == np.packbits(bool, axis=0) per sample (dataset_abdomenatlas_UFO.py:955); the inflate step has no CPU path."""
+    import numpy as np
+    import torch
+    from rsuper_amd.training.dataset import pack_bits, unpack_bits_device
+    from rsuper_amd.hip.lib import RSuperHipError
+    x = (np.random.default_rng(0).random((2, 26, 4, 5, 6)) < 0.5)
+    p = pack_bits(x)
+    assert p.shape == (2, 4, 4, 5, 6) and p.dtype == np.uint8
+    assert np.array_equal(p[1], np.packbits(x[1], axis=0))
+    assert np.array_equal(np.unpackbits(p[0], axis=0)[:26].astype(bool), x[0])
+    with pytest.raises(RSuperHipError):
+        unpack_bits_device(torch.from_numpy(p), 26)
