@@ -140,6 +140,15 @@ int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, 
                               const float* g, float* dx, int accumulate, int planes, size_t V, void* stream);
 int rsuper_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, void* stream);
 
+/* Sliding-window inference -- inference/inference3d.py:28-107 (inference_sliding_window) and :8-25
+ * (inference_whole_image, assign = 1 with the window covering the volume).  The reference accumulates window
+ * probabilities on the host; here acc[BK][D][H][W] (f32, device) receives sigmoid(logits[BK][wd][wh][ww]) at offset
+ * (d0, h0, w0): added (assign = 0) or stored (assign = 1).  rsuper_window_normalize divides by the separable window count
+ * cd[d] * ch[h] * cw[w] (f32 device vectors of D, H, W entries), the `pred_output /= counter` of :101. */
+int rsuper_window_accumulate(const float* logits, float* acc, int BK, int wd, int wh, int ww, int D, int H, int W, int d0, int h0, int w0,
+                             int assign, void* stream);
+int rsuper_window_normalize(float* acc, const float* cd, const float* ch, const float* cw, long BK, int D, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Binary morphology and selection -- training/losses_foundation.py
  * ------------------------------------------------------------------------------------------------ */

@@ -256,6 +256,17 @@ int rsuper_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, 
     return rs_launch_sigmoid_mask(x, m, out, V, ST(stream));
 }
 
+int rsuper_window_accumulate(const float* logits, float* acc, int BK, int wd, int wh, int ww, int D, int H, int W, int d0, int h0, int w0,
+                             int assign, void* stream) {
+    if (!logits || !acc || BK <= 0 || wd <= 0 || wh <= 0 || ww <= 0) return RS_ERR_ARG;
+    if (d0 < 0 || h0 < 0 || w0 < 0 || d0 + wd > D || h0 + wh > H || w0 + ww > W) return RS_ERR_ARG;
+    return rs_launch_window_accumulate(logits, acc, BK, wd, wh, ww, D, H, W, d0, h0, w0, assign, ST(stream));
+}
+int rsuper_window_normalize(float* acc, const float* cd, const float* ch, const float* cw, long BK, int D, int H, int W, void* stream) {
+    if (!acc || !cd || !ch || !cw || BK <= 0 || D <= 0 || H <= 0 || W <= 0) return RS_ERR_ARG;
+    return rs_launch_window_normalize(acc, cd, ch, cw, BK, D, H, W, ST(stream));
+}
+
 int rsuper_dilate_volume(const uint8_t* in, uint8_t* out, uint8_t* tmp, long nvol, int D, int H, int W, int kernel_size, void* stream) {
     if (!in || !out || nvol <= 0 || kernel_size < 1) return RS_ERR_ARG;
     if (kernel_size % 2 == 0) kernel_size += 1;                  // losses_foundation.py:24-25

@@ -116,6 +116,43 @@ __global__ void sigmoid_mask_kernel(const float* x, const uint8_t* m, float* out
         out[i] = (1.f / (1.f + expf(-x[i]))) * ((!m || m[i]) ? 1.f : 0.f);   // accurate exp: feeds argmax / top-k selection
 }
 
+
+// Sliding-window inference (inference/inference3d.py:28-107).  The reference moves every window's sigmoid
+// probabilities to the host and accumulates there; here the accumulator stays in HBM.
+//   acc[b][k][d0+d][h0+h][w0+w] (+)= sigmoid(logits[b][k][d][h][w])      thread = one w-row segment of 4 voxels
+__global__ __launch_bounds__(256) void window_accumulate_kernel(const float* __restrict__ logits, float* __restrict__ acc, int BK,
+                                                                int wd, int wh, int ww, int D, int H, int W, int d0, int h0, int w0, int assign) {
+    const int wq = (ww + 3) / 4;
+    const long total = (long)BK * wd * wh * wq;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        long r = t;
+        const int q = (int)(r % wq); r /= wq;
+        const int h = (int)(r % wh); r /= wh;
+        const int d = (int)(r % wd); r /= wd;
+        const int bk = (int)r;
+        const float* src = logits + (((size_t)bk * wd + d) * wh + h) * ww + q * 4;
+        float* dst = acc + (((size_t)bk * D + d0 + d) * H + h0 + h) * W + w0 + q * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (q * 4 + j < ww) {
+                const float p = 1.f / (1.f + expf(-src[j]));
+                dst[j] = assign ? p : dst[j] + p;
+            }
+        }
+    }
+}
+
+// out = acc / (cd[d] * ch[h] * cw[w]): the per-voxel window count of a half-overlapping grid is separable
+__global__ __launch_bounds__(256) void window_normalize_kernel(float* __restrict__ acc, const float* __restrict__ cd, const float* __restrict__ ch,
+                                                               const float* __restrict__ cw, long BK, int D, int H, int W) {
+    const long total = BK * D * H * W;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int w = (int)(t % W);
+        const int h = (int)((t / W) % H);
+        const int d = (int)((t / ((long)W * H)) % D);
+        acc[t] = acc[t] / (cd[d] * ch[h] * cw[w]);
+    }
+}
 }  // namespace
 
 int rs_launch_plane_partials(const PlaneParams& p, int planes, int bwd, hipStream_t st) {
@@ -134,5 +171,16 @@ int rs_launch_plane_partials(const PlaneParams& p, int planes, int bwd, hipStrea
 
 int rs_launch_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, hipStream_t st) {
     hipLaunchKernelGGL(sigmoid_mask_kernel, dim3(rs_elem_blocks(V)), dim3(256), 0, st, x, m, out, V);
+    return rs_check_launch();
+}
+
+int rs_launch_window_accumulate(const float* logits, float* acc, int BK, int wd, int wh, int ww, int D, int H, int W, int d0, int h0, int w0,
+                                int assign, hipStream_t st) {
+    const long total = (long)BK * wd * wh * ((ww + 3) / 4);
+    hipLaunchKernelGGL(window_accumulate_kernel, dim3(rs_elem_blocks((size_t)total)), dim3(256), 0, st, logits, acc, BK, wd, wh, ww, D, H, W, d0, h0, w0, assign);
+    return rs_check_launch();
+}
+int rs_launch_window_normalize(float* acc, const float* cd, const float* ch, const float* cw, long BK, int D, int H, int W, hipStream_t st) {
+    hipLaunchKernelGGL(window_normalize_kernel, dim3(rs_elem_blocks((size_t)(BK * D * H * W))), dim3(256), 0, st, acc, cd, ch, cw, BK, D, H, W);
     return rs_check_launch();
 }

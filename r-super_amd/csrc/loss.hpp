@@ -19,3 +19,6 @@ struct PlaneParams {
 
 int rs_launch_plane_partials(const PlaneParams& p, int planes, int bwd, hipStream_t st);
 int rs_launch_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, hipStream_t st);
+int rs_launch_window_accumulate(const float* logits, float* acc, int BK, int wd, int wh, int ww, int D, int H, int W, int d0, int h0, int w0,
+                                int assign, hipStream_t st);
+int rs_launch_window_normalize(float* acc, const float* cd, const float* ch, const float* cw, long BK, int D, int H, int W, hipStream_t st);

@@ -42,6 +42,8 @@ _SIGS = {
     'rsuper_plane_partials_fwd': (c_int, [P, c_size_t, P, P, P, P, P, c_int, c_size_t, P]),
     'rsuper_plane_partials_bwd': (c_int, [P, c_size_t, P, P, P, P, P, P, c_int, c_int, c_size_t, P]),
     'rsuper_sigmoid_mask': (c_int, [P, P, P, c_size_t, P]),
+    'rsuper_window_accumulate': (c_int, [P, P] + [c_int] * 11 + [P]),
+    'rsuper_window_normalize': (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, P]),
     'rsuper_dilate_volume': (c_int, [P, P, P, c_long, c_int, c_int, c_int, c_int, P]),
     'rsuper_ball_conv_argmax': (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, P, P]),
     'rsuper_insert_ball': (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -55,6 +55,15 @@ def image(B, S, seed=1234):
     return np.clip(x, -3, 3).astype(np.float32)
 
 
+def volume(shape, seed):
+    """Non-cubic CT-like test volume (1, 1, D, H, W) for the sliding-window inference fixtures."""
+    g = rng(seed)
+    x = g.standard_normal((1, 1) + tuple(shape)).astype(np.float32)
+    z = np.linspace(-1, 1, shape[0], dtype=np.float32)
+    x += 0.5 * np.sin(3.0 * z)[None, None, :, None, None]
+    return np.clip(x, -3, 3).astype(np.float32)
+
+
 def _ellipsoid(S, center, radii):
     z, y, x = np.meshgrid(np.arange(S), np.arange(S), np.arange(S), indexing='ij')
     d = ((z - center[0]) / radii[0]) ** 2 + ((y - center[1]) / radii[1]) ** 2 + ((x - center[2]) / radii[2]) ** 2

@@ -249,3 +249,47 @@ def test_bf16_emulation_distance_is_inherent(golden):
         y16 = uo.unet_forward(sd, img, emulate_bf16=True)
     rel = ((y16 - y32).norm() / y32.norm()).item()
     assert 0.03 < rel < 0.25, rel
+
+
+# ------------------------------------------------------------------ sliding-window inference
+INFER_CASES = ['a', 'pad', 'skip']
+
+
+def _infer_inputs(g, name):
+    shape = tuple(int(v) for v in g[f'{name}_shape'])
+    win = tuple(int(v) for v in g[f'{name}_win'])
+    box = g[f'{name}_box']
+    pan = None
+    if box[0][0] >= 0:
+        pan = np.zeros(shape, np.float32)
+        pan[box[0][0]:box[0][1], box[1][0]:box[1][1], box[2][0]:box[2][1]] = 1
+    return synth.volume(shape, int(g[f'{name}_seed'][0])), win, pan
+
+
+@pytest.mark.parametrize('name', INFER_CASES)
+def test_inference_sliding_window_oracle(golden, name):
+    """oracle/inference_oracle.py (with the oracle UNet) == the imported reference's inference_sliding_window output."""
+    from oracle import inference_oracle as io
+    g = golden['inference']
+    classes = synth.TINY_CLASSES
+    sd = {k: T(v) for k, v in synth.fill_state_dict(uo.unet_param_shapes(1, 8, len(classes)), 3).items()}
+    img, win, pan = _infer_inputs(g, name)
+    pred = io.inference_sliding_window(lambda x: uo.unet_forward(sd, x), T(img), win, len(classes), pancreas=None if pan is None else T(pan)).numpy()
+    sub, step = synth.subsample(pred, 8192)
+    assert step == int(g[f'{name}_step'][0]) and pred.shape == (1, len(classes)) + tuple(int(v) for v in g[f'{name}_shape'])
+    np.testing.assert_allclose(sub, g[f'{name}_sub'], atol=1e-4)
+    np.testing.assert_allclose(synth.summary(pred)[:2], g[f'{name}_summary'][:2], rtol=1e-4)
+
+
+def test_inference_window_counts_are_separable():
+    """The product of the per-axis counts equals the reference's accumulated counter (inference3d.py:68-99)."""
+    from oracle import inference_oracle as io
+    D, H, W, win = 48, 40, 56, (32, 32, 32)
+    cnt = np.zeros((D, H, W))
+    for i in range(D // 16):
+        for j in range(H // 16):
+            for k in range(W // 16):
+                d0, d1 = io.split_idx(16, D, i); h0, h1 = io.split_idx(16, H, j); w0, w1 = io.split_idx(16, W, k)
+                cnt[d0:d1, h0:h1, w0:w1] += 1
+    sep = io.window_counts(D, 32)[:, None, None] * io.window_counts(H, 32)[None, :, None] * io.window_counts(W, 32)[None, None, :]
+    assert np.array_equal(cnt, sep) and cnt.min() >= 1
