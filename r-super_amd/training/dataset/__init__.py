@@ -1,2 +1,3 @@
-"""Host-side data formats of the training hot path: bit-packed label ingestion."""
+"""Host-side data formats of the training hot path: bit-packed label ingestion, epoch/rank sharding."""
 from .packed import pack_bits, unpack_bits_device, ingest_packed_batch  # noqa: F401
+from .sampler import ChunkedSampler  # noqa: F401

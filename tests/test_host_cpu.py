@@ -133,3 +133,24 @@ def test_pack_bits_matches_reference_writer_and_needs_device():
     assert np.array_equal(np.unpackbits(p[0], axis=0)[:26].astype(bool), x[0])
     with pytest.raises(RSuperHipError):
         unpack_bits_device(torch.from_numpy(p), 26)
+
+
+def test_chunked_sampler_matches_reference_sequences():
+    """ChunkedSampler == the imported reference's index sequences for every (case, rank, epoch) in tests/golden/sampler.npz."""
+    import random
+    import numpy as np
+    from rsuper_amd.training.dataset import ChunkedSampler
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'sampler.npz'))
+    for ci, (n, spe, shuffle, seed, world, epochs) in enumerate(g['cases'].tolist()):
+        seen = {}
+        for rank in range(world):
+            s = ChunkedSampler(n, spe, shuffle=bool(shuffle), seed=seed, rank=rank, world_size=world)
+            assert len(s) == int(g[f'c{ci}_r{rank}_len'][0])
+            for e in range(epochs):
+                s.set_epoch(e)
+                random.seed(1000 + e)
+                got = list(iter(s))
+                assert got == g[f'c{ci}_r{rank}_e{e}'].tolist(), (ci, rank, e)
+                seen.setdefault(e, []).append(got)
+        for e, parts in seen.items():              # ranks partition the epoch chunk round-robin
+            assert sum(len(p) for p in parts) == spe
