@@ -156,8 +156,11 @@ int rsuper_window_normalize(float* acc, const float* cd, const float* ch, const 
  * kernel_size <= 7. */
 int rsuper_dilate_volume(const uint8_t* in, uint8_t* out, uint8_t* tmp, long nvol, int D, int H, int W, int kernel_size, void* stream);
 /* isolate_tumor :1423-1445: Gaussian-ball correlation (odd diameter d_odd, std) and first-maximum argmax.
- * best: device u64, pre-zeroed; key = (f32 bits << 32) | (0xFFFFFFFF - linear index). conv_out optional (debug). */
-int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, void* stream);
+ * best: device u64, pre-zeroed; key = (f32 bits << 32) | (0xFFFFFFFF - linear index). conv_out optional (debug).
+ * workspace: (d_odd/2 + 1) * D*H*W floats -> separable two-stage form (row sums per half width, then a k^2 gather per
+ * voxel instead of k^3 taps); NULL -> direct form.  Both are f32; they differ only in summation order. */
+int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, float* workspace,
+                            void* stream);
 /* insert_ball :1336-1385; count (device u32, pre-zeroed) += voxels set. */
 int rsuper_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, void* stream);
 /* exact top-k as radix select over non-negative f32 (torch.topk use at :1483-1492); ties -> lower index first. */

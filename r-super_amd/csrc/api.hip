@@ -286,9 +286,10 @@ int rsuper_dilate_volume(const uint8_t* in, uint8_t* out, uint8_t* tmp, long nvo
     return RS_OK;
 }
 
-int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, void* stream) {
+int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, float* workspace,
+                            void* stream) {
     if (!x || !best || d_odd < 1 || !(d_odd & 1) || std <= 0) return RS_ERR_ARG;
-    return rs_launch_ball_conv_argmax(x, D, H, W, d_odd, std, best, conv_out, ST(stream));
+    return rs_launch_ball_conv_argmax(x, D, H, W, d_odd, std, best, conv_out, workspace, ST(stream));
 }
 int rsuper_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, void* stream) {
     if (!out || !count) return RS_ERR_ARG;

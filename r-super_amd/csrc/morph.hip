@@ -175,6 +175,73 @@ __global__ __launch_bounds__(256) void ball_conv_argmax_kernel(const float* x, i
     }
 }
 
+// Two-stage form of the same correlation, O(k^2) instead of O(k^3) per voxel: the Gaussian factorises per axis and a
+// (dz, dy) row of the ball is the x interval |dx| <= L(dz, dy), so
+//     out(z,y,x) = sum_{dz,dy} g(dz) g(dy) * F_L(dz,dy)(z+dz, y+dy, x),   F_L(z,y,x) = sum_{|dx|<=L} g(dx) x(z,y,x+dx).
+// Stage 1 builds the R+1 running row sums F_0..F_R (F_L = F_{L-1} + g(L) (x[x-L] + x[x+L]), two MACs per L) into the
+// workspace ws[(R+1)][V]; stage 2 gathers k^2 of them per voxel (coalesced along x) and keeps the packed argmax key.
+__global__ __launch_bounds__(256) void ball_rowsum_kernel(const float* __restrict__ x, int D, int H, int W, int R, float inv2s2, float* __restrict__ ws) {
+    const long V = (long)D * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long)gridDim.x * 256) {
+        const int xx = (int)(i % W);
+        const float* row = x + (i - xx);
+        float f = row[xx];
+        ws[i] = f;
+        for (int L = 1; L <= R; ++L) {
+            const float g = expf(-(float)(L * L) * inv2s2);
+            const float a = xx - L >= 0 ? row[xx - L] : 0.f, b = xx + L < W ? row[xx + L] : 0.f;
+            f += g * (a + b);
+            ws[(long)L * V + i] = f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ball_gather_argmax_kernel(const float* __restrict__ ws, int D, int H, int W, int d_odd, float inv2s2,
+                                                                 unsigned long long* best, float* conv_out) {
+    __shared__ float g1[64];
+    __shared__ signed char Lt[64 * 64];                          // row half width per (|dz|, |dy|), -1 outside the ball
+    __shared__ unsigned long long wbest[4];
+    const int R = d_odd >> 1;
+    for (int i = threadIdx.x; i <= R; i += 256) g1[i] = expf(-(float)(i * i) * inv2s2);
+    for (int i = threadIdx.x; i < (R + 1) * (R + 1); i += 256) Lt[(i / (R + 1)) * 64 + i % (R + 1)] = (signed char)row_halfwidth(d_odd, i / (R + 1), i % (R + 1));
+    __syncthreads();
+    const long V = (long)D * H * W;
+    unsigned long long mine = 0ull;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long)gridDim.x * 256) {
+        const int xx = (int)(i % W), yy = (int)((i / W) % H), zz = (int)(i / ((long)W * H));
+        float acc = 0.f;
+        for (int dz = -R; dz <= R; ++dz) {
+            const int z = zz + dz;
+            if (z < 0 || z >= D) continue;
+            const int az = dz < 0 ? -dz : dz;
+            float part = 0.f;
+            for (int dy = -R; dy <= R; ++dy) {
+                const int y = yy + dy;
+                const int ay = dy < 0 ? -dy : dy;
+                const int L = Lt[az * 64 + ay];
+                if (L < 0 || y < 0 || y >= H) continue;
+                part += g1[ay] * ws[(long)L * V + ((long)z * H + y) * W + xx];
+            }
+            acc += g1[az] * part;
+        }
+        if (conv_out) conv_out[i] = acc;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+        mine = key > mine ? key : mine;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(mine, o, 64);
+        mine = other > mine ? other : mine;
+    }
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = wbest[0];
+        for (int i = 1; i < 4; ++i) b = wbest[i] > b ? wbest[i] : b;
+        atomicMax(best, b);
+    }
+}
+
 // binary ball of (odd) diameter d_odd centred at (cz,cy,cx); count of set voxels accumulated into *count
 __global__ void insert_ball_kernel(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count) {
     const long V = (long)D * H * W;
@@ -299,10 +366,16 @@ int rs_launch_dilate_pass(const uint8_t* in, uint8_t* out, long nvol, int D, int
     return rs_check_launch();
 }
 
-int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, hipStream_t st) {
+int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, float* ws,
+                               hipStream_t st) {
     if ((d_odd >> 1) >= 64) return RS_ERR_UNSUPPORTED;
     const long V = (long)D * H * W;
     int blocks = (int)((V + 255) / 256);
+    if (ws) {
+        hipLaunchKernelGGL(ball_rowsum_kernel, dim3(blocks), dim3(256), 0, st, x, D, H, W, d_odd >> 1, 1.f / (2.f * std * std), ws);
+        hipLaunchKernelGGL(ball_gather_argmax_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, D, H, W, d_odd, 1.f / (2.f * std * std), best, conv_out);
+        return rs_check_launch();
+    }
     hipLaunchKernelGGL(ball_conv_argmax_kernel, dim3(blocks), dim3(256), 0, st, x, D, H, W, d_odd, 1.f / (2.f * std * std), best, conv_out);
     return rs_check_launch();
 }

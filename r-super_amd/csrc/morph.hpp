@@ -3,7 +3,8 @@
 #include <stddef.h>
 #include <stdint.h>
 int rs_launch_dilate_pass(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k, hipStream_t st);
-int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, hipStream_t st);
+int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, float* ws,
+                               hipStream_t st);
 int rs_launch_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, hipStream_t st);
 int rs_launch_radix_hist(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist, hipStream_t st);
 int rs_launch_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr, unsigned int need_eq, uint8_t* out, hipStream_t st);

@@ -202,7 +202,9 @@ def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_ma
     if nnz > vol:                         # :1431-1433 (vol becomes a 0-dim tensor there -> float32 products below)
         vol, f32 = nnz - 1, True
     best = torch.zeros(1, device=x.device, dtype=torch.int64)
-    _l.check(_L().rsuper_ball_conv_argmax(_ptr(x), D, H, W, diameter, float(gaussian_std * (diameter / 2.0)), _ptr(best), None, _stream()),
+    # separable two-stage correlation (k^2 gathers per voxel instead of k^3 taps); direct form for tiny balls
+    ws = torch.empty(((diameter // 2 + 1) * V,), device=x.device, dtype=torch.float32) if (diameter >= 5 and os.environ.get('RSUPER_BALL_DIRECT', '0') != '1') else None
+    _l.check(_L().rsuper_ball_conv_argmax(_ptr(x), D, H, W, diameter, float(gaussian_std * (diameter / 2.0)), _ptr(best), None, _ptr(ws), _stream()),
               'ball_conv_argmax')
     key = int(best.item()) & 0xFFFFFFFFFFFFFFFF
     idx = 0xFFFFFFFF - (key & 0xFFFFFFFF)

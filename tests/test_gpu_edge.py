@@ -178,3 +178,25 @@ def test_packed_batch_gives_same_loss():
                                   'volumes': bt['volumes'], 'diameters': bt['diameters']}, len(classes), DEV)
     a, b = run(plain), run(packed)
     assert a.keys() == b.keys() and all(a[k] == b[k] for k in a), (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('d_odd', [5, 9, 21])
+def test_ball_conv_two_stage_equals_direct(d_odd):
+    """The separable two-stage correlation gives the direct kernel's values (f32 summation-order tolerance) and argmax."""
+    from rsuper_amd.hip import lib
+    L = lib.lib()
+    D, H, W = 24, 20, 28
+    g = torch.Generator(device=DEV).manual_seed(d_odd)
+    x = torch.rand((D, H, W), device=DEV, generator=g)
+    outs, keys = [], []
+    for two_stage in (False, True):
+        best = torch.zeros(1, device=DEV, dtype=torch.int64)
+        conv = torch.empty((D, H, W), device=DEV)
+        ws = torch.empty(((d_odd // 2 + 1) * D * H * W,), device=DEV) if two_stage else None
+        rc = L.rsuper_ball_conv_argmax(x.data_ptr(), D, H, W, d_odd, 1.5 * d_odd / 2.0, best.data_ptr(), conv.data_ptr(),
+                                       ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(conv.cpu()); keys.append(int(best.item()) & 0xFFFFFFFF)
+    assert torch.allclose(outs[0], outs[1], rtol=2e-5, atol=1e-5)
+    assert keys[0] == keys[1]
