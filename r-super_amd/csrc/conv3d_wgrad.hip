@@ -353,7 +353,7 @@ int launch(const WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
-// Configuration per launch (measured on MI355X, tests/bench_conv.py):
+// Configuration per launch (measured on MI355X, tools/bench_conv.py):
 //   0: M <= 32           -> 32 rows x 27 taps, 4 waves, one block per CU
 //   1: M > 32, few tiles -> 64 rows x 9 taps (kd split over blocks), 4 waves, two blocks per CU
 //   2: M > 32, >= 128 tiles (bf16) -> 64 rows x 27 taps, 8 waves, one block per CU: the x halo and the dY tile are staged

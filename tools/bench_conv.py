@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the MFMA conv kernels on the layer shapes of the full UNet (B=2, 96^3, base 32).
-Usage: python tests/bench_conv.py [bf16|f32]"""
+Usage: python tools/bench_conv.py [bf16|f32]"""
 import os, sys, math
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
