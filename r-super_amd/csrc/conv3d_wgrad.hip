@@ -18,6 +18,8 @@
 namespace {
 
 constexpr int TD = 4, TH = 4, TW = 16;
+constexpr int WG_BD = 3;                                         // B-fragment prefetch distance (MFMA units), classic kernel (>= 2 waves / SIMD)
+constexpr int WG_PC_BD = 7;                                      // producer/consumer kernel: one MFMA wave per SIMD, latency covered by distance
 constexpr int HH = TH + 2, HW = TW + 2;
 
 typedef short v4s_t __attribute__((__vector_size__(4 * sizeof(short))));
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
                 return frag_bf16<TR>(xb_base[i] + ((dd * HH + hh) * HW) * XP, XP);
             };
             // few waves per SIMD: LDS latency (~130+ cycles) must be covered by prefetch distance, one MFMA is only 32 cycles
-            constexpr int NU = TD * TH * TPW, BD = 3, BR = 4;
+            constexpr int NU = TD * TH * TPW, BD = WG_BD, BR = WG_BD + 1;
             uint4 aq[2], bq[BR];
             aq[0] = fetch_a(0);
 #pragma unroll
@@ -311,10 +313,292 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
     }
 }
 
+// =====================================================================================================================
+// Producer / consumer (wave-specialised) variant, bf16.  NCW consumer waves run the VALU-free MFMA loop (two
+// ds_read_b64_tr_b16 + one MFMA per unit) on one LDS buffer while four producer waves stage the next tile of the split
+// (global loads, norm+ReLU, LDS writes) into the other: the staging VALU no longer serialises with the MFMAs inside a
+// wave (the classic kernel has <= 2 waves per SIMD).  One block barrier per tile.  Both operands come from LDS, so
+// unlike the igemm there is no L1 weight-fragment stream to bound the consumers.
+//   PF2: producers keep two tiles of loads in flight (two register sets); off for the 12-wave configuration (168 VGPRs).
+// =====================================================================================================================
+template <int MT, int NTAPS, int TR, int NCW, bool PF2>
+__global__ __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) void wgrad_pc_kernel(WgradParams p) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KP = 8, XP = 64, YP = MT * 64;                 // unpadded rows: 2-way conflicts only on the (rare) dY fragment reads
+    constexpr int HDN = NTAPS == 27 ? TD + 2 : TD;
+    constexpr int XROWS = HDN * HH * HW;
+    constexpr int XV = 4, YV = MT * 4;
+    constexpr int BUF = XROWS * XP + 256 * YP;                   // bytes per buffer
+    constexpr int WT = NCW / MT;
+    constexpr int TPW = (NTAPS + WT - 1) / WT;
+    constexpr int NT = 256;                                      // producer threads
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= NCW;
+    const int nchA = (p.xa.C + 31) / 32;
+    const bool isB = (int)blockIdx.x >= nchA;
+    const ConvSrc& xs = isB ? p.xb : p.xa;
+    const int c0 = (isB ? blockIdx.x - nchA : blockIdx.x) * 32;
+    const int cin_total = p.xa.C + p.xb.C;
+    const int cin_base = (isB ? p.xa.C : 0) + c0;
+    const int Mtot = p.ya.C + p.yb.C;
+    const int mgroups = (Mtot + MT * 32 - 1) / (MT * 32);
+    const int mg = blockIdx.y % mgroups;
+    const int kdg = NTAPS == 27 ? 0 : blockIdx.y / mgroups;
+    const int m0 = mg * MT * 32;
+    const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH, tiles_d = (p.D + TD - 1) / TD;
+    const int tiles_per_sample = tiles_w * tiles_h * tiles_d;
+    const int tiles = tiles_per_sample * p.N;
+    const int nitems = ((int)blockIdx.z < tiles) ? (tiles - 1 - (int)blockIdx.z) / p.splits + 1 : 0;
+
+    if (producer) {
+        // ------------------------------------------------------------------ producer waves
+        const int ptid = tid - 64 * NCW;
+        const bool norm = xs.mr != nullptr;
+        constexpr int NXV = (XROWS * XV + NT - 1) / NT, NYV = (256 * YV + NT - 1) / NT;
+        constexpr int XRS = NT / XV, YRS = NT / YV;
+        const int xs_slot = ptid % XV, xs_row = ptid / XV;
+        const int ys_slot = ptid % YV, ys_row = ptid / YV;
+        const bool x_cok = c0 + xs_slot * KP < xs.C;
+        const int ym = m0 + ys_slot * KP;
+        const T* ysrc = nullptr; int yld = 0;
+        if (ym < Mtot) {
+            if (ym < p.ya.C) { ysrc = (const T*)p.ya.x + ym; yld = p.ya.ld; }
+            else { ysrc = (const T*)p.yb.x + (ym - p.ya.C); yld = p.yb.ld; }
+        }
+        float sc_[KP], nb_[KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) { sc_[j] = 1.f; nb_[j] = 0.f; }
+        int xdelta[NXV], ydelta[NYV];
+        uint32_t xrows_ok = 0, yrows_ok = 0;
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) {
+            const int r = xs_row + i * XRS;
+            const int hd = r / (HH * HW);
+            const int rem = r - hd * (HH * HW);
+            const int hh = rem / HW, hw = rem - hh * HW;
+            xdelta[i] = (hd * p.H + hh) * p.W + hw;
+            xrows_ok |= (r < XROWS && x_cok) ? (1u << i) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < NYV; ++i) {
+            const int r = ys_row + i * YRS;
+            ydelta[i] = ((r >> 6) * p.H + ((r >> 4) & 3)) * p.W + (r & 15);
+            yrows_ok |= (r < 256 && ysrc != nullptr) ? (1u << i) : 0u;
+        }
+        const uint32_t nvox_total = (uint32_t)(p.N * p.D * p.H * p.W);
+        const uint32_t xrowb = (uint32_t)xs.ld * (uint32_t)sizeof(T);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xs.x, 0, nvox_total * xrowb, 0x00020000);
+        const uint32_t xcol = (uint32_t)(c0 + xs_slot * KP) * (uint32_t)sizeof(T);
+        auto ld16 = [&](uint32_t off) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+            return make_uint4(q[0], q[1], q[2], q[3]);
+        };
+        auto tile_of = [&](int it) { return (int)blockIdx.z + it * p.splits; };
+        auto issue = [&](int it, uint4* px, uint4* py, uint32_t& xmask) {
+            int t = tile_of(it);
+            const int tw = t % tiles_w; t /= tiles_w;
+            const int th = t % tiles_h; t /= tiles_h;
+            const int td = t % tiles_d; t /= tiles_d;
+            const int n = t, d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+            const int dlo = d0 + (NTAPS == 27 ? -1 : kdg - 1);
+            const bool x_in = dlo >= 0 && dlo + HDN <= p.D && h0 >= 1 && h0 + TH + 1 <= p.H && w0 >= 1 && w0 + TW + 1 <= p.W;
+            const bool y_in = d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;
+            if (x_in) {
+                const int base = ((n * p.D + dlo) * p.H + (h0 - 1)) * p.W + (w0 - 1);
+                xmask = xrows_ok;
+#pragma unroll
+                for (int i = 0; i < NXV; ++i) px[i] = ld16(((xrows_ok >> i) & 1u) ? (uint32_t)(base + xdelta[i]) * xrowb + xcol : 0xFFFFFFFFu);
+            } else {
+                xmask = 0;
+#pragma unroll
+                for (int i = 0; i < NXV; ++i) {
+                    const int r = xs_row + i * XRS;
+                    const int hd = r / (HH * HW);
+                    const int rem = r - hd * (HH * HW);
+                    const int hh = rem / HW, hw = rem - hh * HW;
+                    const int d = dlo + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+                    const bool ok = ((xrows_ok >> i) & 1u) && d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W;
+                    const uint32_t vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
+                    px[i] = ld16(ok ? vox * xrowb + xcol : 0xFFFFFFFFu);
+                    xmask |= ok ? (1u << i) : 0u;
+                }
+            }
+            const int ybase = ((n * p.D + d0) * p.H + h0) * p.W + w0;
+#pragma unroll
+            for (int i = 0; i < NYV; ++i) {
+                const int r = ys_row + i * YRS;
+                const int d = d0 + (r >> 6), h = h0 + ((r >> 4) & 3), w = w0 + (r & 15);
+                const bool ok = ((yrows_ok >> i) & 1u) && (y_in || (d < p.D && h < p.H && w < p.W));
+                const T* src = ok ? ysrc + (size_t)(uint32_t)(ybase + ydelta[i]) * (uint32_t)yld : (const T*)p.ya.x;   // branch-free
+                const uint4 q = *(const uint4*)src;
+                py[i] = ok ? q : make_uint4(0, 0, 0, 0);
+            }
+        };
+        int cur_n = -1;
+        auto commit = [&](int it, const uint4* px, const uint4* py, const uint32_t xmask) {
+            const int n = tile_of(it) / tiles_per_sample;
+            if (norm && n != cur_n) {
+                cur_n = n;
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const int c = c0 + xs_slot * KP + j;
+                    const float mu = c < xs.C ? xs.mr[((size_t)n * xs.C + c) * 2] : 0.f, rs = c < xs.C ? xs.mr[((size_t)n * xs.C + c) * 2 + 1] : 1.f;
+                    sc_[j] = rs; nb_[j] = -mu * rs;
+                }
+            }
+            char* buf = smem + (it & 1) * BUF;
+            char* x_lds = buf + xs_row * XP + xs_slot * 16;
+            char* y_lds = buf + XROWS * XP + ys_row * YP + ys_slot * 16;
+#pragma unroll
+            for (int i = 0; i < NXV; ++i) {
+                uint4 q = px[i];
+                if (norm && ((xmask >> i) & 1u)) {
+                    float f[KP];
+                    unpack16<T>(q, f);
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) f[j] = fmaxf(fmaf(f[j], sc_[j], nb_[j]), 0.f);
+                    q = pack16<T>(f);
+                }
+                if (xs_row + i * XRS < XROWS) *(uint4*)(x_lds + i * (XRS * XP)) = q;
+            }
+#pragma unroll
+            for (int i = 0; i < NYV; ++i)
+                if (ys_row + i * YRS < 256) *(uint4*)(y_lds + i * (YRS * YP)) = py[i];
+        };
+        constexpr int NXV2 = PF2 ? NXV : 1, NYV2 = PF2 ? NYV : 1;
+        uint4 pxA[NXV], pyA[NYV], pxB[NXV2], pyB[NYV2];
+        uint32_t xmA = 0, xmB = 0;
+        if constexpr (PF2) {
+            // even items in set A, odd items in set B; loads are issued two items ahead
+            if (nitems > 0) { issue(0, pxA, pyA, xmA); commit(0, pxA, pyA, xmA); }
+            if (nitems > 1) issue(1, pxB, pyB, xmB);
+            if (nitems > 2) issue(2, pxA, pyA, xmA);
+            __syncthreads();
+            for (int it = 0; it < nitems; it += 2) {
+                if (it + 1 < nitems) {
+                    commit(it + 1, pxB, pyB, xmB);
+                    if (it + 3 < nitems) issue(it + 3, pxB, pyB, xmB);
+                }
+                __syncthreads();
+                if (it + 1 < nitems) {
+                    if (it + 2 < nitems) {
+                        commit(it + 2, pxA, pyA, xmA);
+                        if (it + 4 < nitems) issue(it + 4, pxA, pyA, xmA);
+                    }
+                    __syncthreads();
+                }
+            }
+        } else {
+            if (nitems > 0) { issue(0, pxA, pyA, xmA); commit(0, pxA, pyA, xmA); }
+            if (nitems > 1) issue(1, pxA, pyA, xmA);
+            __syncthreads();
+            for (int it = 0; it < nitems; ++it) {
+                if (it + 1 < nitems) {
+                    commit(it + 1, pxA, pyA, xmA);
+                    if (it + 2 < nitems) issue(it + 2, pxA, pyA, xmA);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ consumer waves
+        const int wm = wave % MT, wt = wave / MT;
+        f32x16_t acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        int xb_off[TPW];                                         // per-tap fragment base (lane part folded in), buffer 0
+        {
+            const int wts = __builtin_amdgcn_readfirstlane(wt);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                int tl = wts + i * WT;
+                if (tl >= NTAPS) tl = NTAPS - 1;
+                const int kd = NTAPS == 27 ? tl / 9 : 0, kh = (tl % 9) / 3, kw = tl % 3;
+                xb_off[i] = ((kd * HH + kh) * HW + kw) * XP + frag_lane_off<TR>(XP, lane);
+            }
+        }
+        const int ya_off = XROWS * XP + wm * 64 + frag_lane_off<TR>(YP, lane);
+        __syncthreads();                                         // item 0 staged
+        for (int it = 0; it < nitems; ++it) {
+            const char* buf = smem + (it & 1) * BUF;
+            auto fetch_a = [&](int row) { return frag_bf16<TR>(buf + ya_off + (row * TW) * YP, YP); };
+            auto fetch_b = [&](int row, int i) {
+                const int dd = row / TH, hh = row % TH;
+                return frag_bf16<TR>(buf + xb_off[i] + ((dd * HH + hh) * HW) * XP, XP);
+            };
+            constexpr int NU = TD * TH * TPW, BD = WG_PC_BD, BR = WG_PC_BD + 1;
+            uint4 aq[2], bq[BR];
+            aq[0] = fetch_a(0);
+#pragma unroll
+            for (int u = 0; u < BD; ++u) bq[u] = fetch_b(u / TPW, u % TPW);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int row = u / TPW, i = u % TPW;
+                if (u + BD < NU) bq[(u + BD) % BR] = fetch_b((u + BD) / TPW, (u + BD) % TPW);
+                if (i == 0 && row + 1 < TD * TH) aq[(row + 1) & 1] = fetch_a(row + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma32<bf16_t>(acc[i], aq[row & 1], bq[u % BR]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+        // ---- write this split's partial dW slab: ws[split][tap][m][cin]
+        const int ci = c0 + (lane & 31);
+        float* slab = p.ws + (size_t)blockIdx.z * 27 * Mtot * cin_total;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int tl = wt + i * WT;
+            if (tl >= NTAPS) continue;
+            const int tap = NTAPS == 27 ? tl : kdg * 9 + tl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + cd_row32(r, lane);
+                if (m < Mtot && ci < xs.C) slab[((size_t)tap * Mtot + m) * cin_total + cin_base + (lane & 31)] = acc[i][r];
+            }
+        }
+    }
+}
+
 // dW[m][cin][tap] = sum_s ws[s][tap][m][cin]; rows [0,Ya) -> dwa, [Ya, Ya+Yb) -> dwb.
-// thread = one slab element e = (tap*Mtot + m)*Cin + cin: reads are coalesced across threads for every split.
+// Block = 32 consecutive slab elements x 8 split groups: the loads of one element are spread over 8 threads (a single
+// thread walking 256 slabs serialised ~64 dependent load rounds and dominated small layers), each row of 32 threads
+// reads 128 contiguous bytes per slab; the 8 partials meet in LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Mtot, int Ya, int Cin,
                                                            float* dwa, float* dwb) {
+    __shared__ float part[8][32];
+    const size_t E = (size_t)27 * Mtot * Cin;
+    const int el = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const size_t e = (size_t)blockIdx.x * 32 + el;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < E) {
+        int s = sg;
+        for (; s + 24 < splits; s += 32) {
+            a0 += ws[(size_t)s * E + e]; a1 += ws[(size_t)(s + 8) * E + e];
+            a2 += ws[(size_t)(s + 16) * E + e]; a3 += ws[(size_t)(s + 24) * E + e];
+        }
+        for (; s < splits; s += 8) a0 += ws[(size_t)s * E + e];
+    }
+    part[sg][el] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sg == 0 && e < E) {
+        float v = part[0][el];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += part[k][el];
+        const int c = (int)(e % Cin);
+        const size_t r = e / Cin;
+        const int m = (int)(r % Mtot), tap = (int)(r / Mtot);
+        float* dst = m < Ya ? dwa + ((size_t)m * Cin + c) * 27 : dwb + ((size_t)(m - Ya) * Cin + c) * 27;
+        dst[tap] = v;
+    }
+}
+
+// Few slabs (large weight tensors at low resolution): thread = one slab element, reads coalesced across threads.
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ ws, int splits, int Mtot, int Ya, int Cin,
+                                                                float* dwa, float* dwb) {
     const size_t E = (size_t)27 * Mtot * Cin;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
@@ -332,6 +616,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dst[tap] = (a0 + a1) + (a2 + a3);
 }
 
+static void launch_reduce(const WgradParams& p, hipStream_t st) {
+    const int Mtot = p.ya.C + p.yb.C, Cin = p.xa.C + p.xb.C;
+    const size_t elems = (size_t)27 * Mtot * Cin;
+    if (p.splits >= 16)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C, Cin, p.dwa, p.dwb);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C, Cin, p.dwa, p.dwb);
+}
+
 template <typename T, int MT, int NTAPS, int TR, int NW>
 int launch(const WgradParams& p, hipStream_t st) {
     constexpr int XP = WG<T>::XP;
@@ -345,9 +638,22 @@ int launch(const WgradParams& p, hipStream_t st) {
     auto k = wgrad_kernel<T, MT, NTAPS, TR, NW>;
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
-    const size_t elems = (size_t)27 * Mtot * (p.xa.C + p.xb.C);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C,
-                       p.xa.C + p.xb.C, p.dwa, p.dwb);
+    launch_reduce(p, st);
+    return rs_check_launch();
+}
+
+template <int MT, int NTAPS, int TR, int NCW, bool PF2>
+int launch_pc(const WgradParams& p, hipStream_t st) {
+    constexpr int HDN = NTAPS == 27 ? TD + 2 : TD;
+    const size_t smem = 2 * ((size_t)HDN * HH * HW * 64 + 256 * MT * 64);
+    const int nch = (p.xa.C + 31) / 32 + (p.xb.C + 31) / 32;
+    const int Mtot = p.ya.C + p.yb.C;
+    const int mgroups = (Mtot + MT * 32 - 1) / (MT * 32);
+    dim3 grid(nch, mgroups * (NTAPS == 27 ? 1 : 3), p.splits), block(64 * (NCW + 4));
+    auto k = wgrad_pc_kernel<MT, NTAPS, TR, NCW, PF2>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    launch_reduce(p, st);
     return rs_check_launch();
 }
 
@@ -378,8 +684,10 @@ int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st)
     const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);
     if (dtype == RS_F32) return cfg == 0 ? launch<float, 1, 27, 0, 4>(p, st) : launch<float, 2, 9, 0, 4>(p, st);
     if (dtype == RS_BF16) {
-        if (use_tr) return cfg == 0 ? launch<bf16_t, 1, 27, 1, 4>(p, st) : cfg == 1 ? launch<bf16_t, 2, 9, 1, 4>(p, st) : launch<bf16_t, 2, 27, 1, 8>(p, st);
-        return cfg == 0 ? launch<bf16_t, 1, 27, 0, 4>(p, st) : cfg == 1 ? launch<bf16_t, 2, 9, 0, 4>(p, st) : launch<bf16_t, 2, 27, 0, 8>(p, st);
+        // config 0 runs the producer/consumer kernel (177 -> 131 us on 32->32 @96^3); on configs 1/2 it measured equal or
+        // slower (12 waves hit the 168-VGPR cap) and the classic kernel stays
+        if (use_tr) return cfg == 0 ? launch_pc<1, 27, 1, 4, true>(p, st) : cfg == 1 ? launch<bf16_t, 2, 9, 1, 4>(p, st) : launch<bf16_t, 2, 27, 1, 8>(p, st);
+        return cfg == 0 ? launch_pc<1, 27, 0, 4, true>(p, st) : cfg == 1 ? launch<bf16_t, 2, 9, 0, 4>(p, st) : launch<bf16_t, 2, 27, 0, 8>(p, st);
     }
     return RS_ERR_ARG;
 }
