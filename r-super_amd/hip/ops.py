@@ -176,8 +176,9 @@ def overlap_enabled():
     if os.environ.get('RSUPER_WGRAD_OVERLAP', '1') != '1':
         return False
     import torch.distributed as dist
-    # under DDP the reducer's hooks consume gradients as soon as a block's backward returns -> no deferred join
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    # under DDP (any world size, incl. the 1-rank `bench.py --force-ddp`) the reducer's hooks copy each gradient into its
+    # bucket as soon as the block's backward returns, on the main stream -> no deferred join possible
+    return not (dist.is_available() and dist.is_initialized())
 
 
 def side_stream():
