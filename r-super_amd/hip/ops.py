@@ -161,6 +161,18 @@ class KernelTimer:
 
 
 TIMER = None   # set to a KernelTimer to time conv launches
+GRAD_DEST = None   # optional callable(param) -> tensor view to write that parameter's gradient into (rsuper_amd.reducer)
+
+
+def grad_dest(w, shape=None):
+    """Destination tensor for the gradient of parameter `w`: a flat-bucket view when a GradReducer is attached, else a fresh
+    tensor.  Kernels overwrite it completely."""
+    if GRAD_DEST is not None:
+        v = GRAD_DEST(w)
+        if v is not None:
+            return v
+    return torch.empty_like(w) if shape is None else torch.empty(shape, device=w.device, dtype=torch.float32)
+
 
 # ------------------------------------------------------------------------------------------------ side stream
 # Weight gradients depend only on (x, dY) and are consumed by the optimiser, so they run on a second HIP stream
@@ -173,12 +185,16 @@ _CALLBACK_QUEUED = False
 
 
 def overlap_enabled():
-    if os.environ.get('RSUPER_WGRAD_OVERLAP', '1') != '1':
-        return False
+    return os.environ.get('RSUPER_WGRAD_OVERLAP', '1') == '1'
+
+
+def _join_per_block():
+    """Under DDP (any world size, incl. the 1-rank `bench.py --force-ddp`) the reducer's hooks copy each gradient into its
+    bucket as soon as the block's backward returns, on the main stream: the side stream is joined at the end of every
+    block's backward instead of once at the end of the whole backward pass."""
     import torch.distributed as dist
-    # under DDP (any world size, incl. the 1-rank `bench.py --force-ddp`) the reducer's hooks copy each gradient into its
-    # bucket as soon as the block's backward returns, on the main stream -> no deferred join possible
-    return not (dist.is_available() and dist.is_initialized())
+    # with rsuper_amd.reducer.GradReducer attached (GRAD_DEST set) the collectives are ordered on the side stream itself
+    return GRAD_DEST is None and dist.is_available() and dist.is_initialized()
 
 
 def side_stream():
@@ -227,7 +243,8 @@ class _Side:
             self.ctx.__exit__(*a)
             for t in self.tensors:
                 t.record_stream(side_stream())     # keep inputs alive until the side stream has consumed them
-            _queue_join()
+            if not _join_per_block():
+                _queue_join()
         return False
 
 
@@ -353,7 +370,7 @@ class BasicBlockFn(torch.autograd.Function):
         # the join with the side stream is deferred to the end of backward: only safe when AccumulateGrad merely stores
         # the new gradient (p.grad is None, zero_grad(set_to_none=True)); an in-place `p.grad += dw` would race
         ov = overlap_enabled() and all(w.grad is None for w in (w1, w2, ws) if w is not None)
-        dw2 = torch.empty_like(w2)
+        dw2 = grad_dest(w2)
         with _Side(ov, (ys, mr_y1, dout, dw2)):
             wgrad(y1, None, sdo, None, dw2, None, dims)
         dy1 = in_bwd_finalize(Src(g1), y1, gm1, Cout)
@@ -365,8 +382,8 @@ class BasicBlockFn(torch.autograd.Function):
         part0 = part_buffer(dt, dims, Cin, bn, dev, epi=1)
         igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
         gm0 = stats_finalize(part0, cnt, mode=1)
-        dw1 = torch.empty_like(w1)
-        dws = torch.empty_like(ws) if has_sc else None
+        dw1 = grad_dest(w1)
+        dws = grad_dest(ws) if has_sc else None
         with _Side(ov, (xa, mra, xb, mrb, dy1, dout, dw1, dws)):
             wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims)
         if xb is None:
@@ -375,6 +392,8 @@ class BasicBlockFn(torch.autograd.Function):
         else:
             dxa = in_bwd_finalize(Src(g0, C=Ca), sa, gm0[:, :Ca].contiguous(), Ca)
             dxb = in_bwd_finalize(Src(g0, C=Cb, off=Ca), sb, gm0[:, Ca:].contiguous(), Cb)
+        if ov and _join_per_block():
+            join_side()
         return dxa, None, dxb, None, dw1, dw2, dws, None
 
 
@@ -466,7 +485,7 @@ class StemFn(torch.autograd.Function):
         dy = dy.contiguous()
         N, _, D, H, W = img.shape
         C = w.shape[0]
-        dw = torch.empty_like(w)
+        dw = grad_dest(w)
         _l.check(_L().rsuper_stem_wgrad(_DT[dy.dtype], _ptr(img), _ptr(dy), C, _ptr(dw), N, D, H, W, C, _stream()), 'stem_wgrad')
         return None, dw, None
 
@@ -481,18 +500,18 @@ class HeadFn(torch.autograd.Function):
         K = w.shape[0]
         logits = torch.empty((N, K, D, H, W), device=x.device, dtype=torch.float32)
         _l.check(_L().rsuper_head_fwd(_DT[x.dtype], _ptr(x), C, _ptr(w), _ptr(b), _ptr(logits), N, D * H * W, C, K, _stream()), 'head_fwd')
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, b)
         return logits
 
     @staticmethod
     def backward(ctx, dl):
-        x, w = ctx.saved_tensors
+        x, w, b = ctx.saved_tensors
         dl = dl.contiguous().float()
         N, D, H, W, C = x.shape
         K = w.shape[0]
         dx = torch.empty_like(x)
-        dw = torch.empty_like(w)
-        db = torch.empty((K,), device=x.device, dtype=torch.float32)
+        dw = grad_dest(w)
+        db = grad_dest(b)
         st = _stream()
         _l.check(_L().rsuper_head_bwd_data(_DT[x.dtype], _ptr(dl), _ptr(w), _ptr(dx), C, N, D * H * W, C, K, st), 'head_bwd_data')
         _l.check(_L().rsuper_head_bwd_weight(_DT[x.dtype], _ptr(x), C, _ptr(dl), _ptr(dw), _ptr(db), N, D * H * W, C, K, st), 'head_bwd_weight')

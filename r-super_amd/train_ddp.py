@@ -36,6 +36,9 @@ def train_step(net, ema_net, optimizer, batch, args, classes, step, matcher=None
                                  tumor_volumes_report=batch.get('volumes'), tumor_diameters=batch.get('diameters'),
                                  classes=classes, input_tensor=img, class_weights=batch.get('weights'))
     loss_all['overall'].backward()
+    reducer = getattr(net, '_rsuper_reducer', None)
+    if reducer is not None:
+        reducer.finish()                 # gradients are now the mean over ranks (what DDP's reducer leaves in p.grad)
     gnorm = None
     if isinstance(optimizer, FusedAdamWEMA):
         ema_params = list(ema_net.parameters()) if (ema_net is not None and getattr(args, 'ema', True)) else None
@@ -89,9 +92,16 @@ def init_distributed(backend=None):
 
 
 def wrap_ddp(net, local_rank, bucket_cap_mb=25):
-    """DistributedDataParallel(net, device_ids=[idx], find_unused_parameters=False) (train_ddp.py:663).
-    gradient_as_bucket_view avoids the extra copy of every gradient into the bucket."""
+    """Data-parallel wrapper of main_worker (train_ddp.py:663, DistributedDataParallel(net, device_ids=[idx],
+    find_unused_parameters=False)).  On the GPU the default is rsuper_amd.reducer.GradReducer attached to the bare module
+    (same mathematics: rank-0 parameter broadcast + mean of gradients; flat buckets the HIP kernels write into, one async
+    RCCL all-reduce per bucket from the weight-gradient stream) -- `train_step` calls its finish() after backward.
+    RSUPER_REDUCER=0 (or a CPU module) selects torch's DistributedDataParallel with gradient_as_bucket_view."""
     from torch.nn.parallel import DistributedDataParallel as DDP
+    if next(net.parameters()).is_cuda and os.environ.get('RSUPER_REDUCER', '1') == '1':
+        from .reducer import GradReducer
+        net._rsuper_reducer = GradReducer(net, bucket_mb=int(os.environ.get('RSUPER_DDP_BUCKET_MB', 48)))
+        return net
     if next(net.parameters()).is_cuda:
         bucket_cap_mb = int(os.environ.get('RSUPER_DDP_BUCKET_MB', bucket_cap_mb))
         return DDP(net, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,

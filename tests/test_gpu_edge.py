@@ -200,3 +200,50 @@ def test_ball_conv_two_stage_equals_direct(d_odd):
         outs.append(conv.cpu()); keys.append(int(best.item()) & 0xFFFFFFFF)
     assert torch.allclose(outs[0], outs[1], rtol=2e-5, atol=1e-5)
     assert keys[0] == keys[1]
+
+
+@pytest.mark.gpu
+def test_grad_reducer_single_rank_nccl_matches_plain():
+    """wrap_ddp's GradReducer on a 1-rank RCCL group: gradients land in the flat buckets, two optimiser steps give exactly
+    the parameters of the un-wrapped run (mean over one rank = identity)."""
+    import os
+    import torch.distributed as dist
+    from rsuper_amd.hip import ops
+    from rsuper_amd.model.dim3.unet import UNet
+    from rsuper_amd.train_ddp import train_step, wrap_ddp, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    from rsuper_amd.training import losses_foundation as lf
+    classes = synth.TINY_CLASSES
+    B, S = 2, 32
+    bt = synth.batch(B, S, classes, ['mask', 'mask'], seed=5)
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in bt.items() if k in ('label', 'unk_channels', 'mask', 'volumes', 'diameters')}
+    batch['image'] = torch.from_numpy(synth.image(B, S, seed=3)).to(DEV)
+    la = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.0, volume_loss_tolerance=0.2,
+                            ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                            classification_branch=False, ema=True, ema_alpha=0.99)
+
+    def run(wrapped):
+        torch.manual_seed(0)
+        net = UNet(1, 8, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype='f32').to(DEV)
+        ema = make_ema(net)
+        model = wrap_ddp(net, 0) if wrapped else net
+        opt = FusedAdamWEMA(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        for step in range(2):
+            train_step(model, ema, opt, batch, la, classes, step)
+        if wrapped:
+            red = net._rsuper_reducer
+            for p in net.parameters():
+                b, off = red._slot[p]
+                assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * off
+            red.remove()
+        return [p.detach().clone() for p in net.parameters()]
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29541')
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        a = run(True)
+    finally:
+        dist.destroy_process_group()
+        ops.GRAD_DEST = None
+    b = run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

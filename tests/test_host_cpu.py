@@ -154,3 +154,14 @@ def test_chunked_sampler_matches_reference_sequences():
                 seen.setdefault(e, []).append(got)
         for e, parts in seen.items():              # ranks partition the epoch chunk round-robin
             assert sum(len(p) for p in parts) == spe
+
+
+def test_grad_reducer_world2_gloo_cpu():
+    """rsuper_amd.reducer.GradReducer (the GPU default behind wrap_ddp) on two gloo ranks: rank-0 broadcast, bucketed mean
+    of gradients living in the flat buckets, re-arming across steps, missing-gradient detection."""
+    script = os.path.join(ROOT, 'tests', 'reducer_gloo_worker.py')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29537')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29537', script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'REDUCER_OK' in r.stdout
