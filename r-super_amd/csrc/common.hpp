@@ -67,6 +67,37 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
     return make_uint4(f2bf2(f[0], f[1]), f2bf2(f[2], f[3]), f2bf2(f[4], f[5]), f2bf2(f[6], f[7]));
 }
 
+// x_hat = relu(x * sc + nb) on one 16-byte vector (the InstanceNorm + ReLU prologue of every conv input, sc = rstd,
+// nb = -mean * rstd per channel).  bf16: pairs go through v_pk_fma_f32, are rounded by v_cvt_pk_bf16_f32 and the ReLU is a
+// packed signed 16-bit max on the bf16 bit patterns (negative bf16 == negative int16; rounding is monotonic and
+// round(0) = 0, so max-after-round == round-after-max bit for bit, -0.0 included) -> 20 VALU ops instead of 28.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ uint4 norm_relu16(const uint4& q, const float* sc, const float* nb);
+template <> __device__ __forceinline__ uint4 norm_relu16<float>(const uint4& q, const float* sc, const float* nb) {
+    float f[4];
+    unpack16<float>(q, f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], nb[j]), 0.f);
+    return pack16<float>(f);
+}
+template <> __device__ __forceinline__ uint4 norm_relu16<bf16_t>(const uint4& q, const float* sc, const float* nb) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x2_t x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+        const f32x2_t s2 = {sc[2 * j], sc[2 * j + 1]}, b2 = {nb[2 * j], nb[2 * j + 1]};
+        x = __builtin_elementwise_fma(x, s2, b2);
+        const uint32_t r = f2bf2(x[0], x[1]);
+        i16x2_t v = __builtin_bit_cast(i16x2_t, r);
+        const i16x2_t z = {0, 0};
+        v = __builtin_elementwise_max(v, z);
+        o[j] = __builtin_bit_cast(uint32_t, v);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // One K step of a 32x32 MFMA tile from 16-byte operand vectors.
 //   bf16: 8 k per lane half -> one v_mfma_f32_32x32x16_bf16 (K=16)
 //   f32 : 4 k per lane half -> four v_mfma_f32_32x32x2_f32 (K=8); any k order works as long as

@@ -146,11 +146,7 @@ __global__ __launch_bounds__(256, (MF * NF <= 4 && sizeof(T) == 2) ? 3 : 2) void
         for (int i = 0; i < NVEC; ++i) {
             uint4 q = pre[i];
             if (norm && vi[i] >= 0) {
-                float f[KP];
-                unpack16<T>(q, f);
-#pragma unroll
-                for (int j = 0; j < KP; ++j) f[j] = fmaxf(fmaf(f[j], sc_[j], nb_[j]), 0.f);
-                q = pack16<T>(f);
+                q = norm_relu16<T>(q, sc_, nb_);
             }
             if ((tid >> 2) + 64 * i < HROWS) *(uint4*)(lds_st + i * (64 * PITCH)) = q;
         }
@@ -455,11 +451,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
             for (int i = 0; i < NVEC; ++i) {
                 uint4 q = pre[i];
                 if (norm && ((vmask_pre >> i) & 1u)) {
-                    float f[KP];
-                    unpack16<T>(q, f);
-#pragma unroll
-                    for (int j = 0; j < KP; ++j) f[j] = fmaxf(fmaf(f[j], sc_[j], nb_[j]), 0.f);
-                    q = pack16<T>(f);
+                    q = norm_relu16<T>(q, sc_, nb_);
                 }
                 if ((ptid >> 2) + 64 * i < HROWS) *(uint4*)(lds_st + i * (64 * PITCH)) = q;
             }

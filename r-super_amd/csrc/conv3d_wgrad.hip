@@ -227,11 +227,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
         for (int i = 0; i < NXV; ++i) {
             uint4 q = px[i];
             if (norm && ((xmask >> i) & 1u)) {
-                float f[KP];
-                unpack16<T>(q, f);
-#pragma unroll
-                for (int j = 0; j < KP; ++j) f[j] = fmaxf(fmaf(f[j], sc_[j], nb_[j]), 0.f);
-                q = pack16<T>(f);
+                q = norm_relu16<T>(q, sc_, nb_);
             }
             if (xs_row + i * XRS < XROWS) *(uint4*)(x_lds + i * (XRS * XP)) = q;
         }
@@ -455,11 +451,7 @@ __global__ __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) void wgrad_pc_ker
             for (int i = 0; i < NXV; ++i) {
                 uint4 q = px[i];
                 if (norm && ((xmask >> i) & 1u)) {
-                    float f[KP];
-                    unpack16<T>(q, f);
-#pragma unroll
-                    for (int j = 0; j < KP; ++j) f[j] = fmaxf(fmaf(f[j], sc_[j], nb_[j]), 0.f);
-                    q = pack16<T>(f);
+                    q = norm_relu16<T>(q, sc_, nb_);
                 }
                 if (xs_row + i * XRS < XROWS) *(uint4*)(x_lds + i * (XRS * XP)) = q;
             }
