@@ -108,10 +108,11 @@ int rsuper_conv3_variant(int v) {
     return g_variant;
 }
 // variant 2 (auto, default): producer/consumer kernel where it measured faster on MI355X -- data-gradient launches with
-// bn <= 64 (its epilogue operand prefetch) and small grids (persistent blocks fill the chip); classic kernel elsewhere.
+// bn <= 64 (its epilogue operand prefetch), all 32-column launches, and small grids (persistent blocks fill the chip);
+// classic kernel elsewhere.
 static bool use_pc(int dtype, int epi, int bn, int tiles_total) {
     if (dtype != RS_BF16) return false;
-    if (g_variant == 2) return bn <= 64 && (epi == 1 || tiles_total <= 1024);
+    if (g_variant == 2) return bn <= 64 && (epi == 1 || bn == 32 || tiles_total <= 1024);
     return g_variant == 1;
 }
 

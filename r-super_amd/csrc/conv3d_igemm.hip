@@ -399,11 +399,30 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
         uint4 preA[NVEC], preB[NVEC];                                 // two items in flight (global latency >> one item of MFMA work)
         uint32_t vmA = 0, vmB = 0;                                    // validity of the vectors held in preA / preB
         int vi_tile = -1;
+        // per-thread constants: the halo row of vector i never changes, so an interior tile (wave-uniform test) costs one
+        // add per vector instead of a div/mod decomposition plus six bounds checks
+        int vdelta[NVEC];
+        uint32_t rows_ok = 0;
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+            const int r = (ptid >> 2) + 64 * i;
+            const int hd = r / (HH * HW);
+            const int rem = r - hd * (HH * HW);
+            const int hh = rem / HW, hw = rem - hh * HW;
+            vdelta[i] = (hd * p.H + hh) * p.W + hw;
+            rows_ok |= r < HROWS ? (1u << i) : 0u;
+        }
         auto setup_tile = [&](int k) {
             if (k == vi_tile) return;
             vi_tile = k;
             int d0, h0, w0;
             tile_origin(k, d0, h0, w0);
+            if (d0 >= 1 && d0 + TD + 1 <= p.D && h0 >= 1 && h0 + TH + 1 <= p.H && w0 >= 1 && w0 + TW + 1 <= p.W) {
+                const int base = ((n * p.D + d0 - 1) * p.H + h0 - 1) * p.W + w0 - 1;
+#pragma unroll
+                for (int i = 0; i < NVEC; ++i) vi[i] = ((rows_ok >> i) & 1u) ? base + vdelta[i] : -1;
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NVEC; ++i) {
                 const int r = (ptid >> 2) + 64 * i;
