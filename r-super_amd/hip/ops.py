@@ -47,7 +47,8 @@ def pick_bn(n_cols, dtype, tiles_total=None):
                 return bn
         return 32
     if dtype != torch.float32 and n_cols > 64 and n_cols % 64:
-        return 128        # e.g. 96 columns: one padded 128 tile beats three 32-column tap-split tiles
+        return 32         # e.g. 96 columns (up4.0 data gradient): three exact 32-column tiles on the producer/consumer kernel
+                          # (671 us) beat one 25 %-padded 128 tile on the classic kernel (739 us)        # e.g. 96 columns: one padded 128 tile beats three 32-column tap-split tiles
     best = None
     for bn in cands:
         padded = -(-n_cols // bn) * bn

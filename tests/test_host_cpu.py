@@ -101,7 +101,7 @@ def test_lesion_groups_and_ball_geometry(golden):
 def test_pick_bn():
     from rsuper_amd.hip.ops import pick_bn
     assert pick_bn(32, torch.bfloat16) == 32 and pick_bn(64, torch.bfloat16) == 64 and pick_bn(128, torch.bfloat16) == 128
-    assert pick_bn(96, torch.bfloat16) == 128 and pick_bn(96, torch.float32) == 32 and pick_bn(320, torch.bfloat16) == 64 and pick_bn(128, torch.float32) == 64
+    assert pick_bn(96, torch.bfloat16) == 32 and pick_bn(96, torch.float32) == 32 and pick_bn(320, torch.bfloat16) == 64 and pick_bn(128, torch.float32) == 64
 
 
 def test_shard_indices_round_robin():
