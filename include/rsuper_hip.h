@@ -72,7 +72,9 @@ int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n
  *                             epi 1: data gradient g = conv(dy, flipped w) * [x_hat > 0]; part <- (sum g, sum g*x_n),
  *                                    where x_hat/x_n come from the forward inputs (ex*, with their mean/rstd emr*).
  * mra/mrb: [N][C][2] (mean, rstd) -> fused InstanceNorm(eps=1e-4)+ReLU prologue (conv_layers.py:40-43); NULL = raw.
- * part:    [N][rsuper_conv3_part_rows][n_cols][2] f32 or NULL. */
+ * part:    [N][rsuper_conv3_part_rows][n_cols][2] f32 or NULL.
+ * Every activation tensor must be smaller than 4 GiB (N*D*H*W*ld*sizeof < 2^32: buffer-addressed staging); larger
+ * volumes are refused with RS_ERR_UNSUPPORTED, also by rsuper_conv3_wgrad. */
 int rsuper_conv3_igemm(int dtype, int epi,
                        const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,

@@ -132,6 +132,12 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     if (res && ((ldr % 8) || ldr < n_cols)) return RS_ERR_ARG;
     if (epi == 1 && (!exa || !emra || eCa + eCb != n_cols || (eCb > 0 && (!exb || !emrb)))) return RS_ERR_ARG;
     if (dtype == RS_F32 && bn == 128) return RS_ERR_UNSUPPORTED;   // register budget: f32 parity mode uses bn <= 64
+    {   // buffer-addressed staging / epilogue: every activation tensor must stay below 4 GiB (32-bit byte offsets)
+        const unsigned long long vox = (unsigned long long)N * D * H * W, es = dtype == RS_F32 ? 4 : 2;
+        const int lds[6] = {lda, Cb > 0 ? ldb : 0, ldo, res ? ldr : 0, epi == 1 ? elda : 0, (epi == 1 && eCb > 0) ? eldb : 0};
+        for (int i = 0; i < 6; ++i)
+            if (vox * (unsigned long long)lds[i] * es >= (1ull << 32)) return RS_ERR_UNSUPPORTED;
+    }
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.a = {xa, lda, Ca, mra};
@@ -158,6 +164,10 @@ int rsuper_conv3_wgrad(int dtype, int use_tr, const void* xa, int lda, int Ca, c
     if (Cb > 0 && (!xb || !ch_ok(Cb, ldb))) return RS_ERR_ARG;
     if (Yb > 0 && (!yb || !dwb || !ch_ok(Yb, ldyb))) return RS_ERR_ARG;
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || splits <= 0) return RS_ERR_ARG;
+    {   // same 4 GiB limit for the buffer-addressed x_hat staging
+        const unsigned long long vox = (unsigned long long)N * D * H * W, es = dtype == RS_F32 ? 4 : 2;
+        if (vox * (unsigned long long)lda * es >= (1ull << 32) || (Cb > 0 && vox * (unsigned long long)ldb * es >= (1ull << 32))) return RS_ERR_UNSUPPORTED;
+    }
     WgradParams p;
     memset(&p, 0, sizeof(p));
     p.xa = {xa, lda, Ca, mra};

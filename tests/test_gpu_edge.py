@@ -247,3 +247,20 @@ def test_grad_reducer_single_rank_nccl_matches_plain():
     b = run(False)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_conv_rejects_tensors_beyond_32bit_offsets():
+    """Activation tensors of 4 GiB or more exceed the buffer-addressed staging's 32-bit byte offsets: the C ABI refuses them
+    (RS_ERR_UNSUPPORTED) instead of wrapping around.  Only the size check runs; no memory of that size is touched."""
+    from rsuper_amd.hip import lib
+    L = lib.lib()
+    d = torch.zeros(16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    N, D, H, W, C = 4, 256, 256, 256, 64                      # 67 M voxels x 128 B = 8.6 GB
+    rc = L.rsuper_conv3_igemm(lib.BF16, 0, d.data_ptr(), C, C, None, None, 0, 0, None, d.data_ptr(), C, 64, N, D, H, W, d.data_ptr(), C, None, 0, None,
+                              None, 0, 0, None, None, 0, 0, None, st)
+    assert rc != 0
+    rc = L.rsuper_conv3_wgrad(lib.BF16, 1, d.data_ptr(), C, C, None, None, 0, 0, None, d.data_ptr(), C, C, None, 0, 0, d.data_ptr(), None, d.data_ptr(),
+                              N, D, H, W, 1, st)
+    assert rc != 0
