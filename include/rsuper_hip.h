@@ -169,6 +169,10 @@ int rsuper_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx
 int rsuper_radix_hist(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist256, void* stream);
 /* need_eq = 0xFFFFFFFF: every element equal to the threshold is selected (parallel); otherwise the first need_eq in index order. */
 int rsuper_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr_bits, unsigned int need_eq, uint8_t* out, void* stream);
+/* The same top-k with the radix-select state kept on the device: ONE call, no host round trips (the histogram passes above
+ * need four device->host reads per mask).  workspace: 260 u32 on the device.  out[i] = 1 for the k largest of x*m
+ * (x >= 0), ties -> lower index first.  1 <= k <= V. */
+int rsuper_topk_select(const float* x, const uint8_t* m, long V, unsigned int k, uint8_t* out, unsigned int* workspace, void* stream);
 /* GlobalWeightedRankPooling(return_weights, hard_cutoff) :442-535 restricted to the pseudo mask. */
 int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream);
 int rsuper_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float log2_d, float scale, float* w, void* stream);

@@ -314,6 +314,10 @@ int rsuper_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr_bits
     if (!x || !out) return RS_ERR_ARG;
     return rs_launch_topk_mark(x, m, V, thr_bits, need_eq, out, ST(stream));
 }
+int rsuper_topk_select(const float* x, const uint8_t* m, long V, unsigned int k, uint8_t* out, unsigned int* workspace, void* stream) {
+    if (!x || !out || !workspace || V <= 0 || k == 0 || (long)k > V) return RS_ERR_ARG;
+    return rs_launch_topk_select(x, m, V, k, out, workspace, ST(stream));
+}
 int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream) {
     if (!x || !pm || !vals || !idx || !n) return RS_ERR_ARG;
     return rs_launch_compact(x, pm, V, vals, idx, n, ST(stream));

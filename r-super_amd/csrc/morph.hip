@@ -309,6 +309,87 @@ __global__ void topk_mark_all_kernel(const float* x, const uint8_t* m, long V, u
     }
 }
 
+// Device-resident radix select (no host round trips): state = {prefix, remaining, ties, need} in device memory.
+//   per pass:  hist (as above, prefix read from the state)  ->  scan (one block: pick the digit, update the state)
+//   then:      mark (parallel: bits > thr, and every tie when all ties are wanted)  +  ordered tie pass (single block; exits
+//              immediately unless only some of the elements equal to the threshold are wanted)
+__global__ __launch_bounds__(256) void radix_hist_dev_kernel(const float* x, const uint8_t* m, long V, const unsigned int* state, int shift, unsigned int* hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t prefix = state[0];
+    const uint32_t hmask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long)gridDim.x * 256) {
+        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
+        if ((b & hmask) == (prefix & hmask)) atomicAdd(&h[(b >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// one wave: walk the digits from 255 down until the running count reaches `remaining`; clears the histogram for the next pass
+__global__ __launch_bounds__(64) void radix_scan_kernel(unsigned int* hist, unsigned int* state, int shift) {
+    __shared__ unsigned int h[256];
+    for (int i = threadIdx.x; i < 256; i += 64) { h[i] = hist[i]; hist[i] = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int remaining = state[1];
+        unsigned int acc = 0;
+        for (int digit = 255; digit >= 0; --digit) {
+            if (acc + h[digit] >= remaining) {
+                state[0] |= (unsigned int)digit << shift;
+                state[1] = remaining - acc;
+                state[2] = h[digit];                            // after the last pass: elements equal to the threshold
+                break;
+            }
+            acc += h[digit];
+        }
+        if (shift == 0) state[3] = state[1] >= state[2] ? 0xFFFFFFFFu : state[1];   // need: all ties, or only the first `remaining`
+    }
+}
+
+__global__ void topk_mark_dev_kernel(const float* x, const uint8_t* m, long V, const unsigned int* state, uint8_t* out) {
+    const uint32_t thr = state[0];
+    const bool all_ties = state[3] == 0xFFFFFFFFu;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
+        out[i] = all_ties ? (b >= thr) : (b > thr);
+    }
+}
+
+// ties in index order (lower index first): only runs when some but not all elements equal to the threshold are wanted
+__global__ __launch_bounds__(1024) void topk_ties_dev_kernel(const float* x, const uint8_t* m, long V, const unsigned int* state, uint8_t* out) {
+    __shared__ unsigned int cnt[1024];
+    const unsigned int need_eq = state[3];
+    if (need_eq == 0xFFFFFFFFu) return;
+    const uint32_t thr = state[0];
+    const long per = (V + 1023) / 1024;
+    const long b0 = (long)threadIdx.x * per, b1 = min(V, b0 + per);
+    unsigned int c = 0;
+    for (long i = b0; i < b1; ++i) {
+        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
+        c += (b == thr);
+    }
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned int v = threadIdx.x >= o ? cnt[threadIdx.x - o] : 0u;
+        __syncthreads();
+        cnt[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned int before = cnt[threadIdx.x] - c;
+    for (long i = b0; i < b1; ++i) {
+        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
+        if (b == thr) { out[i] = before < need_eq; ++before; }
+    }
+}
+
+__global__ void topk_state_init_kernel(unsigned int* ws, unsigned int k) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) ws[4 + i] = 0;      // histogram
+    if (threadIdx.x == 0) { ws[0] = 0; ws[1] = k; ws[2] = 0; ws[3] = 0xFFFFFFFFu; }
+}
+
 // ------------------------------------------------------------------------------------------------ GWRP rank weights
 // compact the voxels of the pseudo mask, then rank each by value (desc) / index (asc) against all others.
 __global__ void compact_kernel(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n) {
@@ -393,6 +474,19 @@ int rs_launch_radix_hist(const float* x, const uint8_t* m, long V, uint32_t pref
 int rs_launch_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr, unsigned int need_eq, uint8_t* out, hipStream_t st) {
     if (need_eq == 0xFFFFFFFFu) hipLaunchKernelGGL(topk_mark_all_kernel, dim3(rs_elem_blocks((size_t)V)), dim3(256), 0, st, x, m, V, thr, out);
     else hipLaunchKernelGGL(topk_mark_kernel, dim3(1), dim3(1024), 0, st, x, m, V, thr, need_eq, out);
+    return rs_check_launch();
+}
+
+// workspace: 260 u32 on the device = {prefix, remaining, ties, need, hist[256]}
+int rs_launch_topk_select(const float* x, const uint8_t* m, long V, unsigned int k, uint8_t* out, unsigned int* ws, hipStream_t st) {
+    const int hb = rs_elem_blocks((size_t)V) > 512 ? 512 : rs_elem_blocks((size_t)V);
+    hipLaunchKernelGGL(topk_state_init_kernel, dim3(1), dim3(256), 0, st, ws, k);
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(radix_hist_dev_kernel, dim3(hb), dim3(256), 0, st, x, m, V, (const unsigned int*)ws, shift, ws + 4);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(64), 0, st, ws + 4, ws, shift);
+    }
+    hipLaunchKernelGGL(topk_mark_dev_kernel, dim3(rs_elem_blocks((size_t)V)), dim3(256), 0, st, x, m, V, (const unsigned int*)ws, out);
+    hipLaunchKernelGGL(topk_ties_dev_kernel, dim3(1), dim3(1024), 0, st, x, m, V, (const unsigned int*)ws, out);
     return rs_check_launch();
 }
 

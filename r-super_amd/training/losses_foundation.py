@@ -168,6 +168,11 @@ def _topk_mask(x, ball, k):
     out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
     if k <= 0:
         return out.zero_()
+    if os.environ.get('RSUPER_TOPK_HOST', '0') != '1':
+        # device-resident radix select: one C call, no device->host reads
+        ws = torch.empty(260, device=x.device, dtype=torch.int32)
+        _l.check(_L().rsuper_topk_select(_ptr(x), _ptr(ball), V, k, _ptr(out), _ptr(ws), _stream()), 'topk_select')
+        return out
     prefix, remaining, ties = 0, k, 0
     hist = torch.empty(256, device=x.device, dtype=torch.int32)
     for shift in (24, 16, 8, 0):

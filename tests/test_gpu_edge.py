@@ -296,3 +296,32 @@ def test_training_converges_bf16_like_f32():
     for dt, c in curves.items():
         assert c[-1] < 0.75 * c[0], (dt, c[0], c[-1])
     assert abs(curves['bf16'][-1] - curves['f32'][-1]) < 0.1 * curves['f32'][0], (curves['bf16'][-1], curves['f32'][-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['distinct', 'ties', 'masked', 'k_all'])
+def test_topk_select_device_matches_oracle(case):
+    """rsuper_topk_select (device-resident radix select) == oracle canonical top-k (value desc, index asc), bit-exact,
+    including threshold ties that must be split in index order."""
+    from rsuper_amd.hip import lib
+    from oracle import morph as om
+    L = lib.lib()
+    rng = np.random.default_rng(7)
+    V = 24 * 20 * 28
+    x = rng.random(V).astype(np.float32)
+    m = np.ones(V, np.uint8)
+    k = 1500
+    if case == 'ties':
+        x = (rng.integers(0, 40, V) / 40.0).astype(np.float32)       # many equal values: the threshold class is split by index
+    elif case == 'masked':
+        m = (rng.random(V) < 0.5).astype(np.uint8)
+    elif case == 'k_all':
+        k = V
+    want = om.topk_mask(np.ascontiguousarray((x * m).astype(np.float32)), k)
+    xd, md = torch.from_numpy(x).to(DEV), torch.from_numpy(m).to(DEV)
+    out = torch.empty(V, device=DEV, dtype=torch.uint8)
+    ws = torch.empty(260, device=DEV, dtype=torch.int32)
+    rc = L.rsuper_topk_select(xd.data_ptr(), md.data_ptr(), V, k, out.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    got = out.cpu().numpy()
+    assert got.sum() == k and np.array_equal(got, want)
