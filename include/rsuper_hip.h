@@ -176,6 +176,9 @@ int rsuper_topk_select(const float* x, const uint8_t* m, long V, unsigned int k,
 /* GlobalWeightedRankPooling(return_weights, hard_cutoff) :442-535 restricted to the pseudo mask. */
 int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream);
 int rsuper_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float log2_d, float scale, float* w, void* stream);
+/* flags[p] = any(m[p][:]) for `planes` contiguous byte volumes of V voxels (V % 16 == 0 when planes > 1): the
+ * `.sum() > 0` / `.any()` tests of calculate_loss / ball_loss (:1625, :313, :335) at HBM rate. */
+int rsuper_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, void* stream);
 int rsuper_mask_op(uint8_t* a, const uint8_t* b, long V, int op /*0 and, 1 or, 2 andnot*/, void* stream);
 
 /* Bit-packed label ingestion: device-side np.unpackbits(packed, axis=0)[:C] of the label / unk / chosen-

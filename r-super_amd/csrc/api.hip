@@ -330,6 +330,10 @@ int rsuper_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C,
     if (!packed || !out || B <= 0 || P <= 0 || C <= 0 || C > 8 * P || V <= 0) return RS_ERR_ARG;
     return rs_launch_unpack_bits(packed, out, B, P, C, V, ST(stream));
 }
+int rsuper_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, void* stream) {
+    if (!m || !flags || planes <= 0 || V <= 0 || ((uintptr_t)m & 15) || (V & 15 && planes > 1)) return RS_ERR_ARG;
+    return rs_launch_plane_any(m, planes, V, flags, ST(stream));
+}
 int rsuper_mask_op(uint8_t* a, const uint8_t* b, long V, int op, void* stream) {
     if (!a || !b || op < 0 || op > 2) return RS_ERR_ARG;
     return rs_launch_mask_op(a, b, V, op, ST(stream));

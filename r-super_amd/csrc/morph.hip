@@ -327,24 +327,36 @@ __global__ __launch_bounds__(256) void radix_hist_dev_kernel(const float* x, con
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
-// one wave: walk the digits from 255 down until the running count reaches `remaining`; clears the histogram for the next pass
+// one wave: digits from 255 down until the running count reaches `remaining`.  Lane l owns digits 255-4l .. 252-4l; an
+// inclusive wave scan of the per-lane sums locates the lane, the lane walks its four digits.  Clears the histogram.
 __global__ __launch_bounds__(64) void radix_scan_kernel(unsigned int* hist, unsigned int* state, int shift) {
-    __shared__ unsigned int h[256];
-    for (int i = threadIdx.x; i < 256; i += 64) { h[i] = hist[i]; hist[i] = 0; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int remaining = state[1];
-        unsigned int acc = 0;
-        for (int digit = 255; digit >= 0; --digit) {
-            if (acc + h[digit] >= remaining) {
-                state[0] |= (unsigned int)digit << shift;
+    const int lane = threadIdx.x;
+    unsigned int h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = hist[255 - 4 * lane - j]; hist[255 - 4 * lane - j] = 0; }
+    const unsigned int mine = h[0] + h[1] + h[2] + h[3];
+    unsigned int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const unsigned int remaining = state[1];
+    const unsigned int before = incl - mine;
+    if (before < remaining && incl >= remaining) {               // exactly one lane
+        unsigned int acc = before;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (acc + h[j] >= remaining) {
+                const unsigned int digit = 255 - 4 * lane - j;
+                state[0] |= digit << shift;
                 state[1] = remaining - acc;
-                state[2] = h[digit];                            // after the last pass: elements equal to the threshold
+                state[2] = h[j];                                 // after the last pass: elements equal to the threshold
+                if (shift == 0) state[3] = (remaining - acc) >= h[j] ? 0xFFFFFFFFu : (remaining - acc);
                 break;
             }
-            acc += h[digit];
+            acc += h[j];
         }
-        if (shift == 0) state[3] = state[1] >= state[2] ? 0xFFFFFFFFu : state[1];   // need: all ties, or only the first `remaining`
     }
 }
 
@@ -539,6 +551,29 @@ __global__ __launch_bounds__(256) void unpack_bits_kernel(const uint8_t* __restr
 int rs_launch_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, hipStream_t st) {
     const long nvec = (V + 15) / 16;
     hipLaunchKernelGGL(unpack_bits_kernel, dim3((unsigned)((nvec + 255) / 256), (unsigned)(B * P)), dim3(256), 0, st, packed, out, P, C, V);
+    return rs_check_launch();
+}
+
+// any(plane) for `planes` byte volumes of V voxels each: flags[p] = 1 if the plane has a non-zero byte.  Replaces the ATen
+// `.flatten(1).any(1)` reductions of the loss' host control flow (150 us each on a 46 MB uint8 tensor) at HBM rate.
+__global__ __launch_bounds__(256) void plane_any_kernel(const uint8_t* __restrict__ m, long V, uint8_t* __restrict__ flags) {
+    const uint8_t* pl = m + (size_t)blockIdx.y * V;
+    const long nvec = V / 16;
+    unsigned int any = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const uint4 q = ((const uint4*)pl)[i];
+        any |= q.x | q.y | q.z | q.w;
+    }
+    if (blockIdx.x == 0) for (long i = nvec * 16 + threadIdx.x; i < V; i += 256) any |= pl[i];
+    if (__any(any != 0) && (threadIdx.x & 63) == 0) flags[blockIdx.y] = 1;
+}
+
+int rs_launch_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, hipStream_t st) {
+    if (hipMemsetAsync(flags, 0, (size_t)planes, st) != hipSuccess) return RS_ERR_LAUNCH;
+    long nb = (V / 16 + 255) / 256;
+    if (nb > 32) nb = 32;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(plane_any_kernel, dim3((unsigned)nb, (unsigned)planes), dim3(256), 0, st, m, V, flags);
     return rs_check_launch();
 }
 

@@ -11,6 +11,7 @@ int rs_launch_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr, 
 int rs_launch_topk_select(const float* x, const uint8_t* m, long V, unsigned int k, uint8_t* out, unsigned int* ws, hipStream_t st);
 int rs_launch_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, hipStream_t st);
 int rs_launch_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float dlog2, float scale, float* w, hipStream_t st);
+int rs_launch_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, hipStream_t st);
 int rs_launch_mask_op(uint8_t* a, const uint8_t* b, long V, int op, hipStream_t st);
 int rs_launch_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, hipStream_t st);
 int rs_launch_zero_where(float* x, const uint8_t* m, long V, hipStream_t st);

@@ -325,3 +325,16 @@ def test_topk_select_device_matches_oracle(case):
     assert rc == 0
     got = out.cpu().numpy()
     assert got.sum() == k and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_plane_any_matches_torch():
+    from rsuper_amd.training.losses_foundation import _plane_any
+    g = torch.Generator(device=DEV).manual_seed(3)
+    t = (torch.rand((3, 5, 8, 12, 16), device=DEV, generator=g) < 0.0005).to(torch.uint8)
+    t[1] = 0
+    assert torch.equal(_plane_any(t, 2), t.flatten(2).any(2)) and torch.equal(_plane_any(t, 1), t.flatten(1).any(1))
+    odd = (torch.rand((2, 7, 5, 3), device=DEV, generator=g) < 0.01).to(torch.uint8)      # V % 16 != 0 -> ATen path
+    assert torch.equal(_plane_any(odd, 1), odd.flatten(1).any(1))
+    one = torch.zeros((1, 1, 5, 7, 3), device=DEV, dtype=torch.uint8); one[0, 0, 4, 6, 2] = 1
+    assert bool(_plane_any(one, 0))
