@@ -105,6 +105,7 @@ def main():
         dist.init_process_group(backend='nccl', rank=0, world_size=1)
     rank, local, world = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    local = local % torch.cuda.device_count()          # one rank per GPU; ranks only share a device in the gloo debugging mode
     torch.cuda.set_device(local)
     lib.require_device()
     dev = f'cuda:{local}'

@@ -82,9 +82,11 @@ def init_distributed(backend=None):
         return 0, 0, 1
     rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-        torch.cuda.set_device(local)
+        # RSUPER_DIST_BACKEND=gloo: debugging aid -- several ranks may then share one GPU (RCCL refuses duplicate devices),
+        # which exercises the multi-rank control flow of bench.py / GradReducer on a single-GPU box
+        backend = os.environ.get('RSUPER_DIST_BACKEND', 'nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
