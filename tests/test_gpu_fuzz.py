@@ -1,0 +1,52 @@
+"""Seeded shape fuzzing of the convolution kernels against the torch fp32 reference (tests/gpu_checks.py): ragged spatial
+sizes, channel counts that leave partially filled 32-channel chunks / 32-column tiles, one or two sources, with and without
+the fused shortcut and residual -- under the default kernel choice and with each igemm variant forced."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import gpu_checks as gc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        S = (int(rng.integers(3, 14)), int(rng.integers(3, 14)), int(rng.integers(5, 40)))
+        Ca = int(rng.choice([8, 16, 24, 32, 40, 64, 72]))
+        Cb = int(rng.choice([0, 0, 8, 32, 48]))
+        Cout = int(rng.choice([8, 16, 24, 32, 40, 64, 96]))
+        N = int(rng.integers(1, 3))
+        sc = bool(rng.integers(0, 2)) or (Cb > 0) or (Ca != Cout)
+        out.append((N, S, Ca, Cb, Cout, sc))
+    return out
+
+
+CASES = _cases(10, 2026)
+
+
+@pytest.mark.parametrize('variant', [2, 0, 1])
+@pytest.mark.parametrize('case', CASES, ids=[f'N{c[0]}_S{"x".join(map(str, c[1]))}_{c[2]}+{c[3]}to{c[4]}_sc{int(c[5])}' for c in CASES])
+def test_conv_fuzz_bf16(case, variant):
+    N, S, Ca, Cb, Cout, sc = case
+    r = gc.with_variant(variant, gc.check_conv_fwd, 'bf16', N, S, Ca, Cb, Cout, sc, False)
+    assert r['ok'], (r['name'], r['err'], r['note'])
+    r = gc.with_variant(variant, gc.check_conv_bwd, 'bf16', N, S, Ca, Cb, Cout, sc)
+    assert r['ok'], (r['name'], r['err'], r['note'])
+
+
+@pytest.mark.parametrize('case', CASES[:4], ids=[f'f32_{i}' for i in range(4)])
+def test_conv_fuzz_f32(case):
+    N, S, Ca, Cb, Cout, sc = case
+    r = gc.check_conv_fwd('f32', N, S, Ca, Cb, Cout, sc, False)
+    assert r['ok'], (r['name'], r['err'], r['note'])
+    r = gc.check_conv_bwd('f32', N, S, Ca, Cb, Cout, sc)
+    assert r['ok'], (r['name'], r['err'], r['note'])
