@@ -588,24 +588,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// Few slabs (large weight tensors at low resolution): thread = one slab element, reads coalesced across threads.
+// Few slabs (large weight tensors at low resolution).  Block = one output row m x 64 input channels x 27 taps: the slab rows
+// ws[s][tap][m][c0 .. c0+63] are read coalesced along c, summed over the splits in registers, transposed through LDS and
+// written as ONE contiguous run dW[m][c0 .. c0+63][0 .. 26] (the thread-per-element version scattered 4-byte writes 108 B
+// apart: the (Cout, Cin, 27) layout has the tap innermost).
 __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ ws, int splits, int Mtot, int Ya, int Cin,
                                                                 float* dwa, float* dwb) {
+    __shared__ float tile[64 * 27 + 64];
+    const int cchunks = (Cin + 63) / 64;
+    const int m = blockIdx.x / cchunks, c0 = (blockIdx.x % cchunks) * 64;
+    const int nc = min(64, Cin - c0);
     const size_t E = (size_t)27 * Mtot * Cin;
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= splits; s += 4) {
-        a0 += ws[(size_t)s * E + e]; a1 += ws[(size_t)(s + 1) * E + e];
-        a2 += ws[(size_t)(s + 2) * E + e]; a3 += ws[(size_t)(s + 3) * E + e];
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+        const int tap = i >> 6, c = i & 63;
+        float a0 = 0.f, a1 = 0.f;
+        if (c < nc) {
+            const size_t e = ((size_t)tap * Mtot + m) * Cin + c0 + c;
+            int s = 0;
+            for (; s + 2 <= splits; s += 2) { a0 += ws[(size_t)s * E + e]; a1 += ws[(size_t)(s + 1) * E + e]; }
+            if (s < splits) a0 += ws[(size_t)s * E + e];
+        }
+        tile[c * 27 + tap] = a0 + a1;
     }
-    for (; s < splits; ++s) a0 += ws[(size_t)s * E + e];
-    const int c = (int)(e % Cin);
-    const size_t r = e / Cin;
-    const int m = (int)(r % Mtot), tap = (int)(r / Mtot);
-    float* dst = m < Ya ? dwa + ((size_t)m * Cin + c) * 27 : dwb + ((size_t)(m - Ya) * Cin + c) * 27;
-    dst[tap] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    float* dst = m < Ya ? dwa + ((size_t)m * Cin + c0) * 27 : dwb + ((size_t)(m - Ya) * Cin + c0) * 27;
+    for (int i = threadIdx.x; i < nc * 27; i += 256) dst[i] = tile[i];
 }
 
 static void launch_reduce(const WgradParams& p, hipStream_t st) {
@@ -614,7 +621,7 @@ static void launch_reduce(const WgradParams& p, hipStream_t st) {
     if (p.splits >= 16)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C, Cin, p.dwa, p.dwb);
     else
-        hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C, Cin, p.dwa, p.dwb);
+        hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)(Mtot * ((Cin + 63) / 64))), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C, Cin, p.dwa, p.dwb);
 }
 
 template <typename T, int MT, int NTAPS, int TR, int NW>
