@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
 # Fabric-side bytes (FETCH_SIZE x2 + WRITE_SIZE) of all conv MFMA launches of ONE default step, from the rocprofv3 PMC
 # passes in profiles/r01_pmc_step.md (bf16, base 32, B=2, 96^3, report losses off); other workloads report null.
-CONV_TRAFFIC_BYTES_PER_STEP = 22.6e9
+CONV_TRAFFIC_BYTES_PER_STEP = 20.7e9
 
 
 def conv_stack_flops(base, S, B):
