@@ -18,17 +18,38 @@ __device__ __forceinline__ int find_tensor(const MTChunk& c, int blk, int& local
 
 constexpr int MT_ELEMS = 256 * 4 * 4;   // elements per block
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(MTChunk c, double* total) {
+// Per-block partial sums (no atomics: thousands of blocks adding f64 into ONE address serialised in L2 and made the kernel
+// 3x slower than its HBM bound), then one small block adds them to *total in a fixed order -> the norm is deterministic.
+__global__ __launch_bounds__(256) void sqnorm_kernel(MTChunk c, double* partial) {
     int local; const int ti = find_tensor(c, blockIdx.x, local);
     const float* g = (const float*)c.g[ti];
     const size_t n = c.numel[ti], base = (size_t)local * MT_ELEMS;
     float s = 0.f;
-    for (size_t i = base + threadIdx.x; i < base + MT_ELEMS && i < n; i += 256) { const float v = g[i]; s += v * v; }
+    if (base + MT_ELEMS <= n && (((uintptr_t)(g + base)) & 15) == 0) {
+        const float4* g4 = (const float4*)(g + base);
+#pragma unroll
+        for (int k = 0; k < MT_ELEMS / 1024; ++k) { const float4 v = g4[threadIdx.x + 256 * k]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    } else {
+        for (size_t i = base + threadIdx.x; i < base + MT_ELEMS && i < n; i += 256) { const float v = g[i]; s += v * v; }
+    }
     s = wave_sum(s);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(total, (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+}
+
+__global__ __launch_bounds__(256) void sqnorm_reduce_kernel(const double* partial, int n, double* total) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total += red[0];
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(MTChunk c, AdamParams a, const double* total_sq) {
@@ -66,7 +87,15 @@ __global__ __launch_bounds__(256) void scale_kernel(MTChunk c, float max_norm, c
 int rs_mt_blocks(size_t numel) { return (int)((numel + MT_ELEMS - 1) / MT_ELEMS); }
 
 int rs_launch_sqnorm(const MTChunk& c, double* total, hipStream_t st) {
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(c.blk_start[c.n]), dim3(256), 0, st, c, total);
+    static double* ws[16] = {};                                  // per-device partial sums (stream-ordered reuse)
+    constexpr int WS_BLOCKS = 1 << 16;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return RS_ERR_LAUNCH;
+    if (!ws[dev] && hipMalloc((void**)&ws[dev], (size_t)WS_BLOCKS * sizeof(double)) != hipSuccess) return RS_ERR_LAUNCH;
+    const int blocks = c.blk_start[c.n];
+    if (blocks > WS_BLOCKS) return RS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, st, c, ws[dev]);
+    hipLaunchKernelGGL(sqnorm_reduce_kernel, dim3(1), dim3(256), 0, st, (const double*)ws[dev], blocks, total);
     return rs_check_launch();
 }
 int rs_launch_adamw_ema(const MTChunk& c, const AdamParams& a, const double* total_sq, hipStream_t st) {
