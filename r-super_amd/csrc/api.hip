@@ -46,8 +46,10 @@ const char* rsuper_version(void) { return "rsuper-hip 0.1 (gfx950)"; }
 int rsuper_device_check(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return RSUPER_ERR_NO_DEVICE;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RSUPER_ERR_NO_DEVICE;
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return RSUPER_ERR_NO_DEVICE;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return RSUPER_ERR_NO_DEVICE;   // the calling thread's current device
     return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? RSUPER_OK : RSUPER_ERR_NO_DEVICE;
 }
 
