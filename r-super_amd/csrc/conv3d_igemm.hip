@@ -383,8 +383,16 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
     if (normB) for (int i = tid; i < 2 * p.b.C; i += 512) mr_lds[2 * p.a.C + i] = p.b.mr[(size_t)n * 2 * p.b.C + i];
     __syncthreads();
 
+    // XCD-aware tile order (same bijection as the classic kernel): the logical index L = blockIdx.x + k * gridDim.x of the
+    // blocks running concurrently covers a contiguous range; linear workgroup id b lands on XCD b % 8, so L -> tile gives
+    // every XCD (private L2) a contiguous run of tiles and the halo rows shared by neighbouring tiles are fetched once
+    const bool xcd_remap = (gridDim.x & 7) == 0 && tiles >= 64;
     auto tile_origin = [&](int k, int& d0, int& h0, int& w0) {
         int t = (int)blockIdx.x + k * (int)gridDim.x;
+        if (xcd_remap) {
+            const int q = tiles >> 3, r = tiles & 7, xcd = t & 7, kk = t >> 3;
+            t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+        }
         const int tw = t % tiles_w; t /= tiles_w;
         const int th = t % tiles_h; t /= tiles_h;
         d0 = t * TD; h0 = th * TH; w0 = tw * TW;
