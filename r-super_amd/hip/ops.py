@@ -181,6 +181,8 @@ class KernelTimer:
 
 
 TIMER = None   # set to a KernelTimer to time conv launches
+WEIGHTS_EPOCH = 0   # bumped whenever a HIP kernel rewrites parameters behind autograd's back (fused optimiser / EMA update):
+                    # invalidates cached weight fragments (tensor._version does not see raw-pointer writes)
 GRAD_DEST = None   # optional callable(param) -> tensor view to write that parameter's gradient into (rsuper_amd.reducer)
 
 

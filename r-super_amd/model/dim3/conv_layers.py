@@ -1,6 +1,7 @@
 """Modules mirroring rsuper_train/model/dim3/conv_layers.py (ConvNormAct :16-53, BasicBlock :71-94) so that
 parameter names/shapes match the reference state_dict; the math runs in fused gfx950 kernels
 (rsuper_amd.hip.ops.BasicBlockFn) instead of module-by-module ATen calls."""
+import torch
 import torch.nn as nn
 
 from ...hip import ops
@@ -37,4 +38,22 @@ class BasicBlock(nn.Module):
     def forward(self, xa, mra, xb=None, mrb=None):
         w1, w2, ws = self.weights()
         packs = getattr(self, '_packs', None)        # set by UNet.forward (whole-network batched weight packing)
+        if packs is None and not torch.is_grad_enabled():
+            packs = self._cached_forward_packs(xa, xb, w1, w2, ws)
         return ops.BasicBlockFn.apply(xa, mra, xb, mrb, w1, w2, ws, packs)
+
+    def _cached_forward_packs(self, xa, xb, w1, w2, ws):
+        """Inference (no_grad): the MFMA fragment buffers only change when the weights do, so sliding-window inference packs
+        each layer once instead of once per window.  Keyed on the parameters' version counters, ops.WEIGHTS_EPOCH (the fused optimiser
+        writes parameters through raw pointers) and the launch geometry."""
+        N, D, H, W, Ca = xa.shape
+        Cb = 0 if xb is None else xb.shape[-1]
+        tiles_total = ops._L().rsuper_conv3_tiles(D, H, W) * N
+        key = (ops.WEIGHTS_EPOCH, w1._version, w2._version, None if ws is None else ws._version, w1.data_ptr(), xa.dtype, Ca, Cb, tiles_total)
+        hit = getattr(self, '_pack_cache', None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        specs, bns = ops.block_pack_specs(w1, w2, ws, Ca, Cb, xa.dtype, tiles_total, False)
+        packs = (ops.pack_weights_batch(xa.dtype, specs), bns)
+        self._pack_cache = (key, packs)
+        return packs

@@ -75,6 +75,7 @@ class FusedAdamWEMA(torch.optim.Optimizer):
                 group['lr'], b1, b2, group['eps'], group['weight_decay'], step, float(ema_alpha),
                 float(max_norm if max_norm is not None else 0.0), total.data_ptr() if total is not None else None, _stream()),
                 'adamw_ema_step')
+        _ops.WEIGHTS_EPOCH += 1            # parameters (and EMA) were rewritten through raw pointers: drop cached fragments
         return total.sqrt().float() if total is not None else None
 
     @torch.no_grad()

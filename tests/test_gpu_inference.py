@@ -88,3 +88,34 @@ def test_window_accumulate_rejects_out_of_range_window():
     lg = torch.zeros((1, 2, 4, 4, 4), device=DEV)
     rc = lib.lib().rsuper_window_accumulate(lg.data_ptr(), acc.data_ptr(), 2, 4, 4, 4, 8, 8, 8, 6, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
     assert rc != 0
+
+
+def test_inference_pack_cache_follows_fused_optimizer_updates():
+    """Cached inference fragments must not survive a fused optimiser step (it writes parameters through raw pointers, which
+    tensor._version does not see): eval -> train step -> eval gives the new weights' output, identical to a fresh module."""
+    from rsuper_amd.model.dim3.unet import UNet
+    from rsuper_amd.train_ddp import train_step, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    classes = synth.TINY_CLASSES
+    net = _net('f32')
+    x = torch.from_numpy(synth.volume((32, 32, 32), 11)).to(DEV)
+    with torch.no_grad():
+        y0 = net(x)['segmentation'].clone()
+        y0b = net(x)['segmentation'].clone()          # second call uses the cached fragments
+    assert torch.equal(y0, y0b)
+    B, S = 1, 32
+    bt = synth.batch(B, S, classes, ['mask'], seed=5)
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in bt.items() if k in ('label', 'unk_channels', 'mask', 'volumes', 'diameters')}
+    batch['image'] = torch.from_numpy(synth.image(B, S, seed=3)).to(DEV)
+    la = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.0, volume_loss_tolerance=0.2,
+                            ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                            classification_branch=False, ema=True, ema_alpha=0.99)
+    opt = FusedAdamWEMA(net.parameters(), lr=1e-2, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+    train_step(net, make_ema(net), opt, batch, la, classes, 0)
+    with torch.no_grad():
+        y1 = net(x)['segmentation'].clone()
+    fresh = UNet(1, 8, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype='f32').to(DEV)
+    fresh.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        y2 = fresh(x)['segmentation']
+    assert not torch.equal(y1, y0) and torch.equal(y1, y2)
