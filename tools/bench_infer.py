@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--size', type=int, default=192)
     ap.add_argument('--window', type=int, default=96)
     ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--window-batch', type=int, default=8)
     a = ap.parse_args()
     import synth
     from rsuper_amd.hip import lib
@@ -31,11 +32,11 @@ def main():
     net = UNet(1, 32, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype=a.dtype).to('cuda')
     img = torch.randn((1, 1, a.size, a.size, a.size), device='cuda').clamp_(-3, 3)
     args = argparse.Namespace(window_size=[a.window] * 3, classes=len(classes))
-    inference_sliding_window(net, img, args, to_cpu=False)
+    inference_sliding_window(net, img, args, to_cpu=False, window_batch=a.window_batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.reps):
-        out = inference_sliding_window(net, img, args, to_cpu=False)
+        out = inference_sliding_window(net, img, args, to_cpu=False, window_batch=a.window_batch)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.reps
     nwin = (a.size // (a.window // 2)) ** 3
