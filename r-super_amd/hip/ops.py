@@ -20,8 +20,16 @@ def use_tr():
     return int(os.environ.get('RSUPER_WGRAD_TR', '1'))
 
 
+_DEV_INDEX = None
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the calling thread's current HIP stream.  torch.cuda.current_stream() builds a Python Stream object per
+    call (~8 us, ~110 launches per forward): the C accessor returns the same handle in well under a microsecond."""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()           # one device per process (set before the first launch)
+    return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
 
 
 def _ptr(t, off_elems=0):
