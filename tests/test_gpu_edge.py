@@ -338,3 +338,23 @@ def test_plane_any_matches_torch():
     assert torch.equal(_plane_any(odd, 1), odd.flatten(1).any(1))
     one = torch.zeros((1, 1, 5, 7, 3), device=DEV, dtype=torch.uint8); one[0, 0, 4, 6, 2] = 1
     assert bool(_plane_any(one, 0))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """The N = 2 flow of bench.py as the driver launches it (torchrun, one process per rank, GradReducer, barrier + max over
+    ranks, rank-0 JSON) -- on a single-GPU box the two ranks share the device through RSUPER_DIST_BACKEND=gloo (RCCL refuses
+    duplicate devices); only RCCL's own transport is not exercised."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSUPER_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29571', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--size', '64',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['scaling'] == 'weak'
+    assert d['value'] > 0 and np.isfinite(d['config']['final_loss'])
