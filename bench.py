@@ -165,7 +165,7 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
-            'metric': 'CT voxels/sec/node (96^3 patch, bs=2/GPU)', 'value': world * B * S ** 3 * args.steps / dt, 'unit': 'voxels/s',
+            'metric': 'CT voxels/sec/node (96\u00b3 patch, bs=2/GPU)', 'value': world * B * S ** 3 * args.steps / dt, 'unit': 'voxels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'R-Super 3D UNet(base {args.base}, {len(classes)} classes, BasicBlock/IN) full training step '
