@@ -44,14 +44,15 @@ def _L():
 
 def pick_bn(n_cols, dtype, tiles_total=None):
     """Block N tile of the implicit GEMM (32/64/128 output columns); f32 parity mode is limited to 64.
-    tiles_total (spatial tiles x batch): on small volumes prefer the largest tile that still yields >= 128 workgroups
-    (12^3 and 6^3 levels would otherwise run on 36 / 12 of the 256 CUs)."""
+    tiles_total (spatial tiles x batch): on small volumes prefer the largest tile that still yields >= 512 workgroups
+    (24^3 and below would otherwise leave most of the 256 CUs idle; the narrower tiles also run on the persistent kernel)."""
     cands = (32, 64) if dtype == torch.float32 else (32, 64, 128)
     if n_cols <= 32:
         return 32
-    if tiles_total is not None and tiles_total * -(-n_cols // 128) < 128:
+    fill = int(os.environ.get('RSUPER_BN_FILL', '512'))       # two resident blocks per CU (measured 128 / 256 / 512: 13.89 / - / 13.80 ms per step)
+    if tiles_total is not None and tiles_total * -(-n_cols // 128) < fill:
         for bn in reversed(cands):
-            if tiles_total * -(-n_cols // bn) >= 128:
+            if tiles_total * -(-n_cols // bn) >= fill:
                 return bn
         return 32
     if dtype != torch.float32 and n_cols > 64 and n_cols % 64:
