@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the R-Super training hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without WORLD_SIZE: re-executes itself under
+                                                          torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one iteration of train_epoch (rsuper_train/train_ddp.py:308-357) on a synthetic batch already resident
@@ -9,10 +10,16 @@ in HBM: zero_grad -> UNet forward -> calculate_loss -> backward -> clip_grad_nor
 Workload = BASELINE.json configs[1]: full R-Super 3D UNet (base 32, 26 PanTS classes, 40.56 M parameters), bf16,
 96^3 patches, batch 2 per GPU, segmentation loss (masked BCE + adaptive-Tversky Dice), report losses off.
 Rank 0 prints ONE JSON line; `value` = voxels processed by all ranks / max-over-ranks time of the K timed steps.
+
+The timed region contains nothing but the K steps (no event records).  The roofline numbers come from a separate pass
+AFTER it (same model, same batch, HIP events around every conv MFMA launch on the launch stream); at N = 1 further short
+legs report config 3 (report supervision), the f32 parity mode and the cost of bf16 (`secondary`), then the CPU baseline.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,9 +32,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
-# Fabric-side bytes (FETCH_SIZE x2 + WRITE_SIZE) of all conv MFMA launches of ONE default step, from the rocprofv3 PMC
-# passes in profiles/r01_pmc_step.md (bf16, base 32, B=2, 96^3, report losses off); other workloads report null.
-CONV_TRAFFIC_BYTES_PER_STEP = 20.7e9
+# Fabric-side bytes (FETCH_SIZE x2 + WRITE_SIZE) of the conv MFMA launches of ONE default step are read from this file
+# (written by tools/pmc_step_summary.py from the rocprofv3 --pmc passes of tools/pmc_step.sh; see its "source" key).
+TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'conv_traffic.json')
 
 
 def conv_stack_flops(base, S, B):
@@ -54,50 +61,148 @@ def conv_stack_flops(base, S, B):
     return total
 
 
+def loss_args(report):
+    return argparse.Namespace(loss='ball_dice_both' if report else 'ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0,
+                              report_volume_loss_basic=0.1 if report else 0.0, volume_loss_tolerance=0.2,
+                              ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False,
+                              stardard_ce_ball=False, classification_branch=False, ema=True, ema_alpha=0.99)
+
+
 def cpu_baseline(args, classes):
-    """Oracle (CPU restatement of the reference, kind='port') timed on the host cores on a bounded sample."""
-    from oracle import unet_oracle as uo, losses_oracle as lo
+    """Oracle (CPU restatement of the reference, kind='port') timed on the host cores on a bounded sample: one complete
+    training step (fwd + seg loss + bwd + clip + AdamW + EMA) at B=1 after a small warm-up step that pages the ATen CPU
+    kernels in."""
+    from oracle import unet_oracle as uo, losses_oracle as lo, train_oracle as to
     import synth
     ncores = min(os.cpu_count(), 32)      # ATen CPU conv3d stops scaling (and thrashes) far below 256 threads
     torch.set_num_threads(ncores)
-    B, S = 1, args.size                   # bounded sample (one B=1 step): ~10-30 s of CPU work
-    shapes = uo.unet_param_shapes(1, args.base, len(classes))
-    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes, 3).items()}
-    img = torch.from_numpy(synth.image(B, S, seed=1234))
-    bt = synth.batch(B, S, classes, ['mask'] * B, seed=7)
-    la = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.0,
-                            volume_loss_tolerance=0.2, ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2,
-                            multi_ch_tumor=False, stardard_ce_ball=False, classification_branch=False)
-    t0 = time.time()
-    r = uo.unet_forward(sd, img)
-    res = lo.calculate_loss({'segmentation': r}, torch.from_numpy(bt['label']), torch.from_numpy(bt['unk_channels']), la,
-                            torch.from_numpy(bt['mask']), torch.from_numpy(bt['volumes']), torch.from_numpy(bt['diameters']), classes)
-    res['overall'].backward()
-    dt = time.time() - t0
+    la = loss_args(False)
+
+    def step(B, S, base):
+        shapes = uo.unet_param_shapes(1, base, len(classes))
+        sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes, 3).items()}
+        params = list(sd.values())
+        ema = [p.detach().clone() for p in params]
+        opt = to.AdamW([p.detach() for p in params], lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        img = torch.from_numpy(synth.image(B, S, seed=1234))
+        bt = synth.batch(B, S, classes, ['mask'] * B, seed=7)
+        t0 = time.time()
+        r = uo.unet_forward(sd, img)
+        res = lo.calculate_loss({'segmentation': r}, torch.from_numpy(bt['label']), torch.from_numpy(bt['unk_channels']), la,
+                                torch.from_numpy(bt['mask']), torch.from_numpy(bt['volumes']), torch.from_numpy(bt['diameters']), classes)
+        res['overall'].backward()
+        grads = [p.grad for p in params]
+        with torch.no_grad():
+            to.clip_grad_norm_(grads, 1.0)
+            opt.step(grads)
+            to.update_ema(opt.params, ema, 0.99, 0)
+        return time.time() - t0
+    step(1, 32, 8)                         # warm-up (thread pool, oneDNN primitives)
+    B, S = 1, args.size
+    dt = step(B, S, args.base)
     return {'value': B * S ** 3 / dt, 'unit': 'voxels/s', 'cores': ncores, 'kind': 'port',
-            'sample': f'1 un-warmed step (fwd + seg loss + bwd, no optimiser) of the fp32 torch-CPU oracle, B={B}, {S}^3, base {args.base}, '
-                      f'{len(classes)} classes, {ncores} threads, {dt:.1f} s'}
+            'sample': f'1 full training step (fwd + seg loss + bwd + clip + AdamW + EMA) of the fp32 torch-CPU oracle after a 32^3 warm-up '
+                      f'step, B={B}, {S}^3, base {args.base}, {len(classes)} classes, {ncores} threads, {dt:.1f} s'}
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start one rank per GPU ourselves
+    (train_ddp.py:726 uses mp.spawn; torchrun gives the same RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* contract)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.call(cmd, env=env)
+
+
+class Leg:
+    """One model + optimiser + resident synthetic batch of the bench workload."""
+
+    def __init__(self, args, dtype, report, rank, world, local, force_ddp, classes, B, S):
+        import synth
+        from rsuper_amd.model.dim3.unet import UNet
+        from rsuper_amd.train_ddp import wrap_ddp, make_ema
+        from rsuper_amd.training.utils import FusedAdamWEMA
+        dev = f'cuda:{local}'
+        torch.manual_seed(0)                 # identical random-init weights on every rank and in every leg
+        self.net = UNet(1, args.base, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype=dtype).to(dev)
+        self.ema = make_ema(self.net)
+        self.model = wrap_ddp(self.net, local) if (world > 1 or force_ddp) else self.net
+        self.opt = FusedAdamWEMA(self.net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        kinds = (['mask', 'report'] * B)[:B] if report else ['mask'] * B
+        bt = synth.batch(B, S, classes, kinds, seed=7 + rank, diam_range=(5.0, 40.0), max_tumors=3)
+        self.batch = dict(image=torch.from_numpy(synth.image(B, S, seed=1234 + rank)).to(dev),
+                          label=torch.from_numpy(bt['label']).to(dev), unk_channels=torch.from_numpy(bt['unk_channels']).to(dev),
+                          mask=torch.from_numpy(bt['mask']).to(dev), volumes=torch.from_numpy(bt['volumes']).to(dev),
+                          diameters=torch.from_numpy(bt['diameters']).to(dev))
+        self.largs = loss_args(report)
+        self.classes = classes
+        self.step = 0
+        self.world = world
+        self.last = None
+
+    def run(self, n):
+        from rsuper_amd.train_ddp import train_step
+        for _ in range(n):
+            self.last = train_step(self.model, self.ema, self.opt, self.batch, self.largs, self.classes, self.step)
+            self.step += 1
+
+    def sync(self):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        self.run(warmup)
+        self.sync()
+        t0 = time.perf_counter()
+        self.run(steps)
+        self.sync()
+        return time.perf_counter() - t0
+
+    def loss(self):
+        v = float(self.last[0]['overall'].detach())
+        if not np.isfinite(v):
+            raise ValueError('loss is nan, propagating this can destroy the network weights, STOP!')
+        return v
+
+    def logits(self):
+        with torch.no_grad():
+            return self.net(self.batch['image'])['segmentation'].float()
+
+    def close(self):
+        red = getattr(self.net, '_rsuper_reducer', None)
+        if red is not None:
+            red.remove()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)       # SURVEY.md 8(d): >= 50 timed steps after >= 10 warm-up
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--size', type=int, default=96)
     ap.add_argument('--batch', type=int, default=2, help='per-GPU batch (bs=2/GPU in BASELINE.json)')
     ap.add_argument('--base', type=int, default=32)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--report', action='store_true', help='config 3: report supervision on (ball_dice_both, 50/50 mask/report batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--force-ddp', action='store_true', help='wrap in DistributedDataParallel even with one rank (exercises the RCCL reducer path)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the config-3 / f32 / bf16-vs-f32 legs')
+    ap.add_argument('--roofline-steps', type=int, default=10, help='steps of the separate HIP-event pass after the timed region')
+    ap.add_argument('--force-ddp', action='store_true', help='wrap in the data-parallel reducer even with one rank (exercises the RCCL path)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
 
     import synth
     from rsuper_amd.hip import lib, ops
-    from rsuper_amd.model.dim3.unet import UNet
-    from rsuper_amd.train_ddp import init_distributed, wrap_ddp, train_step, make_ema
-    from rsuper_amd.training.utils import FusedAdamWEMA
+    from rsuper_amd.train_ddp import init_distributed
     from rsuper_amd.training import losses_foundation as lf
 
     if args.force_ddp and int(os.environ.get('WORLD_SIZE', '1')) == 1:
@@ -113,80 +218,99 @@ def main():
     classes = synth.PANTS_CLASSES
     B, S = args.batch, args.size
 
-    torch.manual_seed(0)                 # identical random-init weights on every rank (DDP broadcasts anyway)
-    net = UNet(1, args.base, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype=args.dtype).to(dev)
-    ema = make_ema(net)
-    model = wrap_ddp(net, local) if (world > 1 or args.force_ddp) else net
-    opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
-    kinds = (['mask', 'report'] * B)[:B] if args.report else ['mask'] * B
-    bt = synth.batch(B, S, classes, kinds, seed=7 + rank, diam_range=(5.0, 40.0), max_tumors=3)
-    batch = dict(image=torch.from_numpy(synth.image(B, S, seed=1234 + rank)).to(dev),
-                 label=torch.from_numpy(bt['label']).to(dev), unk_channels=torch.from_numpy(bt['unk_channels']).to(dev),
-                 mask=torch.from_numpy(bt['mask']).to(dev), volumes=torch.from_numpy(bt['volumes']).to(dev),
-                 diameters=torch.from_numpy(bt['diameters']).to(dev))
-    largs = argparse.Namespace(loss='ball_dice_both' if args.report else 'ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0,
-                               report_volume_loss_basic=0.1 if args.report else 0.0, volume_loss_tolerance=0.2,
-                               ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False,
-                               stardard_ce_ball=False, classification_branch=False, ema=True, ema_alpha=0.99)
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    step = 0
-    for _ in range(args.warmup):
-        la, _ = train_step(model, ema, opt, batch, largs, classes, step)
-        step += 1
-    sync()
-    timer = ops.KernelTimer() if rank == 0 else None
-    ops.TIMER = timer
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        la, gn = train_step(model, ema, opt, batch, largs, classes, step)
-        step += 1
-    sync()
-    dt = time.perf_counter() - t0
-    ops.TIMER = None
+    leg = Leg(args, args.dtype, args.report, rank, world, local, args.force_ddp, classes, B, S)
+    dt = leg.timed(args.steps, args.warmup)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    loss_val = float(la['overall'].detach())
-    if not np.isfinite(loss_val):
-        raise ValueError('loss is nan, propagating this can destroy the network weights, STOP!')
+    loss_val = leg.loss()
 
+    out = None
+    if rank == 0:
+        # ---- roofline pass (outside the timed region): HIP events around every conv MFMA launch, on the launch stream
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+    if args.roofline_steps > 0:
+        leg.run(args.roofline_steps)      # every rank runs the same steps (the reducer's collectives need all ranks)
+        leg.sync()
+    ops.TIMER = None
     if rank == 0:
         ksum = timer.summary()
+        rs = max(args.roofline_steps, 1)
         conv_ms_sum = sum(d['ms'] for d in ksum.values())
-        conv_ms = timer.busy_ms            # union of the launch intervals: weight gradients overlap the data-gradient chain on a second stream
+        conv_ms = timer.busy_ms            # union of the launch intervals (weight gradients may overlap the data-gradient chain)
         conv_fl = sum(d['flops'] for d in ksum.values())
         fwd_fl = conv_stack_flops(args.base, S, B)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        default_wl = args.dtype == 'bf16' and args.base == 32 and B == 2 and S == 96 and not args.report
+        if default_wl and os.path.exists(TRAFFIC_PROFILE):
+            tp = json.load(open(TRAFFIC_PROFILE))
+            traffic, traffic_src = tp.get('conv_bytes_per_step'), tp.get('source')
         out = {
-            'metric': 'CT voxels/sec/node (96\u00b3 patch, bs=2/GPU)', 'value': world * B * S ** 3 * args.steps / dt, 'unit': 'voxels/s',
+            'metric': 'CT voxels/sec/node (96³ patch, bs=2/GPU)', 'value': world * B * S ** 3 * args.steps / dt, 'unit': 'voxels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'R-Super 3D UNet(base {args.base}, {len(classes)} classes, BasicBlock/IN) full training step '
                                    f'(fwd + {"seg+Volume+Ball" if args.report else "masked BCE + Dice"} loss + bwd + clip + AdamW + EMA), '
                                    f'{S}^3 patches, batch {B}/GPU (BASELINE.json configs[{2 if args.report else 1}])',
-                       'global_batch': world * B, 'patch': S, 'parallelism': f'dp{world}', 'final_loss': loss_val},
+                       'global_batch': world * B, 'patch': S, 'parallelism': f'dp{world}', 'final_loss': loss_val,
+                       'sanity_checks_in_timed_region': False},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': (CONV_TRAFFIC_BYTES_PER_STEP if (args.dtype == 'bf16' and args.base == 32 and B == 2 and S == 96 and not args.report) else None),
-                         'traffic_unit': 'bytes per step over all conv MFMA launches (rocprofv3 PMC, profiles/r01_pmc_step.md)',
-                         'sustained_mfma_peak_measured': 2110.0,
+                         'traffic': traffic, 'traffic_unit': 'bytes per step over all conv MFMA launches (FETCH_SIZE x2 + WRITE_SIZE)',
+                         'traffic_source': traffic_src,
                          'kernel': 'conv3d MFMA kernels (igemm fwd + dgrad, wgrad): 3x the 43 3x3x3 convs',
-                         'algorithmic_gflop_per_step': conv_fl / args.steps / 1e9, 'expected_gflop_per_step': 3 * fwd_fl / 1e9,
-                         'conv_ms_per_step': conv_ms / args.steps, 'conv_ms_per_step_sum_of_launches': conv_ms_sum / args.steps,
-                         'note': 'achieved = algorithmic FLOPs of all conv MFMA launches / union of their launch intervals (HIP events on the launch '
-                                 'streams); per_kernel.avg_us are raw per-launch durations and include time shared with concurrently running kernels',
+                         'algorithmic_gflop_per_step': conv_fl / rs / 1e9, 'expected_gflop_per_step': 3 * fwd_fl / 1e9,
+                         'conv_ms_per_step': conv_ms / rs, 'conv_ms_per_step_sum_of_launches': conv_ms_sum / rs,
+                         'measured_in': f'separate pass of {args.roofline_steps} steps after the timed region (HIP events on the launch stream)',
+                         'note': 'achieved = algorithmic FLOPs of all conv MFMA launches / union of their launch intervals; '
+                                 'per_kernel.avg_us are raw per-launch durations',
                          'step_level_frac': (3 * fwd_fl / (dt / args.steps)) / 1e12 / peak,
-                         'per_kernel': {k: {'launches_per_step': d['launches'] / args.steps, 'avg_us': d['ms'] * 1e3 / d['launches'],
+                         'per_kernel': {k: {'launches_per_step': d['launches'] / rs, 'avg_us': d['ms'] * 1e3 / d['launches'],
                                             'tflops': d['flops'] / (d['ms'] * 1e-3) / 1e12} for k, d in ksum.items()}},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(args, classes)
+    if world == 1 and not args.no_secondary and not args.force_ddp:
+        # ---- secondary legs (N = 1 only): the workloads / modes the headline does not show
+        sec = {}
+        n2, w2 = min(args.steps, 20), min(args.warmup, 5)
+        ref_logits = leg.logits() if not args.report and args.dtype == 'bf16' else None
+        headline_steps = leg.step
+        bf16_last_loss = leg.loss()
+        leg.close()
+        del leg
+        torch.cuda.empty_cache()
+        if not args.report:
+            l3 = Leg(args, args.dtype, True, rank, world, local, False, classes, B, S)
+            sec['config3_ms_per_step'] = l3.timed(n2, w2) / n2 * 1e3
+            sec['config3_final_loss'] = l3.loss()
+            sec['config3_workload'] = 'same UNet + Volume + Ball report losses (ball_dice_both, weight 0.1, 50/50 mask/report batch), BASELINE configs[2]'
+            l3.close()
+            del l3
+        if args.dtype == 'bf16':
+            lf32 = Leg(args, 'f32', args.report, rank, world, local, False, classes, B, S)
+            n3 = min(n2, 10)
+            sec['f32_ms_per_step'] = lf32.timed(n3, 2) / n3 * 1e3
+            if ref_logits is not None:
+                # same init, same batch, same number of optimiser steps in both arithmetic modes
+                lf32.run(headline_steps - lf32.step)
+                lf32.sync()
+                f32_logits = lf32.logits()
+                sec['bf16_vs_f32'] = {
+                    'steps': headline_steps,
+                    'abs_delta_overall_loss': abs(lf32.loss() - bf16_last_loss),
+                    'bf16_overall_loss': bf16_last_loss, 'f32_overall_loss': lf32.loss(),
+                    'logits_rel_l2': float(((ref_logits - f32_logits).double().norm() / f32_logits.double().norm()).item()),
+                    'note': 'identical init and batch, same number of optimiser steps in both arithmetic modes (full size); loss of the last step, '
+                            'logits of the trained weights on the training batch',
+                }
+            lf32.close()
+            del lf32
+        torch.cuda.empty_cache()
+        out['secondary'] = sec
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(args, classes)
     if world > 1 or args.force_ddp:
         dist.barrier()
         dist.destroy_process_group()

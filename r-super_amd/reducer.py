@@ -23,7 +23,7 @@ class _Bucket:
 
 
 class GradReducer:
-    def __init__(self, module, bucket_mb=48, process_group=None, broadcast=True):
+    def __init__(self, module, bucket_mb=48, process_group=None, broadcast=True, tail_mb=8):
         assert dist.is_available() and dist.is_initialized(), 'init_distributed() first'
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
@@ -41,6 +41,16 @@ class GradReducer:
             cur.append(p); n += p.numel()
         if cur:
             groups.append(cur)
+        # The bucket that completes LAST (first-registered layers: stem / inc / down1) has nothing left to hide behind, so
+        # its ring time is exposed at the end of backward: keep it small (<= tail_mb) by splitting it off the last group.
+        tcap = int(tail_mb * (1 << 20) // 4)
+        last = groups[-1]
+        if tail_mb and sum(p.numel() for p in last) > tcap and len(last) > 1:
+            k, n = len(last), 0
+            while k > 1 and n + last[k - 1].numel() <= tcap:
+                k -= 1; n += last[k].numel()
+            if 0 < k < len(last):
+                groups[-1:] = [last[:k], last[k:]]
         self.buckets, self._slot = [], {}
         for g in groups:
             flat = torch.zeros(sum(p.numel() for p in g), device=g[0].device, dtype=torch.float32)
@@ -67,8 +77,23 @@ class GradReducer:
         return b.flat[off:off + p.numel()].view(p.shape)
 
     # ------------------------------------------------------------------ hooks
+    def __deepcopy__(self, memo):
+        # make_ema(net) after wrap_ddp deep-copies the module's attributes: the EMA copy must not own buckets or hooks
+        return None
+
+    def reset(self):
+        """Re-arm after a failed / interrupted backward pass: waits for in-flight collectives and restores the counters."""
+        for b in self.buckets:
+            if b.handle is not None:
+                b.handle.wait()
+                b.handle = None
+            b.pending = len(b.params)
+
     def _on_grad(self, p):
         b, off = self._slot[p]
+        if b.pending <= 0:
+            raise RuntimeError('GradReducer: a second gradient arrived for a parameter before finish() -- exactly one backward pass per '
+                               'finish() is supported (no gradient accumulation; call reducer.reset() after an aborted backward)')
         g = p.grad
         if g.data_ptr() != b.flat.data_ptr() + 4 * off:         # produced elsewhere (ATen op, CPU tests): move it in
             v = self.view_for(p)

@@ -256,7 +256,7 @@ def _plane_any(t, lead_dims):
     planes = int(np.prod(shape)) if len(shape) else 1
     V = t.numel() // max(planes, 1)
     flags = torch.empty(planes, device=t.device, dtype=torch.uint8)
-    if V % 16 == 0 or planes == 1:
+    if (V % 16 == 0 or planes == 1) and t.data_ptr() % 16 == 0:
         _l.check(_L().rsuper_plane_any(_ptr(t), planes, V, _ptr(flags), _stream()), 'plane_any')
         return flags.view(shape).bool()
     return t.flatten(lead_dims).any(lead_dims)

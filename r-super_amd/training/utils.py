@@ -28,7 +28,20 @@ class FusedAdamWEMA(torch.optim.Optimizer):
             st['step'] = 0
             st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        elif not isinstance(st['step'], int):
+            # resumed from a torch.optim.AdamW / reference optimizer_state_dict (train_ddp.py:184-189): torch keeps `step`
+            # as a per-parameter tensor
+            st['step'] = int(st['step'].item()) if torch.is_tensor(st['step']) else int(st['step'])
         return st
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if 'step' in st and not isinstance(st['step'], int):
+                st['step'] = int(st['step'].item()) if torch.is_tensor(st['step']) else int(st['step'])
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if k in st:
+                    st[k] = st[k].float().contiguous()
 
     @torch.no_grad()
     def grad_sqnorm(self):
@@ -135,11 +148,13 @@ def ema_alpha_for_step(alpha, global_step):
 @torch.no_grad()
 def update_ema_variables(model, ema_model, alpha, global_step):
     """Stand-alone EMA update (training/utils.py:154-161); the training step normally uses the fused path."""
+    from ..hip import ops as _ops
     a = ema_alpha_for_step(alpha, global_step)
     for e, p in zip(ema_model.parameters(), model.parameters()):
-        e.data.mul_(a).add_(p.data, alpha=1 - a)
+        e.mul_(a).add_(p, alpha=1 - a)       # in place on the parameter itself (under no_grad): bumps e._version
     for eb, mb in zip(ema_model.buffers(), model.buffers()):
         eb.copy_(mb)
+    _ops.WEIGHTS_EPOCH += 1                  # cached MFMA weight fragments of the EMA network are stale now
 
 
 def unwrap_model_checkpoint(net, ema_net, args):

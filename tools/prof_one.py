@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rsuper_amd.hip import ops
 LAYERS = [('inc 32->32', 96, 32, 0, 32, False), ('up4.0 96->32+sc', 96, 32, 64, 32, True), ('down1.0 32->64+sc', 48, 32, 0, 64, True),
-          ('64->64', 48, 64, 0, 64, False), ('up3.0 192->64+sc', 48, 64, 128, 64, True), ('128->128', 24, 128, 0, 128, False)]
+          ('64->64', 48, 64, 0, 64, False), ('up3.0 192->64+sc', 48, 64, 128, 64, True), ('128->128', 24, 128, 0, 128, False),
+          ('up2.0 384->128+sc', 24, 128, 256, 128, True), ('256->256', 12, 256, 0, 256, False), ('320->320', 6, 320, 0, 320, False)]
 name, S, Ca, Cb, Cout, sc = LAYERS[int(sys.argv[1])]
 which = sys.argv[2]
 dt, dev, N = torch.bfloat16, 'cuda', 2
@@ -23,11 +24,11 @@ sa, sb = ops.Src(xa, mr=mra), (ops.Src(xb, mr=mrb) if Cb else None)
 dy1 = torch.randn((N, S, S, S, Cout), device=dev).to(dt)
 dy2 = torch.randn((N, S, S, S, Cout), device=dev).to(dt) if sc else None
 if which == 'fwd':
-    bn = ops.pick_bn(nc, dt); wp = ops.pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if sc else 0, bn)
+    bn = ops.pick_bn(nc, dt, tiles * N); wp = ops.pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if sc else 0, bn)
     out = torch.empty((N, S, S, S, nc), device=dev, dtype=dt); part = ops.part_buffer(dt, dims, nc, bn, dev)
     fn = lambda: ops.igemm(0, sa, sb, wp, nc, bn, dims, out, part=part)
 elif which == 'dgrad':
-    bn = ops.pick_bn(Cin, dt); wp = ops.pack_weights(dt, 1, w1, ws, Cout, Cout if sc else 0, Cin, 0, bn)
+    bn = ops.pick_bn(Cin, dt, tiles * N); wp = ops.pack_weights(dt, 1, w1, ws, Cout, Cout if sc else 0, Cin, 0, bn)
     g0 = torch.empty((N, S, S, S, Cin), device=dev, dtype=dt); part = ops.part_buffer(dt, dims, Cin, bn, dev, epi=1)
     fn = lambda: ops.igemm(1, ops.Src(dy1), ops.Src(dy2) if sc else None, wp, Cin, bn, dims, g0, part=part, ea=sa, eb=sb)
 else:
