@@ -60,8 +60,10 @@ int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, cons
 int rsuper_conv3_tiles(int D, int H, int W);
 
 /* Kernel variant of rsuper_conv3_igemm: 0 = classic one-tile-per-block kernel (always used for f32), 1 = wave-specialised
- * producer/consumer persistent kernel (bf16), 2 (default) = per-launch choice between the two.  v < 0 queries.
- * Returns the variant in effect. */
+ * producer/consumer persistent kernel (bf16), 2 = per-launch choice between the two (round-1 default), 3 (default) = as 2,
+ * with the weight-stationary 8-wave kernel (weights in registers, activation fragments re-used across taps, epilogue
+ * straight from the accumulators) for 32-column launches over a single 32-channel K chunk, 4 = weight-stationary kernel
+ * for every bf16 32-column launch.  v < 0 queries.  Returns the variant in effect. */
 int rsuper_conv3_variant(int v);
 
 /* Rows per sample of the `part` buffer rsuper_conv3_igemm(dtype, epi, ..., n_cols, bn, N, D, H, W) writes under the

@@ -100,6 +100,9 @@ def test_lesion_groups_and_ball_geometry(golden):
 
 def test_pick_bn():
     from rsuper_amd.hip.ops import pick_bn
+    from rsuper_amd.hip import lib
+    L = lib.lib()
+    assert L.rsuper_conv3_variant(-1) == 3          # default: round-1 choice + weight-stationary kernel on single-chunk 32-column launches
     assert pick_bn(32, torch.bfloat16) == 32 and pick_bn(64, torch.bfloat16) == 64 and pick_bn(128, torch.bfloat16) == 128
     assert pick_bn(96, torch.bfloat16) == 32 and pick_bn(96, torch.float32) == 32 and pick_bn(320, torch.bfloat16) == 64 and pick_bn(128, torch.float32) == 64
 
