@@ -115,6 +115,15 @@ int rsuper_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, flo
 int rsuper_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx,
                         int N, int D, int H, int W, int C, void* stream);
 
+/* Stride-(2,2,2) down-sampling of down_block(pool=False) -- model/dim3/unet_utils.py:38-39 (`block(in_ch, out_ch,
+ * stride=down_scale)`; conv_layers.py:29-38 with stride 2, padding 1).  The strided convolution is the stride-1 convolution
+ * (rsuper_conv3_igemm) evaluated at the even voxels: fwd picks y[od,oh,ow] = x[2od,2oh,2ow] (output ceil(D/2) x ceil(H/2) x
+ * ceil(W/2)) and writes the partial stats of y; bwd scatters dy back to the even voxels of a zero-filled dx (D, H, W = the
+ * full-resolution dims in both calls). */
+int rsuper_subsample2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, float* part, int blocks,
+                          int N, int D, int H, int W, int C, void* stream);
+int rsuper_subsample2_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx, int N, int D, int H, int W, int C, void* stream);
+
 /* F.interpolate(mode='trilinear', align_corners=True) -- model/dim3/unet_utils.py:69 */
 int rsuper_upsample_fwd(int dtype, const void* x, int ldx, void* y, int ldy, float* part, int blocks,
                         int N, int ID, int IH, int IW, int OD, int OH, int OW, int C, void* stream);

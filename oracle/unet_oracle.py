@@ -103,9 +103,10 @@ def _unet_forward(p, x, pool=True):
     return F.conv3d(o, p['outc.weight'], p['outc.bias'])       # unet.py:47 (f32 weights, f32 logits)
 
 
-def unet_param_shapes(in_ch, base_ch, num_classes):
-    """state_dict shapes of UNet(in_ch, base_ch, num_classes, block='BasicBlock') (unet.py:31-47;
-    bottleneck is 10*base_ch)."""
+def unet_param_shapes(in_ch, base_ch, num_classes, pool=True):
+    """state_dict shapes of UNet(in_ch, base_ch, num_classes, block='BasicBlock', pool=pool) (unet.py:31-47;
+    bottleneck is 10*base_ch).  pool=False: no pooling layer in down_block.conv, the strided first block sits at index 0
+    and always has a convolutional shortcut (unet_utils.py:38-39, conv_layers.py:82-84)."""
     b = base_ch
     s = {'inc.conv1.weight': (b, in_ch, 3, 3, 3)}
 
@@ -118,8 +119,9 @@ def unet_param_shapes(in_ch, base_ch, num_classes):
     blk('inc.conv2', b, b)
     chans = [b, 2 * b, 4 * b, 8 * b, 10 * b]
     for i in range(4):
-        blk(f'down{i + 1}.conv.1', chans[i], chans[i + 1])
-        blk(f'down{i + 1}.conv.2', chans[i + 1], chans[i + 1])
+        o = 1 if pool else 0
+        blk(f'down{i + 1}.conv.{o}', chans[i], chans[i + 1])
+        blk(f'down{i + 1}.conv.{o + 1}', chans[i + 1], chans[i + 1])
     for i in range(4):
         ci, co = chans[4 - i], chans[3 - i]
         blk(f'up{i + 1}.conv.0', ci + co, co)

@@ -216,6 +216,18 @@ int rsuper_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int l
     return rs_launch_pool(p, dtype, 1, 1, ST(stream));
 }
 
+int rsuper_subsample2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, float* part, int blocks,
+                          int N, int D, int H, int W, int C, void* stream) {
+    if (!dt_ok(dtype) || !x || !y || !ch_ok(C, ldx) || !ch_ok(C, ldy) || blocks <= 0 || D < 1 || H < 1 || W < 1 || N <= 0) return RS_ERR_ARG;
+    PoolParams p = {x, ldx, y, ldy, nullptr, 0, part, N, D, H, W, C};
+    return rs_launch_subsample(p, dtype, 0, blocks, ST(stream));
+}
+int rsuper_subsample2_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx, int N, int D, int H, int W, int C, void* stream) {
+    if (!dt_ok(dtype) || !dy || !dx || !ch_ok(C, lddy) || !ch_ok(C, lddx) || D < 1 || H < 1 || W < 1 || N <= 0) return RS_ERR_ARG;
+    PoolParams p = {nullptr, 0, (void*)dy, lddy, dx, lddx, nullptr, N, D, H, W, C};
+    return rs_launch_subsample(p, dtype, 1, 1, ST(stream));
+}
+
 int rsuper_upsample_fwd(int dtype, const void* x, int ldx, void* y, int ldy, float* part, int blocks,
                         int N, int ID, int IH, int IW, int OD, int OH, int OW, int C, void* stream) {
     if (!dt_ok(dtype) || !x || !y || !ch_ok(C, ldx) || !ch_ok(C, ldy) || blocks <= 0) return RS_ERR_ARG;

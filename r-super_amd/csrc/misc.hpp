@@ -54,6 +54,7 @@ int rs_launch_stats_finalize(const float* part, int N, int nblk, int C, double c
 int rs_elem_blocks(size_t items);
 int rs_launch_in_bwd(const InBwdParams& p, int dtype, hipStream_t st);
 int rs_launch_pool(const PoolParams& p, int dtype, int bwd, int blocks, hipStream_t st);
+int rs_launch_subsample(const PoolParams& p, int dtype, int bwd, int blocks, hipStream_t st);
 int rs_launch_upsample(const UpParams& p, int dtype, int bwd, int blocks, hipStream_t st);
 int rs_launch_stem(const StemParams& p, int dtype, int wgrad, hipStream_t st);
 int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st);

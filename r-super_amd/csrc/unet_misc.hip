@@ -191,6 +191,55 @@ __global__ void maxpool_bwd_kernel(PoolParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stride-2 subsample
+// y[od, oh, ow] = x[2 od, 2 oh, 2 ow] (output size ceil(D / 2)): the stride-(2,2,2) / pad-1 convolution of down_block(pool=False)
+// (model/dim3/unet_utils.py:38-39) is the stride-1 convolution evaluated at the even voxels.  Output partial stats for the next
+// InstanceNorm, same grid / partial layout as the max pool.
+template <typename T>
+__global__ void subsample_fwd_kernel(PoolParams p) {
+    constexpr int KP = Elem<T>::KP;
+    const int CV = p.C / KP, VL = 256 / CV;
+    const int vl = threadIdx.x / CV, s = threadIdx.x % CV;
+    const bool active = vl < VL;
+    const int n = blockIdx.y;
+    const int OD = (p.D + 1) / 2, OH = (p.H + 1) / 2, OW = (p.W + 1) / 2;
+    const int ovox = OD * OH * OW;
+    const int per_blk = (ovox + gridDim.x - 1) / gridDim.x;
+    const int v0 = blockIdx.x * per_blk, v1 = min(ovox, v0 + per_blk);
+    float s1[KP], s2[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (active)
+        for (int v = v0 + vl; v < v1; v += VL) {
+            const int ow = v % OW, oh = (v / OW) % OH, od = v / (OW * OH);
+            const uint4 q = *(const uint4*)((const T*)p.x + ((((size_t)n * p.D + 2 * od) * p.H + 2 * oh) * p.W + 2 * ow) * (size_t)p.ldx + s * KP);
+            *(uint4*)((T*)p.y + ((size_t)n * ovox + v) * p.ldy + s * KP) = q;
+            float m[KP];
+            unpack16<T>(q, m);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) { s1[j] += m[j]; s2[j] += m[j] * m[j]; }
+        }
+    if (p.part) block_channel_sums<KP>(s1, s2, p.C, CV, VL, vl, s, active, p.part + ((size_t)n * gridDim.x + blockIdx.x) * p.C * 2);
+}
+
+// dx[d, h, w] = dy[d / 2, h / 2, w / 2] at the even voxels, 0 elsewhere (every input voxel is written)
+template <typename T>
+__global__ void subsample_bwd_kernel(PoolParams p) {
+    constexpr int KP = Elem<T>::KP;
+    const int CV = p.C / KP;
+    const int n = blockIdx.y;
+    const int OH = (p.H + 1) / 2, OW = (p.W + 1) / 2, OD = (p.D + 1) / 2;
+    const size_t total = (size_t)p.D * p.H * p.W * CV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % CV); const size_t v = i / CV;
+        const int w = (int)(v % p.W), h = (int)((v / p.W) % p.H), d = (int)(v / ((size_t)p.W * p.H));
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (!((d | h | w) & 1))
+            q = *(const uint4*)((const T*)p.y + (((size_t)n * OD + d / 2) * OH + h / 2) * OW * (size_t)p.ldy + (size_t)(w / 2) * p.ldy + s * KP);
+        *(uint4*)((T*)p.dx + ((size_t)n * p.D * p.H * p.W + v) * (size_t)p.lddx + s * KP) = q;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ trilinear, align_corners
 __device__ __forceinline__ void lin_coord(int o, float scale, int I, int& i0, int& i1, float& l1) {
     // ATen area_pixel_compute_source_index(align_corners=True): src = scale * dst (float32)
@@ -668,6 +717,22 @@ int rs_launch_pool(const PoolParams& p, int dtype, int bwd, int blocks, hipStrea
         const int b = rs_elem_blocks((size_t)(p.D / 2) * (p.H / 2) * (p.W / 2) * CV);
         if (dtype == RS_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(b, p.N), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(b, p.N), dim3(256), 0, st, p);
+    }
+    return rs_check_launch();
+}
+
+int rs_launch_subsample(const PoolParams& p, int dtype, int bwd, int blocks, hipStream_t st) {
+    const int KP = dtype == RS_F32 ? 4 : 8;
+    const int CV = p.C / KP;
+    if (CV > 256) return RS_ERR_UNSUPPORTED;
+    if (!bwd) {
+        const size_t smem = (size_t)(256 / CV) * p.C * 2 * sizeof(float);
+        if (dtype == RS_F32) hipLaunchKernelGGL(subsample_fwd_kernel<float>, dim3(blocks, p.N), dim3(256), smem, st, p);
+        else hipLaunchKernelGGL(subsample_fwd_kernel<bf16_t>, dim3(blocks, p.N), dim3(256), smem, st, p);
+    } else {
+        const int b = rs_elem_blocks((size_t)p.D * p.H * p.W * CV);
+        if (dtype == RS_F32) hipLaunchKernelGGL(subsample_bwd_kernel<float>, dim3(b, p.N), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(subsample_bwd_kernel<bf16_t>, dim3(b, p.N), dim3(256), 0, st, p);
     }
     return rs_check_launch();
 }

@@ -339,8 +339,15 @@ class BasicBlockFn(torch.autograd.Function):
     conv1 and the shortcut conv read the same normalised input and run as ONE GEMM with N = 2*Cout."""
 
     @staticmethod
-    def forward(ctx, xa, mra, xb, mrb, w1, w2, ws, packs=None):
-        """packs: optional (tensors, bns) from pack_weights_batch / block_pack_specs (whole-network batched packing)."""
+    def forward(ctx, xa, mra, xb, mrb, w1, w2, ws, packs=None, stride=1):
+        """packs: optional (tensors, bns) from pack_weights_batch / block_pack_specs (whole-network batched packing).
+        stride 2 (down_block(pool=False), unet_utils.py:38-39): conv1 and the shortcut conv are evaluated at full resolution
+        and sampled at the even voxels (8x the minimal FLOPs of these two convolutions; the shipped configs use MaxPool and
+        never take this path), conv2 runs at the half resolution."""
+        if stride == 2:
+            return BasicBlockFn._forward_s2(ctx, xa, mra, w1, w2, ws)
+        assert stride == 1
+        ctx.stride = 1
         _chk_act(xa)
         N, D, H, W, Ca = xa.shape
         Cb = 0 if xb is None else xb.shape[-1]
@@ -378,7 +385,82 @@ class BasicBlockFn(torch.autograd.Function):
         return out, mr_out
 
     @staticmethod
+    def _forward_s2(ctx, xa, mra, w1, w2, ws):
+        _chk_act(xa)
+        assert ws is not None, 'a strided BasicBlock always has a convolutional shortcut (conv_layers.py:82-84)'
+        N, D, H, W, Ca = xa.shape
+        Cout = w1.shape[0]
+        dims = (N, D, H, W)
+        dev, dt = xa.device, xa.dtype
+        tiles = _L().rsuper_conv3_tiles(D, H, W)
+        sa = Src(xa, mr=mra)
+        nc1 = 2 * Cout
+        specs, bns = block_pack_specs(w1, w2, ws, Ca, 0, dt, tiles * N, False)
+        wp = pack_weights_batch(dt, specs)
+        full = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
+        igemm(0, sa, None, wp[0], nc1, bns[0], dims, full)                       # [conv1 | shortcut] at stride 1, no statistics
+        ys, mr_ys = subsample2(full)
+        del full
+        OD, OH, OW = ys.shape[1:4]
+        dims2 = (N, OD, OH, OW)
+        mr_y1 = mr_ys[:, :Cout].contiguous()
+        tiles2 = _L().rsuper_conv3_tiles(OD, OH, OW)
+        bn2 = pick_bn(Cout, dt, tiles2 * N)
+        wp2 = pack_weights(dt, 0, w2, None, Cout, 0, Cout, 0, bn2)
+        out = torch.empty((N, OD, OH, OW, Cout), device=dev, dtype=dt)
+        part2 = part_buffer(dt, dims2, Cout, bn2, dev)
+        igemm(0, Src(ys, C=Cout, mr=mr_y1), None, wp2, Cout, bn2, dims2, out, res=Src(ys, C=Cout, off=Cout), part=part2)
+        mr_out = stats_finalize(part2, OD * OH * OW)
+        ctx.save_for_backward(xa, mra, None, None, ys, mr_y1, w1, w2, ws)
+        ctx.packs = None
+        ctx.stride = 2
+        ctx.mark_non_differentiable(mr_out)
+        ctx.set_materialize_grads(False)
+        return out, mr_out
+
+    @staticmethod
+    def _backward_s2(ctx, dout):
+        xa, mra, _, _, ys, mr_y1, w1, w2, ws = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, D, H, W, Ca = xa.shape
+        Cout = w1.shape[0]
+        OD, OH, OW = ys.shape[1:4]
+        dims, dims2 = (N, D, H, W), (N, OD, OH, OW)
+        dev, dt = xa.device, xa.dtype
+        y1 = Src(ys, C=Cout, mr=mr_y1)
+        sdo = Src(dout)
+        # conv2 at the half resolution: as in the stride-1 block
+        tiles2 = _L().rsuper_conv3_tiles(OD, OH, OW)
+        bn = pick_bn(Cout, dt, tiles2 * N)
+        wpd2 = pack_weights(dt, 1, w2, None, Cout, 0, Cout, 0, bn)
+        g1 = torch.empty((N, OD, OH, OW, Cout), device=dev, dtype=dt)
+        part = part_buffer(dt, dims2, Cout, bn, dev, epi=1)
+        igemm(1, sdo, None, wpd2, Cout, bn, dims2, g1, part=part, ea=y1)
+        gm1 = stats_finalize(part, OD * OH * OW, mode=1)
+        dw2 = grad_dest(w2)
+        wgrad(y1, None, sdo, None, dw2, None, dims2)
+        dy1 = in_bwd_finalize(Src(g1), y1, gm1, Cout)
+        # conv1 + shortcut: the output gradient lives at the even voxels of the full-resolution grid
+        dfull = torch.empty((N, D, H, W, 2 * Cout), device=dev, dtype=dt)
+        subsample2_scatter(dy1, dfull, 0, dims)
+        subsample2_scatter(dout, dfull, Cout, dims)
+        sa = Src(xa, mr=mra)
+        tiles = _L().rsuper_conv3_tiles(D, H, W)
+        bnd = pick_bn(Ca, dt, tiles * N)
+        wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, bnd)
+        g0 = torch.empty((N, D, H, W, Ca), device=dev, dtype=dt)
+        part0 = part_buffer(dt, dims, Ca, bnd, dev, epi=1)
+        igemm(1, Src(dfull, C=Cout), Src(dfull, C=Cout, off=Cout), wpd1, Ca, bnd, dims, g0, part=part0, ea=sa)
+        gm0 = stats_finalize(part0, D * H * W, mode=1)
+        dw1, dws = grad_dest(w1), grad_dest(ws)
+        wgrad(sa, None, Src(dfull, C=Cout), Src(dfull, C=Cout, off=Cout), dw1, dws, dims)
+        dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca)
+        return dxa, None, None, None, dw1, dw2, dws, None, None
+
+    @staticmethod
     def backward(ctx, dout, _unused):
+        if ctx.stride == 2:
+            return BasicBlockFn._backward_s2(ctx, dout)
         xa, mra, xb, mrb, ys, mr_y1, w1, w2, ws = ctx.saved_tensors
         dout = dout.contiguous()
         N, D, H, W, Ca = xa.shape
@@ -429,7 +511,7 @@ class BasicBlockFn(torch.autograd.Function):
             dxb = in_bwd_finalize(Src(g0, C=Cb, off=Ca), sb, gm0[:, Ca:].contiguous(), Cb)
         if ov and _join_per_block():
             join_side()
-        return dxa, None, dxb, None, dw1, dw2, dws, None
+        return dxa, None, dxb, None, dw1, dw2, dws, None, None
 
 
 # ------------------------------------------------------------------------------------------------ pool / upsample
@@ -463,6 +545,24 @@ class MaxPoolFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         _l.check(_L().rsuper_maxpool2_bwd(_DT[x.dtype], _ptr(x), C, _ptr(dy), C, _ptr(dx), C, N, D, H, W, C, _stream()), 'maxpool2_bwd')
         return dx
+
+
+def subsample2(x, with_stats=True):
+    """y = x[:, ::2, ::2, ::2] (channels-last) + the InstanceNorm statistics of y (stride-2 evaluation of a stride-1 convolution)."""
+    N, D, H, W, C = x.shape
+    OD, OH, OW = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    y = torch.empty((N, OD, OH, OW, C), device=x.device, dtype=x.dtype)
+    blocks = _stat_blocks(OD * OH * OW)
+    part = torch.empty((N, blocks, C, 2), device=x.device, dtype=torch.float32) if with_stats else None
+    _l.check(_L().rsuper_subsample2_fwd(_DT[x.dtype], _ptr(x), C, _ptr(y), C, _ptr(part), blocks, N, D, H, W, C, _stream()), 'subsample2_fwd')
+    return y, (stats_finalize(part, OD * OH * OW) if with_stats else None)
+
+
+def subsample2_scatter(dy, out, off, dims):
+    """out[..., off:off+C] at the even voxels of the (N, D, H, W) grid = dy, zero elsewhere."""
+    N, D, H, W = dims
+    C = dy.shape[-1]
+    _l.check(_L().rsuper_subsample2_bwd(_DT[dy.dtype], _ptr(dy), C, _ptr(out, off), out.shape[-1], N, D, H, W, C, _stream()), 'subsample2_bwd')
 
 
 class UpsampleFn(torch.autograd.Function):

@@ -15,20 +15,24 @@ class ConvNormAct(nn.Module):
         super().__init__()
         ks = tuple(kernel_size) if isinstance(kernel_size, (list, tuple)) else (kernel_size,) * 3
         st = tuple(stride) if isinstance(stride, (list, tuple)) else (stride,) * 3
-        if ks != (3, 3, 3) or st != (1, 1, 1) or not preact or norm != 'in' or act != 'relu':
-            raise NotImplementedError('gfx950 hot path implements the shipped configuration: 3x3x3, stride 1, '
-                                      'pre-activation InstanceNorm+ReLU (conv_layers.py:46-51)')
-        self.conv = nn.Conv3d(in_ch, out_ch, kernel_size=3, stride=1, padding=1, bias=False)   # holder: weight + default init
+        if ks != (3, 3, 3) or st not in ((1, 1, 1), (2, 2, 2)) or not preact or norm != 'in' or act != 'relu':
+            raise NotImplementedError('gfx950 hot path implements 3x3x3 convolutions with stride 1 (shipped configuration) or 2 '
+                                      '(pool=False down-sampling), pre-activation InstanceNorm+ReLU (conv_layers.py:46-51); '
+                                      'LeakyReLU / other norms are not reachable from the reference UNet')
+        self.conv = nn.Conv3d(in_ch, out_ch, kernel_size=3, stride=st[0], padding=1, bias=False)   # holder: weight + default init
+        self.stride = st[0]
         self.preact = True
 
 
 class BasicBlock(nn.Module):
     def __init__(self, in_ch, out_ch, kernel_size=(3, 3, 3), stride=1, norm='in', act='relu', preact=True):
         super().__init__()
+        st = tuple(stride) if isinstance(stride, (list, tuple)) else (stride,) * 3
+        self.stride = st[0]
         self.conv1 = ConvNormAct(in_ch, out_ch, kernel_size, stride, 1, norm, act, preact)
         self.conv2 = ConvNormAct(out_ch, out_ch, kernel_size, 1, 1, norm, act, preact)
         self.shortcut = nn.Sequential()
-        if stride != 1 or in_ch != out_ch:
+        if st != (1, 1, 1) or in_ch != out_ch:
             self.shortcut = ConvNormAct(in_ch, out_ch, kernel_size, stride, 1, norm, act, preact)
 
     def weights(self):
@@ -40,7 +44,10 @@ class BasicBlock(nn.Module):
         packs = getattr(self, '_packs', None)        # set by UNet.forward (whole-network batched weight packing)
         if packs is None and not torch.is_grad_enabled():
             packs = self._cached_forward_packs(xa, xb, w1, w2, ws)
-        return ops.BasicBlockFn.apply(xa, mra, xb, mrb, w1, w2, ws, packs)
+        if self.stride == 2:
+            assert xb is None
+            return ops.BasicBlockFn.apply(xa, mra, None, None, w1, w2, ws, None, 2)
+        return ops.BasicBlockFn.apply(xa, mra, xb, mrb, w1, w2, ws, packs, 1)
 
     def _cached_forward_packs(self, xa, xb, w1, w2, ws):
         """Inference (no_grad): the MFMA fragment buffers only change when the weights do, so sliding-window inference packs

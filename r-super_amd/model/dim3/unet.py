@@ -48,6 +48,7 @@ class UNet(nn.Module):
         self.up4 = up_block(2 * b, b, num_block, blk, ks[0], scale[0], norm)
         self.outc = nn.Conv3d(b, num_classes, kernel_size=1)          # holder: weight (K,C,1,1,1) + bias
         self.compute_dtype = compute_dtype or os.environ.get('RSUPER_DTYPE', 'bf16')
+        self.pool = bool(pool)
 
     def _dtype(self):
         return {'bf16': torch.bfloat16, 'f32': torch.float32}[self.compute_dtype]
@@ -98,7 +99,7 @@ class UNet(nn.Module):
         dt = self._dtype()
         # Batched packing (one launch for all layers) is opt-in: measured SLOWER (+1.2 ms/step) than packing each layer
         # right before its convolution, because fragments packed up front are cold in L2/MALL when finally used.
-        batch_pack = os.environ.get('RSUPER_BATCH_PACK', '0') == '1'
+        batch_pack = os.environ.get('RSUPER_BATCH_PACK', '0') == '1' and self.pool
         if batch_pack:
             self._pack_all(tuple(x.shape), dt)
         x1, m1 = self.inc(x, dt)

@@ -28,17 +28,23 @@ class down_block(nn.Module):
     def __init__(self, in_ch, out_ch, num_block, block=BasicBlock, kernel_size=(3, 3, 3), down_scale=(2, 2, 2), pool=True, norm='in'):
         super().__init__()
         ds = tuple(down_scale) if isinstance(down_scale, (list, tuple)) else (down_scale,) * 3
-        if not pool or ds != (2, 2, 2):
-            raise NotImplementedError('gfx950 hot path implements MaxPool3d(2) down-sampling (get_model never passes pool=False, '
-                                      'model/utils.py:87-89)')
-        layers = [_Pool(), block(in_ch, out_ch, kernel_size=kernel_size, norm=norm)]
+        if ds != (2, 2, 2):
+            raise NotImplementedError('gfx950 hot path implements down_scale (2, 2, 2) (every shipped config)')
+        self.pool = bool(pool)
+        if pool:                                               # unet_utils.py:35-37 (what get_model builds, model/utils.py:87-89)
+            layers = [_Pool(), block(in_ch, out_ch, kernel_size=kernel_size, norm=norm)]
+        else:                                                  # unet_utils.py:38-39: strided first block, no pooling layer
+            layers = [block(in_ch, out_ch, kernel_size=kernel_size, stride=2, norm=norm)]
         for _ in range(num_block - 1):
             layers.append(block(out_ch, out_ch, kernel_size=kernel_size, norm=norm))
         self.conv = nn.Sequential(*layers)
 
     def forward(self, x, mr):
-        x, mr = self.conv[0](x)
-        for blk in list(self.conv)[1:]:
+        blocks = list(self.conv)
+        if self.pool:
+            x, mr = blocks[0](x)
+            blocks = blocks[1:]
+        for blk in blocks:
             x, mr = blk(x, mr)
         return x, mr
 

@@ -32,19 +32,39 @@ def _u8(t):
     return (t != 0).to(torch.uint8).contiguous()
 
 
-def lesion_groups(classes):
-    """get_lesion_channels (:204-221): lesion/cyst/pdac/pnet channels grouped per organ, in class order."""
+def lesion_channel_lists(classes):
+    """get_lesion_channels (:204-221): lesion/cyst/pdac/pnet channels grouped per organ, in class order; every group is
+    the list of channels the reference max-merges (:218-219)."""
     groups = {}
     for i, c in enumerate(classes):
         for suffix in ['lesion', 'cyst', 'pdac', 'pnet']:
             if suffix in c:
                 name = c[:c.index('_' + suffix) + len('_' + suffix)].replace('pancreatic', 'pancreas')
                 groups.setdefault(name, []).append(i)
+    return groups
+
+
+def lesion_groups(classes):
+    """Single-channel view {group name: channel} used by the fused loss kernels; a group spanning several channels has
+    to be merged first (`merge_lesion_channels`), which calculate_loss does on its own."""
+    groups = lesion_channel_lists(classes)
     for k, v in groups.items():
         if len(set(v)) != 1:
-            raise NotImplementedError(f'lesion group {k!r} spans several channels {v}: multi-channel tumour merging '
-                                      '(--multi_ch_tumor, unused in the paper) is not on the gfx950 hot path')
+            raise NotImplementedError(f'lesion group {k!r} spans several channels {v}: merge them with merge_lesion_channels first')
     return {k: v[0] for k, v in groups.items()}
+
+
+def merge_lesion_channels(t, classes):
+    """get_lesion_channels (:204-228): (B, C, ...) -> (B, L, ...) with every organ's lesion sub-channels max-merged
+    (logits: max, differentiable through the arg-max channel; 0/1 masks: OR).  Returns (merged, group names)."""
+    groups = lesion_channel_lists(classes)
+    cols = []
+    for idx in groups.values():
+        m = t[:, idx[0]]
+        for i in idx[1:]:
+            m = torch.maximum(m, t[:, i])
+        cols.append(m)
+    return torch.stack(cols, dim=1).contiguous(), list(groups.keys())
 
 
 def dilate_volume(volume, kernel_size, full_pass_radius=3):
@@ -354,6 +374,60 @@ def _ball_plans(out, label_u8, unk_u8, mask_u8, volumes, diameters, groups, marg
 
 
 # ------------------------------------------------------------------------------------------------ calculate_loss
+def _calculate_loss_merged(model_output, label, unk_voxels, args, matcher, chosen_segment_mask, tumor_volumes_report,
+                           tumor_diameters, classes, input_tensor, class_weights):
+    """Lesion groups spanning several channels (e.g. pancreatic_lesion_1 / _2).  The reference max-merges the sub-channels of
+    every tensor the report losses read (get_lesion_channels, :204-221, called at :286-297 and :1571-1583) while the
+    segmentation term keeps all C channels (:945-957).  Same arithmetic here as two passes of the fused single-channel path:
+      1. segmentation term on the original C channels (report losses off);
+      2. report terms on the merged problem -- L channels named after the groups, logits max-merged (the gradient flows to
+         the arg-max sub-channel, as torch.max does in the reference), labels / unknown / segment masks OR-merged, class
+         weights max-merged -- with the segmentation weight set to zero."""
+    import copy
+    rw = float(args.report_volume_loss_basic)
+    a_seg = copy.copy(args)
+    a_seg.report_volume_loss_basic = 0.0
+    seg = calculate_loss(model_output, label, unk_voxels, a_seg, matcher, chosen_segment_mask, tumor_volumes_report, tumor_diameters,
+                         _delesioned(classes), input_tensor, class_weights)
+    loss = {'segmentation': seg['segmentation']}
+    if rw > 0:
+        result = model_output['segmentation']
+        deep = isinstance(result, (tuple, list))
+        heads = [merge_lesion_channels(r.float(), classes)[0] for r in (result if deep else [result])]
+        names = list(lesion_channel_lists(classes).keys())
+        lab = merge_lesion_channels(_u8(label), classes)[0]
+        unk = merge_lesion_channels(_u8(unk_voxels), classes)[0] if unk_voxels is not None else None
+        msk = merge_lesion_channels(_u8(chosen_segment_mask), classes)[0] if chosen_segment_mask is not None else None
+        cw = None
+        if class_weights is not None:
+            cw = merge_lesion_channels(class_weights.reshape(class_weights.shape[0], -1).float(), classes)[0]
+        a_rep = copy.copy(args)
+        a_rep.seg_loss = 0.0
+        rep = calculate_loss({'segmentation': heads if deep else heads[0]}, lab, unk, a_rep, matcher, msk, tumor_volumes_report,
+                             tumor_diameters, names, input_tensor, cw)
+        for k, v in rep.items():
+            if k not in ('segmentation', 'overall'):
+                loss[k] = v
+    else:
+        loss['report'] = seg['report']
+    overall = 0
+    for k in list(loss.keys()):
+        overall = overall + loss[k]
+    loss['overall'] = overall
+    return loss
+
+
+def _delesioned(classes):
+    """Class names for the segmentation-only pass: the lesion sub-channels keep their positions but lose the suffixes the
+    grouping keys on, so no report term (there is none in that pass) and no merge is attempted."""
+    out = []
+    for c in classes:
+        for suffix in ['lesion', 'cyst', 'pdac', 'pnet']:
+            c = c.replace(suffix, 'x')
+        out.append(c)
+    return out
+
+
 def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segment_mask,
                    tumor_volumes_report, tumor_diameters, classes, input_tensor=None, class_weights=None,
                    model_genesis=False, clip_only=False, report_embeddings=None, dist=None):
@@ -362,6 +436,9 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         raise NotImplementedError('model_genesis / clip_only / classification_branch / multi_ch_tumor are baselines outside '
                                   'the accelerated R-Super path (SURVEY.md section 2.1)')
     _l.require_device()
+    if any(len(v) > 1 for v in lesion_channel_lists(classes).values()):
+        return _calculate_loss_merged(model_output, label, unk_voxels, args, matcher, chosen_segment_mask, tumor_volumes_report,
+                                      tumor_diameters, classes, input_tensor, class_weights)
     result = model_output['segmentation']
     deep = isinstance(result, (tuple, list))
     heads = list(result) if deep else [result]

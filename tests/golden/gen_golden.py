@@ -163,11 +163,15 @@ def main():
     # ------------------------------------------------------------------ B. blocks
     blk = {}
     import torch.nn as nn
-    for tag, (ci, co, S) in {'b8_16': (8, 16, 12), 'b16_16': (16, 16, 10), 'b24_8': (24, 8, 12)}.items():
-        m = cl.BasicBlock(ci, co, kernel_size=[3, 3, 3], norm=nn.InstanceNorm3d)
-        load_sd(m, seed=hash(tag) % 1000 if False else {'b8_16': 1, 'b16_16': 2, 'b24_8': 3}[tag])
+    # *_s2: stride-(2,2,2) first block of down_block(pool=False) (unet_utils.py:38-39); b16_16_s2 on an odd size (9 -> 5)
+    for tag, (ci, co, S) in {'b8_16': (8, 16, 12), 'b16_16': (16, 16, 10), 'b24_8': (24, 8, 12), 'b8_16_s2': (8, 16, 12), 'b16_16_s2': (16, 16, 9)}.items():
+        st = 2 if tag.endswith('_s2') else 1
+        m = cl.BasicBlock(ci, co, kernel_size=[3, 3, 3], norm=nn.InstanceNorm3d, stride=st) if st == 2 else \
+            cl.BasicBlock(ci, co, kernel_size=[3, 3, 3], norm=nn.InstanceNorm3d)
+        load_sd(m, seed={'b8_16': 1, 'b16_16': 2, 'b24_8': 3, 'b8_16_s2': 4, 'b16_16_s2': 5}[tag])
+        So = (S + 1) // 2 if st == 2 else S
         x = synth.rng(40 + ci).standard_normal((2, ci, S, S, S)).astype(np.float32)
-        go = synth.rng(50 + co).standard_normal((2, co, S, S, S)).astype(np.float32)
+        go = synth.rng(50 + co).standard_normal((2, co, So, So, So)).astype(np.float32)
         xt = t(x).requires_grad_(True)
         y = m(xt)
         y.backward(t(go))
@@ -210,6 +214,15 @@ def main():
         gnp = v.grad.numpy()
         un[f'g_{k}_head'] = gnp.reshape(-1)[:64].copy()
         un[f'g_{k}_summary'] = synth.summary(gnp)
+    # the same network with strided down-sampling instead of MaxPool (UNet(..., pool=False), unet.py:36-39)
+    net2 = unet_mod.UNet(1, 8, num_classes=len(classes), scale=[2, 2, 2, 2], kernel_size=[3, 3, 3, 3, 3], block='BasicBlock', norm='in', pool=False)
+    load_sd(net2, seed=3)
+    y2 = net2(t(img))
+    y2.backward(t(go))
+    un['nopool_logits_sub'], _ = synth.subsample(y2.detach().numpy(), 8192)
+    un['nopool_logits_summary'] = synth.summary(y2.detach().numpy())
+    for k, v in net2.named_parameters():
+        un[f'nopool_g_{k}_summary'] = synth.summary(v.grad.numpy())
     np.savez_compressed(os.path.join(HERE, 'unet_tiny.npz'), **un)
     print('unet_tiny.npz', len(un))
 
@@ -222,7 +235,7 @@ def main():
     lg1 = synth.logits(B, C, S, seed=100)
     cwts = synth.rng(5).uniform(0.5, 2.0, (B, C)).astype(np.float32)
 
-    def run(tag, args, deep, with_report=True, class_weights=None, batch=bt):
+    def run(tag, args, deep, with_report=True, class_weights=None, batch=bt, classes=classes, lg0=lg0, lg1=lg1):
         a = t(lg0).requires_grad_(True)
         b = t(lg1).requires_grad_(True)
         mo = {'segmentation': [a, b] if deep else a}
@@ -255,6 +268,13 @@ def main():
     run('single_both_cw', make_args(loss='ball_dice_both'), deep=False, class_weights=cwts)
     bt2 = synth.batch(B, S, classes, ['healthy', 'mask'], seed=8)
     run('single_both_norpt', make_args(loss='ball_dice_both'), deep=False, batch=bt2)
+    # lesion group spanning two channels: get_lesion_channels max-merge (training/losses_foundation.py:218-219)
+    mcls = synth.MULTI_CH_CLASSES
+    btm = synth.multi_ch_batch(B, S, ['mask', 'report'], seed=7, diam_range=(5.0, 9.0), max_tumors=2)
+    run('multi_ch_both', make_args(loss='ball_dice_both'), deep=False, batch=btm, classes=mcls,
+        lg0=synth.logits(B, len(mcls), S, seed=199), lg1=synth.logits(B, len(mcls), S, seed=200))
+    run('multi_ch_deep_last', make_args(loss='ball_dice_last'), deep=True, batch=btm, classes=mcls,
+        lg0=synth.logits(B, len(mcls), S, seed=199), lg1=synth.logits(B, len(mcls), S, seed=200))
     cl_out['cw'] = cwts
     np.savez_compressed(os.path.join(HERE, 'calc_loss.npz'), **cl_out)
     print('calc_loss.npz', len(cl_out))

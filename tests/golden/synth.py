@@ -24,6 +24,16 @@ PANTS_CLASSES = [
     'veins']
 
 
+# dataset_conversion/label_names_mask_dataset.yaml (42 entries, alphabetical): BASELINE.json configs[4] (--classes_number 42)
+MASK42_CLASSES = [
+    'adrenal_gland_left', 'adrenal_gland_right', 'aorta', 'bladder', 'celiac_trunk', 'colon', 'common_bile_duct', 'duodenum',
+    'esophagus', 'femur_left', 'femur_right', 'gall_bladder', 'hepatic_vessel', 'intestine', 'kidney_left', 'kidney_lesion',
+    'kidney_right', 'liver', 'liver_lesion', 'liver_segment_1', 'liver_segment_2', 'liver_segment_3', 'liver_segment_4',
+    'liver_segment_5', 'liver_segment_6', 'liver_segment_7', 'liver_segment_8', 'lung_left', 'lung_right', 'pancreas',
+    'pancreas_body', 'pancreas_head', 'pancreas_tail', 'pancreatic_lesion', 'portal_vein_and_splenic_vein', 'postcava',
+    'prostate', 'rectum', 'spleen', 'stomach', 'superior_mesenteric_artery', 'veins']
+
+
 def rng(seed):
     return np.random.Generator(np.random.PCG64(seed))
 
@@ -122,6 +132,29 @@ def batch(B, S, classes, kinds, seed=7, diam_range=(5.0, 12.0), max_tumors=2):
         else:
             raise ValueError(kind)
     return dict(label=label, unk_channels=unk, mask=mask, volumes=volumes, diameters=diameters)
+
+
+# two sub-channels of one organ's lesion: get_lesion_channels max-merges them into 'pancreas_lesion'
+# (training/losses_foundation.py:204-221)
+MULTI_CH_CLASSES = ['kidney_left', 'kidney_right', 'pancreas', 'pancreatic_lesion_1', 'pancreatic_lesion_2']
+
+
+def multi_ch_batch(B, S, kinds, seed=7, **kw):
+    """batch() for MULTI_CH_CLASSES with the annotations spread over both lesion sub-channels: per-voxel tumours of 'mask'
+    samples live in sub-channel 1, the unknown / report masks of 'report' samples are split between the two (lower half of
+    the volume in sub-channel 1, upper half in sub-channel 2), so only the max-merge sees the whole organ."""
+    bt = batch(B, S, MULTI_CH_CLASSES, kinds, seed=seed, **kw)
+    c1, c2 = 3, 4
+    for b, kind in enumerate(kinds):
+        if kind == 'mask':
+            bt['label'][b, c1] = bt['label'][b, c2]
+            bt['label'][b, c2] = 0
+        elif kind == 'report':
+            for key in ('unk_channels', 'mask'):
+                full = bt[key][b, c2].copy()
+                bt[key][b, c1, :S // 2] = full[:S // 2]
+                bt[key][b, c2, :S // 2] = 0
+    return bt
 
 
 def logits(B, C, S, seed=99, scale=2.0, smooth=True):

@@ -47,6 +47,27 @@ def main():
             assert torch.allclose(p.grad, a, atol=1e-6), (p.grad - a).abs().max()
             b, off = red._slot[p]
             assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * off, 'gradient does not live in its bucket'
+    # a second backward pass before finish() (gradient accumulation) is refused instead of corrupting the buckets
+    for p in net.parameters():
+        p.grad = None
+    x = torch.randn(2, 1, 6, 6, 6)
+    net(x).square().mean().backward()
+    try:
+        net(x).square().mean().backward()
+        raise SystemExit('second backward before finish() was not detected')
+    except RuntimeError:
+        pass
+    red.reset()
+    # the bucket that completes last (first-registered parameters) is split off and kept small
+    big = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4096), torch.nn.Linear(4096, 64))
+    red.remove()
+    red2 = GradReducer(big, bucket_mb=64, tail_mb=0.001)
+    assert len(red2.buckets) == 2 and red2.buckets[-1].flat.numel() <= 262 and red2.buckets[-1].params[-1] is big[0].weight
+    import copy
+    big._rsuper_reducer = red2
+    assert copy.deepcopy(big)._rsuper_reducer is None          # make_ema() after wrap_ddp must not clone buckets / hooks
+    red2.remove()
+    red = GradReducer(net, bucket_mb=0.0005)
     # a parameter without gradient must be reported (find_unused_parameters=False semantics)
     for p in net.parameters():
         p.grad = None

@@ -358,3 +358,21 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['scaling'] == 'weak'
     assert d['value'] > 0 and np.isfinite(d['config']['final_loss'])
+
+
+@pytest.mark.gpu
+def test_bench_self_spawns_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher environment (how the driver ran N = 1 in round 1): bench.py re-executes
+    itself under torch.distributed.run, one rank per GPU; on this single-GPU box the ranks share the device through gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['RSUPER_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--size', '64',
+                        '--roofline-steps', '1', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['roofline']['frac'] > 0

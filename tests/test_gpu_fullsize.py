@@ -190,3 +190,37 @@ def test_train_steps_fullsize_loss_decreases():
     # EMA after step >= 1 lies between the initial and the current weights: just check it moved and is finite
     p, e = next(net.parameters()), next(ema.parameters())
     assert bool(torch.isfinite(e).all()) and not torch.equal(p, e)
+
+
+def test_config5_mixed_batch_128_42_classes():
+    """BASELINE.json configs[4] on one GPU: B = 2, 128^3 patches, the 42-class label list, a 50/50 mask / report batch
+    (Merlin-style metadata), `--loss ball_dice_last`, report weight 0.1.  Size-independent properties:
+    every loss key finite, the loss goes down over a few optimiser steps, and the whole step (incl. the ball search on the
+    report sample) is run-to-run deterministic -- identical loss values from identical initial weights."""
+    from rsuper_amd.model.dim3.unet import UNet
+    from rsuper_amd.train_ddp import train_step, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    classes = synth.MASK42_CLASSES
+    assert len(classes) == 42
+    S5 = 128
+    bt = synth.batch(2, S5, classes, ['mask', 'report'], seed=11, diam_range=(5.0, 40.0), max_tumors=3)
+    batch = dict(image=torch.from_numpy(synth.image(2, S5, seed=99)).to(DEV), **{k: torch.from_numpy(v).to(DEV) for k, v in bt.items()})
+    args = _args(loss='ball_dice_last', report_volume_loss_basic=0.1)
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(0)
+        net = UNet(1, 32, num_classes=42, compute_dtype='bf16').to(DEV)
+        ema = make_ema(net)
+        opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        losses = []
+        for step in range(5 if rep == 0 else 2):
+            la, gn = train_step(net, ema, opt, batch, args, classes, step)
+            vals = {k: float(v.detach()) for k, v in la.items()}
+            assert all(math.isfinite(v) for v in vals.values()) and math.isfinite(float(gn)), vals
+            assert {'segmentation', 'ball_loss_bce', 'ball_loss_dice', 'overall'} <= set(vals), vals
+            losses.append(vals['overall'])
+        runs.append(losses)
+        del net, ema, opt
+        torch.cuda.empty_cache()
+    assert runs[0][-1] < runs[0][0], runs[0]
+    assert runs[1] == runs[0][:2], (runs[0][:2], runs[1])

@@ -94,8 +94,12 @@ def test_lesion_groups_and_ball_geometry(golden):
     for d in [1, 3, 5, 7, 8, 10, 15, 31, 40]:
         d_odd, ks = lf.ball_kernel_geometry(d)
         assert [ks, lf.ball_nnz(d_odd)] == list(p[f'ball_{d}_edge_nnz'])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):                 # the single-channel view refuses; calculate_loss merges first
         lf.lesion_groups(['kidney_lesion_1', 'kidney_lesion_2'])
+    assert lf.lesion_channel_lists(synth.MULTI_CH_CLASSES) == {'pancreas_lesion': [3, 4]}
+    t = torch.arange(2 * 5 * 2, dtype=torch.float32).reshape(2, 5, 2)
+    m, names = lf.merge_lesion_channels(t, synth.MULTI_CH_CLASSES)
+    assert names == ['pancreas_lesion'] and torch.equal(m[:, 0], torch.maximum(t[:, 3], t[:, 4]))
 
 
 def test_pick_bn():
@@ -105,6 +109,26 @@ def test_pick_bn():
     assert L.rsuper_conv3_variant(-1) == 3          # default: round-1 choice + weight-stationary kernel on single-chunk 32-column launches
     assert pick_bn(32, torch.bfloat16) == 32 and pick_bn(64, torch.bfloat16) == 64 and pick_bn(128, torch.bfloat16) == 128
     assert pick_bn(96, torch.bfloat16) == 32 and pick_bn(96, torch.float32) == 32 and pick_bn(320, torch.bfloat16) == 64 and pick_bn(128, torch.float32) == 64
+
+
+def test_fused_optimizer_resumes_from_torch_adamw_state():
+    """resume_load_optimizer_state (rsuper_train/utils.py:58-62) hands FusedAdamWEMA a torch.optim.AdamW state_dict, whose
+    `step` entries are per-parameter tensors: they are normalised to the shared int step count the fused kernel takes."""
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    ref = torch.optim.AdamW(ps, lr=6e-4, eps=1e-5, weight_decay=0.05)
+    for _ in range(3):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        ref.step()
+    sd = ref.state_dict()
+    assert torch.is_tensor(sd['state'][0]['step'])
+    opt = FusedAdamWEMA(ps, lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+    opt.load_state_dict(sd)
+    sts = [opt._state_for(p) for p in ps]
+    assert all(isinstance(st['step'], int) and st['step'] == 3 for st in sts)
+    assert all(torch.equal(st['exp_avg'], ref.state[p]['exp_avg']) for st, p in zip(sts, ps))
+    assert len({st['step'] for st in sts}) == 1
 
 
 def test_shard_indices_round_robin():

@@ -113,16 +113,19 @@ def test_isolate_tumor_border_growth(golden):
 
 
 # ------------------------------------------------------------------ network
-@pytest.mark.parametrize('tag,ci,co,S,seed', [('b8_16', 8, 16, 12, 1), ('b16_16', 16, 16, 10, 2), ('b24_8', 24, 8, 12, 3)])
+@pytest.mark.parametrize('tag,ci,co,S,seed', [('b8_16', 8, 16, 12, 1), ('b16_16', 16, 16, 10, 2), ('b24_8', 24, 8, 12, 3),
+                                              ('b8_16_s2', 8, 16, 12, 4), ('b16_16_s2', 16, 16, 9, 5)])     # *_s2: stride 2 (pool=False)
 def test_basic_block(golden, tag, ci, co, S, seed):
     g = golden['blocks']
+    stride = 2 if tag.endswith('_s2') else 1
     shapes = {'conv1.conv.weight': (co, ci, 3, 3, 3), 'conv2.conv.weight': (co, co, 3, 3, 3)}
-    if ci != co:
+    if ci != co or stride == 2:
         shapes['shortcut.conv.weight'] = (co, ci, 3, 3, 3)
     sd = {'blk.' + k: T(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes, seed).items()}
     x = T(synth.rng(40 + ci).standard_normal((2, ci, S, S, S)).astype(np.float32)).requires_grad_(True)
-    go = T(synth.rng(50 + co).standard_normal((2, co, S, S, S)).astype(np.float32))
-    y = uo.basic_block(x, sd, 'blk')
+    So = (S + 1) // 2 if stride == 2 else S
+    go = T(synth.rng(50 + co).standard_normal((2, co, So, So, So)).astype(np.float32))
+    y = uo.basic_block(x, sd, 'blk', stride=stride)
     y.backward(go)
     np.testing.assert_allclose(y.detach().numpy(), g[f'{tag}_y'], atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(x.grad.numpy(), g[f'{tag}_dx'], atol=1e-4, rtol=1e-3)
@@ -161,6 +164,22 @@ def test_unet_tiny(golden):
         np.testing.assert_allclose(gr.reshape(-1)[:64] / scale, g[f"g_{k}_head"] / scale, atol=1e-2, err_msg=k)
 
 
+def test_unet_tiny_strided_downsampling(golden):
+    """UNet(..., pool=False): stride-2 first block instead of MaxPool (unet_utils.py:38-39)."""
+    g = golden['unet_tiny']
+    shapes = uo.unet_param_shapes(1, 8, len(synth.TINY_CLASSES), pool=False)
+    sd = {k: T(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes, 3).items()}
+    y = uo.unet_forward(sd, T(synth.image(1, 48, seed=1234)), pool=False)
+    go = synth.rng(77).standard_normal(tuple(y.shape)).astype(np.float32) / y.numel()
+    y.backward(T(go))
+    sub, _ = synth.subsample(y.detach().numpy(), 8192)
+    np.testing.assert_allclose(sub, g['nopool_logits_sub'], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(synth.summary(y.detach().numpy()), g['nopool_logits_summary'], rtol=1e-4)
+    for k in shapes:
+        ref = g[f'nopool_g_{k}_summary']
+        np.testing.assert_allclose(synth.summary(sd[k].grad.numpy())[1], ref[1], rtol=2e-2, err_msg=k)     # sum of squares of the gradient
+
+
 # ------------------------------------------------------------------ calculate_loss
 CASES = [('single_last', dict(loss='ball_dice_last'), False, 7, None),
          ('single_both', dict(loss='ball_dice_both'), False, 7, None),
@@ -170,10 +189,16 @@ CASES = [('single_last', dict(loss='ball_dice_last'), False, 7, None),
          ('deep_last', dict(loss='ball_dice_last'), True, 7, None),
          ('deep_dice', dict(loss='dice'), True, 7, None),
          ('single_both_cw', dict(loss='ball_dice_both'), False, 7, 'cw'),
-         ('single_both_norpt', dict(loss='ball_dice_both'), False, 8, None)]
+         ('single_both_norpt', dict(loss='ball_dice_both'), False, 8, None),
+         ('multi_ch_both', dict(loss='ball_dice_both'), False, 'multi', None),       # lesion group over two channels (max-merge)
+         ('multi_ch_deep_last', dict(loss='ball_dice_last'), True, 'multi', None)]
 
 
 def calc_loss_inputs(seed):
+    if seed == 'multi':
+        classes = synth.MULTI_CH_CLASSES
+        bt = synth.multi_ch_batch(2, 32, ['mask', 'report'], seed=7, diam_range=(5.0, 9.0), max_tumors=2)
+        return classes, bt, synth.logits(2, len(classes), 32, seed=199), synth.logits(2, len(classes), 32, seed=200)
     classes = synth.TINY_CLASSES
     kinds = ['mask', 'report'] if seed == 7 else ['healthy', 'mask']
     kw = dict(diam_range=(5.0, 9.0), max_tumors=2) if seed == 7 else {}
