@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/r02_gpu_tests.txt
-timeout 300 python tools/in_sweep.py > gpurun_out/r02_in_sweep.md 2> gpurun_out/r02_in_sweep.err
-head -5 gpurun_out/r02_gpu_tests.txt; cat gpurun_out/r02_in_sweep.md; tail -3 gpurun_out/r02_in_sweep.err
+bash tools/pmc_step.sh
+bash tools/pmc_one.sh "0 fwd" "0 dgrad" "0 wgrad" "1 fwd" "1 dgrad" "1 wgrad" "3 fwd" "3 dgrad" "3 wgrad" "4 fwd" "4 wgrad" "5 fwd" "5 wgrad" "7 fwd"
+ls gpurun_out | grep -c pc_

@@ -70,7 +70,8 @@ def main():
                 print(f'| {a} | {b} |')
         # MFMA utilisation: busy cycles summed over all SIMDs / (SIMD count x kernel cycles); kernel cycles from GRBM_GUI_ACTIVE if present
         if 'GRBM_GUI_ACTIVE' in e:
-            print(f'| MFMA busy = MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE) | {100 * mf / (1024 * g("GRBM_GUI_ACTIVE")):.1f} % |')
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs: kernel cycles = GRBM_GUI_ACTIVE / 8
+            print(f'| MFMA busy = MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) | {100 * mf * 8 / (1024 * g("GRBM_GUI_ACTIVE")):.1f} % |')
         print()
 
 
