@@ -14,15 +14,23 @@
 // reduce kernel sums the slabs into the f32 dW (deterministic; f32 atomics measured ~14 G/s were the bottleneck).
 #include "common.hpp"
 #include "kernels.hpp"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
 constexpr int TD = 4, TH = 4, TW = 16;
 constexpr int WG_BD = 3;                                         // B-fragment prefetch distance (MFMA units), classic kernel (>= 2 waves / SIMD)
+#ifndef WG_LS
+#define WG_LS 5
+#endif
 constexpr int WG_PC_BD = 7;                                      // producer/consumer kernel: one MFMA wave per SIMD, latency covered by distance
 constexpr int HH = TH + 2, HW = TW + 2;
 
 typedef short v4s_t __attribute__((__vector_size__(4 * sizeof(short))));
+#ifdef RS_WG_PROF
+__device__ unsigned long long g_wg_prof[16 * 8];                 // block 0: [wave][wait+commit, barrier, issue, mfma, tiles]
+#endif
 
 template <typename T> struct WG;
 // bf16 rows are only read with ds_read_b64_tr_b16 ([4 rows] x [32 B] per 16-lane group, two groups side by side): the
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
     constexpr int XRS = NT / XV, YRS = NT / YV;                  // rows advanced per vector index
     static_assert(NT % XV == 0 && NT % YV == 0, "staging rows per vector index must be whole");
     uint4 px[NXV], py[NYV];
-    uint32_t xmask = 0;                                          // bit i: px[i] is inside the volume (gets norm+ReLU)
+    uint32_t xmask = 0, ymask = 0;                               // bit i: px[i] / py[i] is inside the volume (x: gets norm+ReLU; y: else zero)
     const int xs_slot = tid % XV, xs_row = tid / XV;             // per-thread constants: 16-byte slot and first row
     const int ys_slot = tid % YV, ys_row = tid / YV;
     const bool x_cok = c0 + xs_slot * KP < xs.C;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
     // Per-thread constants of the staging vectors: voxel delta of every vector relative to the tile's halo / tile
     // origin (the (hd, hh, hw) decomposition of its row never changes), so an interior tile costs one add per vector.
     int xdelta[NXV], ydelta[NYV];
-    uint32_t xrows_ok = 0, yrows_ok = 0;
+    uint32_t xpm[NXV], ypm[NYV];                                 // one-hot row positions; bit 31: the vector never holds data
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
         const int r = xs_row + i * XRS;
@@ -163,13 +171,13 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
         const int rem = r - hd * (HH * HW);
         const int hh = rem / HW, hw = rem - hh * HW;
         xdelta[i] = (hd * p.H + hh) * p.W + hw;
-        xrows_ok |= (r < XROWS && x_cok) ? (1u << i) : 0u;
+        xpm[i] = (r < XROWS && x_cok) ? ((1u << hd) | (1u << (6 + hh)) | (1u << (12 + hw))) : (1u << 31);
     }
 #pragma unroll
     for (int i = 0; i < NYV; ++i) {
         const int r = ys_row + i * YRS;
         ydelta[i] = ((r >> 6) * p.H + ((r >> 4) & 3)) * p.W + (r & 15);
-        yrows_ok |= (r < 256 && ysrc != nullptr) ? (1u << i) : 0u;
+        ypm[i] = (r < 256 && ysrc != nullptr) ? ((1u << (r >> 6)) | (1u << (4 + ((r >> 4) & 3))) | (1u << (8 + (r & 15)))) : (1u << 31);
     }
     const uint32_t nvox_total = (uint32_t)(p.N * p.D * p.H * p.W);
     const uint32_t xrowb = (uint32_t)xs.ld * (uint32_t)sizeof(T);
@@ -181,46 +189,45 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
         const auto q = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);     // out-of-range offsets return zeros
         return make_uint4(q[0], q[1], q[2], q[3]);
     };
-    auto issue = [&](int tile) {
+    // Staging loads of one tile, one 16-byte vector per call so that the MFMA loop can interleave them (a burst of all
+    // NXV + NYV loads stalls at the CU's ~10 B/clk request rate for ~7.7k cycles per tile -- longer than the MFMA phase --
+    // with the matrix pipes idle; tools: RS_WG_PROF).  `IssueTile` holds the wave-uniform part.
+    // Bounds are bit tests (no branches -- a branch per load makes the compiler wait for every load at once): xpm / ypm are the
+    // per-thread one-hot positions of a vector's row inside the halo / tile, the tile contributes the mask of INVALID positions.
+    struct IssueTile { int base, ybase; uint32_t xbad, ybad; };
+    auto prepare = [&](int tile) {
+        IssueTile t;
         int n, d0, h0, w0;
         tile_coords(tile, n, d0, h0, w0);
         const int dlo = d0 + (NTAPS == 27 ? -1 : kdg - 1);
-        const bool x_in = dlo >= 0 && dlo + HDN <= p.D && h0 >= 1 && h0 + TH + 1 <= p.H && w0 >= 1 && w0 + TW + 1 <= p.W;
-        const bool y_in = d0 + TD <= p.D && h0 + TH <= p.H && w0 + TW <= p.W;
-        if (x_in) {                                              // interior halo (wave-uniform): no per-vector bounds checks
-            const int base = ((n * p.D + dlo) * p.H + (h0 - 1)) * p.W + (w0 - 1);
-            xmask = xrows_ok;
+        auto range = [](int o, int len, int nh) {                // bits hd in [0, nh) with 0 <= o + hd < len
+            const int lo = o >= 0 ? 0 : -o;
+            int hi_ = len - 1 - o; if (hi_ > nh - 1) hi_ = nh - 1;
+            return hi_ < lo ? 0u : (((2u << hi_) - 1u) & ~((1u << lo) - 1u));
+        };
+        t.xbad = ~(range(dlo, p.D, HDN) | (range(h0 - 1, p.H, HH) << 6) | (range(w0 - 1, p.W, HW) << 12));
+        t.ybad = ~(range(d0, p.D, TD) | (range(h0, p.H, TH) << 4) | (range(w0, p.W, TW) << 8));
+        t.base = ((n * p.D + dlo) * p.H + (h0 - 1)) * p.W + (w0 - 1);
+        t.ybase = ((n * p.D + d0) * p.H + h0) * p.W + w0;
+        return t;
+    };
+    auto issue_x = [&](const IssueTile& t, int i) {
+        const bool ok = (xpm[i] & t.xbad) == 0u;
+        px[i] = ld16(ok ? (uint32_t)(t.base + xdelta[i]) * xrowb + xcol : 0xFFFFFFFFu);
+        xmask = (xmask & ~(1u << i)) | (ok ? (1u << i) : 0u);
+    };
+    auto issue_y = [&](const IssueTile& t, int i) {
+        const bool ok = (ypm[i] & t.ybad) == 0u;
+        const T* src = ok ? ysrc + (size_t)(uint32_t)(t.ybase + ydelta[i]) * (uint32_t)yld : (const T*)p.ya.x;   // address select, no branch
+        py[i] = *(const uint4*)src;                              // masked at commit time (a select here would wait for the load)
+        ymask = (ymask & ~(1u << i)) | (ok ? (1u << i) : 0u);
+    };
+    auto issue = [&](int tile) {
+        const IssueTile t = prepare(tile);
 #pragma unroll
-            for (int i = 0; i < NXV; ++i) px[i] = ld16(((xrows_ok >> i) & 1u) ? (uint32_t)(base + xdelta[i]) * xrowb + xcol : 0xFFFFFFFFu);
-        } else {
-            xmask = 0;
+        for (int i = 0; i < NXV; ++i) issue_x(t, i);
 #pragma unroll
-            for (int i = 0; i < NXV; ++i) {
-                const int r = xs_row + i * XRS;
-                const int hd = r / (HH * HW);
-                const int rem = r - hd * (HH * HW);
-                const int hh = rem / HW, hw = rem - hh * HW;
-                const int d = dlo + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
-                const bool ok = ((xrows_ok >> i) & 1u) && d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W;
-                const uint32_t vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
-                px[i] = ld16(ok ? vox * xrowb + xcol : 0xFFFFFFFFu);
-                xmask |= ok ? (1u << i) : 0u;
-            }
-        }
-        const int ybase = ((n * p.D + d0) * p.H + h0) * p.W + w0;
-        if (y_in) {
-#pragma unroll
-            for (int i = 0; i < NYV; ++i)
-                py[i] = ((yrows_ok >> i) & 1u) ? *(const uint4*)(ysrc + (size_t)(uint32_t)(ybase + ydelta[i]) * (uint32_t)yld) : make_uint4(0, 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NYV; ++i) {
-                const int r = ys_row + i * YRS;                  // voxel of the tile: (r/64, (r/16)%4, r%16)
-                const int d = d0 + (r >> 6), h = h0 + ((r >> 4) & 3), w = w0 + (r & 15);
-                const bool ok = ((yrows_ok >> i) & 1u) && d < p.D && h < p.H && w < p.W;
-                py[i] = ok ? *(const uint4*)(ysrc + (size_t)(uint32_t)(ybase + ydelta[i]) * (uint32_t)yld) : make_uint4(0, 0, 0, 0);
-            }
-        }
+        for (int i = 0; i < NYV; ++i) issue_y(t, i);
     };
     auto commit = [&]() {
 #pragma unroll
@@ -233,14 +240,23 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
         }
 #pragma unroll
         for (int i = 0; i < NYV; ++i)
-            if (ys_row + i * YRS < 256) *(uint4*)(y_lds + i * (YRS * YP)) = py[i];
+            if (ys_row + i * YRS < 256) *(uint4*)(y_lds + i * (YRS * YP)) = ((ymask >> i) & 1u) ? py[i] : make_uint4(0, 0, 0, 0);
     };
 
     int cur_n = -1;
     if ((int)blockIdx.z < tiles) issue(blockIdx.z);
+#ifdef RS_WG_PROF
+    unsigned long long pf[5] = {0, 0, 0, 0, 0};
+#endif
     for (int tile = blockIdx.z; tile < tiles; tile += p.splits) {
         const int n = tile / (tiles_w * tiles_h * tiles_d);
+#ifdef RS_WG_PROF
+        const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
         __syncthreads();                                         // previous tile consumed
+#ifdef RS_WG_PROF
+        const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
         if (norm && n != cur_n) {                                // per-sample statistics of this thread's KP channels
             cur_n = n;
 #pragma unroll
@@ -251,8 +267,20 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
             }
         }
         commit();
+#ifdef RS_WG_PROF
+        const unsigned long long q2 = __builtin_readcyclecounter();
+#endif
         __syncthreads();
-        if (tile + p.splits < tiles) issue(tile + p.splits);     // loads fly during the MFMA phase
+#ifdef RS_WG_PROF
+        const unsigned long long q3 = __builtin_readcyclecounter();
+#endif
+        const bool has_next = tile + p.splits < tiles;
+        if (sizeof(T) != 2 && has_next) issue(tile + p.splits);  // f32 parity mode: burst; bf16: interleaved with the MFMAs below
+        const IssueTile nt = prepare(has_next ? tile + p.splits : tile);   // last tile: harmless re-load of itself
+#ifdef RS_WG_PROF
+        const unsigned long long q4 = __builtin_readcyclecounter();
+        pf[0] += q1 - q0; pf[1] += q2 - q1; pf[2] += q3 - q2; pf[3] += q4 - q3; pf[4] += 1;
+#endif
         // ---- MFMA over the 16 (d,h) rows of the tile; k = 16 voxels along w.  Software pipelined with static
         //      indices: the operand fragments of unit (row, tap i)+1 are fetched from LDS while unit (row, i) issues.
         if constexpr (sizeof(T) == 2) {
@@ -274,6 +302,10 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
                 if (i == 0 && row + 1 < TD * TH) aq[(row + 1) & 1] = fetch_a(row + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma32<bf16_t>(acc[i], aq[row & 1], bq[u % BR]);    // invalid taps multiply by a zeroed accumulator slot (never stored)
+                // one staging load of the next tile every LS units, from the start of the phase (latency budget = the rest of it)
+                constexpr int LS = WG_LS < (NU - 8) / (NXV + NYV) ? WG_LS : ((NU - 8) / (NXV + NYV) > 0 ? (NU - 8) / (NXV + NYV) : 1);
+                if (u % LS == 0 && u / LS < NXV) issue_x(nt, u / LS);
+                if (u % LS == 0 && u / LS >= NXV && u / LS < NXV + NYV) issue_y(nt, u / LS - NXV);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -292,7 +324,18 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
                 }
             }
         }
+#ifdef RS_WG_PROF
+        pf[3] += 0; g_wg_prof[127] = 0;
+        { const unsigned long long q5 = __builtin_readcyclecounter(); if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_wg_prof[wave * 8 + 6] += q5 - q4; }
+#endif
     }
+#ifdef RS_WG_PROF
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+        for (int i = 0; i < 5; ++i) g_wg_prof[wave * 8 + i] = pf[i];
+        g_wg_prof[wave * 8 + 7] = g_wg_prof[wave * 8 + 6]; g_wg_prof[wave * 8 + 6] = 0;
+        g_wg_prof[wave * 8 + 5] = __builtin_readcyclecounter();
+    }
+#endif
     // ---- write this split's partial dW slab: ws[split][tap][m][cin]  (coalesced along cin)
     const int ci = c0 + (lane & 31);
     float* slab = p.ws + (size_t)blockIdx.z * 27 * Mtot * cin_total;
@@ -636,7 +679,20 @@ int launch(const WgradParams& p, hipStream_t st) {
     dim3 grid(nch, mgroups * (NTAPS == 27 ? 1 : 3), p.splits), block(64 * NW);
     auto k = wgrad_kernel<T, MT, NTAPS, TR, NW>;
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#ifdef RS_WG_PROF
+    static unsigned long long t_prev = 0;
+#endif
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
+#ifdef RS_WG_PROF
+    if (getenv("RSUPER_WG_PROF")) {
+        unsigned long long h[128];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wg_prof), sizeof(h));
+        for (int w = 0; w < NW; w += 3) fprintf(stderr, "wg_prof MT%d taps%d NW%d wave %d: tiles %llu | per tile: barrier1 %.0f commit(+wait loads) %.0f barrier2 %.0f issue %.0f mfma %.0f\n", MT, NTAPS, NW, w, h[w * 8 + 4],
+                                             (double)h[w * 8] / h[w * 8 + 4], (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4], (double)h[w * 8 + 3] / h[w * 8 + 4], (double)h[w * 8 + 7] / h[w * 8 + 4]);
+        (void)t_prev;
+    }
+#endif
     launch_reduce(p, st);
     return rs_check_launch();
 }
@@ -659,7 +715,7 @@ int launch_pc(const WgradParams& p, hipStream_t st) {
 }  // namespace
 
 // Configuration per launch (measured on MI355X, tools/bench_conv.py):
-//   0: M <= 32           -> 32 rows x 27 taps, 4 waves, one block per CU
+//   0: M <= 32           -> 32 rows x 27 taps, 8 waves (four taps per wave), one block per CU
 //   1: M > 32, few tiles -> 64 rows x 9 taps (kd split over blocks), 4 waves, two blocks per CU
 //   2: M > 32, >= 128 tiles (bf16) -> 64 rows x 27 taps, 8 waves, one block per CU: the x halo and the dY tile are staged
 //      once for all 27 taps (2.4x less operand traffic than config 1), seven taps per A fragment
@@ -685,6 +741,9 @@ int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st)
     if (dtype == RS_BF16) {
         // config 0 runs the producer/consumer kernel (177 -> 131 us on 32->32 @96^3); on configs 1/2 it measured equal or
         // slower (12 waves hit the 168-VGPR cap) and the classic kernel stays
+        static const int c0 = getenv("RSUPER_WGRAD_CFG0") ? atoi(getenv("RSUPER_WGRAD_CFG0")) : 2;   // 0: producer/consumer kernel, 1 / 2: classic kernel with 4 / 8 waves (155 vs 161 us on 32 -> 32 @96^3)
+        if (use_tr && cfg == 0 && c0 == 1) return launch<bf16_t, 1, 27, 1, 4>(p, st);
+        if (use_tr && cfg == 0 && c0 == 2) return launch<bf16_t, 1, 27, 1, 8>(p, st);
         if (use_tr) return cfg == 0 ? launch_pc<1, 27, 1, 4, true>(p, st) : cfg == 1 ? launch<bf16_t, 2, 9, 1, 4>(p, st) : launch<bf16_t, 2, 27, 1, 8>(p, st);
         return cfg == 0 ? launch_pc<1, 27, 0, 4, true>(p, st) : cfg == 1 ? launch<bf16_t, 2, 9, 0, 4>(p, st) : launch<bf16_t, 2, 27, 0, 8>(p, st);
     }

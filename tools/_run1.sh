@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-bash tools/pmc_step.sh
-bash tools/pmc_one.sh "0 fwd" "0 dgrad" "0 wgrad" "1 fwd" "1 dgrad" "1 wgrad" "3 fwd" "3 dgrad" "3 wgrad" "4 fwd" "4 wgrad" "5 fwd" "5 wgrad" "7 fwd"
-ls gpurun_out | grep -c pc_
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | head -2 > gpurun_out/r02_gpu_tests.txt
+timeout 900 python bench.py --no-cpu-baseline > gpurun_out/r02_bench_b.json 2> gpurun_out/r02_bench_b.err
+cat gpurun_out/r02_gpu_tests.txt; python -c "
+import json; d=json.loads(open('gpurun_out/r02_bench_b.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['frac'], d['roofline']['conv_ms_per_step'], {k:(round(v['avg_us'],1)) for k,v in d['roofline']['per_kernel'].items()}, d.get('secondary'))"
