@@ -106,7 +106,7 @@ int rsuper_conv3_tiles(int D, int H, int W) { return ((D + 3) / 4) * ((H + 3) / 
 
 static int g_variant = 3;
 int rsuper_conv3_variant(int v) {
-    if (v >= 0 && v <= 4) g_variant = v;
+    if (v >= 0 && v <= 5) g_variant = v;
     return g_variant;
 }
 // variant 2 (auto, default): producer/consumer kernel where it measured faster on MI355X -- data-gradient launches with
@@ -118,6 +118,7 @@ int rsuper_conv3_variant(int v) {
 static bool use_pc(int dtype, int epi, int bn, int tiles_total) {
     if (dtype != RS_BF16) return false;
     if (g_variant == 4) return bn == 32 || (bn <= 64 && (epi == 1 || tiles_total <= 1024));
+    if (g_variant == 5) return bn <= 64;
     if (g_variant == 2 || g_variant == 3) return bn <= 64 && (epi == 1 || bn == 32 || tiles_total <= 1024);
     return g_variant == 1;
 }
@@ -154,6 +155,7 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     p.ea = {exa, elda, eCa, emra};
     p.eb = {exb, eldb, eCb, emrb};
     p.pc = use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0;
+    if (p.pc && g_variant == 5) p.pc = 3;
     if (p.pc && bn == 32 && (g_variant == 4 || (g_variant == 3 && (Ca + 31) / 32 + (Cb + 31) / 32 == 1))) p.pc = 2;
     return rs_launch_igemm(p, dtype, epi, ST(stream));
 }

@@ -22,7 +22,7 @@ struct IgemmParams {
     void* out; int ldo;
     const void* res; int ldr;   // EPI 0: optional residual added before store
     float* part;           // per-block partial sums [N][rows][Cout][2] or nullptr (rows = rs_igemm_part_rows)
-    int pc;                // 1: producer/consumer persistent kernel (bf16); 2: weight-stationary persistent kernel (bf16, bn <= 64)
+    int pc;                // 1: producer/consumer persistent kernel (bf16); 2: weight-stationary kernel (bf16, bn 32); 3: producer/consumer v2 (bf16, bn <= 64)
     ConvSrc ea, eb;        // EPI 1: forward inputs (with mr) whose relu mask / x_n the data-gradient needs
 };
 
@@ -55,6 +55,8 @@ int rs_igemm_part_rows(int bn, int pc, int tiles, int n_cols, int N);
 // weight-stationary variant (conv3d_igemm_ws.hip): bf16, bn 32 / 64; same partial-row count as the producer/consumer kernel
 bool rs_igemm_ws_supported(const IgemmParams& p, int dtype, int epi);
 int rs_launch_igemm_ws(const IgemmParams& p, int epi, hipStream_t st);
+// second-generation producer/consumer kernel (conv3d_igemm_pc2.hip): bf16, bn 32 / 64, partial rows as igemm_pc_kernel
+int rs_launch_igemm_pc2(const IgemmParams& p, int epi, hipStream_t st);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st);

@@ -625,7 +625,7 @@ def all_checks(quick=False):
             (check_unet_tiny_nopool, (mode,)),
             (check_unet_tiny, (mode,)),
         ]
-    for variant in (0, 1, 4):           # every bf16 igemm kernel on every conv case (the default picks per launch)
+    for variant in (0, 1, 4, 5):        # every bf16 igemm kernel on every conv case (the default picks per launch)
         cs += [(with_variant, (variant, fn) + a) for fn, a in list(cs) if fn in (check_conv_fwd, check_conv_bwd) and a[0] == 'bf16']
     cs += [(with_variant, (1, check_conv_fwd, 'bf16', 2, (8, 24, 32), 32, 0, 32, False, True)),       # persistent: several tiles per block
            (with_variant, (1, check_conv_fwd, 'bf16', 1, (12, 20, 48), 64, 64, 128, True, False)),    # 128 columns, 4 chunks, 2 sources
@@ -636,7 +636,13 @@ def all_checks(quick=False):
            (with_variant, (4, check_conv_fwd, 'bf16', 2, (16, 32, 64), 64, 0, 64, False, True)),      # 64-column blocks with residual
            (with_variant, (4, check_conv_bwd, 'bf16', 2, (8, 24, 32), 64, 64, 64, True)),
            (with_variant, (4, check_conv_bwd, 'bf16', 1, (12, 20, 48), 128, 0, 128, False)),
-           (with_variant, (4, check_conv_bwd, 'bf16', 2, (16, 32, 64), 32, 64, 32, True))]            # 96-column data gradient (three 32-column tiles)
+           (with_variant, (4, check_conv_bwd, 'bf16', 2, (16, 32, 64), 32, 64, 32, True)),            # 96-column data gradient (three 32-column tiles)
+           (with_variant, (5, check_conv_fwd, 'bf16', 2, (8, 24, 32), 32, 0, 32, False, True)),       # producer/consumer v2: the same stress cases
+           (with_variant, (5, check_conv_fwd, 'bf16', 1, (12, 20, 48), 64, 64, 128, True, False)),
+           (with_variant, (5, check_conv_fwd, 'bf16', 2, (16, 32, 64), 64, 0, 64, False, True)),
+           (with_variant, (5, check_conv_bwd, 'bf16', 2, (8, 24, 32), 64, 64, 64, True)),
+           (with_variant, (5, check_conv_bwd, 'bf16', 1, (12, 20, 48), 128, 0, 128, False)),
+           (with_variant, (5, check_conv_bwd, 'bf16', 2, (16, 32, 64), 32, 64, 32, True))]
     cs += [(check_conv_bwd, ('bf16', 2, (16, 16, 64), 32, 32, 64, True)),      # >= 128 tiles, M = 128: 27-tap / 8-wave weight-gradient config
            (check_conv_bwd, ('bf16', 1, (16, 32, 64), 64, 0, 64, False))]
     cs += [(check_conv_bwd, ('bf16', 1, (4, 4, 16), 32, 0, 32, False, 0, 0)), (check_conv_bwd, ('bf16', 1, (8, 12, 20), 64, 32, 64, True, 0, 0)),

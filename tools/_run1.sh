@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_edge.py -x -q -m gpu 2>&1 | tail -4 > gpurun_out/r02_ws_tests.txt
-timeout 600 python tools/bench_conv.py bf16 2>&1 | grep -v amdgpu | cut -c1-60,118-160 > gpurun_out/r02_conv_table_w3.txt
-tail -3 gpurun_out/r02_ws_tests.txt; cat gpurun_out/r02_conv_table_w3.txt
+export RSUPER_IGEMM_VARIANT=5 RSUPER_PC2_PROF=1
+for L in "3 dgrad" "0 dgrad"; do echo "== $L"; timeout 300 python tools/prof_one.py $L 2>&1 | grep pc2_prof | tail -8 | sed -n '1p;5p'; done

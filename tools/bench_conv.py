@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 from rsuper_amd.hip import ops
 
 mode = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+if len(sys.argv) > 2:
+    ops._L().rsuper_conv3_variant(int(sys.argv[2]))      # force an igemm kernel variant
 dt = {'bf16': torch.bfloat16, 'f32': torch.float32}[mode]
 dev = 'cuda'
 N = 2
