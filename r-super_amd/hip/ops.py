@@ -518,7 +518,7 @@ class BasicBlockFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ pool / upsample
 def _stat_blocks(ovox):
-    return max(1, min(1024, ovox // 64))
+    return max(1, min(2048, ovox // 64))
 
 
 class MaxPoolFn(torch.autograd.Function):

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-export RSUPER_IGEMM_VARIANT=5 RSUPER_PC2_PROF=1
-for L in "3 dgrad" "0 dgrad"; do echo "== $L"; timeout 300 python tools/prof_one.py $L 2>&1 | grep pc2_prof | tail -8 | sed -n '1p;5p'; done
+timeout 300 python tools/in_sweep.py 2>/dev/null | grep -E "upsample|maxpool" | head -8
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -2
