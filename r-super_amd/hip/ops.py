@@ -221,8 +221,24 @@ _PENDING = []
 _CALLBACK_QUEUED = False
 
 
-def overlap_enabled():
-    return os.environ.get('RSUPER_WGRAD_OVERLAP', '0') == '1'
+def overlap_mode():
+    """RSUPER_WGRAD_OVERLAP: '0' never (default), '1' always, 'auto': only where a launch cannot fill the chip.
+    Same-box step times of round 2: 12.58 ms ('0'), 12.57 ms ('auto'), 12.72 ms ('1')."""
+    return os.environ.get('RSUPER_WGRAD_OVERLAP', '0')
+
+
+def overlap_enabled(voxels=None):
+    """Weight gradients on the side stream?  `auto`: for volumes of at most 24^3 voxels per sample -- there the
+    data-gradient and the weight-gradient launches each occupy a fraction of the 256 CUs (72-144 persistent blocks), so the
+    two chains run side by side instead of taking turns; at 48^3 / 96^3 every launch fills the chip and concurrency only
+    interleaves them.  voxels=None asks whether the side stream is in use at all (the gradient reducer orders its
+    collectives after it)."""
+    m = overlap_mode()
+    if m == '1':
+        return True
+    if m == 'auto':
+        return voxels is None or voxels <= 24 ** 3
+    return False
 
 
 def _join_per_block():
@@ -488,7 +504,7 @@ class BasicBlockFn(torch.autograd.Function):
         gm1 = stats_finalize(part, cnt, mode=1)
         # the join with the side stream is deferred to the end of backward: only safe when AccumulateGrad merely stores
         # the new gradient (p.grad is None, zero_grad(set_to_none=True)); an in-place `p.grad += dw` would race
-        ov = overlap_enabled() and all(w.grad is None for w in (w1, w2, ws) if w is not None)
+        ov = overlap_enabled(D * H * W) and all(w.grad is None for w in (w1, w2, ws) if w is not None)
         dw2 = grad_dest(w2)
         with _Side(ov, (ys, mr_y1, dout, dw2)):
             wgrad(y1, None, sdo, None, dw2, None, dims)
