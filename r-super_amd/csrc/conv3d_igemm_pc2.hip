@@ -132,7 +132,8 @@ __global__ __launch_bounds__(512, 1) void igemm_pc2_kernel(IgemmParams p) {
         const int st_off = (ptid >> 2) * PITCH + slot * 16;
         uint4 preA[NVEC], preB[NVEC];                                 // two items in flight
         uint32_t vmA = 0, vmB = 0;
-        auto issue = [&](int it, uint4* pre, uint32_t& vmask_pre) {
+        bool fastA = false, fastB = false;                            // item lies inside the volume: no padding to keep at zero
+        auto issue = [&](int it, uint4* pre, uint32_t& vmask_pre, bool& fast) {
             const bool valid = it < nitems;
             const int itc = valid ? it : 0;
             const int k = itc / nch, ch = itc - k * nch;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pc2_kernel(IgemmParams p) {
             const uint32_t tm = range(d0, p.D, HD) | (range(h0, p.H, HH) << 6) | (range(w0, p.W, HW) << 12);
             const uint32_t ntm = valid ? ~tm : 0xFFFFFFFFu;
             const int base = ((n * p.D + d0 - 1) * p.H + h0 - 1) * p.W + w0 - 1;
+            fast = valid && tm == 0x3FFFFFFFu && (src.C & 31) == 0;   // whole halo and every channel slot valid (wave-uniform)
             vmask_pre = 0;
 #pragma unroll
             for (int i = 0; i < NVEC; ++i) {
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pc2_kernel(IgemmParams p) {
                 vmask_pre |= ok ? (1u << i) : 0u;
             }
         };
-        auto commit = [&](int it, const uint4* pre, const uint32_t vmask_pre) {   // writes item `it` (held in pre) into buffer it & 1
+        auto commit = [&](int it, const uint4* pre, const uint32_t vmask_pre, const bool fast) {   // writes item `it` (held in pre) into buffer it & 1
             const int itc = it < nitems ? it : 0;
             const int ch = itc % nch;
             const bool isB = ch >= nchA;
@@ -175,6 +177,13 @@ __global__ __launch_bounds__(512, 1) void igemm_pc2_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < KP; ++j) { sc_[j] = norm ? mr[2 * j + 1] : 1.f; nb_[j] = norm ? -mr[2 * j] * mr[2 * j + 1] : 0.f; }
             char* lds_st = bufs + (it & 1) * HB + st_off;
+            if (norm && fast) {
+                // interior item: nothing to mask (rows past the halo hold normalised zeros in the pad rows nobody reads);
+                // the producers' VALU issue is the bottleneck of the forward path (one slot per co-resident MFMA)
+#pragma unroll
+                for (int i = 0; i < NVEC; ++i) *(uint4*)(lds_st + i * (64 * PITCH)) = norm_relu16<bf16_t>(pre[i], sc_, nb_);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NVEC; ++i) {
                 uint4 q = pre[i];
@@ -186,9 +195,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pc2_kernel(IgemmParams p) {
                 *(uint4*)(lds_st + i * (64 * PITCH)) = q;             // rows 648..703 of the padded buffer take the 11th vector's spill-over
             }
         };
-        issue(0, preA, vmA); commit(0, preA, vmA);
-        issue(1, preB, vmB);
-        issue(2, preA, vmA);
+        issue(0, preA, vmA, fastA); commit(0, preA, vmA, fastA);
+        issue(1, preB, vmB, fastB);
+        issue(2, preA, vmA, fastA);
         __syncthreads();                                              // item 0 visible
         int it = 0;
 #ifdef RS_PC2_PROF
@@ -200,22 +209,22 @@ __global__ __launch_bounds__(512, 1) void igemm_pc2_kernel(IgemmParams p) {
             __builtin_amdgcn_s_waitcnt(0xF7B);                        // vmcnt(11): the item about to be written has landed
             { const unsigned long long qw = __builtin_readcyclecounter(); if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) g_pc2_prof[wave * 8 + 4] += qw - q0; }
 #endif
-            commit(it + 1, preB, vmB);
+            commit(it + 1, preB, vmB, fastB);
             PC2_T(q1)
-            issue(it + 3, preB, vmB);
+            issue(it + 3, preB, vmB, fastB);
             PC2_T(q2)
             __syncthreads();
             PC2_T(q3)
-            commit(it + 2, preA, vmA);
+            commit(it + 2, preA, vmA, fastA);
             PC2_T(q4)
-            issue(it + 4, preA, vmA);
+            issue(it + 4, preA, vmA, fastA);
             PC2_T(q5)
             __syncthreads();
             PC2_T(q6)
             PC2_ACC(pf[0], q0, q1) PC2_ACC(pf[1], q1, q2) PC2_ACC(pf[2], q2, q3) PC2_ACC(pf[0], q3, q4) PC2_ACC(pf[1], q4, q5) PC2_ACC(pf[2], q5, q6)
         }
         if (it < nitems) {                                            // odd item count: one more barrier to match the consumers
-            commit(it + 1, preB, vmB);
+            commit(it + 1, preB, vmB, fastB);
             __syncthreads();
         }
 #ifdef RS_PC2_PROF

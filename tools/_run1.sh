@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for m in 0 auto 1; do echo "overlap=$m"; RSUPER_WGRAD_OVERLAP=$m timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 40 --warmup 8 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],3), round(d['roofline']['frac'],4), round(d['roofline']['conv_ms_per_step'],3))"; done
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|error" | tail -5 > gpurun_out/r02_ws_tests.txt
+timeout 600 python tools/bench_conv.py bf16 5 2>&1 | grep -v amdgpu | cut -c1-117 > gpurun_out/r02_conv_table_pc2.txt
+cat gpurun_out/r02_ws_tests.txt gpurun_out/r02_conv_table_pc2.txt
