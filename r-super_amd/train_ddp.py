@@ -6,9 +6,16 @@ with clip + AdamW + EMA fused into one HBM pass.  One process per GPU; gradients
 (`torch.distributed` backend 'nccl') by torch's DistributedDataParallel, whose bucketed all-reduce overlaps the
 backward kernels because every block's weight gradients are separate autograd leaves.
 """
+import argparse
 import copy
+import logging
 import os
+import random
+import sys
+import time
+from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -115,3 +122,247 @@ def wrap_ddp(net, local_rank, bucket_cap_mb=25):
 def shard_indices(chunk, rank, world_size):
     """Round-robin rank sharding of an epoch chunk (training/dataset/dim3/sampler.py:132)."""
     return chunk[rank::world_size]
+
+
+# ------------------------------------------------------------------------------------------------ epoch loop / driver
+class AverageMeter:
+    """utils.AverageMeter of the reference (rsuper_train/utils.py): running value / average of one logged quantity."""
+
+    def __init__(self, name, fmt=':f'):
+        self.name, self.fmt = name, fmt
+        self.val = self.avg = self.sum = 0.0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+    def __str__(self):
+        return ('{name} {val' + self.fmt + '} ({avg' + self.fmt + '})').format(**self.__dict__)
+
+
+class ProgressMeter:
+    def __init__(self, num_batches, meters, prefix=''):
+        n = len(str(num_batches // 1))
+        self.fmt = '[{:' + str(n) + 'd}/' + ('{:' + str(n) + 'd}').format(num_batches) + ']'
+        self.meters, self.prefix = meters, prefix
+
+    def display(self, batch):
+        logging.info('\t'.join([self.prefix + self.fmt.format(batch)] + [str(m) for m in self.meters]))
+
+
+def is_master(args):
+    return getattr(args, 'rank', 0) % max(getattr(args, 'ngpus_per_node', 1), 1) == 0 if getattr(args, 'distributed', False) else True
+
+
+def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, args, matcher=None):
+    """train_epoch (train_ddp.py:235-389): same signature and control flow -- batch dictionary keys (:247-262), host->device
+    copies, the input range asserts (:311-313), one `train_step` per batch (zero_grad -> forward -> calculate_loss ->
+    backward -> clip -> optimizer -> EMA), loss meters over every key calculate_loss returns, progress lines every
+    args.print_freq, the 3D epoch length check (`iter_num_per_epoch > args.iter_per_epoch`, :380-383: a loader with more
+    batches would run iter_per_epoch + 1 iterations; the ChunkedSampler of train_net serves exactly iter_per_epoch) and the
+    per-epoch TensorBoard scalars."""
+    if getattr(args, 'amp', False):
+        raise ValueError('MedFormer seems unstable with amp, please use float32 precision')        # train_ddp.py:316
+    net.train()
+    start = time.time()
+    loss_meters = OrderedDict()
+    progress = None
+    iter_num_per_epoch = 0
+    dev = next(net.parameters()).device
+    classes = trainLoader.dataset.classes
+    for i, inputs in enumerate(trainLoader):
+        batch = dict(image=inputs['image'], label=inputs['label'], unk_channels=inputs['unk_channels'],
+                     volumes=inputs['volumes'].float(), mask=inputs['mask'], diameters=inputs['diameters'].float())
+        if 'weights' in inputs:
+            batch['weights'] = inputs['weights'].float()
+        batch = {k: v.to(dev, non_blocking=True) for k, v in batch.items()}
+        img = batch['image']
+        step = i + epoch * len(trainLoader)                      # global steps (:306)
+        if lf.SANITY_CHECKS:
+            assert not torch.isnan(img).any(), 'Input is nan'
+            assert torch.max(img) <= 100, f'Input is bigger than 100: {torch.max(img)}'
+            assert torch.min(img) >= -100, f'Input is smaller than -100: {torch.min(img)}'
+        loss_all, _ = train_step(net, ema_net, optimizer, batch, args, classes, step, matcher=matcher)
+        if len(loss_meters) == 0:
+            loss_meters = OrderedDict((k, AverageMeter(k, ':6.4f')) for k in loss_all.keys())
+            loss_meters['Elapsed Time'] = AverageMeter('Elapsed Time', ':6.2f')
+        for k, v in loss_all.items():
+            loss_meters[k].update(v.item(), img.shape[0])
+        loss_meters['Elapsed Time'].update(time.time() - start, n=1)
+        if progress is None:
+            progress = ProgressMeter(len(trainLoader) if args.dimension == '2d' else args.iter_per_epoch, list(loss_meters.values()),
+                                     prefix=f"{getattr(args, 'unique_name', 'test')} epoch: [{epoch + 1}]")
+        if i % args.print_freq == 0:
+            progress.display(i)
+        if args.dimension == '3d':
+            iter_num_per_epoch += 1
+            if iter_num_per_epoch > args.iter_per_epoch:
+                break
+    if is_master(args) and writer is not None:
+        for key, meter in loss_meters.items():
+            writer.add_scalar(f'Train/{key}', meter.avg, epoch + 1)
+    return loss_meters
+
+
+def merge_config(args, config):
+    """The YAML merge of get_parser (train_ddp.py:491-502): a config key only fills an attribute the command line does not
+    define at all (`if not hasattr(args, key)`), so every argparse option -- set or defaulted -- wins over the file."""
+    for key, value in config.items():
+        if not hasattr(args, key):
+            setattr(args, key, value)
+    return args
+
+
+def get_parser(argv=None, config_root=None):
+    """The command line of train_ddp.py:392-548 restricted to the options the accelerated path reads (same names, types and
+    defaults), the YAML merge and the override rules that follow it (:504-546)."""
+    import yaml
+    parser = argparse.ArgumentParser(description='R-Super 3D segmentation training on MI355X (rsuper_amd)')
+    parser.add_argument('--dataset', type=str, default='abdomenatlas_ufo')
+    parser.add_argument('--reports', default=None)
+    parser.add_argument('--model', type=str, default='unet')
+    parser.add_argument('--dimension', type=str, default='3d')
+    parser.add_argument('--pretrain', action='store_true')
+    parser.add_argument('--amp', action='store_true')
+    parser.add_argument('--batch_size', default=2, type=int, help='GLOBAL batch size (divided by the GPUs of the node, :632)')
+    parser.add_argument('--resume', action='store_true')
+    parser.add_argument('--cp_path', type=str, default='./exp/')
+    parser.add_argument('--log_path', type=str, default='./log/')
+    parser.add_argument('--unique_name', type=str, default='test')
+    parser.add_argument('--workers', type=int, default=None)
+    parser.add_argument('--data_root', type=str, default=None)
+    parser.add_argument('--UFO_root', type=str, default=None)
+    parser.add_argument('--world_size', type=int, default=1)
+    parser.add_argument('--rank', type=int, default=0)
+    parser.add_argument('--dist_url', type=str, default='tcp://127.0.0.1:8001')
+    parser.add_argument('--dist_backend', type=str, default='nccl')
+    parser.add_argument('--report_volume_loss_basic', type=float, default=1)
+    parser.add_argument('--seg_loss', type=float, default=1)
+    parser.add_argument('--warmup', type=int, default=5)
+    parser.add_argument('--loss', type=str, default='ball_dice_last')
+    parser.add_argument('--classification_branch', action='store_true')
+    parser.add_argument('--multi_ch_tumor', action='store_true')
+    parser.add_argument('--model_genesis_pretrain', action='store_true')
+    parser.add_argument('--clip_pretrain', action='store_true')
+    parser.add_argument('--epochs', type=int, default=None)
+    parser.add_argument('--classes_number', type=int, default=None)
+    parser.add_argument('--ball_bce_weight', type=float, default=1)
+    parser.add_argument('--ball_dice_weight', type=float, default=1)
+    parser.add_argument('--stardard_ce_ball', action='store_true')
+    parser.add_argument('--lr', type=float, default=0.0006)
+    parser.add_argument('--ball_volume_margin', type=float, default=0.2)
+    parser.add_argument('--volume_loss_tolerance', type=float, default=0.2)
+    parser.add_argument('--crop_size', default=None, type=int)
+    parser.add_argument('--synthetic', type=int, default=0, help='rsuper_amd extension: train on N synthetic samples (no dataset on disk)')
+    args = parser.parse_args(argv)
+
+    reports, dr, epochs, ufo_root, w, lr, classes_number = args.reports, args.data_root, args.epochs, args.UFO_root, args.workers, args.lr, args.classes_number
+    root = config_root or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'config')
+    config_path = os.path.join(root, args.dataset, f'{args.model}_{args.dimension}.yaml')
+    if not os.path.exists(config_path):
+        raise ValueError("The specified configuration doesn't exist: %s" % config_path)
+    with open(config_path, 'r') as f:
+        config = yaml.load(f, Loader=yaml.SafeLoader)
+    merge_config(args, config)
+    # overrides after the merge (:513-529): options that exist on BOTH sides under different names, or that argparse always defines
+    if w is not None:
+        args.num_workers = w
+    if dr is not None:
+        args.data_root = dr
+    if epochs is not None:
+        args.epochs = epochs
+    if ufo_root is not None:
+        args.UFO_root = ufo_root
+    if classes_number is not None:
+        args.classes = classes_number
+    if lr is not None:
+        args.base_lr = lr
+    if reports is not None:
+        args.reports = reports
+    if args.crop_size is not None:
+        args.training_size = [args.crop_size] * 3
+    for k, v in dict(num_workers=0, start_epoch=0, aug_device='cpu', val_freq=10 ** 9).items():
+        if not hasattr(args, k):
+            setattr(args, k, v)
+    args.batch_size_global = args.batch_size
+    return args
+
+
+def train_net(net, trainset, testset, args, ema_net=None, fold_idx=0, writer=None):
+    """Training half of train_net (train_ddp.py:65-232): ChunkedSampler + DataLoader (:105-123), optimizer (:141), per epoch
+    the sampler reshuffle, the exponential warm-up / polynomial LR schedule (:170) and train_epoch, the `latest` checkpoint of
+    every epoch and the numbered one every 25 (:181-200).  Validation (:203-230) is outside the hot path."""
+    from torch.utils import data
+    from .training.dataset import ChunkedSampler
+    leng = len(trainset.img_list) if hasattr(trainset, 'img_list') else len(trainset)
+    distributed = getattr(args, 'distributed', False)
+    ngpus = getattr(args, 'ngpus_per_node', 1)
+    sampler = ChunkedSampler(dataset_size=leng, samples_per_epoch=args.iter_per_epoch * args.batch_size * ngpus, shuffle=True, seed=42,
+                             rank=dist.get_rank() if distributed else 0, world_size=dist.get_world_size() if distributed else 1)
+    loader = data.DataLoader(trainset, batch_size=args.batch_size, shuffle=False, sampler=sampler, pin_memory=(args.aug_device != 'gpu'),
+                             num_workers=args.num_workers, persistent_workers=(args.num_workers > 0))
+    optimizer = get_optimizer(args, net)
+    cp_dir = os.path.join(args.cp_path, args.dataset, args.unique_name)
+    if getattr(args, 'resume', False):
+        args.start_epoch = load_checkpoint(os.path.join(cp_dir, f'fold_{fold_idx}_latest.pth'), net, ema_net, optimizer)
+    if args.epochs is None:
+        raise ValueError('--epochs is required: argparse defines the attribute, so the YAML value never fills it (train_ddp.py:491-502)')
+    history = []
+    for epoch in range(args.start_epoch, args.epochs):
+        sampler.set_epoch(epoch)
+        lr = exp_lr_scheduler_with_warmup(optimizer, epoch=epoch, warmup_epoch=args.warmup, max_epoch=args.epochs)
+        logging.info(f'Starting epoch {epoch + 1}/{args.epochs}, lr {lr:.4e}')
+        meters = train_epoch(loader, net, ema_net, optimizer, epoch, writer, None, args, matcher=None)
+        history.append({k: m.avg for k, m in meters.items()})
+        if is_master(args):
+            os.makedirs(cp_dir, exist_ok=True)
+            save_checkpoint(os.path.join(cp_dir, f'fold_{fold_idx}_latest.pth'), epoch, net, ema_net, optimizer, args)
+            if (epoch + 1) % 25 == 0:
+                save_checkpoint(os.path.join(cp_dir, f'fold_{fold_idx}_epoch_{epoch + 1}.pth'), epoch, net, ema_net, optimizer, args)
+    return history
+
+
+def main_worker(proc_idx, ngpus_per_node, fold_idx, args, result_dict=None, trainset=None, testset=None):
+    """main_worker (train_ddp.py:593-691): per-process seeding (:595-604), one process per GPU with the global batch divided
+    by the GPUs of the node (:632), model + EMA construction (init_network :549-590), the data-parallel wrapper (:663) and
+    train_net.  Ranks come from the launcher environment (torchrun / bench.py) or from proc_idx under mp.spawn."""
+    from .model.utils import get_model
+    if getattr(args, 'reproduce_seed', None) is not None:
+        random.seed(args.reproduce_seed); np.random.seed(args.reproduce_seed); torch.manual_seed(args.reproduce_seed)
+    args.proc_idx, args.ngpus_per_node = proc_idx, ngpus_per_node
+    args.distributed = int(os.environ.get('WORLD_SIZE', getattr(args, 'world_size', 1))) > 1
+    if args.distributed:
+        os.environ.setdefault('RANK', str(args.rank * ngpus_per_node + proc_idx))
+        os.environ.setdefault('LOCAL_RANK', str(proc_idx))
+        os.environ.setdefault('WORLD_SIZE', str(args.world_size))
+        rank, local, world = init_distributed(args.dist_backend if torch.cuda.is_available() else 'gloo')
+        args.rank = rank
+        args.batch_size = int(args.batch_size / ngpus_per_node)
+        args.num_workers = int((args.num_workers + ngpus_per_node - 1) / ngpus_per_node)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(proc_idx % torch.cuda.device_count())
+    args.classes = len(trainset.classes)
+    net = get_model(args, pretrain=args.pretrain, classes=trainset.classes).to('cuda')
+    ema_net = make_ema(net) if args.ema else None
+    model = wrap_ddp(net, proc_idx) if args.distributed else net
+    return train_net(model, trainset, testset, args, ema_net, fold_idx=fold_idx)
+
+
+def main(argv=None):
+    args = get_parser(argv)
+    logging.basicConfig(level=logging.INFO, format='%(message)s')
+    if not args.synthetic:
+        raise SystemExit('rsuper_amd.train_ddp: pass --synthetic N for a smoke run; real crops are served by '
+                         'rsuper_amd.training.dataset.load_augmented (see INTEGRATION.md)')
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
+    from .training.dataset import SyntheticUFODataset
+    names = [f'organ_{i}' for i in range(args.classes - 2)] + ['pancreas', 'pancreatic_lesion']
+    trainset = SyntheticUFODataset(sorted(names), size=args.training_size[0], length=args.synthetic)
+    return main_worker(int(os.environ.get('LOCAL_RANK', 0)), max(torch.cuda.device_count(), 1), 0, args, trainset=trainset)
+
+
+if __name__ == '__main__':
+    main()

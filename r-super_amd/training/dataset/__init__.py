@@ -1,3 +1,4 @@
 """Host-side data formats of the training hot path: bit-packed label ingestion, epoch/rank sharding."""
 from .packed import pack_bits, unpack_bits_device, ingest_packed_batch  # noqa: F401
 from .sampler import ChunkedSampler  # noqa: F401
+from .synthetic import SyntheticUFODataset  # noqa: F401

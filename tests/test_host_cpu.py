@@ -131,6 +131,26 @@ def test_fused_optimizer_resumes_from_torch_adamw_state():
     assert len({st['step'] for st in sts}) == 1
 
 
+def test_parser_yaml_merge_fills_only_unset_attributes():
+    """get_parser (train_ddp.py:392-548): a YAML key only fills attributes argparse does not define (:491-502); the named
+    overrides follow (:513-529); `--batch_size` is the global batch (:632)."""
+    from rsuper_amd.train_ddp import get_parser, merge_config, AverageMeter
+    a = get_parser(['--lr', '0.001', '--classes_number', '42', '--batch_size', '4', '--epochs', '3', '--crop_size', '64'])
+    assert a.base_lr == 0.001 and a.classes == 42 and a.batch_size == 4 and a.batch_size_global == 4 and a.epochs == 3
+    assert a.training_size == [64, 64, 64]
+    assert a.block == 'BasicBlock' and a.iter_per_epoch == 1000 and a.optimizer == 'adamw' and a.ema is True     # YAML-only keys
+    assert a.loss == 'ball_dice_last' and a.report_volume_loss_basic == 1 and a.volume_loss_tolerance == 0.2       # CLI defaults
+    b = get_parser([])
+    assert b.epochs is None            # argparse defines --epochs (default None): the YAML's `epochs: 100` never fills it
+    assert b.base_lr == 0.0006         # --lr always has a value, so it always overrides base_lr
+    ns = argparse.Namespace(x=1)
+    merge_config(ns, {'x': 2, 'y': 3})
+    assert ns.x == 1 and ns.y == 3
+    m = AverageMeter('loss', ':6.4f')
+    m.update(2.0, 2); m.update(4.0, 2)
+    assert m.avg == 3.0 and m.val == 4.0 and 'loss' in str(m)
+
+
 def test_shard_indices_round_robin():
     from rsuper_amd.train_ddp import shard_indices
     chunk = list(range(10))
