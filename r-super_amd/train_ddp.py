@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 
 from .training import losses_foundation as lf
+from .training.dataset.packed import ingest_packed_batch
 from .training.utils import FusedAdamWEMA, ema_alpha_for_step, get_optimizer, exp_lr_scheduler_with_warmup, unwrap_model_checkpoint
 
 
@@ -173,12 +174,16 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
     iter_num_per_epoch = 0
     dev = next(net.parameters()).device
     classes = trainLoader.dataset.classes
+    packed = getattr(trainLoader.dataset, 'packed', False)
     for i, inputs in enumerate(trainLoader):
         batch = dict(image=inputs['image'], label=inputs['label'], unk_channels=inputs['unk_channels'],
                      volumes=inputs['volumes'].float(), mask=inputs['mask'], diameters=inputs['diameters'].float())
         if 'weights' in inputs:
             batch['weights'] = inputs['weights'].float()
-        batch = {k: v.to(dev, non_blocking=True) for k, v in batch.items()}
+        if packed:      # bit-packed label volumes cross PCIe as stored and are inflated on the device (dataset/packed.py)
+            batch = ingest_packed_batch(batch, len(classes), dev)
+        else:
+            batch = {k: v.to(dev, non_blocking=True) for k, v in batch.items()}
         img = batch['image']
         step = i + epoch * len(trainLoader)                      # global steps (:306)
         if lf.SANITY_CHECKS:
@@ -256,6 +261,8 @@ def get_parser(argv=None, config_root=None):
     parser.add_argument('--ball_volume_margin', type=float, default=0.2)
     parser.add_argument('--volume_loss_tolerance', type=float, default=0.2)
     parser.add_argument('--crop_size', default=None, type=int)
+    parser.add_argument('--load_augmented', action='store_true', help='Loads pre-saved crops for training (:414)')
+    parser.add_argument('--save_destination', type=str, default=None, help='directory of the pre-saved crops (:415)')
     parser.add_argument('--synthetic', type=int, default=0, help='rsuper_amd extension: train on N synthetic samples (no dataset on disk)')
     args = parser.parse_args(argv)
 
@@ -351,16 +358,32 @@ def main_worker(proc_idx, ngpus_per_node, fold_idx, args, result_dict=None, trai
     return train_net(model, trainset, testset, args, ema_net, fold_idx=fold_idx)
 
 
+def load_label_names(args, root_attr='data_root', required=True):
+    """Sorted class names from <root>/list/label_names.yaml (dataset_abdomenatlas_UFO.py:289-300)."""
+    import yaml
+    root = getattr(args, root_attr, None)
+    path = os.path.join(root, 'list', 'label_names.yaml') if root else None
+    if path is None or not os.path.exists(path):
+        if required:
+            raise ValueError('class names not found: %s/list/label_names.yaml' % root)
+        return None
+    with open(path) as f:
+        return sorted(yaml.load(f, Loader=yaml.SafeLoader))
+
+
 def main(argv=None):
     args = get_parser(argv)
     logging.basicConfig(level=logging.INFO, format='%(message)s')
-    if not args.synthetic:
-        raise SystemExit('rsuper_amd.train_ddp: pass --synthetic N for a smoke run; real crops are served by '
-                         'rsuper_amd.training.dataset.load_augmented (see INTEGRATION.md)')
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
-    from .training.dataset import SyntheticUFODataset
-    names = [f'organ_{i}' for i in range(args.classes - 2)] + ['pancreas', 'pancreatic_lesion']
-    trainset = SyntheticUFODataset(sorted(names), size=args.training_size[0], length=args.synthetic)
+    from .training.dataset import SyntheticUFODataset, AugmentedCropDataset
+    if args.synthetic:
+        names = [f'organ_{i}' for i in range(args.classes - 2)] + ['pancreas', 'pancreatic_lesion']
+        trainset = SyntheticUFODataset(sorted(names), size=args.training_size[0], length=args.synthetic)
+    elif args.load_augmented:
+        trainset = AugmentedCropDataset.from_directory(args.save_destination, load_label_names(args), packed=True,
+                                                       classes_ufo=load_label_names(args, 'UFO_root', required=False))
+    else:
+        raise SystemExit('rsuper_amd.train_ddp trains from pre-saved crops: pass --load_augmented --save_destination DIR '
+                         '(or --synthetic N for a smoke run); cropping raw volumes is offline preprocessing (INTEGRATION.md)')
     return main_worker(int(os.environ.get('LOCAL_RANK', 0)), max(torch.cuda.device_count(), 1), 0, args, trainset=trainset)
 
 

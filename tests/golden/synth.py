@@ -179,3 +179,69 @@ def subsample(a, n=4096):
 def summary(a):
     f = np.asarray(a, dtype=np.float64).reshape(-1)
     return np.array([f.sum(), (f * f).sum(), np.abs(f).max(), f.size], np.float64)
+
+
+# ---- crop directories for the loader tests (dataset_abdomenatlas_UFO.py:937-1118) --------------------------------------
+LOADER_SHAPE = (16, 20, 12)
+LOADER_REPORTS = {
+    # organ crop: rows are matched on 'Standardized Organ'
+    'BDMAP_00000002': dict(tumor_in_crop='pancreas', rows=[
+        dict(organ='pancreas', location='pancreas head', size='12'),
+        dict(organ='pancreas', location='u', size='10 x 20'),
+        dict(organ='kidney', location='kidney left', size='33'),
+        dict(organ='pancreas', location='pancreas tail', size='5.5 x 6 x 7.25'),
+        dict(organ='u', location='u', size='9'),
+        dict(organ=float('nan'), location=float('nan'), size='4')]),
+    # segment crop given as a list: rows are matched on 'Standardized Location', ' / ' lists must be fully inside
+    'BDMAP_00000003': dict(tumor_in_crop=['head', 'body'], rows=[
+        dict(organ='pancreas', location='head / body', size='8 x 4'),
+        dict(organ='pancreas', location='head / tail', size='30'),
+        dict(organ='pancreas', location='body', size='3.0'),
+        dict(organ='pancreas', location='u', size='50'),
+        dict(organ='pancreas', location=float('nan'), size='51')]),
+    # crop not taken on a tumour
+    'BDMAP_00000004': dict(tumor_in_crop='random', rows=[dict(organ='pancreas', location='pancreas head', size='12')]),
+    'BDMAP_00000005': dict(tumor_in_crop=None, rows=[dict(organ='liver', location='liver segment 2', size='7 x 9')]),
+    # organ crop given as a list; ' / ' lists in the organ column
+    'BDMAP_00000006': dict(tumor_in_crop=['kidney left', 'kidney right'], rows=[
+        dict(organ='kidney left', location='left', size='10'),
+        dict(organ='kidney right / kidney left', location='right', size='2 x 3 x 4'),
+        dict(organ='kidney', location='left', size='99')]),
+}
+LOADER_MASK_CASES = ['BDMAP_00000000', 'BDMAP_00000001']
+
+
+def loader_names():
+    return LOADER_MASK_CASES + sorted(LOADER_REPORTS)
+
+
+def loader_lists(root='/data/npy'):
+    """(img_list, lab_list, ufo_paths) with the reference's naming: <id>.npy / <id>_gt.npy; one entry is listed as .npz."""
+    names = loader_names()
+    img = ['%s/%s.npy' % (root, n) for n in names]
+    lab = ['%s/%s_gt.npy' % (root, n) for n in names]
+    img[1], lab[1] = img[1].replace('.npy', '.npz'), lab[1].replace('.npy', '.npz')
+    return img, lab, [p for p, n in zip(img, names) if n in LOADER_REPORTS]
+
+
+def loader_crop(i, classes):
+    """Deterministic content of crop i: image (1,D,H,W) f32, label / unk / mask (C,D,H,W) uint8 0/1."""
+    g = rng(4200 + i)
+    D, H, W = LOADER_SHAPE
+    C = len(classes)
+    img = np.clip(g.standard_normal((1, D, H, W)).astype(np.float32) * 1.5, -3, 3)
+    label = (g.random((C, D, H, W)) < 0.2).astype(np.uint8)
+    lesion = [c for c, n in enumerate(classes) if 'lesion' in n]
+    unk = np.zeros_like(label)
+    mask = np.zeros_like(label)
+    if loader_names()[i] in LOADER_REPORTS:
+        for c in lesion:
+            label[c] = 0
+            unk[c] = (g.random((D, H, W)) < 0.3)
+            mask[c] = (g.random((D, H, W)) < 0.25)
+    return img, label, unk, mask
+
+
+def loader_report_rows(name):
+    return [{'BDMAP_ID': name, 'Standardized Organ': r['organ'], 'Standardized Location': r['location'],
+             'Tumor Size (mm)': r['size']} for r in LOADER_REPORTS[name]['rows']]

@@ -418,3 +418,50 @@ def test_train_epoch_driver_runs_reference_loop(tmp_path):
     args2.base_chan, args2.iter_per_epoch, args2.print_freq, args2.compute_dtype = 8, 2, 1, 'f32'
     hist2 = main_worker(0, 1, 0, args2, trainset=ds)
     assert len(hist2) == 1 and args2.start_epoch == 2   # resumed after the two finished epochs
+
+
+@pytest.mark.gpu
+def test_augmented_loader_feeds_packed_ingest(tmp_path):
+    """Crop directory -> AugmentedCropDataset(packed=True) -> DataLoader -> ingest_packed_batch on the device gives exactly the
+    volumes the host-unpacking loader (reference behaviour, dataset_abdomenatlas_UFO.py:1028-1036,1083-1101) yields, and one epoch of
+    the driver runs from the directory through `main(['--load_augmented', ...])`'s dataset path."""
+    import os
+    import yaml
+    import synth
+    from rsuper_amd.training.dataset import AugmentedCropDataset, save_crop, ingest_packed_batch, SyntheticUFODataset
+    from rsuper_amd.train_ddp import get_parser, main_worker, load_label_names
+    classes = ['kidney_left', 'kidney_right', 'liver', 'pancreas', 'pancreatic_lesion']
+    src = SyntheticUFODataset(classes, size=32, length=6, seed=5)
+    crops, root = str(tmp_path / 'crops'), str(tmp_path / 'root')
+    os.makedirs(os.path.join(root, 'list'))
+    with open(os.path.join(root, 'list', 'label_names.yaml'), 'w') as f:
+        yaml.safe_dump(list(reversed(classes)), f)
+    for i in range(len(src)):
+        s = src[i]
+        name = 'BDMAP_%08d' % i
+        report = i % 2 == 1
+        rows = [{'Standardized Organ': 'pancreas', 'Standardized Location': 'pancreas head', 'Tumor Size (mm)': '%g' % d[0].item()}
+                for d in s['diameters'] if d[0] > 0]
+        save_crop(crops, name + '.npy', name + '_gt.npy', s['image'], s['label'],
+                  s['unk_channels'] if report else None, s['mask'] if report else None,
+                  {'tumor_in_crop': 'pancreas'} if report else None, rows if report else None)
+    args = get_parser(['--epochs', '1', '--batch_size', '2', '--cp_path', str(tmp_path) + '/', '--unique_name', 'aug',
+                       '--load_augmented', '--save_destination', crops, '--data_root', root, '--loss', 'ball_dice_both',
+                       '--report_volume_loss_basic', '0.1'])
+    assert load_label_names(args) == classes
+    host = AugmentedCropDataset.from_directory(crops, classes, packed=False, augment=False)
+    dev = AugmentedCropDataset.from_directory(crops, classes, packed=True, augment=False)
+    assert len(host) == 6 and len(host.ufo_paths) == 3
+    for bi, (hb, db) in enumerate(zip(torch.utils.data.DataLoader(host, batch_size=3), torch.utils.data.DataLoader(dev, batch_size=3))):
+        got = ingest_packed_batch(db, len(classes))
+        for k in ('label', 'unk_channels', 'mask'):
+            assert got[k].dtype == torch.uint8 and torch.equal(got[k].cpu(), hb[k].to(torch.uint8)), k
+        for k in ('image', 'volumes', 'diameters'):
+            assert torch.equal(got[k].cpu(), hb[k].float()), k
+        for j in range(3):                                               # odd crops carry report supervision
+            assert bool(got['volumes'][j].sum() > 0) == bool((3 * bi + j) % 2) == bool(got['mask'][j].any())
+    args.base_chan, args.iter_per_epoch, args.print_freq, args.compute_dtype = 8, 2, 1, 'f32'
+    np.random.seed(0); torch.manual_seed(0)
+    train = AugmentedCropDataset.from_directory(crops, classes, packed=True)
+    hist = main_worker(0, 1, 0, args, trainset=train)
+    assert len(hist) == 1 and all(np.isfinite(v) for v in hist[0].values()) and 'overall' in hist[0]
