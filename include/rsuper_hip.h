@@ -102,8 +102,10 @@ int rsuper_conv3_wgrad(int dtype, int use_tr,
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine=False) statistics and backward tail -- conv_layers.py:40-42
  * ------------------------------------------------------------------------------------------------ */
-/* part [N][nblk][C][2] -> out [N][C][2]: mode 0 (mean, rstd = 1/sqrt(var+eps)), mode 1 (sum0/cnt, sum1/cnt). */
-int rsuper_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, float* out, void* stream);
+/* part [N][nblk][C][2] -> out [N][C][2]: mode 0 (mean, rstd = 1/sqrt(var+eps)), mode 1 (sum0/cnt, sum1/cnt).
+ * split > 0 writes two contiguous tables instead, [N][split][2] followed by [N][C-split][2] (the column groups of a fused
+ * conv1 + shortcut GEMM, or the two sources of a concatenated input), so each can be handed to a kernel as-is. */
+int rsuper_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, int split, float* out, void* stream);
 /* dx = rstd * (g - gm0 - x_n * gm1) [+ add1] [+ add2] */
 int rsuper_in_bwd_finalize(int dtype, const void* g, int ldg, const void* x, int ldx, const float* mr, const float* gm,
                            const void* add1, int lda1, const void* add2, int lda2, void* out, int ldo,
@@ -146,11 +148,18 @@ int rsuper_head_bwd_weight(int dtype, const void* x, int ldx, const float* dlogi
  * Loss reductions -- training/losses_foundation.py:945-956 (masked BCE), :541-607 (DiceLossMultiClass),
  * :329/:367 (soft volume), :1743-1811 (ball loss BCE with GWRP / background weights).
  * sums[planes][6] f64 (pre-zeroed): S=sum bce*k, A=sum sig*k, B=sum sig*t*k, Cn=sum t*k, F1=sum bce*k*w1, F2=sum bce*k*(1-w2)
+ * flags: bit 0 (backward only) dx += instead of dx =; bit 1: `k` holds the dilated UNKNOWN mask and the voxel weight is
+ * 1 - k (get_known_voxels, :150-165) -- saves materialising `1 - dilate(unk)`.
  * ------------------------------------------------------------------------------------------------ */
 int rsuper_plane_partials_fwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
-                              double* sums, int planes, size_t V, void* stream);
+                              double* sums, int flags, int planes, size_t V, void* stream);
 int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
-                              const float* g, float* dx, int accumulate, int planes, size_t V, void* stream);
+                              const float* g, float* dx, int flags, int planes, size_t V, void* stream);
+/* Segmentation term from the sums of the (B*C) label planes: loss[0] = scale * ( sum(S*cw)/(B*C*V) + DiceLossMultiClass ),
+ * :945-956 with the adaptive-Tversky Dice of :541-607 (alpha_c = clamp(sum_b FP / (sum_b FP + sum_b FN + 1e-5), 0.2, 0.8),
+ * dice = TP / (TP + alpha FP + (1-alpha) FN + 1e-5), mean over (b, c) of (1 - dice) * cw).  sums f32 [B*C][6] as produced
+ * by rsuper_plane_partials_fwd (cast to f32); cw [B*C] or NULL; dsums [B*C][6] receives d loss / d sums. */
+int rsuper_seg_from_sums(const float* sums, const float* cw, int B, int C, size_t V, double scale, float* loss, float* dsums, void* stream);
 int rsuper_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, void* stream);
 
 /* Sliding-window inference -- inference/inference3d.py:28-107 (inference_sliding_window) and :8-25

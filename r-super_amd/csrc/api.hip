@@ -187,9 +187,9 @@ int rsuper_conv3_wgrad(int dtype, int use_tr, const void* xa, int lda, int Ca, c
     return rs_launch_wgrad(p, dtype, use_tr, ST(stream));
 }
 
-int rsuper_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, float* out, void* stream) {
-    if (!part || !out || N <= 0 || nblk <= 0 || C <= 0 || cnt <= 0) return RS_ERR_ARG;
-    return rs_launch_stats_finalize(part, N, nblk, C, cnt, eps, mode, out, ST(stream));
+int rsuper_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, int split, float* out, void* stream) {
+    if (!part || !out || N <= 0 || nblk <= 0 || C <= 0 || cnt <= 0 || split < 0 || split >= C || (mode != 0 && mode != 1)) return RS_ERR_ARG;
+    return rs_launch_stats_finalize(part, N, nblk, C, cnt, eps, mode, split, out, ST(stream));
 }
 
 int rsuper_in_bwd_finalize(int dtype, const void* g, int ldg, const void* x, int ldx, const float* mr, const float* gm,
@@ -272,16 +272,21 @@ int rsuper_head_bwd_weight(int dtype, const void* x, int ldx, const float* dlogi
 }
 
 int rsuper_plane_partials_fwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
-                              double* sums, int planes, size_t V, void* stream) {
-    if (!x || !sums || planes <= 0 || V == 0) return RS_ERR_ARG;
-    PlaneParams p = {x, xstride, t, k, w1, w2, sums, nullptr, nullptr, 0, V};
+                              double* sums, int flags, int planes, size_t V, void* stream) {
+    if (!x || !sums || planes <= 0 || V == 0 || (flags & ~2)) return RS_ERR_ARG;
+    PlaneParams p = {x, xstride, t, k, w1, w2, sums, nullptr, nullptr, 0, V, k ? (flags >> 1) & 1 : 0};
     return rs_launch_plane_partials(p, planes, 0, ST(stream));
 }
 int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
-                              const float* g, float* dx, int accumulate, int planes, size_t V, void* stream) {
-    if (!x || !g || !dx || planes <= 0 || V == 0) return RS_ERR_ARG;
-    PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, accumulate, V};
+                              const float* g, float* dx, int flags, int planes, size_t V, void* stream) {
+    if (!x || !g || !dx || planes <= 0 || V == 0 || (flags & ~3)) return RS_ERR_ARG;
+    PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, flags & 1, V, k ? (flags >> 1) & 1 : 0};
     return rs_launch_plane_partials(p, planes, 1, ST(stream));
+}
+int rsuper_seg_from_sums(const float* sums, const float* cw, int B, int C, size_t V, double scale, float* loss, float* dsums, void* stream) {
+    if (!sums || !loss || !dsums || B <= 0 || C <= 0 || V == 0) return RS_ERR_ARG;
+    SegSumsParams p = {sums, cw, B, C, 1.0 / ((double)B * C * (double)V), scale, loss, dsums};
+    return rs_launch_seg_from_sums(p, ST(stream));
 }
 int rsuper_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, void* stream) {
     if (!x || !out || V == 0) return RS_ERR_ARG;

@@ -19,6 +19,7 @@
 //   global --(16-B loads, norm+relu in registers)--> LDS halo tile [6][6][18] rows x 80-B pitch
 //   LDS --ds_read_b128--> A fragments;  packed weights (fragment order, L1/L2 resident) --> B fragments
 //   v_mfma_f32_32x32x16_bf16 (or 4x v_mfma_f32_32x32x2_f32 in the f32 parity mode), f32 accumulate.
+#include <cstring>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -781,58 +782,92 @@ int launch_dt(const IgemmParams& p, int epi, hipStream_t st) {
 //                    value = w[n][k][tap]                (weights are (Cout, Cin, 27) as in the state_dict)
 // mode 1 (dgrad):    GEMM-K = forward Cout, source A = wa's rows (ka), source B = wb's rows (kb),
 //                    GEMM-N = forward Cin (na);  value = w[k][n][26 - tap]   (flipped taps)
+// One block re-orders one (chunk, kstep, ntile) slab = 32 columns x KC/2 k-values x 27 taps.  In the state_dict layout that
+// slab is 32 (mode 0: one per column n) or KC/2 (mode 1: one per row k) contiguous runs of floats, so it is read with
+// unit-stride loads into LDS and written back as 27 fully coalesced 1 KB fragment rows (64 lanes x 16 B).  The earlier
+// gather-per-output-vector form read every float with a 108 B stride and cost 0.58 ms per step.
 template <typename T>
-__device__ __forceinline__ void pack_one(const PackParams& q, T* out, size_t idx);
-
-template <typename T>
-__global__ void pack_kernel(PackParams q, T* out) {
-    pack_one<T>(q, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
-}
-
-// all layers of a network in one launch: descriptor table in the kernel argument, vector index -> layer by binary search
-template <typename T>
-__global__ void pack_batch_kernel(PackBatch b, T* out) {
-    const unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= b.vec_start[b.n]) return;
+__global__ __launch_bounds__(256) void pack_tile_kernel(PackBatch b, T* out) {
+    constexpr int KC = Elem<T>::KC, KP = Elem<T>::KP, KH = KC / 2;
+    constexpr int RS0 = KH * 27 + 1, RS1 = 32 * 27 + 1;               // odd run strides: conflict-free column reads
+    extern __shared__ float sm[];
     int lo = 0, hi = b.n;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.vec_start[mid] <= v) lo = mid; else hi = mid; }
-    pack_one<T>(b.q[lo], out + b.vec_start[lo] * Elem<T>::KP, (size_t)(v - b.vec_start[lo]));
-}
-
-template <typename T>
-__device__ __forceinline__ void pack_one(const PackParams& q, T* out, size_t idx) {
-    constexpr int KC = Elem<T>::KC, KP = Elem<T>::KP;
-    const int nchA = (q.ka + KC - 1) / KC, nchB = (q.kb + KC - 1) / KC;
-    const size_t total = (size_t)(nchA + nchB) * 27 * 2 * q.ntiles * 64;
-    if (idx >= total) return;
-    const int lane = idx & 63;
-    size_t r = idx >> 6;
-    const int ntile = r % q.ntiles; r /= q.ntiles;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.blk_start[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const PackParams& q = b.q[lo];
+    unsigned r = blockIdx.x - b.blk_start[lo];
     const int ks = r & 1; r >>= 1;
-    const int tap = r % 27; r /= 27;
-    const int ch = (int)r;
+    const int ntile = r % q.ntiles, ch = r / q.ntiles;
+    const int nchA = (q.ka + KC - 1) / KC;
     const bool isB = ch >= nchA;
-    const int kloc = (isB ? ch - nchA : ch) * KC + ks * (KC / 2) + (lane >> 5) * KP;
+    const int kbase = (isB ? ch - nchA : ch) * KC + ks * KH;
     const int klim = isB ? q.kb : q.ka;
-    const int n = ntile * 32 + (lane & 31);
-    float f[KP];
+    const int n0 = ntile * 32;
+    const int tid = threadIdx.x;
+    // loads are issued in batches of UB before any of them is consumed: a slab is only 54 (bf16) / 27 (f32) floats per
+    // thread, so the kernel is pure latency unless many are in flight
+    constexpr int PER = 32 * KH * 27 / 256, UB = PER % 18 == 0 ? 18 : 9;
+    static_assert(PER % UB == 0, "slab size");
+    // Loads go through buffer descriptors: an invalid element gets an out-of-range offset and the hardware returns zero, so
+    // there is no branch around any load (a load inside a branch is waited for at the join, which would serialise the batch).
+    const int na = q.na, nb = q.nb;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)q.wa, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(q.wb ? q.wb : q.wa), 0, 0x7FFFFFFF, 0x00020000);
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    if (q.mode == 0) {
+        const int cin = q.ka + q.kb, kin0 = (isB ? q.ka : 0) + kbase;
+        const int len = min(max(klim - kbase, 0), KH) * 27;
+        const bool two = nb > 0 && n0 + 32 > na;                        // block-uniform: this tile has shortcut columns
+        for (int it = 0; it < PER; it += UB) {
+            uint32_t v[UB];
+            int at[UB];
 #pragma unroll
-    for (int j = 0; j < KP; ++j) {
-        const int k = kloc + j;
-        float v = 0.f;
-        if (k < klim && n < q.na + q.nb) {
-            if (q.mode == 0) {
-                const int kin = (isB ? q.ka : 0) + k;                    // forward input channel
-                const int cin = q.ka + q.kb;
-                v = n < q.na ? q.wa[((size_t)n * cin + kin) * 27 + tap] : q.wb[((size_t)(n - q.na) * cin + kin) * 27 + tap];
-            } else {
-                const float* w = isB ? q.wb : q.wa;                      // rows = forward couts of that conv
-                v = w[((size_t)k * q.na + n) * 27 + (26 - tap)];
+            for (int u = 0; u < UB; ++u) {
+                const int e = tid + (it + u) * 256;
+                const int nl = e / (KH * 27), o = e - nl * (KH * 27), n = n0 + nl;
+                at[u] = nl * RS0 + o;
+                const bool ok = o < len;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b32(ra, (ok && n < na) ? (uint32_t)((n * cin + kin0) * 27 + o) * 4u : OOB, 0, 0);
             }
+            if (two) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int e = tid + (it + u) * 256;
+                    const int nl = e / (KH * 27), o = e - nl * (KH * 27), n = n0 + nl;
+                    const bool ok = o < len && n >= na && n < na + nb;
+                    v[u] |= __builtin_amdgcn_raw_buffer_load_b32(rb, ok ? (uint32_t)(((n - na) * cin + kin0) * 27 + o) * 4u : OOB, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) sm[at[u]] = __builtin_bit_cast(float, v[u]);
         }
-        f[j] = v;
+    } else {
+        const __amdgpu_buffer_rsrc_t rw = isB ? rb : ra;
+        const int len = min(max(na - n0, 0), 32) * 27;
+        for (int it = 0; it < PER; it += UB) {
+            uint32_t v[UB];
+            int at[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int e = tid + (it + u) * 256;
+                const int kl = e / (32 * 27), o = e - kl * (32 * 27), k = kbase + kl;
+                at[u] = kl * RS1 + o;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b32(rw, (o < len && k < klim) ? (uint32_t)((k * na + n0) * 27 + o) * 4u : OOB, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) sm[at[u]] = __builtin_bit_cast(float, v[u]);
+        }
     }
-    *(uint4*)(out + idx * KP) = pack16<T>(f);
+    __syncthreads();
+    const int lane = tid & 63, nl = lane & 31, k0 = (lane >> 5) * KP;
+    T* dst = out + b.vec_start[lo] * KP;
+    for (int tap = tid >> 6; tap < 27; tap += 4) {
+        float f[KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+            f[j] = q.mode == 0 ? sm[nl * RS0 + (k0 + j) * 27 + tap] : sm[(k0 + j) * RS1 + nl * 27 + (26 - tap)];
+        const size_t idx = ((((size_t)ch * 27 + tap) * 2 + ks) * q.ntiles + ntile) * 64 + lane;
+        *(uint4*)(dst + idx * KP) = pack16<T>(f);
+    }
 }
 
 }  // namespace
@@ -866,19 +901,31 @@ size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles) {
     return nch * 27 * 2 * ntiles * 64 * KP;
 }
 
-int rs_launch_pack_batch(const PackBatch& b, int dtype, void* out, hipStream_t st) {
-    const unsigned long long vecs = b.vec_start[b.n];
-    if (!vecs) return RS_OK;
-    const unsigned blocks = (unsigned)((vecs + 255) / 256);
-    if (dtype == RS_F32) hipLaunchKernelGGL(pack_batch_kernel<float>, dim3(blocks), dim3(256), 0, st, b, (float*)out);
-    else hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, b, (bf16_t*)out);
+int rs_launch_pack_batch(PackBatch& b, int dtype, void* out, hipStream_t st) {
+    const int KC = dtype == RS_F32 ? 16 : 32;
+    unsigned blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+        b.blk_start[i] = blocks;
+        blocks += (unsigned)(((b.q[i].ka + KC - 1) / KC + (b.q[i].kb + KC - 1) / KC) * b.q[i].ntiles * 2);
+    }
+    b.blk_start[b.n] = blocks;
+    if (!blocks) return RS_OK;
+    const size_t smem = (size_t)(dtype == RS_F32 ? 8 : 16) * (32 * 27 + 1) * sizeof(float) + 32 * sizeof(float);
+    if (dtype == RS_F32) {
+        hipLaunchKernelGGL(pack_tile_kernel<float>, dim3(blocks), dim3(256), smem, st, b, (float*)out);
+    } else {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)pack_tile_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+        hipLaunchKernelGGL(pack_tile_kernel<bf16_t>, dim3(blocks), dim3(256), smem, st, b, (bf16_t*)out);
+    }
     return rs_check_launch();
 }
 
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st) {
-    const size_t vecs = rs_packed_elems(dtype, q.ka, q.kb, q.ntiles) / (dtype == RS_F32 ? 4 : 8);
-    const int blocks = (int)((vecs + 255) / 256);
-    if (dtype == RS_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, q, (float*)out);
-    else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, q, (bf16_t*)out);
-    return rs_check_launch();
+    PackBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = 1;
+    b.q[0] = q;
+    b.vec_start[1] = rs_packed_elems(dtype, q.ka, q.kb, q.ntiles) / (dtype == RS_F32 ? 4 : 8);
+    return rs_launch_pack_batch(b, dtype, out, st);
 }

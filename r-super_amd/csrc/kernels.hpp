@@ -48,8 +48,9 @@ struct PackBatch {
     int n;
     PackParams q[RS_PACK_BATCH_MAX];
     unsigned long long vec_start[RS_PACK_BATCH_MAX + 1];   // prefix sum of 16-byte vectors; entry i writes at out + vec_start[i]*16 B
+    unsigned blk_start[RS_PACK_BATCH_MAX + 1];             // prefix sum of blocks (filled by rs_launch_pack_batch)
 };
-int rs_launch_pack_batch(const PackBatch& b, int dtype, void* out, hipStream_t st);
+int rs_launch_pack_batch(PackBatch& b, int dtype, void* out, hipStream_t st);
 int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st);
 int rs_igemm_part_rows(int bn, int pc, int tiles, int n_cols, int N);
 // weight-stationary variant (conv3d_igemm_ws.hip): bf16, bn 32 / 64; same partial-row count as the producer/consumer kernel

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) 
                 if (w2) w2v[j] = w2[i + j];
                 if (w1) w1v[j] = w1[i + j];
             }
-            const float tt = tv[j] ? 1.f : 0.f, kk = kv[j] ? 1.f : 0.f;
+            const float tt = tv[j] ? 1.f : 0.f, kk = ((kv[j] != 0) != (p.kinv != 0)) ? 1.f : 0.f;
             float sg, b;
             sig_bce(xv[j], tt, sg, b);
             b *= kk;
@@ -95,19 +95,89 @@ __global__ __launch_bounds__(256) void plane_partials_bwd_kernel(PlaneParams p) 
     const float* w1 = p.w1 ? p.w1 + base : nullptr;
     const uint8_t* w2 = p.w2 ? p.w2 + base : nullptr;
     const float gS = p.g[plane * 6], gA = p.g[plane * 6 + 1], gB = p.g[plane * 6 + 2], gF1 = p.g[plane * 6 + 4], gF2 = p.g[plane * 6 + 5];
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)p.V; i += (size_t)gridDim.x * 256) {
-        const float xv = x[i];
-        const float tt = (t && t[i]) ? 1.f : 0.f;
-        const float kk = (!k || k[i]) ? 1.f : 0.f;
+    const bool kinv = p.kinv != 0;
+    auto one = [&](size_t i, float xv, bool tb, bool kb, float w1v, bool w2b, float old) {
+        const float tt = tb ? 1.f : 0.f;
         const float e = __expf(-fabsf(xv));
         const float r = __frcp_rn(1.f + e);
         const float sg = xv >= 0.f ? r : e * r;
-        float gb = gS;
-        if (w1) gb += gF1 * w1[i];
-        gb += gF2 * ((w2 && w2[i]) ? 0.f : 1.f);
-        const float v = kk * (gb * (sg - tt) + sg * (1.f - sg) * (gA + gB * tt));
-        dx[i] = p.accumulate ? dx[i] + v : v;
+        const float gb = gS + gF1 * w1v + gF2 * (w2b ? 0.f : 1.f);
+        const float v = kb ? (gb * (sg - tt) + sg * (1.f - sg) * (gA + gB * tt)) : 0.f;
+        return p.accumulate ? old + v : v;
+    };
+    if ((p.V & 3) == 0 && (p.xstride & 3) == 0) {                        // 16-byte aligned planes: four voxels per thread
+        for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < (size_t)p.V; i += (size_t)gridDim.x * 1024) {
+            const float4 xq = *(const float4*)(x + i);
+            uchar4 tq = {0, 0, 0, 0}, kq = {1, 1, 1, 1}, w2q = {0, 0, 0, 0};
+            float4 w1q = {0.f, 0.f, 0.f, 0.f}, oq = {0.f, 0.f, 0.f, 0.f};
+            if (t) tq = *(const uchar4*)(t + i);
+            if (k) kq = *(const uchar4*)(k + i);
+            if (w2) w2q = *(const uchar4*)(w2 + i);
+            if (w1) w1q = *(const float4*)(w1 + i);
+            if (p.accumulate) oq = *(const float4*)(dx + i);
+            float4 o;
+            o.x = one(i, xq.x, tq.x, k ? ((kq.x != 0) != kinv) : true, w1q.x, w2q.x, oq.x);
+            o.y = one(i, xq.y, tq.y, k ? ((kq.y != 0) != kinv) : true, w1q.y, w2q.y, oq.y);
+            o.z = one(i, xq.z, tq.z, k ? ((kq.z != 0) != kinv) : true, w1q.z, w2q.z, oq.z);
+            o.w = one(i, xq.w, tq.w, k ? ((kq.w != 0) != kinv) : true, w1q.w, w2q.w, oq.w);
+            *(float4*)(dx + i) = o;
+        }
+        return;
     }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)p.V; i += (size_t)gridDim.x * 256)
+        dx[i] = one(i, x[i], t && t[i], k ? ((k[i] != 0) != kinv) : true, w1 ? w1[i] : 0.f, w2 && w2[i], p.accumulate ? dx[i] : 0.f);
+}
+
+// One block.  Thread c owns class c: column sums over the batch give the adaptive Tversky alpha (clamped to [0.2, 0.8];
+// the clamp passes gradient inside the interval, like torch.clamp), then loss and Jacobian per (b, c).  f64 arithmetic on
+// the f32 sums: (B, C) is tiny and the ~60 ATen launches this replaces were pure launch latency.
+__global__ __launch_bounds__(256) void seg_from_sums_kernel(SegSumsParams p) {
+    const int B = p.B, C = p.C;
+    const double inv_n = 1.0 / ((double)B * C);
+    double acc = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double sFP = 0.0, sFN = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const float* s = p.sums + ((size_t)b * C + c) * 6;
+            sFP += (double)s[1] - (double)s[2];
+            sFN += (double)s[3] - (double)s[2];
+        }
+        const double den_a = sFP + sFN + 1e-5;
+        const double a_raw = sFP / den_a;
+        const double alpha = fmin(fmax(a_raw, 0.2), 0.8);
+        const bool pass = a_raw >= 0.2 && a_raw <= 0.8;
+        double g_alpha = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const float* s = p.sums + ((size_t)b * C + c) * 6;
+            const double w = p.cw ? (double)p.cw[(size_t)b * C + c] : 1.0;
+            const double TP = s[2], FP = (double)s[1] - TP, FN = (double)s[3] - TP;
+            const double den = TP + alpha * FP + (1.0 - alpha) * FN + 1e-5;
+            acc += (double)s[0] * w * p.inv_bcv + (1.0 - TP / den) * w * inv_n;
+            g_alpha += w * inv_n * TP * (FP - FN) / (den * den);           // d(1 - dice)/d alpha
+        }
+        const double ga_fp = pass ? g_alpha * (sFN + 1e-5) / (den_a * den_a) : 0.0;
+        const double ga_fn = pass ? -g_alpha * sFP / (den_a * den_a) : 0.0;
+        for (int b = 0; b < B; ++b) {
+            const size_t o = ((size_t)b * C + c) * 6;
+            const float* s = p.sums + o;
+            const double w = p.cw ? (double)p.cw[(size_t)b * C + c] : 1.0;
+            const double TP = s[2], FP = (double)s[1] - TP, FN = (double)s[3] - TP;
+            const double den = TP + alpha * FP + (1.0 - alpha) * FN + 1e-5;
+            const double k = w * inv_n / (den * den);
+            const double dTP = -k * (den - TP), dFP = k * TP * alpha + ga_fp, dFN = k * TP * (1.0 - alpha) + ga_fn;
+            p.dsums[o + 0] = (float)(p.scale * w * p.inv_bcv);
+            p.dsums[o + 1] = (float)(p.scale * dFP);                         // A  = FP + TP
+            p.dsums[o + 2] = (float)(p.scale * (dTP - dFP - dFN));           // Bs = TP
+            p.dsums[o + 3] = (float)(p.scale * dFN);                         // Cn = FN + TP
+            p.dsums[o + 4] = 0.f;
+            p.dsums[o + 5] = 0.f;
+        }
+    }
+    __shared__ double red[4];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.loss[0] = (float)(p.scale * (red[0] + red[1] + red[2] + red[3]));
 }
 
 // out[i] = sigmoid(x[i]) * (m ? m[i] : 1)      (x_iter of ball_loss, :1691-1694)
@@ -166,6 +236,11 @@ int rs_launch_plane_partials(const PlaneParams& p, int planes, int bwd, hipStrea
         if (b2 > 256) b2 = 256;
         hipLaunchKernelGGL(plane_partials_bwd_kernel, dim3(b2, planes), dim3(256), 0, st, p);
     }
+    return rs_check_launch();
+}
+
+int rs_launch_seg_from_sums(const SegSumsParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(seg_from_sums_kernel, dim3(1), dim3(256), 0, st, p);
     return rs_check_launch();
 }
 

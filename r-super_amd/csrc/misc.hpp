@@ -50,7 +50,7 @@ struct HeadParams {
     int N, vox, C, K;
 };
 
-int rs_launch_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, float* out, hipStream_t st);
+int rs_launch_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, int split, float* out, hipStream_t st);
 int rs_elem_blocks(size_t items);
 int rs_launch_in_bwd(const InBwdParams& p, int dtype, hipStream_t st);
 int rs_launch_pool(const PoolParams& p, int dtype, int bwd, int blocks, hipStream_t st);

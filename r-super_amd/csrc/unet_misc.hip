@@ -18,7 +18,7 @@ namespace {
 // part: [N][nblk][C][2] floats.  mode 0: out = (mean, rstd);  mode 1: out = (sum0/cnt, sum1/cnt).
 // 1024 threads = 32 channels x 32 row groups: every row read is 32 channels x 8 B contiguous, four independent loads
 // in flight per thread; f64 accumulation.
-__global__ __launch_bounds__(1024) void stats_finalize_kernel(const float* part, int nblk, int C, double cnt, float eps, int mode, float* out) {
+__global__ __launch_bounds__(1024) void stats_finalize_kernel(const float* part, int nblk, int C, double cnt, float eps, int mode, int split, float* out) {
     __shared__ double red[32][32][2];
     const int n = blockIdx.y;
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -42,7 +42,10 @@ __global__ __launch_bounds__(1024) void stats_finalize_kernel(const float* part,
     __syncthreads();
     if (g == 0 && c < C) {
         for (int k = 1; k < 32; ++k) { s0 += red[k][cl][0]; s1 += red[k][cl][1]; }
-        float* o = out + ((size_t)n * C + c) * 2;
+        // split > 0: two contiguous tables [N][split][2] | [N][C-split][2] (fused conv1+shortcut columns, concatenated sources)
+        float* o = split <= 0 ? out + ((size_t)n * C + c) * 2
+                   : c < split ? out + ((size_t)n * split + c) * 2
+                               : out + (size_t)gridDim.y * split * 2 + ((size_t)n * (C - split) + (c - split)) * 2;
         if (mode == 0) {
             const double mean = s0 / cnt;
             double var = s1 / cnt - mean * mean;
@@ -706,8 +709,8 @@ template <typename F> void set_smem(F k, size_t smem) {
 
 }  // namespace
 
-int rs_launch_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 31) / 32, N), dim3(1024), 0, st, part, nblk, C, cnt, eps, mode, out);
+int rs_launch_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, int split, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 31) / 32, N), dim3(1024), 0, st, part, nblk, C, cnt, eps, mode, split, out);
     return rs_check_launch();
 }
 

@@ -28,7 +28,7 @@ _SIGS = {
                                    P, c_int, P, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, P]),
     'rsuper_conv3_wgrad': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int,
                                    P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    'rsuper_stats_finalize': (c_int, [P, c_int, c_int, c_int, c_double, c_float, c_int, P, P]),
+    'rsuper_stats_finalize': (c_int, [P, c_int, c_int, c_int, c_double, c_float, c_int, c_int, P, P]),
     'rsuper_in_bwd_finalize': (c_int, [c_int, P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     'rsuper_maxpool2_fwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_maxpool2_bwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -41,7 +41,8 @@ _SIGS = {
     'rsuper_head_fwd': (c_int, [c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
     'rsuper_head_bwd_data': (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_head_bwd_weight': (c_int, [c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
-    'rsuper_plane_partials_fwd': (c_int, [P, c_size_t, P, P, P, P, P, c_int, c_size_t, P]),
+    'rsuper_plane_partials_fwd': (c_int, [P, c_size_t, P, P, P, P, P, c_int, c_int, c_size_t, P]),
+    'rsuper_seg_from_sums': (c_int, [P, P, c_int, c_int, c_size_t, c_double, P, P, P]),
     'rsuper_plane_partials_bwd': (c_int, [P, c_size_t, P, P, P, P, P, P, c_int, c_int, c_size_t, P]),
     'rsuper_sigmoid_mask': (c_int, [P, P, P, c_size_t, P]),
     'rsuper_window_accumulate': (c_int, [P, P] + [c_int] * 11 + [P]),

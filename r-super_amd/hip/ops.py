@@ -84,11 +84,14 @@ def part_buffer(dtype, dims, n_cols, bn, device, fill=None, epi=0):
     return torch.full((N, rows, n_cols, 2), fill, device=device, dtype=torch.float32)
 
 
-def stats_finalize(part, cnt, mode=0):
-    """part (N, nblk, C, 2) f32 -> (N, C, 2)."""
+def stats_finalize(part, cnt, mode=0, split=0):
+    """part (N, nblk, C, 2) f32 -> (N, C, 2); with 0 < split < C two contiguous tables (N, split, 2), (N, C - split, 2)."""
     N, nblk, C, _ = part.shape
     out = torch.empty((N, C, 2), device=part.device, dtype=torch.float32)
-    _l.check(_L().rsuper_stats_finalize(_ptr(part), N, nblk, C, float(cnt), EPS, mode, _ptr(out), _stream()), 'stats_finalize')
+    _l.check(_L().rsuper_stats_finalize(_ptr(part), N, nblk, C, float(cnt), EPS, mode, split, _ptr(out), _stream()), 'stats_finalize')
+    if split:
+        flat = out.view(-1)
+        return flat[:N * split * 2].view(N, split, 2), flat[N * split * 2:].view(N, C - split, 2)
     return out
 
 
@@ -387,8 +390,7 @@ class BasicBlockFn(torch.autograd.Function):
         ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
         part = part_buffer(dt, dims, nc1, bn1, dev)
         igemm(0, sa, sb, wp1, nc1, bn1, dims, ys, part=part)
-        mr_ys = stats_finalize(part, cnt)
-        mr_y1 = mr_ys[:, :Cout].contiguous() if has_sc else mr_ys
+        mr_y1 = stats_finalize(part, cnt, split=Cout)[0] if has_sc else stats_finalize(part, cnt)
         # conv2 + residual
         bn2, wp2 = packs[1][1], packs[0][1]
         out = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
@@ -516,7 +518,7 @@ class BasicBlockFn(torch.autograd.Function):
         g0 = torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
         part0 = part_buffer(dt, dims, Cin, bn, dev, epi=1)
         igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
-        gm0 = stats_finalize(part0, cnt, mode=1)
+        gm0 = stats_finalize(part0, cnt, mode=1, split=0 if xb is None else Ca)
         dw1 = grad_dest(w1)
         dws = grad_dest(ws) if has_sc else None
         with _Side(ov, (xa, mra, xb, mrb, dy1, dout, dw1, dws)):
@@ -525,8 +527,8 @@ class BasicBlockFn(torch.autograd.Function):
             dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca, add1=None if has_sc else dout)
             dxb = None
         else:
-            dxa = in_bwd_finalize(Src(g0, C=Ca), sa, gm0[:, :Ca].contiguous(), Ca)
-            dxb = in_bwd_finalize(Src(g0, C=Cb, off=Ca), sb, gm0[:, Ca:].contiguous(), Cb)
+            dxa = in_bwd_finalize(Src(g0, C=Ca), sa, gm0[0], Ca)
+            dxb = in_bwd_finalize(Src(g0, C=Cb, off=Ca), sb, gm0[1], Cb)
         if ov and _join_per_block():
             join_side()
         return dxa, None, dxb, None, dw1, dw2, dws, None, None

@@ -240,7 +240,7 @@ class AugmentedCropDataset(data.Dataset):
         if not os.path.exists(paths['csv']):
             return None
         import pandas as pd
-        return pd.read_csv(paths['csv'])
+        return pd.read_csv(paths['csv'], dtype=str)    # sizes such as '12' must stay text ('x' in size, float(size))
 
     def _check(self, lab, lab_packed, unk, seg):
         """`check_sample`, evaluated on the packed bytes when that is how the volumes are stored (channel 8p+j is bit 7-j

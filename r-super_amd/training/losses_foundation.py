@@ -96,10 +96,11 @@ def dice_based_volume_loss(x, y, tolerance=0.1, E=500, cross_entropy=False):
 # ------------------------------------------------------------------------------------------------ fused partial sums
 class _Term:
     """One family of planes of the logits tensor: plane p lives at element offset x_off + p * xstride."""
-    __slots__ = ('x_off', 'xstride', 'planes', 't', 'k', 'w1', 'w2')
+    __slots__ = ('x_off', 'xstride', 'planes', 't', 'k', 'w1', 'w2', 'kinv')
 
-    def __init__(self, x_off, xstride, planes, t=None, k=None, w1=None, w2=None):
+    def __init__(self, x_off, xstride, planes, t=None, k=None, w1=None, w2=None, kinv=False):
         self.x_off, self.xstride, self.planes, self.t, self.k, self.w1, self.w2 = x_off, xstride, planes, t, k, w1, w2
+        self.kinv = bool(kinv)       # k is the dilated UNKNOWN mask: voxel weight = 1 - k (no `1 - dilate(unk)` tensor)
 
 
 class _PartialsFn(torch.autograd.Function):
@@ -114,7 +115,7 @@ class _PartialsFn(torch.autograd.Function):
         for tm in terms:
             sums = torch.zeros((tm.planes, 6), device=logits.device, dtype=torch.float64)
             _l.check(_L().rsuper_plane_partials_fwd(_ptr(logits, tm.x_off), tm.xstride, _ptr(tm.t), _ptr(tm.k), _ptr(tm.w1), _ptr(tm.w2),
-                                                    _ptr(sums), tm.planes, V, _stream()), 'plane_partials_fwd')
+                                                    _ptr(sums), 2 if tm.kinv else 0, tm.planes, V, _stream()), 'plane_partials_fwd')
             outs.append(sums.to(torch.float32))
         ctx.terms = terms
         ctx.save_for_backward(logits)
@@ -134,9 +135,32 @@ class _PartialsFn(torch.autograd.Function):
                 continue
             g = g.contiguous().float()
             _l.check(_L().rsuper_plane_partials_bwd(_ptr(logits, tm.x_off), tm.xstride, _ptr(tm.t), _ptr(tm.k), _ptr(tm.w1), _ptr(tm.w2),
-                                                    _ptr(g), _ptr(dl, tm.x_off), 0 if i == 0 else 1, tm.planes, V, _stream()),
+                                                    _ptr(g), _ptr(dl, tm.x_off), (0 if i == 0 else 1) | (2 if tm.kinv else 0), tm.planes, V,
+                                                    _stream()),
                       'plane_partials_bwd')
         return dl, None
+
+
+class _SegFromSums(torch.autograd.Function):
+    """scale * (masked BCE mean + DiceLossMultiClass) from the (B*C, 6) sums of the label planes, one launch forward (which also
+    writes the Jacobian) -- replaces ~60 launch-bound ATen kernels of (B, C) algebra per step (csrc/loss.hip seg_from_sums_kernel)."""
+
+    @staticmethod
+    def forward(ctx, sums, cw, B, C, V, scale):
+        sums = sums.contiguous()
+        assert sums.dtype == torch.float32 and sums.shape == (B * C, 6)
+        if cw is not None:
+            cw = cw.contiguous().float()
+        loss = torch.empty((), device=sums.device, dtype=torch.float32)
+        d = torch.empty_like(sums)
+        _l.check(_L().rsuper_seg_from_sums(_ptr(sums), _ptr(cw), B, C, V, float(scale), _ptr(loss), _ptr(d), _stream()), 'seg_from_sums')
+        ctx.save_for_backward(d)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return d * g, None, None, None, None, None
 
 
 def _dice_from_sums(A, Bs, Cn, w=None):
@@ -410,9 +434,9 @@ def _calculate_loss_merged(model_output, label, unk_voxels, args, matcher, chose
                 loss[k] = v
     else:
         loss['report'] = seg['report']
-    overall = 0
+    overall = None
     for k in list(loss.keys()):
-        overall = overall + loss[k]
+        overall = loss[k] if overall is None else overall + loss[k]
     loss['overall'] = overall
     return loss
 
@@ -469,15 +493,15 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         cw = class_weights.to(label.device).float()
         assert cw.shape == (B, C), f'Class weights should be (B, C), got {tuple(cw.shape)}'
 
-    known = (1 - ops.dilate_volume(unk_u8, 5)) if unk_voxels is not None else None      # :899 / get_known_voxels :150
+    unk5 = ops.dilate_volume(unk_u8, 5) if unk_voxels is not None else None      # :899 / get_known_voxels :150; known = 1 - unk5
     groups = lesion_groups(classes)
     chs = list(groups.values())
     L = len(chs)
     rw = float(args.report_volume_loss_basic)
 
-    loss_seg_total = 0
+    loss_seg_total = None
     rep = {}
-    rep_scalar = 0
+    rep_scalar = None
     mseg31 = None
     for j, r in enumerate(heads):
         r = r.contiguous().float() if (not r.is_contiguous() or r.dtype != torch.float32) else r
@@ -488,7 +512,7 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
             if deep:
                 use_ball = use_ball and not (j != 0 and 'last' in args.loss)        # :924
             use_vol = (not use_ball) or ('both' in args.loss)
-        terms = [_Term(0, V, B * C, t=label_u8, k=known)]
+        terms = [_Term(0, V, B * C, t=label_u8, k=unk5, kinv=True)]
         if use_vol and L > 0:
             if mseg31 is None:
                 mseg31 = [ops.dilate_volume(mask_u8[:, c].contiguous(), 31) for c in chs]   # :308
@@ -508,11 +532,8 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         sums = _PartialsFn.apply(r, terms)
         ti = 0
         # ---- segmentation: masked BCE mean + adaptive-Tversky Dice (:945-956)
-        s = sums[ti].view(B, C, 6); ti += 1
-        S, A, Bs, Cn = s[..., 0], s[..., 1], s[..., 2], s[..., 3]
-        bce = ((S * cw) if cw is not None else S).sum() / float(B * C * V)
-        seg = bce + _dice_from_sums(A, Bs, Cn, cw)
-        loss_seg_total = loss_seg_total + aw * args.seg_loss * seg
+        seg = _SegFromSums.apply(sums[ti], cw, B, C, V, aw * args.seg_loss); ti += 1
+        loss_seg_total = seg if loss_seg_total is None else loss_seg_total + seg
         loss_r = {}
         # ---- volume loss (:250-349)
         if use_vol and L > 0:
@@ -552,8 +573,8 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
                                                       None if wc is None else wc.view(1, 1)))
             loss_r['ball_loss_bce'] = torch.stack(l_bce).mean()
             loss_r['ball_loss_dice'] = torch.stack(l_dice).mean() if apply_dice else torch.zeros_like(loss_r['ball_loss_bce'])
-        if not loss_r:
-            rep_scalar = rep_scalar + aw * rw * torch.zeros((), device=r.device)
+        if not loss_r and rep_scalar is None:
+            rep_scalar = torch.zeros((), device=r.device)                   # aw * rw * 0 for every head
         for k, v in loss_r.items():
             wk = {'ball_loss_bce': args.ball_bce_weight, 'ball_loss_dice': args.ball_dice_weight}.get(k, 1)
             term = aw * rw * wk * v
@@ -567,9 +588,9 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
                 loss[k] = rep[k]
     else:
         loss['report'] = rep_scalar
-    overall = 0
+    overall = None
     for k in list(loss.keys()):
-        overall = overall + loss[k]
+        overall = loss[k] if overall is None else overall + loss[k]
     loss['overall'] = overall
     if SANITY_CHECKS and bool(torch.isnan(overall).any()):                 # :1070-1071
         raise ValueError('loss is nan, propagating this can destroy the network weights, STOP!')

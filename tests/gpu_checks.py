@@ -406,7 +406,46 @@ def check_plane_partials():
     torch.cuda.synchronize()
     e1 = relerr(sums.detach().cpu(), ref.detach())
     e2 = relerr(xd.grad.cpu(), xr.grad)
-    return result('plane_partials', max(e1, e2), 2e-5, f'sums {e1:.2e} grad {e2:.2e}')
+    # the same term given the complementary ("unknown") mask with the inverted-k flag must give identical results
+    xi = x.to(DEV).requires_grad_(True)
+    (sums_i,) = lf._PartialsFn.apply(xi, [lf._Term(0, V, B * C, t=t.to(DEV), k=(1 - k).to(DEV), w1=w1.to(DEV), w2=w2.to(DEV), kinv=True)])
+    (sums_i * gs.to(DEV)).sum().backward()
+    e3 = max(relerr(sums_i.detach().cpu(), sums.detach().cpu()), relerr(xi.grad.cpu(), xd.grad.cpu()))
+    return result('plane_partials', max(e1, e2, e3), 2e-5, f'sums {e1:.2e} grad {e2:.2e} inverted-k {e3:.2e}')
+
+
+def check_seg_from_sums(B, C, weighted, seed):
+    """rsuper_seg_from_sums (loss + Jacobian) against the torch formulation of losses_foundation.py:945-956 / :541-607, including
+    classes whose alpha is clamped at 0.2 / 0.8 (no gradient through alpha there) and classes with TP = 0."""
+    from rsuper_amd.training import losses_foundation as lf
+    g = synth.rng(seed)
+    V = 1000
+    A = g.random((B, C)) * 400 + 1
+    Bs = A * g.random((B, C)) * 0.9
+    Cn = Bs + g.random((B, C)) * 300
+    A[:, 0] = Bs[:, 0] + 1e-3            # FP ~ 0  -> alpha clamps to 0.2
+    Cn[:, 1 % C] = Bs[:, 1 % C]          # FN = 0  -> alpha clamps to 0.8
+    if C > 2:
+        Bs[:, 2] = 0                     # empty prediction overlap
+    S = g.random((B, C)) * 500
+    sums = np.zeros((B * C, 6), np.float32)
+    sums[:, 0], sums[:, 1], sums[:, 2], sums[:, 3] = S.ravel(), A.ravel(), Bs.ravel(), Cn.ravel()
+    sums[:, 4:] = g.random((B * C, 2))
+    cw = (g.random((B, C)) + 0.5).astype(np.float32) if weighted else None
+    scale = 0.7
+    sr = T(sums).double().requires_grad_(True)
+    s4 = sr.view(B, C, 6)
+    cwt = None if cw is None else T(cw).double()
+    bce = ((s4[..., 0] * cwt) if cwt is not None else s4[..., 0]).sum() / float(B * C * V)
+    ref = scale * (bce + lf._dice_from_sums(s4[..., 1], s4[..., 2], s4[..., 3], cwt))
+    ref.backward()
+    sd = T(sums).to(DEV).requires_grad_(True)
+    got = lf._SegFromSums.apply(sd, None if cw is None else T(cw).to(DEV), B, C, V, scale)
+    (got * 1.5).backward()
+    torch.cuda.synchronize()
+    e1 = abs(got.item() - ref.item()) / max(abs(ref.item()), 1e-12)
+    e2 = relerr(sd.grad.cpu() / 1.5, sr.grad)
+    return result(f'seg_from_sums B{B} C{C} w{int(weighted)}', max(e1, e2), 2e-6, f'loss {e1:.2e} jac {e2:.2e}')
 
 
 def check_dilate():
@@ -647,7 +686,8 @@ def all_checks(quick=False):
            (check_conv_bwd, ('bf16', 1, (16, 32, 64), 64, 0, 64, False))]
     cs += [(check_conv_bwd, ('bf16', 1, (4, 4, 16), 32, 0, 32, False, 0, 0)), (check_conv_bwd, ('bf16', 1, (8, 12, 20), 64, 32, 64, True, 0, 0)),
            (check_tr16_probe, ()),
-           (check_plane_partials, ()), (check_dilate, ()), (check_isolate_tumor, ()), (check_gwrp, ()), (check_optimizer, ())]
+           (check_plane_partials, ()), (check_seg_from_sums, (2, 26, False, 1)), (check_seg_from_sums, (3, 5, True, 2)),
+           (check_seg_from_sums, (1, 300, True, 3)), (check_dilate, ()), (check_isolate_tumor, ()), (check_gwrp, ()), (check_optimizer, ())]
     cs += [(check_calculate_loss, c) for c in LOSS_CASES]
     cs += [(check_train_steps, ('f32',)), (check_train_steps, ('bf16',))]
     return cs
