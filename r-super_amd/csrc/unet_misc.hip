@@ -81,39 +81,63 @@ __device__ __forceinline__ void block_channel_sums(const float* s1, const float*
 }
 
 // ------------------------------------------------------------------------------------------------ IN backward tail
+// dx = rstd * (g - gm0 - x_n * gm1) [+ add1] [+ add2],  x_n = (x - mean) * rstd.
+// The launch makes the grid stride a multiple of the channel-vector count whenever 256 % (C / KP) == 0, so a thread keeps its
+// channel slot for the whole loop: the 4 x KP per-channel constants are loaded once (they were 32 loads per 16-byte vector)
+// and the index math is 32-bit (the old size_t div / mod per vector cost more issue slots than the arithmetic).
 template <typename T>
-__global__ void in_bwd_finalize_kernel(InBwdParams p) {
+__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(InBwdParams p) {
     constexpr int KP = Elem<T>::KP;
-    const int CV = p.C / KP;
-    const size_t total = (size_t)p.vox * CV;                    // per sample
-    const int n = blockIdx.y;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t v = i / CV; const int s = (int)(i % CV);
-        const size_t vox = (size_t)n * p.vox + v;
-        const int c = s * KP;
-        float g[KP], x[KP], o[KP];
-        unpack16<T>(*(const uint4*)((const T*)p.g + vox * p.ldg + c), g);
-        unpack16<T>(*(const uint4*)((const T*)p.x + vox * p.ldx + c), x);
+    const uint32_t CV = (uint32_t)p.C / KP;
+    const uint32_t total = (uint32_t)p.vox * CV;                 // per sample (< 2^32: checked by the launcher)
+    const uint32_t n = blockIdx.y;
+    const uint32_t stride = gridDim.x * 256u;
+    const bool fixed_slot = (256u % CV) == 0;
+    const T* gp = (const T*)p.g + (size_t)n * p.vox * p.ldg;
+    const T* xp = (const T*)p.x + (size_t)n * p.vox * p.ldx;
+    const T* a1p = p.add1 ? (const T*)p.add1 + (size_t)n * p.vox * p.lda1 : nullptr;
+    const T* a2p = p.add2 ? (const T*)p.add2 + (size_t)n * p.vox * p.lda2 : nullptr;
+    T* op = (T*)p.out + (size_t)n * p.vox * p.ldo;
+    float mu[KP], rs[KP], m1[KP], m2[KP];
+    auto constants = [&](uint32_t c) {
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
-            const float mu = p.mr[((size_t)n * p.C + c + j) * 2], rs = p.mr[((size_t)n * p.C + c + j) * 2 + 1];
-            const float m1 = p.gm[((size_t)n * p.C + c + j) * 2], m2 = p.gm[((size_t)n * p.C + c + j) * 2 + 1];
-            const float xn = (x[j] - mu) * rs;
-            o[j] = rs * (g[j] - m1 - xn * m2);
+            const size_t o = ((size_t)n * p.C + c + j) * 2;
+            mu[j] = p.mr[o]; rs[j] = p.mr[o + 1]; m1[j] = p.gm[o]; m2[j] = p.gm[o + 1];
         }
-        if (p.add1) {
+    };
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t v = i / CV, c = (i - v * CV) * KP;
+    const uint32_t vstep = stride / CV;                          // exact when the slot is fixed
+    if (fixed_slot && i < total) constants(c);
+    for (; i < total; i += stride, v += vstep) {
+        if (!fixed_slot) { v = i / CV; c = (i - v * CV) * KP; constants(c); }
+        float g[KP], x[KP], o[KP];
+        const uint4 gq = *(const uint4*)(gp + (size_t)v * p.ldg + c);
+        const uint4 xq = *(const uint4*)(xp + (size_t)v * p.ldx + c);
+        uint4 a1q = make_uint4(0, 0, 0, 0), a2q = make_uint4(0, 0, 0, 0);
+        if (a1p) a1q = *(const uint4*)(a1p + (size_t)v * p.lda1 + c);
+        if (a2p) a2q = *(const uint4*)(a2p + (size_t)v * p.lda2 + c);
+        unpack16<T>(gq, g);
+        unpack16<T>(xq, x);
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const float xn = (x[j] - mu[j]) * rs[j];
+            o[j] = rs[j] * (g[j] - m1[j] - xn * m2[j]);
+        }
+        if (a1p) {
             float a[KP];
-            unpack16<T>(*(const uint4*)((const T*)p.add1 + vox * p.lda1 + c), a);
+            unpack16<T>(a1q, a);
 #pragma unroll
             for (int j = 0; j < KP; ++j) o[j] += a[j];
         }
-        if (p.add2) {
+        if (a2p) {
             float a[KP];
-            unpack16<T>(*(const uint4*)((const T*)p.add2 + vox * p.lda2 + c), a);
+            unpack16<T>(a2q, a);
 #pragma unroll
             for (int j = 0; j < KP; ++j) o[j] += a[j];
         }
-        *(uint4*)((T*)p.out + vox * p.ldo + c) = pack16<T>(o);
+        *(uint4*)(op + (size_t)v * p.ldo + c) = pack16<T>(o);
     }
 }
 
@@ -721,6 +745,7 @@ int rs_elem_blocks(size_t items) {
 
 int rs_launch_in_bwd(const InBwdParams& p, int dtype, hipStream_t st) {
     const int KP = dtype == RS_F32 ? 4 : 8;
+    if ((size_t)p.vox * (p.C / KP) >= 0xFFFFFFFFull) return RS_ERR_UNSUPPORTED;
     const int blocks = rs_elem_blocks((size_t)p.vox * (p.C / KP));
     if (dtype == RS_F32) hipLaunchKernelGGL(in_bwd_finalize_kernel<float>, dim3(blocks, p.N), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(in_bwd_finalize_kernel<bf16_t>, dim3(blocks, p.N), dim3(256), 0, st, p);

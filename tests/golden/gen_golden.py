@@ -213,6 +213,7 @@ def main():
     for k, v in net.named_parameters():
         gnp = v.grad.numpy()
         un[f'g_{k}_head'] = gnp.reshape(-1)[:64].copy()
+        un[f'g_{k}_sub'], _ = synth.subsample(gnp, 4096)            # strided over the whole tensor (every tap / channel region)
         un[f'g_{k}_summary'] = synth.summary(gnp)
     # the same network with strided down-sampling instead of MaxPool (UNet(..., pool=False), unet.py:36-39)
     net2 = unet_mod.UNet(1, 8, num_classes=len(classes), scale=[2, 2, 2, 2], kernel_size=[3, 3, 3, 3, 3], block='BasicBlock', norm='in', pool=False)
@@ -223,6 +224,7 @@ def main():
     un['nopool_logits_summary'] = synth.summary(y2.detach().numpy())
     for k, v in net2.named_parameters():
         un[f'nopool_g_{k}_summary'] = synth.summary(v.grad.numpy())
+        un[f'nopool_g_{k}_sub'], _ = synth.subsample(v.grad.numpy(), 4096)
     np.savez_compressed(os.path.join(HERE, 'unet_tiny.npz'), **un)
     print('unet_tiny.npz', len(un))
 

@@ -316,6 +316,17 @@ def make_tiny_unet(mode, seed=3, classes=None):
     return net.to(DEV)
 
 
+def f64_tiny_grads(pool):
+    """Gradients of the tiny UNet from the float64 CPU restatement (strided 4k subsample per tensor).  The fp32 reference fixture itself
+    is up to 1.4e-2 of max away from these (profiles/r02_tiny_grad_noise.txt), so fp32 kernels are held to the float64 values."""
+    shapes = uo.unet_param_shapes(1, 8, len(synth.TINY_CLASSES), pool=pool)
+    sd = {k: T(v).double().requires_grad_(True) for k, v in synth.fill_state_dict(shapes, 3).items()}
+    y = uo.unet_forward(sd, T(synth.image(1, 48, seed=1234)).double(), pool=pool)
+    go = synth.rng(77).standard_normal(tuple(y.shape)).astype(np.float32) / y.numel()
+    y.backward(T(go).double())
+    return {k: synth.subsample(v.grad.numpy(), 4096)[0] for k, v in sd.items()}
+
+
 def check_unet_tiny_nopool(mode):
     """UNet(..., pool=False): strided down-sampling (unet_utils.py:38-39) against the reference fixture."""
     from rsuper_amd.model.dim3.unet import UNet
@@ -330,14 +341,21 @@ def check_unet_tiny_nopool(mode):
     torch.cuda.synchronize()
     sub, _ = synth.subsample(y.detach().cpu().numpy(), 8192)
     e_y = err_for(mode, T(sub), T(g['nopool_logits_sub']))
-    worst, wk = 0.0, ''
+    worst, wk, worst64 = 0.0, '', 0.0
+    g64 = f64_tiny_grads(False) if mode == 'f32' else None
     for k, p in net.named_parameters():
-        ref = g[f'nopool_g_{k}_summary'][1]
-        e = abs(float((p.grad.double() ** 2).sum()) - ref) / max(ref, 1e-30)
+        gsub, _ = synth.subsample(p.grad.cpu().numpy(), 4096)        # element-wise over a strided sample of the whole tensor
+        sc = max(g[f'nopool_g_{k}_summary'][2], 1e-12)
+        e = float(np.abs(gsub - g[f'nopool_g_{k}_sub']).max() / sc) if mode == 'f32' else l2err(T(gsub), T(g[f'nopool_g_{k}_sub']))
         if e > worst:
             worst, wk = e, k
-    tol = 1e-3 if mode == 'f32' else 0.25
-    return result(f'unet_tiny_nopool[{mode}]', max(e_y, worst * (1e-3 / 2e-2 if mode == 'f32' else 0.5)), tol, f'logits {e_y:.2e}; grad |.|^2 worst {worst:.2e} @ {wk}')
+        if g64 is not None:
+            worst64 = max(worst64, float(np.abs(gsub - g64[k]).max() / sc))
+    # f32: <= 1.2e-2 of max against the float64 restatement (measured 9.3e-3; the fp32 reference is 1.1e-2 away from it) and <= 2e-2 against
+    # the fp32 reference fixture (measured 1.1e-2, i.e. the reference's own rounding noise)
+    tol_y, tol_g = (1e-3, 2e-2) if mode == 'f32' else (0.25, 0.5)
+    return result(f'unet_tiny_nopool[{mode}]', max(e_y / tol_y, worst / tol_g, worst64 / 1.2e-2), 1.0,
+                  f'logits {e_y:.2e} (tol {tol_y}); worst grad vs reference {worst:.2e} @ {wk} (tol {tol_g}); vs float64 {worst64:.2e} (tol 1.2e-2)')
 
 
 def check_unet_tiny(mode):
@@ -352,21 +370,27 @@ def check_unet_tiny(mode):
     ref = g['logits_sub']
     e_y = err_for(mode, T(sub), T(ref))
     e_abs = float(np.abs(sub - ref).max())
-    worst, wk = 0.0, ''
+    worst, wk, worst64 = 0.0, '', 0.0
+    g64 = f64_tiny_grads(True) if mode == 'f32' else None
     for k, p in net.named_parameters():
         r = g[f'g_{k}_summary']
         sc = max(r[2], 1e-12)
+        gsub, _ = synth.subsample(p.grad.cpu().numpy(), 4096)        # strided over the whole tensor, not the first 64 entries
         if mode == 'f32':
-            e = float(np.abs(p.grad.cpu().numpy().reshape(-1)[:64] - g[f'g_{k}_head']).max() / sc)
+            e = float(np.abs(gsub - g[f'g_{k}_sub']).max() / sc)
+            worst64 = max(worst64, float(np.abs(gsub - g64[k]).max() / sc))
         else:
-            e = l2err(p.grad.cpu().reshape(-1)[:64], T(g[f'g_{k}_head']))
+            e = l2err(T(gsub), T(g[f'g_{k}_sub']))
         if e > worst:
             worst, wk = e, k
     if mode == 'f32':
-        tol_y, tol_g = 1e-4, 1e-2                # deep-chain fp32 noise already ~3e-3 CPU-vs-CPU (test_oracle_vs_golden)
-        ok_err = max(e_y / tol_y, worst / tol_g)
+        # gradients: <= 1e-2 of max against the float64 restatement (measured 7.5e-3) -- the fp32 reference fixture is itself 1.4e-2 away
+        # from float64 on this deep pre-activation chain (profiles/r02_tiny_grad_noise.txt), hence 2e-2 against the fixture
+        tol_y, tol_g, tol_64 = 1e-4, 2e-2, 1e-2
+        ok_err = max(e_y / tol_y, worst / tol_g, worst64 / tol_64)
         return result(f'unet_tiny_golden[{mode}]', ok_err, 1.0,
-                      f'logits rel {e_y:.2e} abs {e_abs:.2e} (tol {tol_y}); worst grad {worst:.2e} @ {wk} (tol {tol_g})')
+                      f'logits rel {e_y:.2e} abs {e_abs:.2e} (tol {tol_y}); worst grad vs reference {worst:.2e} @ {wk} (tol {tol_g}); '
+                      f'vs float64 restatement {worst64:.2e} (tol {tol_64})')
     # bf16: the oracle is the bf16-rounding-emulating CPU restatement (oracle/unet_oracle.py, emulate_bf16=True); the distance
     # to the fp32 golden (~0.11) is inherent to bf16 on this net (tests/test_oracle_vs_golden.py::test_bf16_emulation_...).
     sd = {k: T(v) for k, v in synth.fill_state_dict(uo.unet_param_shapes(1, 8, len(synth.TINY_CLASSES)), 3).items()}
@@ -376,8 +400,9 @@ def check_unet_tiny(mode):
     gfin = all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
     # two valid bf16 executions (different fp32 accumulation orders -> different rounding decisions) differ by ~6e-2 here,
     # i.e. by about as much as either differs from fp32: the bound is the net's conditioning, kernels are checked per layer.
-    return result(f'unet_tiny_bf16_vs_emulated_oracle', e_emu if gfin else float('inf'), 0.10,
-                  f'logits L2 vs bf16-emulating oracle {e_emu:.2e} (tol 0.10); vs fp32 golden {e_y:.2e}; grads finite {gfin}')
+    return result(f'unet_tiny_bf16_vs_emulated_oracle', e_emu if gfin else float('inf'), 0.08,
+                  f'logits L2 vs bf16-emulating oracle {e_emu:.2e} (tol 0.08); vs fp32 golden {e_y:.2e}; worst grad L2 vs fp32 golden '
+                  f'{worst:.2e} @ {wk}; grads finite {gfin}')
 
 
 # ================================================================================================ losses

@@ -162,6 +162,7 @@ def test_unet_tiny(golden):
         scale = max(ref[2], 1e-12)
         # deep pre-activation chain: fp32 round-off between two valid op orders grows to ~3e-3 of max at the stem
         np.testing.assert_allclose(gr.reshape(-1)[:64] / scale, g[f"g_{k}_head"] / scale, atol=1e-2, err_msg=k)
+        np.testing.assert_allclose(synth.subsample(gr, 4096)[0] / scale, g[f"g_{k}_sub"] / scale, atol=1e-2, err_msg=k + ' (strided)')
 
 
 def test_unet_tiny_strided_downsampling(golden):
@@ -178,6 +179,16 @@ def test_unet_tiny_strided_downsampling(golden):
     for k in shapes:
         ref = g[f'nopool_g_{k}_summary']
         np.testing.assert_allclose(synth.summary(sd[k].grad.numpy())[1], ref[1], rtol=2e-2, err_msg=k)     # sum of squares of the gradient
+    # element-wise over a strided sample of every gradient tensor.  This net (four strided blocks, no pooling) is badly conditioned in
+    # fp32: the fp32 restatement and the fp32 reference differ by up to 3.8e-2 of max at the stem, while the SAME restatement evaluated in
+    # float64 is within 1.1e-2 of the reference everywhere (4.5e-3 at the stem) -- so the algorithm is pinned in float64 and fp32 only through the norms above.
+    sd64 = {k: T(v).double().requires_grad_(True) for k, v in synth.fill_state_dict(shapes, 3).items()}
+    y64 = uo.unet_forward(sd64, T(synth.image(1, 48, seed=1234)).double(), pool=False)
+    y64.backward(T(go).double())
+    for k in shapes:
+        scale = max(g[f'nopool_g_{k}_summary'][2], 1e-12)
+        np.testing.assert_allclose(synth.subsample(sd64[k].grad.numpy(), 4096)[0] / scale, g[f'nopool_g_{k}_sub'] / scale, atol=2e-2,
+                                   err_msg=k + ' (strided, float64 restatement)')   # measured worst 1.1e-2: the fp32 reference's own noise
 
 
 # ------------------------------------------------------------------ calculate_loss
