@@ -177,6 +177,10 @@ int rsuper_window_normalize(float* acc, const float* cd, const float* ch, const 
 /* dilate_volume :22-46 (iterated ball dilation).  in/out/tmp: nvol volumes of D*H*W bytes; tmp may be NULL when
  * kernel_size <= 7. */
 int rsuper_dilate_volume(const uint8_t* in, uint8_t* out, uint8_t* tmp, long nvol, int D, int H, int W, int kernel_size, void* stream);
+/* Same, with flags[nvol] (0 = the volume is all zero, e.g. from rsuper_plane_any): flagged-empty volumes are written as zeros without
+ * being read -- most label planes carry no unknown / segment voxels.  flags may be NULL (= dense). */
+int rsuper_dilate_volume_sparse(const uint8_t* in, uint8_t* out, uint8_t* tmp, const uint8_t* flags, long nvol, int D, int H, int W,
+                                int kernel_size, void* stream);
 /* isolate_tumor :1423-1445: Gaussian-ball correlation (odd diameter d_odd, std) and first-maximum argmax.
  * best: device u64, pre-zeroed; key = (f32 bits << 32) | (0xFFFFFFFF - linear index). conv_out optional (debug).
  * workspace: (d_odd/2 + 1) * D*H*W floats -> separable two-stage form (row sums per half width, then a k^2 gather per

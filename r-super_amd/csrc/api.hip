@@ -305,10 +305,14 @@ int rsuper_window_normalize(float* acc, const float* cd, const float* ch, const 
 }
 
 int rsuper_dilate_volume(const uint8_t* in, uint8_t* out, uint8_t* tmp, long nvol, int D, int H, int W, int kernel_size, void* stream) {
+    return rsuper_dilate_volume_sparse(in, out, tmp, nullptr, nvol, D, H, W, kernel_size, stream);
+}
+int rsuper_dilate_volume_sparse(const uint8_t* in, uint8_t* out, uint8_t* tmp, const uint8_t* flags, long nvol, int D, int H, int W, int kernel_size,
+                                void* stream) {
     if (!in || !out || nvol <= 0 || kernel_size < 1) return RS_ERR_ARG;
     if (kernel_size % 2 == 0) kernel_size += 1;                  // losses_foundation.py:24-25
     const int full = 3;
-    if (kernel_size <= 2 * full + 1) return rs_launch_dilate_pass(in, out, nvol, D, H, W, kernel_size, ST(stream));
+    if (kernel_size <= 2 * full + 1) return rs_launch_dilate_pass(in, out, flags, nvol, D, H, W, kernel_size, ST(stream));
     if (!tmp) return RS_ERR_ARG;
     const int radius = (kernel_size - 1) / 2, num_full = radius / full, rem = radius % full;   // :31-44
     const int passes = num_full + (rem > 0 ? 1 : 0);
@@ -316,7 +320,7 @@ int rsuper_dilate_volume(const uint8_t* in, uint8_t* out, uint8_t* tmp, long nvo
     for (int i = 0; i < passes; ++i) {
         uint8_t* dst = ((passes - i) & 1) ? out : tmp;           // last pass lands in `out`
         const int k = i < num_full ? 2 * full + 1 : 2 * rem + 1;
-        const int rc = rs_launch_dilate_pass(src, dst, nvol, D, H, W, k, ST(stream));
+        const int rc = rs_launch_dilate_pass(src, dst, flags, nvol, D, H, W, k, ST(stream));
         if (rc) return rc;
         src = dst;
     }

@@ -22,7 +22,7 @@ __device__ __forceinline__ int row_halfwidth(int k, int dz, int dy) {
     return L;
 }
 
-__global__ __launch_bounds__(256) void dilate_pass_kernel(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k) {
+__global__ __launch_bounds__(256) void dilate_pass_kernel(const uint8_t* in, uint8_t* out, const uint8_t* flags, long nvol, int D, int H, int W, int k) {
     const int W4 = W >> 2;                                       // W % 4 == 0 (checked on the host)
     const long words = (long)nvol * D * H * W4;
     const int r = k >> 1;
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void dilate_pass_kernel(const uint8_t* in, uin
         const int y = (int)(t % H); t /= H;
         const int z = (int)(t % D);
         const long v = t / D;
+        if (flags && !flags[v]) { ((uint32_t*)out)[i] = 0u; continue; }     // all-zero volume: its dilation is zero, nothing to read
         const uint32_t* vol = (const uint32_t*)(in + v * (long)D * H * W);
         uint32_t acc = 0;
         for (int dz = -r; dz <= r; ++dz) {
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void dilate_pass_kernel(const uint8_t* in, uin
 }
 
 // 16 voxels per lane (W % 16 == 0): one 16-byte load per row + the two neighbouring words.
-__global__ __launch_bounds__(256) void dilate_pass16_kernel(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k) {
+__global__ __launch_bounds__(256) void dilate_pass16_kernel(const uint8_t* in, uint8_t* out, const uint8_t* flags, long nvol, int D, int H, int W, int k) {
     const int W16 = W >> 4;
     const long items = (long)nvol * D * H * W16;
     const int r = k >> 1;
@@ -70,8 +71,9 @@ __global__ __launch_bounds__(256) void dilate_pass16_kernel(const uint8_t* in, u
         const int y = (int)(t % H); t /= H;
         const int z = (int)(t % D);
         const long v = t / D;
-        const uint8_t* vol = in + v * (long)D * H * W;
         uint4 acc = make_uint4(0, 0, 0, 0);
+        if (flags && !flags[v]) { ((uint4*)out)[i] = acc; continue; }       // all-zero volume (most label planes carry no unknown voxels)
+        const uint8_t* vol = in + v * (long)D * H * W;
         for (int dz = -r; dz <= r; ++dz) {
             const int zz = z + dz;
             if (zz < 0 || zz >= D) continue;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void dilate_pass16_kernel(const uint8_t* in, u
 }
 
 // generic-width fallback (one voxel per lane)
-__global__ __launch_bounds__(256) void dilate_pass_scalar_kernel(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k) {
+__global__ __launch_bounds__(256) void dilate_pass_scalar_kernel(const uint8_t* in, uint8_t* out, const uint8_t* flags, long nvol, int D, int H, int W, int k) {
     const long total = (long)nvol * D * H * W;
     const int r = k >> 1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void dilate_pass_scalar_kernel(const uint8_t* 
         long t = i / W;
         const int y = (int)(t % H); t /= H;
         const int z = (int)(t % D);
+        if (flags && !flags[t / D]) { out[i] = 0; continue; }
         const uint8_t* vol = in + (t / D) * (long)D * H * W;
         uint8_t acc = 0;
         for (int dz = -r; dz <= r && !acc; ++dz)
@@ -445,16 +448,16 @@ __global__ void count_kernel(const uint8_t* m, long V, unsigned int* count) {
 
 }  // namespace
 
-int rs_launch_dilate_pass(const uint8_t* in, uint8_t* out, long nvol, int D, int H, int W, int k, hipStream_t st) {
+int rs_launch_dilate_pass(const uint8_t* in, uint8_t* out, const uint8_t* flags, long nvol, int D, int H, int W, int k, hipStream_t st) {
     if (k < 1 || k > 7 || !(k & 1)) return RS_ERR_ARG;
     if ((W & 15) == 0) {
         const long items = nvol * D * H * (W >> 4);
-        hipLaunchKernelGGL(dilate_pass16_kernel, dim3(rs_elem_blocks((size_t)items)), dim3(256), 0, st, in, out, nvol, D, H, W, k);
+        hipLaunchKernelGGL(dilate_pass16_kernel, dim3(rs_elem_blocks((size_t)items)), dim3(256), 0, st, in, out, flags, nvol, D, H, W, k);
     } else if ((W & 3) == 0) {
         const long words = nvol * D * H * (W >> 2);
-        hipLaunchKernelGGL(dilate_pass_kernel, dim3(rs_elem_blocks((size_t)words)), dim3(256), 0, st, in, out, nvol, D, H, W, k);
+        hipLaunchKernelGGL(dilate_pass_kernel, dim3(rs_elem_blocks((size_t)words)), dim3(256), 0, st, in, out, flags, nvol, D, H, W, k);
     } else {
-        hipLaunchKernelGGL(dilate_pass_scalar_kernel, dim3(rs_elem_blocks((size_t)(nvol * D * H * W))), dim3(256), 0, st, in, out, nvol, D, H, W, k);
+        hipLaunchKernelGGL(dilate_pass_scalar_kernel, dim3(rs_elem_blocks((size_t)(nvol * D * H * W))), dim3(256), 0, st, in, out, flags, nvol, D, H, W, k);
     }
     return rs_check_launch();
 }

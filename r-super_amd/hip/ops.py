@@ -682,5 +682,12 @@ def dilate_volume(vol_u8, kernel_size):
     out = torch.empty_like(v)
     ks = kernel_size + 1 if kernel_size % 2 == 0 else kernel_size
     tmp = torch.empty_like(v) if ks > 7 else None
-    _l.check(_L().rsuper_dilate_volume(_ptr(v), _ptr(out), _ptr(tmp), nvol, D, H, W, kernel_size, _stream()), 'dilate_volume')
+    flags = None
+    if nvol > 1 and (D * H * W) % 16 == 0 and v.data_ptr() % 16 == 0:
+        # one HBM-rate pass marks the volumes that are entirely zero (most label planes have no unknown / segment voxels);
+        # the dilation passes write zeros for those without reading them
+        flags = torch.empty(nvol, device=v.device, dtype=torch.uint8)
+        _l.check(_L().rsuper_plane_any(_ptr(v), nvol, D * H * W, _ptr(flags), _stream()), 'plane_any')
+    _l.check(_L().rsuper_dilate_volume_sparse(_ptr(v), _ptr(out), _ptr(tmp), _ptr(flags), nvol, D, H, W, kernel_size, _stream()),
+             'dilate_volume')
     return out
