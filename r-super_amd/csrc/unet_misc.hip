@@ -410,6 +410,179 @@ __global__ void upsample_bwd_kernel(UpParams p) {
     }
 }
 
+// ---- second-generation trilinear kernels (round 2).  The first versions were VALU / latency bound at 18-24 % of the HBM
+// rate: three runtime integer divisions per output vector in forward, and in backward 18 float weight evaluations per
+// input voxel plus a load inside a data-dependent branch per tap (each waited for on its own).
+//
+// Forward: a thread keeps its channel slot and walks the block's output range with incrementally updated (od, oh, ow);
+// corner offsets are 32-bit element offsets from one base pointer; the 8-corner accumulation keeps the original order
+// (k = 0..7, fused multiply-add), as packed f32 pairs (v_pk_fma_f32): results are bit-identical to upsample_fwd_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd2_kernel(UpParams p) {
+    constexpr int KP = Elem<T>::KP;
+    const int CV = p.C / KP, VL = 256 / CV;
+    const int vl = threadIdx.x / CV, s = threadIdx.x % CV;
+    const bool active = vl < VL;
+    const int n = blockIdx.y;
+    const int ovox = p.OD * p.OH * p.OW;
+    const int per_blk = (ovox + gridDim.x - 1) / gridDim.x;
+    const int v0 = blockIdx.x * per_blk, v1 = min(ovox, v0 + per_blk);
+    const float sd = p.OD > 1 ? (float)(p.ID - 1) / (float)(p.OD - 1) : 0.f;
+    const float sh = p.OH > 1 ? (float)(p.IH - 1) / (float)(p.OH - 1) : 0.f;
+    const float sw = p.OW > 1 ? (float)(p.IW - 1) / (float)(p.OW - 1) : 0.f;
+    float s1[KP], s2[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const T* xin = (const T*)p.x + (size_t)n * p.ID * p.IH * p.IW * p.ldx + s * KP;
+    T* yout = (T*)p.y + (size_t)n * ovox * p.ldy + s * KP;
+    if (active && v0 + vl < v1) {
+        int v = v0 + vl;
+        int ow = v % p.OW, oh = (v / p.OW) % p.OH, od = v / (p.OW * p.OH);
+        for (; v < v1; v += VL) {
+            int d0, d1, h0, h1, w0, w1; float ld, lh, lw;
+            lin_coord(od, sd, p.ID, d0, d1, ld);
+            lin_coord(oh, sh, p.IH, h0, h1, lh);
+            lin_coord(ow, sw, p.IW, w0, w1, lw);
+            const uint32_t r00 = (uint32_t)(d0 * p.IH + h0) * p.IW, r01 = (uint32_t)(d0 * p.IH + h1) * p.IW;
+            const uint32_t r10 = (uint32_t)(d1 * p.IH + h0) * p.IW, r11 = (uint32_t)(d1 * p.IH + h1) * p.IW;
+            const uint32_t rows[4] = {r00, r01, r10, r11};
+            uint4 q[8];
+            float wt[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                q[k] = *(const uint4*)(xin + (size_t)((rows[k >> 1] + (uint32_t)((k & 1) ? w1 : w0)) * (uint32_t)p.ldx));
+                wt[k] = ((k & 4) ? ld : 1.f - ld) * ((k & 2) ? lh : 1.f - lh) * ((k & 1) ? lw : 1.f - lw);
+            }
+            float acc[KP];
+            if (sizeof(T) == 2) {
+                f32x2_t a2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a2[j] = f32x2_t{0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t wq[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+                    const f32x2_t w2 = {wt[k], wt[k]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2_t x2 = {__uint_as_float(wq[j] << 16), __uint_as_float(wq[j] & 0xffff0000u)};
+                        a2[j] = __builtin_elementwise_fma(w2, x2, a2[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[2 * j] = a2[j][0]; acc[2 * j + 1] = a2[j][1]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KP; ++j) acc[j] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float x[KP];
+                    unpack16<T>(q[k], x);
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) acc[j] = fmaf(wt[k], x[j], acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KP; ++j) acc[j] = Elem<T>::rnd(acc[j]);
+            *(uint4*)(yout + (size_t)v * p.ldy) = pack16<T>(acc);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
+            ow += VL;
+            while (ow >= p.OW) { ow -= p.OW; if (++oh == p.OH) { oh = 0; ++od; } }
+        }
+    }
+    if (p.part) block_channel_sums<KP>(s1, s2, p.C, CV, VL, vl, s, active, p.part + ((size_t)n * gridDim.x + blockIdx.x) * p.C * 2);
+}
+
+// Backward: per-axis tables in LDS (for every input index: first contributing output, count <= 6, weights -- exactly
+// up_axis()'s values with the leading / trailing zero candidates trimmed), built once per block.  A thread then visits its
+// taps in the same ascending (a, b, c) order as upsample_bwd_kernel (zero-weight candidates it skipped contributed
+// nothing), so results are bit-identical; the innermost loop is unrolled to the block's maximal W count and its loads go
+// through a buffer descriptor (out-of-range -> zeros, no branch), so NW loads are in flight per (a, b).
+struct UpEnt { int lo, n; float w[6]; };
+template <typename T, int NW>
+__device__ __forceinline__ void up_bwd_rows(const UpParams& p, const UpEnt* td, const UpEnt* th, const UpEnt* tw, int n, uint32_t i0, uint32_t total,
+                                            uint32_t stride) {
+    constexpr int KP = Elem<T>::KP;
+    const uint32_t CV = (uint32_t)p.C / KP;
+    const uint32_t ovox = (uint32_t)(p.OD * p.OH * p.OW);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.y + (size_t)n * ovox * p.ldy), 0,
+                                                                        ovox * (uint32_t)p.ldy * (uint32_t)sizeof(T), 0x00020000);
+    for (uint32_t i = i0; i < total; i += stride) {
+        const uint32_t v = i / CV, s = i - v * CV;
+        const uint32_t iw = v % (uint32_t)p.IW, t2 = v / (uint32_t)p.IW, ih = t2 % (uint32_t)p.IH, id = t2 / (uint32_t)p.IH;
+        const UpEnt* ed = td + id; const UpEnt* eh = th + ih; const UpEnt* ew = tw + iw;
+        const int na = ed->n, nb = eh->n, nc = ew->n, wlo = ew->lo;
+        float wc[NW];
+#pragma unroll
+        for (int c = 0; c < NW; ++c) wc[c] = c < nc ? ew->w[c] : 0.f;
+        float acc[KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) acc[j] = 0.f;
+        for (int a = 0; a < na; ++a) {
+            const float wa = ed->w[a];
+            for (int b = 0; b < nb; ++b) {
+                const float wdh = wa * eh->w[b];
+                const uint32_t rowo = ((uint32_t)(ed->lo + a) * (uint32_t)p.OH + (uint32_t)(eh->lo + b)) * (uint32_t)p.OW + (uint32_t)wlo;
+                uint4 q[NW];
+#pragma unroll
+                for (int c = 0; c < NW; ++c) {
+                    const uint32_t off = c < nc ? ((rowo + c) * (uint32_t)p.ldy + s * KP) * (uint32_t)sizeof(T) : 0xFFFFFFFFu;
+                    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                    q[c] = make_uint4(r[0], r[1], r[2], r[3]);
+                }
+#pragma unroll
+                for (int c = 0; c < NW; ++c) {
+                    float g[KP];
+                    unpack16<T>(q[c], g);
+                    const float wt = wdh * wc[c];
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) acc[j] = fmaf(wt, g[j], acc[j]);
+                }
+            }
+        }
+        *(uint4*)((T*)p.dx + ((size_t)n * p.ID * p.IH * p.IW + v) * p.lddx + s * KP) = pack16<T>(acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd2_kernel(UpParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    UpEnt* tab = (UpEnt*)smem;                                   // [ID] [IH] [IW]
+    __shared__ int nwmax;
+    if (threadIdx.x == 0) nwmax = 0;
+    __syncthreads();
+    const float sd = p.OD > 1 ? (float)(p.ID - 1) / (float)(p.OD - 1) : 0.f;
+    const float sh = p.OH > 1 ? (float)(p.IH - 1) / (float)(p.OH - 1) : 0.f;
+    const float sw = p.OW > 1 ? (float)(p.IW - 1) / (float)(p.OW - 1) : 0.f;
+    for (int t = threadIdx.x; t < p.ID + p.IH + p.IW; t += 256) {
+        const int axis = t < p.ID ? 0 : (t < p.ID + p.IH ? 1 : 2);
+        const int i = axis == 0 ? t : (axis == 1 ? t - p.ID : t - p.ID - p.IH);
+        const UpAxis a = axis == 0 ? up_axis(i, sd, p.ID, p.OD) : (axis == 1 ? up_axis(i, sh, p.IH, p.OH) : up_axis(i, sw, p.IW, p.OW));
+        int first = 6, last = -1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (a.w[k] != 0.f) { if (first == 6) first = k; last = k; }
+        UpEnt e;
+        e.lo = a.lo + (first == 6 ? 0 : first);
+        e.n = last < 0 ? 0 : last - first + 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            float wv = 0.f;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) if (m == first + k && m <= last) wv = a.w[m];
+            e.w[k] = wv;
+        }
+        tab[t] = e;
+        if (axis == 2) atomicMax(&nwmax, e.n);
+    }
+    __syncthreads();
+    const UpEnt* td = tab; const UpEnt* th = tab + p.ID; const UpEnt* tw = tab + p.ID + p.IH;
+    const uint32_t CV = (uint32_t)p.C / Elem<T>::KP;
+    const uint32_t total = (uint32_t)(p.ID * p.IH * p.IW) * CV;
+    const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    if (nwmax <= 4) up_bwd_rows<T, 4>(p, td, th, tw, blockIdx.y, i0, total, stride);
+    else up_bwd_rows<T, 6>(p, td, th, tw, blockIdx.y, i0, total, stride);
+}
+
 // ------------------------------------------------------------------------------------------------ stem: Conv3d(1 -> C, 3x3x3)
 // thread = one voxel: its 27 neighbours live in registers, the (C,1,27) f32 weights are read through the scalar
 // cache (uniform addresses -> s_load), so the inner loop is pure v_fmac with SGPR operands.
@@ -789,13 +962,28 @@ int rs_launch_upsample(const UpParams& p, int dtype, int bwd, int blocks, hipStr
     const int CV = p.C / KP;
     if (CV > 256) return RS_ERR_UNSUPPORTED;
     if (!bwd) {
+        static const bool v1 = getenv("RSUPER_UPSAMPLE_V1") != nullptr;      // first-generation kernels (A/B, bit-identical results)
         const size_t smem = (size_t)(256 / CV) * p.C * 2 * sizeof(float);
-        if (dtype == RS_F32) hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(blocks, p.N), dim3(256), smem, st, p);
-        else hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(blocks, p.N), dim3(256), smem, st, p);
+        const bool small = (size_t)p.N * p.ID * p.IH * p.IW * p.ldx < 0x7FFFFFFFull;
+        if (v1 || !small) {
+            if (dtype == RS_F32) hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(blocks, p.N), dim3(256), smem, st, p);
+            else hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(blocks, p.N), dim3(256), smem, st, p);
+        } else {
+            if (dtype == RS_F32) hipLaunchKernelGGL(upsample_fwd2_kernel<float>, dim3(blocks, p.N), dim3(256), smem, st, p);
+            else hipLaunchKernelGGL(upsample_fwd2_kernel<bf16_t>, dim3(blocks, p.N), dim3(256), smem, st, p);
+        }
     } else {
+        static const bool v1 = getenv("RSUPER_UPSAMPLE_V1") != nullptr;
         const int b = rs_elem_blocks((size_t)p.ID * p.IH * p.IW * CV);
-        if (dtype == RS_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(b, p.N), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(b, p.N), dim3(256), 0, st, p);
+        const size_t tab = (size_t)(p.ID + p.IH + p.IW) * 32;
+        const bool small = (size_t)p.OD * p.OH * p.OW * p.ldy * (dtype == RS_F32 ? 4 : 2) < 0xFFFFFFFFull && (size_t)p.ID * p.IH * p.IW * CV < 0xFFFFFFFFull && tab <= 48 * 1024;
+        if (v1 || !small) {
+            if (dtype == RS_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(b, p.N), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(b, p.N), dim3(256), 0, st, p);
+        } else {
+            if (dtype == RS_F32) hipLaunchKernelGGL(upsample_bwd2_kernel<float>, dim3(b, p.N), dim3(256), tab, st, p);
+            else hipLaunchKernelGGL(upsample_bwd2_kernel<bf16_t>, dim3(b, p.N), dim3(256), tab, st, p);
+        }
     }
     return rs_check_launch();
 }

@@ -384,7 +384,10 @@ class BasicBlockFn(torch.autograd.Function):
         # conv1 (+ shortcut): one GEMM
         nc1 = Cout * (2 if has_sc else 1)
         if packs is None:                  # one pack launch per block and direction (fragments stay hot in L2 for the convs below)
-            specs, bns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, False)
+            # with gradients wanted, the data-gradient fragments are packed by the same launch (one pack launch per block instead of
+            # two; they are read once, much later, so being cold in L2 by then costs nothing measurable)
+            both = os.environ.get('RSUPER_PACK_BOTH', '1') == '1' and any(ctx.needs_input_grad)
+            specs, bns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, both)
             packs = (pack_weights_batch(dt, specs), bns)
         bn1, wp1 = packs[1][0], packs[0][0]
         ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
