@@ -1,0 +1,341 @@
+"""Building blocks of MedFormer on MI355X, with the module tree -- hence the state_dict keys -- of
+rsuper_train/model/dim3/medformer_utils.py, conv_layers.py:126-240 and trans_layers.py.
+
+Where the work is: the dense 3x3x3 convolutions of the network live in BasicBlocks at the two highest resolutions (conv stem,
+down1, up3, up4 in config/abdomenatlas_ufo/medformer_3d.yaml) -- those, the trilinear up-sampling in front of them, the stem and
+the output head run on the hand-written gfx950 kernels (hip/ops.py), channels-last, bf16 or f32.  The bidirectional-attention
+stages work on <= 1/64 of the voxels plus a 27-token semantic map; in this first version they are expressed with PyTorch-ROCm ops
+in fp32 (1x1x1 convolutions, attention products and MLPs are plain library GEMMs; depthwise 3x3x3 convolutions, InstanceNorm,
+softmax, LayerNorm, GELU and squeeze-excite are ATen kernels) -- replacing the depthwise / norm / softmax pieces by HIP kernels
+is the next step of this row.  Nothing here runs on the CPU: `Feat` refuses host tensors.
+
+`Feat` carries an activation between the two worlds: channels-last (N, D, H, W, C) in the compute dtype together with the
+InstanceNorm statistics the fused conv prologue needs, or a logical NCDHW fp32 tensor (a channels_last_3d view, no copy).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .conv_layers import BasicBlock
+from ...hip import ops, lib as _lib
+
+IN_EPS = 1e-5          # bare InstanceNorm3d(dim) (medformer_utils.py:117-118, 160)
+IN_EPS_CNA = 1e-4      # ConvNormAct's norm(ch, eps=1e-4) (conv_layers.py:40-43)
+
+
+def channel_stats(x_cl, eps=IN_EPS_CNA):
+    """(mean, rstd) per (sample, channel) of a channels-last tensor, (N, C, 2) f32: what the conv kernels' fused
+    InstanceNorm + ReLU prologue reads.  Not differentiated: BasicBlockFn derives the InstanceNorm backward itself."""
+    with torch.no_grad():
+        xf = x_cl.float()
+        var, mean = torch.var_mean(xf, dim=(1, 2, 3), unbiased=False)
+        return torch.stack([mean, torch.rsqrt(var + eps)], dim=-1).contiguous()
+
+
+class Feat:
+    """One activation, lazily available as (channels-last tensor, stats) for the HIP blocks or as NCDHW fp32 for the glue."""
+
+    def __init__(self, cl=None, mr=None, t=None):
+        src = cl if cl is not None else t
+        if src is None or not src.is_cuda:
+            raise _lib.RSuperHipError('MedFormer runs on MI355X only (no CPU fallback)')
+        self._cl, self._mr, self._t = cl, mr, t
+
+    def cl(self, dtype):
+        if self._cl is None or self._cl.dtype != dtype:
+            src = self._t.permute(0, 2, 3, 4, 1) if self._cl is None else self._cl
+            self._cl = src.contiguous().to(dtype)
+            self._mr = None
+        if self._mr is None:
+            self._mr = channel_stats(self._cl)
+        return self._cl, self._mr
+
+    def t(self):
+        if self._t is None:
+            self._t = self._cl.permute(0, 4, 1, 2, 3).float()
+        return self._t
+
+
+def _conv(x, conv, groups=1):
+    w = conv.weight
+    return F.conv3d(x, w, conv.bias, 1, w.shape[-1] // 2, 1, groups)
+
+
+class GlueConvNormAct(nn.Module):
+    """conv(act(norm(x))) (ConvNormAct with preact=True, conv_layers.py:46-51) for the 1x1x1 and depthwise members of the
+    attention stages; parameter `conv.weight` as in the reference."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, groups=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv3d(in_ch, out_ch, kernel_size, padding=kernel_size // 2, groups=groups, bias=False)
+        self.groups, self.act = groups, act
+
+    def forward(self, x):
+        h = F.instance_norm(x, eps=IN_EPS_CNA)
+        return _conv(F.relu(h) if self.act else h, self.conv, self.groups)
+
+
+class DepthwiseSeparableConv(nn.Module):
+    """Per-channel 3x3x3 then 1x1x1, no bias (conv_layers.py:126-157)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=3):
+        super().__init__()
+        self.depthwise = nn.Conv3d(in_ch, in_ch, kernel_size, padding=kernel_size // 2, groups=in_ch, bias=False)
+        self.pointwise = nn.Conv3d(in_ch, out_ch, 1, bias=False)
+
+    def forward(self, x):
+        return _conv(_conv(x, self.depthwise, self.depthwise.groups), self.pointwise)
+
+
+class SEBlock(nn.Module):
+    def __init__(self, ch, ratio=4):
+        super().__init__()
+        self.excitation = nn.Sequential(nn.Conv3d(ch, ch // ratio, 1), nn.ReLU(), nn.Conv3d(ch // ratio, ch, 1), nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.excitation(x.mean((2, 3, 4), keepdim=True))
+
+
+class MBConv(nn.Module):
+    """Inverted bottleneck of the attention blocks (conv_layers.py:198-240) in the only shape MedFormer uses: in == out,
+    stride 1, squeeze-excite, identity shortcut."""
+
+    def __init__(self, ch, expansion=4):
+        super().__init__()
+        e = expansion * ch
+        self.expand_proj = nn.Identity() if expansion == 1 else GlueConvNormAct(ch, e, 1)
+        self.depthwise = GlueConvNormAct(e, e, 3, groups=e)
+        self.se = SEBlock(e)
+        self.pointwise = GlueConvNormAct(e, ch, 1, act=False)
+
+    def forward(self, x):
+        return self.pointwise(self.se(self.depthwise(self.expand_proj(x)))) + x
+
+
+def _split_heads(t, heads):
+    b, c = t.shape[:2]                                   # channel index = dim_head_index * heads + head (medformer_utils.py:46-55)
+    return t.reshape(b, c // heads, heads, -1).permute(0, 2, 3, 1)
+
+
+def _merge_heads(t, dhw):
+    b, heads, _, dh = t.shape
+    return t.permute(0, 3, 1, 2).reshape(b, heads * dh, *dhw)
+
+
+class BidirectionAttention(nn.Module):
+    """Voxels attend to the semantic-map tokens and the tokens attend to the voxels through ONE score matrix, normalised along
+    either axis (medformer_utils.py:13-99)."""
+
+    def __init__(self, feat_dim, map_dim, out_dim, heads, dim_head, no_map_out=False):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.feat_qv = DepthwiseSeparableConv(feat_dim, 2 * inner)
+        self.feat_out = DepthwiseSeparableConv(inner, out_dim)
+        self.map_qv = nn.Conv3d(map_dim, 2 * inner, 1, bias=False)
+        self.map_out = nn.Identity() if no_map_out else nn.Conv3d(inner, map_dim, 1, bias=False)
+
+    def forward(self, feat, smap):
+        fq, fv = self.feat_qv(feat).chunk(2, 1)
+        mq, mv = _conv(smap, self.map_qv).chunk(2, 1)
+        fq, fv, mq, mv = (_split_heads(t, self.heads) for t in (fq, fv, mq, mv))
+        score = torch.matmul(fq, mq.transpose(-1, -2)) * self.scale                     # b, heads, voxels, tokens
+        f_out = _merge_heads(torch.matmul(F.softmax(score, -1), mv), feat.shape[2:])
+        m_out = _merge_heads(torch.matmul(F.softmax(score, -2).transpose(-1, -2), fv), smap.shape[2:])
+        m_out = m_out if isinstance(self.map_out, nn.Identity) else _conv(m_out, self.map_out)
+        return self.feat_out(f_out), m_out
+
+
+class BidirectionAttentionBlock(nn.Module):
+    def __init__(self, feat_dim, map_dim, out_dim, heads, dim_head, expansion=4, no_map_out=False):
+        super().__init__()
+        self.attn = BidirectionAttention(feat_dim, map_dim, out_dim, heads, dim_head, no_map_out)
+        self.shortcut = nn.Sequential() if feat_dim == out_dim else GlueConvNormAct(feat_dim, out_dim, 1)
+        self.feedforward = MBConv(out_dim, expansion)
+
+    def forward(self, x, smap):
+        out, m = self.attn(F.instance_norm(x, eps=IN_EPS), F.instance_norm(smap, eps=IN_EPS))
+        return self.feedforward(out + self.shortcut(x)), m + smap
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, feat_dim, map_dim, out_dim, num_blocks, heads, dim_head, expansion=4, no_map_out=False):
+        super().__init__()
+        self.blocks = nn.ModuleList(BidirectionAttentionBlock(feat_dim if i == 0 else out_dim, map_dim, out_dim, heads, dim_head, expansion,
+                                                              no_map_out and i == num_blocks - 1) for i in range(num_blocks))
+
+    def forward(self, x, smap):
+        for blk in self.blocks:
+            x, smap = blk(x, smap)
+        return x, smap
+
+
+class PatchMerging(nn.Module):
+    """2x down-sampling: the eight parity sub-lattices stacked on channels (i, j, k nested, k fastest), InstanceNorm,
+    depthwise-separable reduction (medformer_utils.py:142-178)."""
+
+    def __init__(self, dim, out_dim):
+        super().__init__()
+        self.reduction = DepthwiseSeparableConv(8 * dim, out_dim)
+        self.norm = nn.Identity()                          # InstanceNorm3d(affine=False) has no state; applied functionally below
+
+    def forward(self, x):
+        parts = [x[:, :, i::2, j::2, k::2] for i in range(2) for j in range(2) for k in range(2)]
+        return self.reduction(F.instance_norm(torch.cat(parts, 1), eps=IN_EPS))
+
+
+class SemanticMapGeneration(nn.Module):
+    """map[c, code] = sum_voxels base_proj(x)[c, v] * softmax_v(semantic_proj(x)[code, v]) (medformer_utils.py:206-236)."""
+
+    def __init__(self, feat_dim, map_dim, map_size):
+        super().__init__()
+        self.map_size = tuple(map_size)
+        codes = self.map_size[0] * self.map_size[1] * self.map_size[2]
+        self.base_proj = nn.Conv3d(feat_dim, map_dim, 3, padding=1, bias=False)
+        self.semantic_proj = nn.Conv3d(feat_dim, codes, 3, padding=1, bias=False)
+
+    def forward(self, x):
+        feat = _conv(x, self.base_proj).flatten(2)
+        weight = F.softmax(_conv(x, self.semantic_proj).flatten(2), dim=2)
+        return torch.matmul(feat, weight.transpose(1, 2)).reshape(x.shape[0], feat.shape[1], *self.map_size)
+
+
+class _PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(self.norm(x))
+
+
+class _TokenAttention(nn.Module):
+    def __init__(self, dim, heads, dim_head):
+        super().__init__()
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.to_qkv = nn.Linear(dim, 3 * heads * dim_head, bias=False)
+        self.to_out = nn.Linear(heads * dim_head, dim)
+
+    def forward(self, x):
+        B, L, _ = x.shape
+        q, k, v = (t.reshape(B, L, self.heads, -1).transpose(1, 2) for t in self.to_qkv(x).chunk(3, -1))
+        att = F.softmax(torch.matmul(q, k.transpose(-1, -2)) * self.scale, -1)
+        return self.to_out(torch.matmul(att, v).transpose(1, 2).reshape(B, L, -1))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class TransformerBlock(nn.Module):
+    """Pre-LayerNorm attention + GELU MLP with residuals (trans_layers.py:107-125); `layers.i.0.fn.to_qkv`, `layers.i.1.fn.fc1`..."""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim):
+        super().__init__()
+        self.layers = nn.ModuleList(nn.ModuleList([_PreNorm(dim, _TokenAttention(dim, heads, dim_head)), _PreNorm(dim, _Mlp(dim, mlp_dim))])
+                                    for _ in range(depth))
+
+    def forward(self, x):
+        for attn, ffn in self.layers:
+            x = attn(x) + x
+            x = ffn(x) + x
+        return x
+
+
+class SemanticMapFusion(nn.Module):
+    """The three stages' maps as one token sequence through a transformer (medformer_utils.py:239-273)."""
+
+    def __init__(self, in_dims, dim, heads, depth=1):
+        super().__init__()
+        self.dim = dim
+        self.in_proj = nn.ModuleList(nn.Conv3d(c, dim, 1, bias=False) for c in in_dims)
+        self.fusion = TransformerBlock(dim, depth, heads, dim // heads, dim)
+        self.out_proj = nn.ModuleList(nn.Conv3d(dim, c, 1, bias=False) for c in in_dims)
+
+    def forward(self, maps):
+        B, _, D, H, W = maps[0].shape
+        toks = torch.cat([_conv(m, p).flatten(2).transpose(1, 2) for m, p in zip(maps, self.in_proj)], 1)
+        outs = self.fusion(toks).chunk(len(maps), 1)
+        return [_conv(o.transpose(1, 2).reshape(B, self.dim, D, H, W), p) for o, p in zip(outs, self.out_proj)]
+
+
+class inconv(nn.Module):
+    """Conv3d(1 -> C) + BasicBlock on the gfx950 kernels (medformer_utils.py:277-291)."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv1 = nn.Conv3d(in_ch, out_ch, 3, padding=1, bias=False)
+        self.conv2 = BasicBlock(out_ch, out_ch)
+
+    def forward(self, img, dtype):
+        x, mr = ops.StemFn.apply(img, self.conv1.weight, dtype)
+        return Feat(*self.conv2(x, mr))
+
+
+def _run_blocks(blocks, feat, dtype, second=None):
+    """BasicBlocks on the HIP path; `second` is an optional second source of the first block (the concat is not materialised)."""
+    x, mr = feat.cl(dtype)
+    for i, blk in enumerate(blocks):
+        if i == 0 and second is not None:
+            xb, mrb = second.cl(dtype)
+            x, mr = blk(x, mr, xb, mrb)
+        else:
+            x, mr = blk(x, mr)
+    return Feat(x, mr)
+
+
+class down_block(nn.Module):
+    def __init__(self, in_ch, out_ch, conv_num, trans_num, heads=4, dim_head=64, expansion=4, map_size=(8, 8, 8), map_generate=False):
+        super().__init__()
+        self.map_generate = map_generate
+        if map_generate:
+            self.map_gen = SemanticMapGeneration(out_ch, out_ch, map_size)
+        self.patch_merging = PatchMerging(in_ch, out_ch)
+        self.conv_blocks = nn.Sequential(*[BasicBlock(out_ch, out_ch) for _ in range(conv_num)])
+        self.trans_blocks = BasicLayer(out_ch, out_ch, out_ch, trans_num, heads, dim_head, expansion)
+
+    def forward(self, feat, dtype):
+        out = Feat(t=self.patch_merging(feat.t()))
+        if len(self.conv_blocks):
+            out = _run_blocks(self.conv_blocks, out, dtype)
+        smap = self.map_gen(out.t()) if self.map_generate else None
+        if len(self.trans_blocks.blocks):
+            t, smap = self.trans_blocks(out.t(), smap)
+            out = Feat(t=t)
+        return out, smap
+
+
+class up_block(nn.Module):
+    def __init__(self, in_ch, out_ch, conv_num, trans_num, heads=4, dim_head=64, expansion=4, map_shortcut=False, no_map_out=False):
+        super().__init__()
+        self.map_reduction = nn.Conv3d(in_ch + out_ch, out_ch, 1, bias=False) if map_shortcut else nn.Identity()
+        self.trans_blocks = BasicLayer(in_ch + out_ch, out_ch, out_ch, trans_num, heads, dim_head, expansion, no_map_out)
+        dims = [in_ch + out_ch if trans_num == 0 else out_ch] + [out_ch] * conv_num
+        self.conv_blocks = nn.Sequential(*[BasicBlock(dims[i], out_ch) for i in range(conv_num)])
+
+    def forward(self, x1, x2, map1, map2, dtype):
+        """x1: coarse features, x2: encoder skip; cat([up(x1), x2]) (medformer_utils.py:377-378)."""
+        smap = map1
+        if not isinstance(self.map_reduction, nn.Identity) and map2 is not None:
+            smap = _conv(torch.cat([map1, map2], 1), self.map_reduction)
+        has_trans, has_conv = len(self.trans_blocks.blocks) > 0, len(self.conv_blocks) > 0
+        if has_trans or not has_conv:
+            up = F.interpolate(x1.t(), size=x2.t().shape[-3:], mode='trilinear', align_corners=True)
+            out = Feat(t=torch.cat([up, x2.t()], 1))
+            if has_trans:
+                t, smap = self.trans_blocks(out.t(), smap)
+                out = Feat(t=t)
+            if has_conv:
+                out = _run_blocks(self.conv_blocks, out, dtype)
+            return out, smap
+        # convolution-only stage: HIP trilinear up-sampling (it also produces the statistics) feeding a two-source first block
+        xl, _ = x1.cl(dtype)
+        xs, _ = x2.cl(dtype)
+        up, mru = ops.UpsampleFn.apply(xl, tuple(xs.shape[1:4]))
+        return _run_blocks(self.conv_blocks, Feat(up, mru), dtype, second=x2), smap

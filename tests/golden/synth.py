@@ -245,3 +245,9 @@ def loader_crop(i, classes):
 def loader_report_rows(name):
     return [{'BDMAP_ID': name, 'Standardized Organ': r['organ'], 'Standardized Location': r['location'],
              'Tumor Size (mm)': r['size']} for r in LOADER_REPORTS[name]['rows']]
+
+
+# ---- MedFormer: tiny configuration shared by the golden generator, the oracle test and the GPU parity test
+MEDFORMER_TINY = dict(base_chan=8, map_size=[2, 2, 2], conv_num=[2, 0, 0, 0, 0, 0, 2, 2], trans_num=[0, 1, 2, 1, 1, 1, 0, 0],
+                      chan_num=[16, 32, 64, 80, 64, 32, 16, 8], num_heads=[1, 2, 4, 5, 4, 2, 1, 1], fusion_depth=1, fusion_dim=80,
+                      fusion_heads=5, aux_loss=True, size=32, seed=5)

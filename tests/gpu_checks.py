@@ -408,6 +408,44 @@ def check_unet_tiny(mode):
 
 
 # ================================================================================================ losses
+def check_medformer_tiny(mode):
+    """MedFormer forward + backward against the fixture of the reference class (tests/golden/medformer.npz): both heads,
+    encoder features / semantic maps (summaries) and a strided sample of every parameter gradient."""
+    from rsuper_amd.model.dim3.medformer import MedFormer
+    g = golden('medformer')
+    cfg = synth.MEDFORMER_TINY
+    net = MedFormer(1, len(synth.TINY_CLASSES), compute_dtype=mode, **{k: v for k, v in cfg.items() if k not in ('size', 'seed')})
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: T(v) for k, v in synth.fill_state_dict(shapes, cfg['seed']).items()})
+    net = net.to(DEV)
+    y, aux = net(T(synth.image(1, cfg['size'], seed=1234)).to(DEV))['segmentation']
+    go = synth.rng(77).standard_normal(tuple(y.shape)).astype(np.float32) / y.numel()
+    ga = synth.rng(78).standard_normal(tuple(aux.shape)).astype(np.float32) / aux.numel()
+    ((y * T(go).to(DEV)).sum() + (aux * T(ga).to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    e_y = err_for(mode, T(synth.subsample(y.detach().cpu().numpy(), 8192)[0]), T(g['logits_sub']))
+    e_a = err_for(mode, T(synth.subsample(aux.detach().cpu().numpy(), 8192)[0]), T(g['aux_sub']))
+    gmax = max(float(g[f'g_{k}_summary'][2]) for k, _ in net.named_parameters())
+    worst, wk = 0.0, ''
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            return result(f'medformer_tiny[{mode}]', float('inf'), 1.0, f'no gradient for {k}')
+        gsub = synth.subsample(p.grad.cpu().numpy(), 1024)[0]
+        # a few tensors have structurally zero gradients (a bias in front of an InstanceNorm): floor the scale at 1e-3 of the largest
+        sc = max(g[f'g_{k}_summary'][2], 1e-3 * gmax)
+        e = float(np.abs(gsub - g[f'g_{k}_sub']).max() / sc) if mode == 'f32' else float(np.linalg.norm(gsub - g[f'g_{k}_sub']) /
+                                                                                         max(np.linalg.norm(g[f'g_{k}_sub']), 1e-3 * gmax * 32))
+        if e > worst:
+            worst, wk = e, k
+    # f32: logits 1e-4 like every f32 parity check.  Gradients: this deep tiny net is ill-conditioned in fp32 -- the fp32 reference fixture
+    # is itself 3.2e-2 of max away from the float64 restatement, the HIP path 3.4e-2 (tools/medformer_diag.py) -- hence 6e-2.
+    # bf16 (conv stages only; the attention stages stay fp32): loose network-level bounds; per-layer bf16 parity of the conv kernels is
+    # checked block by block.
+    tol_y, tol_g = (1e-4, 6e-2) if mode == 'f32' else (0.15, 1.0)
+    return result(f'medformer_tiny[{mode}]', max(e_y / tol_y, e_a / tol_y, worst / tol_g), 1.0,
+                  f'logits {e_y:.2e} aux {e_a:.2e} (tol {tol_y}); worst grad {worst:.2e} @ {wk} (tol {tol_g})')
+
+
 def check_plane_partials():
     from rsuper_amd.training import losses_foundation as lf
     B, C, S = 2, 3, 12
@@ -718,4 +756,5 @@ def all_checks(quick=False):
            (check_seg_from_sums, (1, 300, True, 3)), (check_dilate, ()), (check_isolate_tumor, ()), (check_gwrp, ()), (check_optimizer, ())]
     cs += [(check_calculate_loss, c) for c in LOSS_CASES]
     cs += [(check_train_steps, ('f32',)), (check_train_steps, ('bf16',))]
+    cs += [(check_medformer_tiny, ('f32',)), (check_medformer_tiny, ('bf16',))]
     return cs
