@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256) void upsample_fwd2_kernel(UpParams p) {
 // taps in the same ascending (a, b, c) order as upsample_bwd_kernel (zero-weight candidates it skipped contributed
 // nothing), so results are bit-identical; the innermost loop is unrolled to the block's maximal W count and its loads go
 // through a buffer descriptor (out-of-range -> zeros, no branch), so NW loads are in flight per (a, b).
-struct UpEnt { int lo, n; float w[6]; };
+constexpr int UP_MAXW = 12;      // contributing outputs per input index: <= 2 / scale + 2, i.e. up to 4x up-sampling (the aux head)
+struct UpEnt { int lo, n; float w[UP_MAXW]; };
 template <typename T, int NW>
 __device__ __forceinline__ void up_bwd_rows(const UpParams& p, const UpEnt* td, const UpEnt* th, const UpEnt* tw, int n, uint32_t i0, uint32_t total,
                                             uint32_t stride) {
@@ -557,18 +558,26 @@ __global__ __launch_bounds__(256) void upsample_bwd2_kernel(UpParams p) {
     for (int t = threadIdx.x; t < p.ID + p.IH + p.IW; t += 256) {
         const int axis = t < p.ID ? 0 : (t < p.ID + p.IH ? 1 : 2);
         const int i = axis == 0 ? t : (axis == 1 ? t - p.ID : t - p.ID - p.IH);
-        const UpAxis a = axis == 0 ? up_axis(i, sd, p.ID, p.OD) : (axis == 1 ? up_axis(i, sh, p.IH, p.OH) : up_axis(i, sw, p.IW, p.OW));
-        int first = 6, last = -1;
+        const float sc = axis == 0 ? sd : (axis == 1 ? sh : sw);
+        const int I = axis == 0 ? p.ID : (axis == 1 ? p.IH : p.IW), O = axis == 0 ? p.OD : (axis == 1 ? p.OH : p.OW);
+        int lo, hi;
+        up_range(i, sc, O, lo, hi);
+        constexpr int CAND = 16;                                  // candidate window; the launcher rejects scales that need more
+        float cw[CAND];
+        int first = CAND, last = -1;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) if (a.w[k] != 0.f) { if (first == 6) first = k; last = k; }
+        for (int k = 0; k < CAND; ++k) {
+            cw[k] = lo + k <= hi ? up_weight(lo + k, i, sc, I) : 0.f;
+            if (cw[k] != 0.f) { if (first == CAND) first = k; last = k; }
+        }
         UpEnt e;
-        e.lo = a.lo + (first == 6 ? 0 : first);
-        e.n = last < 0 ? 0 : last - first + 1;
+        e.lo = lo + (first == CAND ? 0 : first);
+        e.n = last < 0 ? 0 : min(last - first + 1, UP_MAXW);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < UP_MAXW; ++k) {
             float wv = 0.f;
 #pragma unroll
-            for (int m = 0; m < 6; ++m) if (m == first + k && m <= last) wv = a.w[m];
+            for (int m = 0; m < CAND; ++m) if (m == first + k && m <= last) wv = cw[m];
             e.w[k] = wv;
         }
         tab[t] = e;
@@ -580,7 +589,8 @@ __global__ __launch_bounds__(256) void upsample_bwd2_kernel(UpParams p) {
     const uint32_t total = (uint32_t)(p.ID * p.IH * p.IW) * CV;
     const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
     if (nwmax <= 4) up_bwd_rows<T, 4>(p, td, th, tw, blockIdx.y, i0, total, stride);
-    else up_bwd_rows<T, 6>(p, td, th, tw, blockIdx.y, i0, total, stride);
+    else if (nwmax <= 6) up_bwd_rows<T, 6>(p, td, th, tw, blockIdx.y, i0, total, stride);
+    else up_bwd_rows<T, UP_MAXW>(p, td, th, tw, blockIdx.y, i0, total, stride);
 }
 
 // ------------------------------------------------------------------------------------------------ stem: Conv3d(1 -> C, 3x3x3)
@@ -974,8 +984,13 @@ int rs_launch_upsample(const UpParams& p, int dtype, int bwd, int blocks, hipStr
         }
     } else {
         static const bool v1 = getenv("RSUPER_UPSAMPLE_V1") != nullptr;
+        // contributing outputs per input index < 2 * (O-1)/(I-1) + 2: the table kernel holds 12 (up to 4x: the aux head); the
+        // first-generation kernel looks at 6 candidates (2x) and is kept for A/B runs only
+        auto ratio = [](int O, int I) { return I > 1 ? (double)(O - 1) / (double)(I - 1) : (double)O; };
+        const double rmax = fmax(ratio(p.OD, p.ID), fmax(ratio(p.OH, p.IH), ratio(p.OW, p.IW)));
+        if (!v1 && 2.0 * rmax + 2.0 > (double)UP_MAXW + 1e-9) return RS_ERR_UNSUPPORTED;
         const int b = rs_elem_blocks((size_t)p.ID * p.IH * p.IW * CV);
-        const size_t tab = (size_t)(p.ID + p.IH + p.IW) * 32;
+        const size_t tab = (size_t)(p.ID + p.IH + p.IW) * sizeof(UpEnt);
         const bool small = (size_t)p.OD * p.OH * p.OW * p.ldy * (dtype == RS_F32 ? 4 : 2) < 0xFFFFFFFFull && (size_t)p.ID * p.IH * p.IW * CV < 0xFFFFFFFFull && tab <= 48 * 1024;
         if (v1 || !small) {
             if (dtype == RS_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(b, p.N), dim3(256), 0, st, p);

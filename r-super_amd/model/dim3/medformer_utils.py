@@ -56,6 +56,18 @@ class Feat:
         return self._t
 
 
+def upsample_trilinear(t, size):
+    """F.interpolate(t, size, mode='trilinear', align_corners=True) on a logical NCDHW fp32 tensor through the HIP kernels
+    (hip/ops.py UpsampleFn): deterministic backward (ATen's uses atomics) and no NCDHW round trip.  Channels are zero-padded to the
+    kernel's 16-byte vector (4 floats)."""
+    C = t.shape[1]
+    pad = (-C) % 4
+    x = t.permute(0, 2, 3, 4, 1)
+    x = F.pad(x, (0, pad)) if pad else x
+    y, _ = ops.UpsampleFn.apply(x.contiguous().float(), tuple(size))
+    return y[..., :C].permute(0, 4, 1, 2, 3)
+
+
 def _conv(x, conv, groups=1):
     w = conv.weight
     return F.conv3d(x, w, conv.bias, 1, w.shape[-1] // 2, 1, groups)
@@ -326,7 +338,7 @@ class up_block(nn.Module):
             smap = _conv(torch.cat([map1, map2], 1), self.map_reduction)
         has_trans, has_conv = len(self.trans_blocks.blocks) > 0, len(self.conv_blocks) > 0
         if has_trans or not has_conv:
-            up = F.interpolate(x1.t(), size=x2.t().shape[-3:], mode='trilinear', align_corners=True)
+            up = upsample_trilinear(x1.t(), x2.t().shape[-3:])
             out = Feat(t=torch.cat([up, x2.t()], 1))
             if has_trans:
                 t, smap = self.trans_blocks(out.t(), smap)

@@ -722,7 +722,8 @@ def all_checks(quick=False):
             (check_conv_bwd, (mode, 1, (5, 6, 7), 8, 16, 8, True)),
             (check_conv_bwd, (mode, 1, (8, 12, 20), 64, 32, 64, True)),
             (check_conv_bwd, (mode, 1, (6, 6, 6), 80, 0, 80, False)),
-            (check_pool, (mode,)), (check_upsample, (mode,)), (check_upsample, (mode, 16, 6, 12, 70)),
+            (check_pool, (mode,)), (check_upsample, (mode,)), (check_upsample, (mode, 16, 6, 12, 70)), (check_upsample, (mode, 8, 8, 32, 71)), (check_upsample, (mode, 8, 2, 4, 72)),
+            (check_upsample, (mode, 8, 5, 9, 73)),
             (check_stem, (mode,)), (check_stem, (mode, 32, 16)), (check_head, (mode,)), (check_head, (mode, 32, 42, 12)),
             (check_basic_block, (mode, 'b8_16', 8, 16, 12, 1)), (check_basic_block, (mode, 'b16_16', 16, 16, 10, 2)),
             (check_basic_block, (mode, 'b24_8', 24, 8, 12, 3)),

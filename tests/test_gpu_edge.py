@@ -465,3 +465,47 @@ def test_augmented_loader_feeds_packed_ingest(tmp_path):
     train = AugmentedCropDataset.from_directory(crops, classes, packed=True)
     hist = main_worker(0, 1, 0, args, trainset=train)
     assert len(hist) == 1 and all(np.isfinite(v) for v in hist[0].values()) and 'overall' in hist[0]
+
+
+@pytest.mark.gpu
+def test_medformer_train_steps_deep_supervision():
+    """MedFormer (8f-1) through the training step: deep-supervision output [final, aux] (medformer.py:205-222) into calculate_loss with
+    aux_weight (losses_foundation.py:905-930), backward through the HIP conv stages and the attention stages, clip + fused AdamW + EMA over
+    every parameter kind (conv, depthwise, Linear, LayerNorm, biases); finite, decreasing on a repeated batch, and reproducible."""
+    import argparse
+    import synth
+    from rsuper_amd.model.dim3.medformer import MedFormer
+    from rsuper_amd.train_ddp import train_step, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    classes = synth.TINY_CLASSES
+    cfg = {k: v for k, v in synth.MEDFORMER_TINY.items() if k not in ('size', 'seed')}
+    largs = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1, volume_loss_tolerance=0.2,
+                               ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                               classification_branch=False, ema=True, ema_alpha=0.99)
+    bt = synth.batch(2, 32, classes, ['mask', 'report'], seed=11, diam_range=(4.0, 8.0), max_tumors=2)
+    dev = 'cuda'
+    batch = dict(image=torch.from_numpy(synth.image(2, 32, seed=5)).to(dev), label=torch.from_numpy(bt['label']).to(dev),
+                 unk_channels=torch.from_numpy(bt['unk_channels']).to(dev), mask=torch.from_numpy(bt['mask']).to(dev),
+                 volumes=torch.from_numpy(bt['volumes']).to(dev), diameters=torch.from_numpy(bt['diameters']).to(dev))
+
+    def run(mode):
+        torch.manual_seed(0)
+        net = MedFormer(1, len(classes), compute_dtype=mode, **cfg).to(dev)
+        ema = make_ema(net)
+        opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        hist = []
+        for i in range(8):
+            loss, gnorm = train_step(net, ema, opt, batch, largs, classes, i)
+            hist.append({k: float(v.detach()) for k, v in loss.items()})
+        return hist, net, ema
+
+    for mode in ('f32', 'bf16'):
+        h1, net, ema = run(mode)
+        assert all(np.isfinite(v) for e in h1 for v in e.values()), h1
+        assert {'segmentation', 'overall'} <= set(h1[0]) and h1[-1]['overall'] < h1[0]['overall'], (mode, h1[0], h1[-1])
+        h2, _, _ = run(mode)
+        assert h1 == h2, 'MedFormer training steps are not reproducible'
+        moved = sum(float((a - b).abs().sum()) for a, b in zip(net.state_dict().values(), ema.state_dict().values()))
+        assert moved > 0                                    # EMA lags the weights
+        sd = net.state_dict()
+        assert 'down2.trans_blocks.blocks.0.attn.feat_qv.depthwise.weight' in sd and 'map_fusion.fusion.layers.0.0.fn.to_qkv.weight' in sd

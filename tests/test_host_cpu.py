@@ -68,7 +68,16 @@ def test_get_model_and_yaml_keys():
     net = get_model(args)
     assert net.outc.weight.shape == (26, 32, 1, 1, 1)
     with pytest.raises(NotImplementedError):
-        get_model(argparse.Namespace(model='medformer', dimension='3d', **cfg))
+        get_model(argparse.Namespace(model='attention_unet', dimension='3d', **cfg))
+    # MedFormer from its YAML (reference key names, config/abdomenatlas_ufo/medformer_3d.yaml); chan_num is not forwarded, as in the reference
+    mcfg = yaml.safe_load(open(os.path.join(ROOT, 'r-super_amd', 'config', 'abdomenatlas_ufo', 'medformer_3d.yaml')))
+    margs = argparse.Namespace(model='medformer', dimension='3d', classification_branch=False, **mcfg)
+    mf = get_model(margs, classes=['c%d' % i for i in range(42)])
+    assert mf.outc.weight.shape == (42, 32, 1, 1, 1) and mf.aux_out.weight.shape == (42, 128, 1, 1, 1)
+    assert len(mf.down4.trans_blocks.blocks) == 6 and len(mf.up4.conv_blocks) == 2 and mf.map_fusion.in_proj[2].weight.shape == (320, 320, 1, 1, 1)
+    assert 35e6 < sum(p.numel() for p in mf.parameters()) < 40e6          # SURVEY: 37.9 M parameters
+    with pytest.raises(NotImplementedError):
+        get_model(argparse.Namespace(**{**vars(margs), 'classification_branch': True}))
 
 
 def test_lr_schedule_and_ema_alpha(golden):
