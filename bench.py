@@ -123,14 +123,20 @@ def respawn_under_torchrun(args):
 class Leg:
     """One model + optimiser + resident synthetic batch of the bench workload."""
 
-    def __init__(self, args, dtype, report, rank, world, local, force_ddp, classes, B, S):
+    def __init__(self, args, dtype, report, rank, world, local, force_ddp, classes, B, S, medformer=False):
         import synth
         from rsuper_amd.model.dim3.unet import UNet
         from rsuper_amd.train_ddp import wrap_ddp, make_ema
         from rsuper_amd.training.utils import FusedAdamWEMA
         dev = f'cuda:{local}'
         torch.manual_seed(0)                 # identical random-init weights on every rank and in every leg
-        self.net = UNet(1, args.base, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype=dtype).to(dev)
+        if medformer:       # config/abdomenatlas_ufo/medformer_3d.yaml: the network R-Super trains (SURVEY 8f-1), deep supervision on
+            from rsuper_amd.model.dim3.medformer import MedFormer
+            self.net = MedFormer(1, len(classes), base_chan=args.base, map_size=[3, 3, 3], conv_num=[2, 0, 0, 0, 0, 0, 2, 2],
+                                 trans_num=[0, 2, 4, 6, 4, 2, 0, 0], num_heads=[1, 4, 8, 10, 8, 4, 1, 1], fusion_depth=2, fusion_dim=320,
+                                 fusion_heads=10, expansion=4, aux_loss=True, compute_dtype=dtype).to(dev)
+        else:
+            self.net = UNet(1, args.base, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype=dtype).to(dev)
         self.ema = make_ema(self.net)
         self.model = wrap_ddp(self.net, local) if (world > 1 or force_ddp) else self.net
         self.opt = FusedAdamWEMA(self.net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
@@ -288,6 +294,17 @@ def main():
             sec['config3_workload'] = 'same UNet + Volume + Ball report losses (ball_dice_both, weight 0.1, 50/50 mask/report batch), BASELINE configs[2]'
             l3.close()
             del l3
+        if not args.report and args.base == 32:
+            lm = Leg(args, args.dtype, False, rank, world, local, False, classes, B, S, medformer=True)
+            nm = min(n2, 10)
+            sec['medformer_ms_per_step'] = lm.timed(nm, 3) / nm * 1e3
+            sec['medformer_final_loss'] = lm.loss()
+            sec['medformer_workload'] = ('MedFormer of config/abdomenatlas_ufo/medformer_3d.yaml (37.9 M parameters, deep supervision), same batch and '
+                                         'segmentation loss: conv stem / BasicBlock stages / up-sampling / head on the HIP kernels, attention stages as '
+                                         'fp32 PyTorch-ROCm ops (first version, SURVEY 8f-1)')
+            lm.close()
+            del lm
+            torch.cuda.empty_cache()
         if args.dtype == 'bf16':
             lf32 = Leg(args, 'f32', args.report, rank, world, local, False, classes, B, S)
             n3 = min(n2, 10)

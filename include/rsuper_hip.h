@@ -172,6 +172,17 @@ int rsuper_window_accumulate(const float* logits, float* acc, int BK, int wd, in
 int rsuper_window_normalize(float* acc, const float* cd, const float* ch, const float* cw, long BK, int D, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Depthwise 3x3x3 convolution (groups = C, stride 1, padding 1, no bias), channels-last f32 [N][D][H][W][C], C % 4 == 0 --
+ * DepthwiseSeparableConv.depthwise / MBConv.depthwise of MedFormer (model/dim3/conv_layers.py:126-157, :198-240).
+ * w: (C, 1, 3, 3, 3) as in the state_dict.  flip = 1 evaluates the data gradient (x := dy, taps mirrored).
+ * wgrad: part = workspace of rsuper_depthwise3_rows(N*D*H*W) * 27 * C floats; dw (C, 1, 3, 3, 3) is overwritten (fixed-order
+ * reduction, deterministic).
+ * ------------------------------------------------------------------------------------------------ */
+int rsuper_depthwise3_rows(long vox);
+int rsuper_depthwise3_fwd(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, void* stream);
+int rsuper_depthwise3_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int D, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Binary morphology and selection -- training/losses_foundation.py
  * ------------------------------------------------------------------------------------------------ */
 /* dilate_volume :22-46 (iterated ball dilation).  in/out/tmp: nvol volumes of D*H*W bytes; tmp may be NULL when

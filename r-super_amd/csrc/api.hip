@@ -283,6 +283,15 @@ int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, 
     PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, flags & 1, V, k ? (flags >> 1) & 1 : 0};
     return rs_launch_plane_partials(p, planes, 1, ST(stream));
 }
+int rsuper_depthwise3_rows(long vox) { return rs_depthwise_rows(vox); }
+int rsuper_depthwise3_fwd(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, void* stream) {
+    if (!x || !w || !y || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (flip != 0 && flip != 1)) return RS_ERR_ARG;
+    return rs_launch_depthwise(x, w, y, N, D, H, W, C, flip, ST(stream));
+}
+int rsuper_depthwise3_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int D, int H, int W, int C, void* stream) {
+    if (!x || !dy || !part || !dw || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return RS_ERR_ARG;
+    return rs_launch_depthwise_wgrad(x, dy, part, dw, N, D, H, W, C, ST(stream));
+}
 int rsuper_seg_from_sums(const float* sums, const float* cw, int B, int C, size_t V, double scale, float* loss, float* dsums, void* stream) {
     if (!sums || !loss || !dsums || B <= 0 || C <= 0 || V == 0) return RS_ERR_ARG;
     SegSumsParams p = {sums, cw, B, C, 1.0 / ((double)B * C * (double)V), scale, loss, dsums};

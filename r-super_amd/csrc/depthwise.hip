@@ -1,0 +1,178 @@
+// Depthwise 3x3x3 convolution (groups = C, stride 1, zero padding 1, no bias) on channels-last fp32 activations -- the
+// `depthwise` member of DepthwiseSeparableConv and MBConv in MedFormer's attention stages (SURVEY 8f-1;
+// rsuper_train/model/dim3/conv_layers.py:126-157, :198-240).  HBM / L2-bound elementwise-with-halo work, no MFMA: one
+// output element costs 27 multiply-adds on data it shares with its neighbours.
+//
+//   forward        y[v][c]  = sum_tap w[c][tap] * x[v + off(tap)][c]
+//   data gradient  dx[v][c] = sum_tap w[c][26 - tap] * dy[v + off(tap)][c]          (same kernel, flipped taps)
+//   weight grad.   dw[c][tap] = sum_v dy[v][c] * x[v + off(tap)][c]                 (per-block partial rows + fixed-order reduce)
+//
+// Thread = (voxel, 4 consecutive channels): the 16 threads of a 64-channel group read 256 contiguous bytes per neighbour.
+// A block owns one 64-channel group (blockIdx.y) so its 27 x 64 weights sit in LDS transposed to [tap][channel]
+// (the state_dict layout (C, 1, 3, 3, 3) has the tap innermost).  MIOpen runs these shapes on its naive reference kernels
+// (2.4-2.9 ms per call; 1.2 s per training step at 96^3).
+#include "common.hpp"
+#include "misc.hpp"
+
+namespace {
+
+constexpr int DW_CG = 64;              // channels per block
+constexpr int DW_VPB = 16;             // voxels per pass: 256 threads = 16 voxels x 16 channel vectors
+
+struct DwParams {
+    const float* x;        // [N][D][H][W][C] input (forward) / dy (data gradient)
+    const float* w;        // (C, 1, 3, 3, 3)
+    float* y;              // output, same layout
+    int N, D, H, W, C;
+    int flip;              // 1: use w[c][26 - tap] (data gradient)
+};
+
+__global__ __launch_bounds__(256) void depthwise_fwd_kernel(DwParams p) {
+    __shared__ float wl[27][DW_CG];
+    const int c0 = blockIdx.y * DW_CG;
+    const int ncl = min(DW_CG, p.C - c0);
+    for (int i = threadIdx.x; i < 27 * DW_CG; i += 256) {
+        const int c = i / 27, tap = i - c * 27;                       // coalesced over the (c, tap) source order
+        wl[p.flip ? 26 - tap : tap][c] = c < ncl ? p.w[(size_t)(c0 + c) * 27 + tap] : 0.f;
+    }
+    __syncthreads();
+    const int cv = threadIdx.x & 15, vl = threadIdx.x >> 4;
+    const int c = c0 + cv * 4;
+    if (c >= p.C) return;
+    float4 wr[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) wr[t] = *(const float4*)&wl[t][cv * 4];
+    const long vox = (long)p.N * p.D * p.H * p.W;
+    for (long v = (long)blockIdx.x * DW_VPB + vl; v < vox; v += (long)gridDim.x * DW_VPB) {
+        const int xw = (int)(v % p.W);
+        long t2 = v / p.W;
+        const int yh = (int)(t2 % p.H); t2 /= p.H;
+        const int zd = (int)(t2 % p.D);
+        const float* base = p.x + (size_t)v * p.C + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const bool okd = (unsigned)(zd + kd - 1) < (unsigned)p.D;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const bool okh = okd && (unsigned)(yh + kh - 1) < (unsigned)p.H;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const bool ok = okh && (unsigned)(xw + kw - 1) < (unsigned)p.W;
+                    const long off = (((long)(kd - 1) * p.H + (kh - 1)) * p.W + (kw - 1)) * p.C;
+                    // clamp the address instead of branching around the load; the value is masked by the select below
+                    const float4 q = *(const float4*)(ok ? base + off : base);
+                    const float4 wv = wr[(kd * 3 + kh) * 3 + kw];
+                    acc.x = fmaf(ok ? q.x : 0.f, wv.x, acc.x);
+                    acc.y = fmaf(ok ? q.y : 0.f, wv.y, acc.y);
+                    acc.z = fmaf(ok ? q.z : 0.f, wv.z, acc.z);
+                    acc.w = fmaf(ok ? q.w : 0.f, wv.w, acc.w);
+                }
+            }
+        }
+        *(float4*)(p.y + (size_t)v * p.C + c) = acc;
+    }
+}
+
+// Weight gradient, stage 1: block (bx, channel group) accumulates dw over its voxels in registers (27 taps x 4 channels per
+// thread), then the 16 voxel lanes of each channel vector are summed through LDS in a fixed order and the block writes one
+// row part[bx][tap][c].  Stage 2 sums the rows (fixed order: deterministic) into (C, 1, 3, 3, 3).
+struct DwWgParams {
+    const float* x; const float* dy;
+    float* part;           // [rows][27][C]
+    int N, D, H, W, C;
+};
+
+__global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwWgParams p) {
+    __shared__ float red[4][27][DW_CG + 4];                        // one partial per wave (29 KB)
+    const int c0 = blockIdx.y * DW_CG;
+    const int cv = threadIdx.x & 15, vl = threadIdx.x >> 4;
+    const int c = c0 + cv * 4;
+    const bool cok = c < p.C;
+    float4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long vox = (long)p.N * p.D * p.H * p.W;
+    if (cok)
+        for (long v = (long)blockIdx.x * DW_VPB + vl; v < vox; v += (long)gridDim.x * DW_VPB) {
+            const int xw = (int)(v % p.W);
+            long t2 = v / p.W;
+            const int yh = (int)(t2 % p.H); t2 /= p.H;
+            const int zd = (int)(t2 % p.D);
+            const float4 g = *(const float4*)(p.dy + (size_t)v * p.C + c);
+            const float* base = p.x + (size_t)v * p.C + c;
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const bool okd = (unsigned)(zd + kd - 1) < (unsigned)p.D;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const bool okh = okd && (unsigned)(yh + kh - 1) < (unsigned)p.H;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const bool ok = okh && (unsigned)(xw + kw - 1) < (unsigned)p.W;
+                        const long off = (((long)(kd - 1) * p.H + (kh - 1)) * p.W + (kw - 1)) * p.C;
+                        const float4 q = *(const float4*)(ok ? base + off : base);
+                        float4& a = acc[(kd * 3 + kh) * 3 + kw];
+                        a.x = fmaf(ok ? q.x : 0.f, g.x, a.x);
+                        a.y = fmaf(ok ? q.y : 0.f, g.y, a.y);
+                        a.z = fmaf(ok ? q.z : 0.f, g.z, a.z);
+                        a.w = fmaf(ok ? q.w : 0.f, g.w, a.w);
+                    }
+                }
+            }
+        }
+    // the four voxel lanes of a wave that share a channel vector sit 16 and 32 lanes apart: two butterfly steps, fixed order
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        float4 a = acc[t];
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+        }
+        if ((threadIdx.x & 63) < 16) *(float4*)&red[threadIdx.x >> 6][t][cv * 4] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * DW_CG; i += 256) {
+        const int t = i / DW_CG, cc = i - t * DW_CG;
+        if (c0 + cc >= p.C) continue;
+        p.part[((size_t)blockIdx.x * 27 + t) * p.C + c0 + cc] = (red[0][t][cc] + red[1][t][cc]) + (red[2][t][cc] + red[3][t][cc]);
+    }
+}
+
+__global__ __launch_bounds__(256) void depthwise_wgrad_reduce_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                     // i = tap * C + c
+    if (i >= 27 * C) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 4 <= rows; r += 4) {
+        s0 += part[(size_t)r * 27 * C + i]; s1 += part[(size_t)(r + 1) * 27 * C + i];
+        s2 += part[(size_t)(r + 2) * 27 * C + i]; s3 += part[(size_t)(r + 3) * 27 * C + i];
+    }
+    for (; r < rows; ++r) s0 += part[(size_t)r * 27 * C + i];
+    const int tap = i / C, c = i - tap * C;
+    dw[(size_t)c * 27 + tap] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace
+
+int rs_depthwise_rows(long vox) {
+    long b = (vox + DW_VPB * 8 - 1) / (DW_VPB * 8);                   // >= 8 passes per block
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, hipStream_t st) {
+    DwParams p = {x, w, y, N, D, H, W, C, flip};
+    const long vox = (long)N * D * H * W;
+    long bx = (vox + DW_VPB - 1) / DW_VPB;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(depthwise_fwd_kernel, dim3((unsigned)bx, (C + DW_CG - 1) / DW_CG), dim3(256), 0, st, p);
+    return rs_check_launch();
+}
+
+int rs_launch_depthwise_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int D, int H, int W, int C, hipStream_t st) {
+    const int rows = rs_depthwise_rows((long)N * D * H * W);
+    DwWgParams p = {x, dy, part, N, D, H, W, C};
+    hipLaunchKernelGGL(depthwise_wgrad_kernel, dim3(rows, (C + DW_CG - 1) / DW_CG), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(depthwise_wgrad_reduce_kernel, dim3((27 * C + 255) / 256), dim3(256), 0, st, (const float*)part, rows, C, dw);
+    return rs_check_launch();
+}

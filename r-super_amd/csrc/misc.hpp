@@ -50,6 +50,9 @@ struct HeadParams {
     int N, vox, C, K;
 };
 
+int rs_depthwise_rows(long vox);
+int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, hipStream_t st);
+int rs_launch_depthwise_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int D, int H, int W, int C, hipStream_t st);
 int rs_launch_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, int split, float* out, hipStream_t st);
 int rs_elem_blocks(size_t items);
 int rs_launch_in_bwd(const InBwdParams& p, int dtype, hipStream_t st);

@@ -676,6 +676,40 @@ class HeadFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class DepthwiseConvFn(torch.autograd.Function):
+    """Conv3d(C, C, 3, padding=1, groups=C, bias=False) on a channels-last fp32 tensor (N, D, H, W, C) -- the depthwise member of
+    MedFormer's DepthwiseSeparableConv / MBConv (model/dim3/conv_layers.py:126-157, :198-240).  csrc/depthwise.hip."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        if not x.is_cuda:
+            raise _l.RSuperHipError('DepthwiseConvFn needs a device tensor (no CPU fallback)')
+        assert x.dim() == 5 and x.is_contiguous() and x.dtype == torch.float32 and x.shape[-1] % 4 == 0, (tuple(x.shape), x.dtype)
+        N, D, H, W, C = x.shape
+        assert tuple(w.shape) == (C, 1, 3, 3, 3) and w.dtype == torch.float32
+        wc = w.contiguous()
+        y = torch.empty_like(x)
+        _l.check(_L().rsuper_depthwise3_fwd(_ptr(x), _ptr(wc), _ptr(y), N, D, H, W, C, 0, _stream()), 'depthwise3_fwd')
+        ctx.save_for_backward(x, wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, D, H, W, C = x.shape
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _l.check(_L().rsuper_depthwise3_fwd(_ptr(dy), _ptr(w), _ptr(dx), N, D, H, W, C, 1, _stream()), 'depthwise3_bwd_data')
+        if ctx.needs_input_grad[1]:
+            rows = _L().rsuper_depthwise3_rows(N * D * H * W)
+            part = torch.empty((rows, 27, C), device=x.device, dtype=torch.float32)
+            dw = torch.empty_like(w)
+            _l.check(_L().rsuper_depthwise3_wgrad(_ptr(x), _ptr(dy), _ptr(part), _ptr(dw), N, D, H, W, C, _stream()), 'depthwise3_wgrad')
+        return dx, dw
+
+
 def dilate_volume(vol_u8, kernel_size):
     """dilate_volume (training/losses_foundation.py:22-46) on a uint8 0/1 tensor (..., D, H, W)."""
     v = vol_u8.contiguous()

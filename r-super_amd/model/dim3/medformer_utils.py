@@ -59,9 +59,9 @@ class Feat:
 def upsample_trilinear(t, size):
     """F.interpolate(t, size, mode='trilinear', align_corners=True) on a logical NCDHW fp32 tensor through the HIP kernels
     (hip/ops.py UpsampleFn): deterministic backward (ATen's uses atomics) and no NCDHW round trip.  Channels are zero-padded to the
-    kernel's 16-byte vector (4 floats)."""
+    multiple of 8 the activation kernels work in."""
     C = t.shape[1]
-    pad = (-C) % 4
+    pad = (-C) % 8
     x = t.permute(0, 2, 3, 4, 1)
     x = F.pad(x, (0, pad)) if pad else x
     y, _ = ops.UpsampleFn.apply(x.contiguous().float(), tuple(size))
@@ -69,7 +69,18 @@ def upsample_trilinear(t, size):
 
 
 def _conv(x, conv, groups=1):
+    """Convolution of the glue stages on a logical NCDHW fp32 tensor.  1x1x1: a plain GEMM over the channels-last view (rocBLAS /
+    hipBLASLt through torch.matmul, forward and both gradients -- MIOpen's grouped-conv weight gradient for these was 100x slower);
+    depthwise 3x3x3: the HIP kernels of csrc/depthwise.hip; the two dense 3x3x3 projections of the semantic map: MIOpen."""
     w = conv.weight
+    if w.shape[-1] == 1 and groups == 1:
+        xl = x.permute(0, 2, 3, 4, 1)                                  # channels-last view (no copy for channels_last_3d tensors)
+        y = torch.matmul(xl, w.reshape(w.shape[0], w.shape[1]).t())
+        if conv.bias is not None:
+            y = y + conv.bias
+        return y.permute(0, 4, 1, 2, 3)
+    if groups == w.shape[0] and w.shape[1] == 1 and tuple(w.shape[2:]) == (3, 3, 3) and conv.bias is None:
+        return ops.DepthwiseConvFn.apply(x.permute(0, 2, 3, 4, 1).contiguous(), w).permute(0, 4, 1, 2, 3)
     return F.conv3d(x, w, conv.bias, 1, w.shape[-1] // 2, 1, groups)
 
 

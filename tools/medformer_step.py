@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""A few MedFormer training steps (config/abdomenatlas_ufo/medformer_3d.yaml at 96^3, B = 2, 26 classes) -- the target of
+`rocprofv3 --kernel-trace` runs for SURVEY 8f-1.  Usage: python tools/medformer_step.py [steps] [dtype]"""
+import argparse, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+import synth
+from rsuper_amd.model.dim3.medformer import MedFormer
+from rsuper_amd.train_ddp import train_step, make_ema
+from rsuper_amd.training.utils import FusedAdamWEMA
+from rsuper_amd.training import losses_foundation as lf
+lf.SANITY_CHECKS = False
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dtype = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
+dev = 'cuda'; B, S = 2, 96; classes = synth.PANTS_CLASSES
+torch.manual_seed(0)
+net = MedFormer(1, len(classes), base_chan=32, map_size=[3, 3, 3], conv_num=[2, 0, 0, 0, 0, 0, 2, 2], trans_num=[0, 2, 4, 6, 4, 2, 0, 0],
+                num_heads=[1, 4, 8, 10, 8, 4, 1, 1], fusion_depth=2, fusion_dim=320, fusion_heads=10, expansion=4, aux_loss=True, compute_dtype=dtype).to(dev)
+ema = make_ema(net); opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+bt = synth.batch(B, S, classes, ['mask'] * B, seed=7, diam_range=(5.0, 40.0), max_tumors=3)
+batch = dict(image=torch.from_numpy(synth.image(B, S, seed=1234)).to(dev), label=torch.from_numpy(bt['label']).to(dev),
+             unk_channels=torch.from_numpy(bt['unk_channels']).to(dev), mask=torch.from_numpy(bt['mask']).to(dev),
+             volumes=torch.from_numpy(bt['volumes']).to(dev), diameters=torch.from_numpy(bt['diameters']).to(dev))
+largs = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.0, volume_loss_tolerance=0.2,
+                           ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                           classification_branch=False, ema=True, ema_alpha=0.99)
+for i in range(2):
+    train_step(net, ema, opt, batch, largs, classes, i)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    loss, _ = train_step(net, ema, opt, batch, largs, classes, 2 + i)
+torch.cuda.synchronize()
+print(f'medformer {dtype}: {1e3 * (time.perf_counter() - t0) / steps:.1f} ms/step, loss {float(loss["overall"]):.4f}, '
+      f'peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
