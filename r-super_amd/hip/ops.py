@@ -676,6 +676,44 @@ class HeadFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class Conv3Fn(torch.autograd.Function):
+    """Conv3d(Cin, Cout, 3, padding=1, bias=False) on a RAW channels-last input (no InstanceNorm / ReLU prologue): implicit-GEMM forward,
+    the same kernel with mirrored taps for the data gradient, MFMA weight gradient.  Used by MedFormer's SemanticMapGeneration
+    (model/dim3/medformer_utils.py:206-236).  Cin and Cout multiples of 8."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _chk_act(x)
+        N, D, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        assert tuple(w.shape[1:]) == (Cin, 3, 3, 3) and Cout % 8 == 0 and w.dtype == torch.float32
+        dt, dims = x.dtype, (N, D, H, W)
+        tiles = _L().rsuper_conv3_tiles(D, H, W) * N
+        bn = pick_bn(Cout, dt, tiles)
+        wc = w.contiguous()
+        out = torch.empty((N, D, H, W, Cout), device=x.device, dtype=dt)
+        igemm(0, Src(x), None, pack_weights(dt, 0, wc, None, Cin, 0, Cout, 0, bn), Cout, bn, dims, out)
+        ctx.save_for_backward(x, wc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        N, D, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        dt, dims = x.dtype, (N, D, H, W)
+        dout = dout.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            bn = pick_bn(Cin, dt, _L().rsuper_conv3_tiles(D, H, W) * N)
+            dx = torch.empty_like(x)
+            igemm(0, Src(dout), None, pack_weights(dt, 1, w, None, Cout, 0, Cin, 0, bn), Cin, bn, dims, dx)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            wgrad(Src(x), None, Src(dout), None, dw, None, dims)
+        return dx, dw
+
+
 class DepthwiseConvFn(torch.autograd.Function):
     """Conv3d(C, C, 3, padding=1, groups=C, bias=False) on a channels-last fp32 tensor (N, D, H, W, C) -- the depthwise member of
     MedFormer's DepthwiseSeparableConv / MBConv (model/dim3/conv_layers.py:126-157, :198-240).  csrc/depthwise.hip."""

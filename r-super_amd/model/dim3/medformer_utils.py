@@ -217,10 +217,18 @@ class SemanticMapGeneration(nn.Module):
         self.base_proj = nn.Conv3d(feat_dim, map_dim, 3, padding=1, bias=False)
         self.semantic_proj = nn.Conv3d(feat_dim, codes, 3, padding=1, bias=False)
 
-    def forward(self, x):
-        feat = _conv(x, self.base_proj).flatten(2)
-        weight = F.softmax(_conv(x, self.semantic_proj).flatten(2), dim=2)
-        return torch.matmul(feat, weight.transpose(1, 2)).reshape(x.shape[0], feat.shape[1], *self.map_size)
+    def forward(self, feat_in, dtype):
+        """Both 3x3x3 projections read the same raw input: ONE implicit GEMM on the gfx950 kernel (hip/ops.py Conv3Fn) with the two
+        weight tensors stacked along the output channels (zero rows pad the count to a multiple of 8)."""
+        x, _ = feat_in.cl(dtype)
+        md, codes = self.base_proj.weight.shape[0], self.semantic_proj.weight.shape[0]
+        w = torch.cat([self.base_proj.weight, self.semantic_proj.weight], 0)
+        pad = (-(md + codes)) % 8
+        if pad:
+            w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
+        y = ops.Conv3Fn.apply(x, w).float().flatten(1, 3)                       # (B, voxels, md + codes + pad)
+        weight = F.softmax(y[..., md:md + codes], dim=1)                        # softmax over the voxels of every code
+        return torch.matmul(y[..., :md].transpose(1, 2), weight).reshape(x.shape[0], md, *self.map_size)
 
 
 class _PreNorm(nn.Module):
@@ -327,7 +335,7 @@ class down_block(nn.Module):
         out = Feat(t=self.patch_merging(feat.t()))
         if len(self.conv_blocks):
             out = _run_blocks(self.conv_blocks, out, dtype)
-        smap = self.map_gen(out.t()) if self.map_generate else None
+        smap = self.map_gen(out, dtype) if self.map_generate else None
         if len(self.trans_blocks.blocks):
             t, smap = self.trans_blocks(out.t(), smap)
             out = Feat(t=t)
