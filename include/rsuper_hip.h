@@ -172,6 +172,18 @@ int rsuper_window_accumulate(const float* logits, float* acc, int BK, int wd, in
 int rsuper_window_normalize(float* acc, const float* cd, const float* ch, const float* cw, long BK, int D, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Stand-alone InstanceNorm3d(affine=False) [+ ReLU], channels-last f32 [N][vox][C], C % 4 == 0 -- the bare norm layers of
+ * MedFormer's attention stages (model/dim3/medformer_utils.py:117-118, :160; conv_layers.py:46-51 for 1x1x1 / depthwise members).
+ * stats: part [N][rsuper_cnorm_rows(vox)][C][2]; mode 0 (sum x, sum x^2) -> rsuper_stats_finalize(mode 0) gives mr = (mean, rstd);
+ *        mode 1 (sum g, sum g * x_hat) with g = dy * [x_hat > 0 when relu] -> rsuper_stats_finalize(mode 1) gives gm.
+ * apply: mode 0 out = x_hat (max(x_hat, 0) when relu); mode 1 out = rstd * (g - gm0 - x_hat * gm1).
+ * ------------------------------------------------------------------------------------------------ */
+int rsuper_cnorm_rows(long vox);
+int rsuper_cnorm_stats(const float* x, const float* dy, const float* mr, float* part, int N, long vox, int C, int relu, int mode, void* stream);
+int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Depthwise 3x3x3 convolution (groups = C, stride 1, padding 1, no bias), channels-last f32 [N][D][H][W][C], C % 4 == 0 --
  * DepthwiseSeparableConv.depthwise / MBConv.depthwise of MedFormer (model/dim3/conv_layers.py:126-157, :198-240).
  * w: (C, 1, 3, 3, 3) as in the state_dict.  flip = 1 evaluates the data gradient (x := dy, taps mirrored).

@@ -283,6 +283,16 @@ int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, 
     PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, flags & 1, V, k ? (flags >> 1) & 1 : 0};
     return rs_launch_plane_partials(p, planes, 1, ST(stream));
 }
+int rsuper_cnorm_rows(long vox) { return rs_cnorm_rows(vox); }
+int rsuper_cnorm_stats(const float* x, const float* dy, const float* mr, float* part, int N, long vox, int C, int relu, int mode, void* stream) {
+    if (!x || !part || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || (mode != 0 && mode != 1) || (mode == 1 && (!dy || !mr))) return RS_ERR_ARG;
+    return rs_launch_cnorm_stats(x, dy, mr, part, N, vox, C, relu ? 1 : 0, mode, ST(stream));
+}
+int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode,
+                       void* stream) {
+    if (!x || !mr || !out || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || (mode != 0 && mode != 1) || (mode == 1 && (!dy || !gm))) return RS_ERR_ARG;
+    return rs_launch_cnorm_apply(x, dy, mr, gm, out, N, vox, C, relu ? 1 : 0, mode, ST(stream));
+}
 int rsuper_depthwise3_rows(long vox) { return rs_depthwise_rows(vox); }
 int rsuper_depthwise3_fwd(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, void* stream) {
     if (!x || !w || !y || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (flip != 0 && flip != 1)) return RS_ERR_ARG;

@@ -1,0 +1,132 @@
+// Stand-alone InstanceNorm3d(affine = False) [+ ReLU] on channels-last fp32 activations, forward and backward -- the bare
+// norm layers of MedFormer's attention stages (rsuper_train/model/dim3/medformer_utils.py:117-118, :160; the norm + act of the
+// 1x1x1 / depthwise ConvNormAct members, conv_layers.py:46-51).  (The dense 3x3x3 convolutions never need this: their norm +
+// ReLU is fused into the conv kernels' staging.)  HBM-bound: forward 2 reads + 1 write, backward 4 reads + 1 write per element.
+//
+//   stats  mode 0: part[n][row][c] = (sum x, sum x^2)                              -> rsuper_stats_finalize mode 0 -> (mean, rstd)
+//          mode 1: part[n][row][c] = (sum g, sum g * x_hat),  g = dy * [x_hat > 0 if relu]   -> mode 1 -> (m1, m2)
+//   apply  mode 0: y  = x_hat, or max(x_hat, 0) with relu                          x_hat = (x - mean) * rstd
+//          mode 1: dx = rstd * (g - m1 - x_hat * m2)
+// Thread = (voxel, 4 consecutive channels); a block owns 64 channels (blockIdx.y) of one sample (blockIdx.z) and walks voxels
+// with stride rows * 16; per-block partial rows + the existing fixed-order f64 finalize keep the reduction deterministic.
+// ATen's reductions over the middle axes of a channels-last tensor ran at ~100 us per call (21 ms per MedFormer step).
+#include "common.hpp"
+#include "misc.hpp"
+
+namespace {
+
+constexpr int CN_CG = 64, CN_VPB = 16;
+
+struct CnParams {
+    const float* x; const float* dy; const float* mr; const float* gm;
+    float* out; float* part;
+    long vox; int C; int relu; int rows;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void cnorm_stats_kernel(CnParams p) {
+    __shared__ float red[4][2][CN_CG];
+    const int n = blockIdx.z;
+    const int cv = threadIdx.x & 15, vl = threadIdx.x >> 4;
+    const int c = blockIdx.y * CN_CG + cv * 4;
+    const bool cok = c < p.C;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float4 mu = s1, rs = s1;
+    if (MODE == 1 && cok) {
+        const float* m = p.mr + ((size_t)n * p.C + c) * 2;
+        mu = make_float4(m[0], m[2], m[4], m[6]); rs = make_float4(m[1], m[3], m[5], m[7]);
+    }
+    if (cok) {
+        const float* xb = p.x + (size_t)n * p.vox * p.C + c;
+        const float* gb = MODE == 1 ? p.dy + (size_t)n * p.vox * p.C + c : nullptr;
+        for (long v = (long)blockIdx.x * CN_VPB + vl; v < p.vox; v += (long)gridDim.x * CN_VPB) {
+            const float4 q = *(const float4*)(xb + (size_t)v * p.C);
+            if (MODE == 0) {
+                s1.x += q.x; s1.y += q.y; s1.z += q.z; s1.w += q.w;
+                s2.x += q.x * q.x; s2.y += q.y * q.y; s2.z += q.z * q.z; s2.w += q.w * q.w;
+            } else {
+                float4 g = *(const float4*)(gb + (size_t)v * p.C);
+                const float4 xh = make_float4((q.x - mu.x) * rs.x, (q.y - mu.y) * rs.y, (q.z - mu.z) * rs.z, (q.w - mu.w) * rs.w);
+                if (p.relu) { g.x = xh.x > 0.f ? g.x : 0.f; g.y = xh.y > 0.f ? g.y : 0.f; g.z = xh.z > 0.f ? g.z : 0.f; g.w = xh.w > 0.f ? g.w : 0.f; }
+                s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+                s2.x += g.x * xh.x; s2.y += g.y * xh.y; s2.z += g.z * xh.z; s2.w += g.w * xh.w;
+            }
+        }
+    }
+    // lanes that share a channel vector sit 16 and 32 lanes apart inside a wave: two butterfly steps, then the four waves through LDS
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+        s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+    }
+    if ((threadIdx.x & 63) < 16) {
+        *(float4*)&red[threadIdx.x >> 6][0][cv * 4] = s1;
+        *(float4*)&red[threadIdx.x >> 6][1][cv * 4] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * CN_CG) {
+        const int k = threadIdx.x / CN_CG, cc = threadIdx.x - k * CN_CG;
+        if (blockIdx.y * CN_CG + cc < p.C)
+            p.part[(((size_t)n * gridDim.x + blockIdx.x) * p.C + blockIdx.y * CN_CG + cc) * 2 + k] =
+                (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void cnorm_apply_kernel(CnParams p) {
+    const int n = blockIdx.z;
+    const int cv = threadIdx.x & 15, vl = threadIdx.x >> 4;
+    const int c = blockIdx.y * CN_CG + cv * 4;
+    if (c >= p.C) return;
+    const float* m = p.mr + ((size_t)n * p.C + c) * 2;
+    const float4 mu = make_float4(m[0], m[2], m[4], m[6]), rs = make_float4(m[1], m[3], m[5], m[7]);
+    float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f), g2 = g1;
+    if (MODE == 1) {
+        const float* gm = p.gm + ((size_t)n * p.C + c) * 2;
+        g1 = make_float4(gm[0], gm[2], gm[4], gm[6]); g2 = make_float4(gm[1], gm[3], gm[5], gm[7]);
+    }
+    const float* xb = p.x + (size_t)n * p.vox * p.C + c;
+    const float* gb = MODE == 1 ? p.dy + (size_t)n * p.vox * p.C + c : nullptr;
+    float* ob = p.out + (size_t)n * p.vox * p.C + c;
+    for (long v = (long)blockIdx.x * CN_VPB + vl; v < p.vox; v += (long)gridDim.x * CN_VPB) {
+        const float4 q = *(const float4*)(xb + (size_t)v * p.C);
+        const float4 xh = make_float4((q.x - mu.x) * rs.x, (q.y - mu.y) * rs.y, (q.z - mu.z) * rs.z, (q.w - mu.w) * rs.w);
+        float4 o;
+        if (MODE == 0) {
+            o = p.relu ? make_float4(fmaxf(xh.x, 0.f), fmaxf(xh.y, 0.f), fmaxf(xh.z, 0.f), fmaxf(xh.w, 0.f)) : xh;
+        } else {
+            float4 g = *(const float4*)(gb + (size_t)v * p.C);
+            if (p.relu) { g.x = xh.x > 0.f ? g.x : 0.f; g.y = xh.y > 0.f ? g.y : 0.f; g.z = xh.z > 0.f ? g.z : 0.f; g.w = xh.w > 0.f ? g.w : 0.f; }
+            o = make_float4(rs.x * (g.x - g1.x - xh.x * g2.x), rs.y * (g.y - g1.y - xh.y * g2.y), rs.z * (g.z - g1.z - xh.z * g2.z),
+                            rs.w * (g.w - g1.w - xh.w * g2.w));
+        }
+        *(float4*)(ob + (size_t)v * p.C) = o;
+    }
+}
+
+}  // namespace
+
+int rs_cnorm_rows(long vox) {
+    long b = (vox + CN_VPB * 8 - 1) / (CN_VPB * 8);
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+
+int rs_launch_cnorm_stats(const float* x, const float* dy, const float* mr, float* part, int N, long vox, int C, int relu, int mode, hipStream_t st) {
+    const int rows = rs_cnorm_rows(vox);
+    CnParams p = {x, dy, mr, nullptr, nullptr, part, vox, C, relu, rows};
+    dim3 grid(rows, (C + CN_CG - 1) / CN_CG, N);
+    if (mode == 0) hipLaunchKernelGGL(cnorm_stats_kernel<0>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(cnorm_stats_kernel<1>, grid, dim3(256), 0, st, p);
+    return rs_check_launch();
+}
+
+int rs_launch_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode,
+                          hipStream_t st) {
+    CnParams p = {x, dy, mr, gm, out, nullptr, vox, C, relu, 0};
+    long bx = (vox + CN_VPB - 1) / CN_VPB;
+    if (bx > 2048) bx = 2048;
+    dim3 grid((unsigned)bx, (C + CN_CG - 1) / CN_CG, N);
+    if (mode == 0) hipLaunchKernelGGL(cnorm_apply_kernel<0>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(cnorm_apply_kernel<1>, grid, dim3(256), 0, st, p);
+    return rs_check_launch();
+}

@@ -714,6 +714,47 @@ class Conv3Fn(torch.autograd.Function):
         return dx, dw
 
 
+class ChannelNormFn(torch.autograd.Function):
+    """InstanceNorm3d(affine=False, eps) [+ ReLU] of a channels-last fp32 tensor (N, D, H, W, C), forward and backward on
+    csrc/instnorm.hip (per-block partial sums + the deterministic f64 finalize shared with the conv epilogues)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, relu):
+        if not x.is_cuda:
+            raise _l.RSuperHipError('ChannelNormFn needs a device tensor (no CPU fallback)')
+        x = x.contiguous()
+        assert x.dim() == 5 and x.dtype == torch.float32 and x.shape[-1] % 4 == 0, (tuple(x.shape), x.dtype)
+        N, C = x.shape[0], x.shape[-1]
+        vox = x.shape[1] * x.shape[2] * x.shape[3]
+        rows = _L().rsuper_cnorm_rows(vox)
+        part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
+        mr = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
+        y = torch.empty_like(x)
+        st = _stream()
+        _l.check(_L().rsuper_cnorm_stats(_ptr(x), None, None, _ptr(part), N, vox, C, int(relu), 0, st), 'cnorm_stats')
+        _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), float(eps), 0, 0, _ptr(mr), st), 'stats_finalize')
+        _l.check(_L().rsuper_cnorm_apply(_ptr(x), None, _ptr(mr), None, _ptr(y), N, vox, C, int(relu), 0, st), 'cnorm_apply')
+        ctx.save_for_backward(x, mr)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mr = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, C = x.shape[0], x.shape[-1]
+        vox = x.shape[1] * x.shape[2] * x.shape[3]
+        rows = _L().rsuper_cnorm_rows(vox)
+        part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
+        gm = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        st = _stream()
+        _l.check(_L().rsuper_cnorm_stats(_ptr(x), _ptr(dy), _ptr(mr), _ptr(part), N, vox, C, int(ctx.relu), 1, st), 'cnorm_bwd_stats')
+        _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), 0.0, 1, 0, _ptr(gm), st), 'stats_finalize')
+        _l.check(_L().rsuper_cnorm_apply(_ptr(x), _ptr(dy), _ptr(mr), _ptr(gm), _ptr(dx), N, vox, C, int(ctx.relu), 1, st), 'cnorm_bwd_apply')
+        return dx, None, None
+
+
 class DepthwiseConvFn(torch.autograd.Function):
     """Conv3d(C, C, 3, padding=1, groups=C, bias=False) on a channels-last fp32 tensor (N, D, H, W, C) -- the depthwise member of
     MedFormer's DepthwiseSeparableConv / MBConv (model/dim3/conv_layers.py:126-157, :198-240).  csrc/depthwise.hip."""

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .medformer_utils import Feat, inconv, down_block, up_block, SemanticMapFusion, _conv, upsample_trilinear
+from .medformer_utils import Feat, inconv, down_block, up_block, SemanticMapFusion, pointwise, upsample_trilinear
 from ...hip import ops, lib as _lib
 
 _DEFAULTS = dict(conv_num=[2, 1, 0, 0, 0, 1, 2, 2], trans_num=[0, 1, 2, 2, 2, 1, 0, 0], chan_num=[64, 128, 256, 320, 256, 128, 64, 32],
@@ -77,7 +77,7 @@ class MedFormer(nn.Module):
         out, smap = self.up2(out, x2, smap, maps[0], dt)
         aux = None
         if self.aux_loss:                                      # deep supervision head at 1/4 resolution, up-sampled (medformer.py:190-194)
-            aux = upsample_trilinear(_conv(out.t(), self.aux_out), x.shape[-3:]).contiguous()
+            aux = upsample_trilinear(pointwise(out.g(), self.aux_out), x.shape[-3:]).permute(0, 4, 1, 2, 3).contiguous()
         out, smap = self.up3(out, x1, smap, None, dt)
         out, smap = self.up4(out, x0, smap, None, dt)
         feat, _ = out.cl(dt)

@@ -9,8 +9,10 @@ in fp32 (1x1x1 convolutions, attention products and MLPs are plain library GEMMs
 softmax, LayerNorm, GELU and squeeze-excite are ATen kernels) -- replacing the depthwise / norm / softmax pieces by HIP kernels
 is the next step of this row.  Nothing here runs on the CPU: `Feat` refuses host tensors.
 
-`Feat` carries an activation between the two worlds: channels-last (N, D, H, W, C) in the compute dtype together with the
-InstanceNorm statistics the fused conv prologue needs, or a logical NCDHW fp32 tensor (a channels_last_3d view, no copy).
+Everything is channels-last (N, D, H, W, C), the layout of the HIP kernels: a 1x1x1 convolution is `F.linear` over the last axis,
+the head split of the attention is a reshape of that axis, no NCDHW tensor is ever materialised.  `Feat` carries an activation
+between the two worlds: in the compute dtype together with the InstanceNorm statistics the fused conv prologue needs (HIP
+BasicBlocks), or as fp32 (attention stages).
 """
 import torch
 import torch.nn as nn
@@ -27,61 +29,57 @@ def channel_stats(x_cl, eps=IN_EPS_CNA):
     """(mean, rstd) per (sample, channel) of a channels-last tensor, (N, C, 2) f32: what the conv kernels' fused
     InstanceNorm + ReLU prologue reads.  Not differentiated: BasicBlockFn derives the InstanceNorm backward itself."""
     with torch.no_grad():
-        xf = x_cl.float()
-        var, mean = torch.var_mean(xf, dim=(1, 2, 3), unbiased=False)
+        var, mean = torch.var_mean(x_cl.float(), dim=(1, 2, 3), unbiased=False)
         return torch.stack([mean, torch.rsqrt(var + eps)], dim=-1).contiguous()
 
 
 class Feat:
-    """One activation, lazily available as (channels-last tensor, stats) for the HIP blocks or as NCDHW fp32 for the glue."""
+    """One channels-last activation, lazily available as (compute-dtype tensor, stats) for the HIP blocks or as fp32 for the glue."""
 
-    def __init__(self, cl=None, mr=None, t=None):
-        src = cl if cl is not None else t
+    def __init__(self, cl=None, mr=None, g=None):
+        src = cl if cl is not None else g
         if src is None or not src.is_cuda:
             raise _lib.RSuperHipError('MedFormer runs on MI355X only (no CPU fallback)')
-        self._cl, self._mr, self._t = cl, mr, t
+        self._cl, self._mr, self._g = cl, mr, g
 
     def cl(self, dtype):
         if self._cl is None or self._cl.dtype != dtype:
-            src = self._t.permute(0, 2, 3, 4, 1) if self._cl is None else self._cl
-            self._cl = src.contiguous().to(dtype)
+            self._cl = (self._g if self._cl is None else self._cl).contiguous().to(dtype)
             self._mr = None
         if self._mr is None:
             self._mr = channel_stats(self._cl)
         return self._cl, self._mr
 
-    def t(self):
-        if self._t is None:
-            self._t = self._cl.permute(0, 4, 1, 2, 3).float()
-        return self._t
+    def g(self):
+        if self._g is None:
+            self._g = self._cl.float()
+        return self._g
 
 
-def upsample_trilinear(t, size):
-    """F.interpolate(t, size, mode='trilinear', align_corners=True) on a logical NCDHW fp32 tensor through the HIP kernels
-    (hip/ops.py UpsampleFn): deterministic backward (ATen's uses atomics) and no NCDHW round trip.  Channels are zero-padded to the
-    multiple of 8 the activation kernels work in."""
-    C = t.shape[1]
+def instance_norm(x, eps, relu=False):
+    """InstanceNorm3d(affine=False) [+ ReLU] on a channels-last fp32 tensor: csrc/instnorm.hip (hip/ops.py ChannelNormFn)."""
+    return ops.ChannelNormFn.apply(x, eps, relu)
+
+
+def upsample_trilinear(x, size):
+    """F.interpolate(size, mode='trilinear', align_corners=True) of a channels-last fp32 tensor on the HIP kernels (hip/ops.py
+    UpsampleFn): deterministic backward (ATen's uses atomics).  Channels are zero-padded to the multiple of 8 the activation kernels
+    work in."""
+    C = x.shape[-1]
     pad = (-C) % 8
-    x = t.permute(0, 2, 3, 4, 1)
-    x = F.pad(x, (0, pad)) if pad else x
-    y, _ = ops.UpsampleFn.apply(x.contiguous().float(), tuple(size))
-    return y[..., :C].permute(0, 4, 1, 2, 3)
+    y, _ = ops.UpsampleFn.apply((F.pad(x, (0, pad)) if pad else x).contiguous().float(), tuple(size))
+    return y[..., :C] if pad else y
 
 
-def _conv(x, conv, groups=1):
-    """Convolution of the glue stages on a logical NCDHW fp32 tensor.  1x1x1: a plain GEMM over the channels-last view (rocBLAS /
-    hipBLASLt through torch.matmul, forward and both gradients -- MIOpen's grouped-conv weight gradient for these was 100x slower);
-    depthwise 3x3x3: the HIP kernels of csrc/depthwise.hip; the two dense 3x3x3 projections of the semantic map: MIOpen."""
+def pointwise(x, conv):
+    """Conv3d(k=1) as a GEMM over the channel axis (rocBLAS / hipBLASLt through F.linear, forward and both gradients)."""
     w = conv.weight
-    if w.shape[-1] == 1 and groups == 1:
-        xl = x.permute(0, 2, 3, 4, 1)                                  # channels-last view (no copy for channels_last_3d tensors)
-        y = torch.matmul(xl, w.reshape(w.shape[0], w.shape[1]).t())
-        if conv.bias is not None:
-            y = y + conv.bias
-        return y.permute(0, 4, 1, 2, 3)
-    if groups == w.shape[0] and w.shape[1] == 1 and tuple(w.shape[2:]) == (3, 3, 3) and conv.bias is None:
-        return ops.DepthwiseConvFn.apply(x.permute(0, 2, 3, 4, 1).contiguous(), w).permute(0, 4, 1, 2, 3)
-    return F.conv3d(x, w, conv.bias, 1, w.shape[-1] // 2, 1, groups)
+    return F.linear(x, w.reshape(w.shape[0], w.shape[1]), conv.bias)
+
+
+def depthwise(x, conv):
+    """Conv3d(C, C, 3, padding=1, groups=C, bias=False): csrc/depthwise.hip."""
+    return ops.DepthwiseConvFn.apply(x.contiguous(), conv.weight)
 
 
 class GlueConvNormAct(nn.Module):
@@ -90,12 +88,13 @@ class GlueConvNormAct(nn.Module):
 
     def __init__(self, in_ch, out_ch, kernel_size, groups=1, act=True):
         super().__init__()
+        assert (kernel_size == 1 and groups == 1) or (kernel_size == 3 and groups == in_ch == out_ch)
         self.conv = nn.Conv3d(in_ch, out_ch, kernel_size, padding=kernel_size // 2, groups=groups, bias=False)
-        self.groups, self.act = groups, act
+        self.act = act
 
     def forward(self, x):
-        h = F.instance_norm(x, eps=IN_EPS_CNA)
-        return _conv(F.relu(h) if self.act else h, self.conv, self.groups)
+        h = instance_norm(x, IN_EPS_CNA, relu=self.act)
+        return pointwise(h, self.conv) if self.conv.kernel_size[0] == 1 else depthwise(h, self.conv)
 
 
 class DepthwiseSeparableConv(nn.Module):
@@ -103,20 +102,25 @@ class DepthwiseSeparableConv(nn.Module):
 
     def __init__(self, in_ch, out_ch, kernel_size=3):
         super().__init__()
-        self.depthwise = nn.Conv3d(in_ch, in_ch, kernel_size, padding=kernel_size // 2, groups=in_ch, bias=False)
+        assert kernel_size == 3
+        self.depthwise = nn.Conv3d(in_ch, in_ch, 3, padding=1, groups=in_ch, bias=False)
         self.pointwise = nn.Conv3d(in_ch, out_ch, 1, bias=False)
 
     def forward(self, x):
-        return _conv(_conv(x, self.depthwise, self.depthwise.groups), self.pointwise)
+        return pointwise(depthwise(x, self.depthwise), self.pointwise)
 
 
 class SEBlock(nn.Module):
+    """Squeeze-excite (conv_layers.py:159-174): the two 1x1x1 convolutions act on one vector per sample -> linear layers."""
+
     def __init__(self, ch, ratio=4):
         super().__init__()
         self.excitation = nn.Sequential(nn.Conv3d(ch, ch // ratio, 1), nn.ReLU(), nn.Conv3d(ch // ratio, ch, 1), nn.Sigmoid())
 
     def forward(self, x):
-        return x * self.excitation(x.mean((2, 3, 4), keepdim=True))
+        s = x.mean((1, 2, 3), keepdim=True)
+        s = torch.sigmoid(pointwise(F.relu(pointwise(s, self.excitation[0])), self.excitation[2]))
+        return x * s
 
 
 class MBConv(nn.Module):
@@ -136,13 +140,15 @@ class MBConv(nn.Module):
 
 
 def _split_heads(t, heads):
-    b, c = t.shape[:2]                                   # channel index = dim_head_index * heads + head (medformer_utils.py:46-55)
-    return t.reshape(b, c // heads, heads, -1).permute(0, 2, 3, 1)
+    """(B, ..., C) -> (B, heads, L, dim_head); channel index = dim_head_index * heads + head (medformer_utils.py:46-55)."""
+    B, C = t.shape[0], t.shape[-1]
+    return t.reshape(B, -1, C // heads, heads).permute(0, 3, 1, 2)
 
 
 def _merge_heads(t, dhw):
-    b, heads, _, dh = t.shape
-    return t.permute(0, 3, 1, 2).reshape(b, heads * dh, *dhw)
+    """(B, heads, L, dim_head) -> (B, d, h, w, dim_head * heads) (medformer_utils.py:56-63)."""
+    B, heads, _, dh = t.shape
+    return t.permute(0, 2, 3, 1).reshape(B, *dhw, dh * heads)
 
 
 class BidirectionAttention(nn.Module):
@@ -159,13 +165,14 @@ class BidirectionAttention(nn.Module):
         self.map_out = nn.Identity() if no_map_out else nn.Conv3d(inner, map_dim, 1, bias=False)
 
     def forward(self, feat, smap):
-        fq, fv = self.feat_qv(feat).chunk(2, 1)
-        mq, mv = _conv(smap, self.map_qv).chunk(2, 1)
+        fq, fv = self.feat_qv(feat).chunk(2, -1)
+        mq, mv = pointwise(smap, self.map_qv).chunk(2, -1)
         fq, fv, mq, mv = (_split_heads(t, self.heads) for t in (fq, fv, mq, mv))
-        score = torch.matmul(fq, mq.transpose(-1, -2)) * self.scale                     # b, heads, voxels, tokens
-        f_out = _merge_heads(torch.matmul(F.softmax(score, -1), mv), feat.shape[2:])
-        m_out = _merge_heads(torch.matmul(F.softmax(score, -2).transpose(-1, -2), fv), smap.shape[2:])
-        m_out = m_out if isinstance(self.map_out, nn.Identity) else _conv(m_out, self.map_out)
+        score = torch.matmul(mq, fq.transpose(-1, -2)) * self.scale                     # b, heads, tokens, voxels
+        # softmax over the map tokens for the feature update, over the voxels (the contiguous axis here) for the map update
+        f_out = _merge_heads(torch.matmul(F.softmax(score, -2).transpose(-1, -2), mv), feat.shape[1:4])
+        m_out = _merge_heads(torch.matmul(F.softmax(score, -1), fv), smap.shape[1:4])
+        m_out = m_out if isinstance(self.map_out, nn.Identity) else pointwise(m_out, self.map_out)
         return self.feat_out(f_out), m_out
 
 
@@ -177,7 +184,7 @@ class BidirectionAttentionBlock(nn.Module):
         self.feedforward = MBConv(out_dim, expansion)
 
     def forward(self, x, smap):
-        out, m = self.attn(F.instance_norm(x, eps=IN_EPS), F.instance_norm(smap, eps=IN_EPS))
+        out, m = self.attn(instance_norm(x, IN_EPS), instance_norm(smap, IN_EPS))
         return self.feedforward(out + self.shortcut(x)), m + smap
 
 
@@ -203,12 +210,12 @@ class PatchMerging(nn.Module):
         self.norm = nn.Identity()                          # InstanceNorm3d(affine=False) has no state; applied functionally below
 
     def forward(self, x):
-        parts = [x[:, :, i::2, j::2, k::2] for i in range(2) for j in range(2) for k in range(2)]
-        return self.reduction(F.instance_norm(torch.cat(parts, 1), eps=IN_EPS))
+        parts = [x[:, i::2, j::2, k::2, :] for i in range(2) for j in range(2) for k in range(2)]
+        return self.reduction(instance_norm(torch.cat(parts, -1), IN_EPS))
 
 
 class SemanticMapGeneration(nn.Module):
-    """map[c, code] = sum_voxels base_proj(x)[c, v] * softmax_v(semantic_proj(x)[code, v]) (medformer_utils.py:206-236)."""
+    """map[code, c] = sum_voxels softmax_v(semantic_proj(x)[v, code]) * base_proj(x)[v, c] (medformer_utils.py:206-236)."""
 
     def __init__(self, feat_dim, map_dim, map_size):
         super().__init__()
@@ -227,8 +234,8 @@ class SemanticMapGeneration(nn.Module):
         if pad:
             w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
         y = ops.Conv3Fn.apply(x, w).float().flatten(1, 3)                       # (B, voxels, md + codes + pad)
-        weight = F.softmax(y[..., md:md + codes], dim=1)                        # softmax over the voxels of every code
-        return torch.matmul(y[..., :md].transpose(1, 2), weight).reshape(x.shape[0], md, *self.map_size)
+        weight = F.softmax(y[..., md:md + codes].transpose(1, 2), dim=-1)       # (B, codes, voxels): softmax over the voxels of a code
+        return torch.matmul(weight, y[..., :md]).reshape(x.shape[0], *self.map_size, md)
 
 
 class _PreNorm(nn.Module):
@@ -284,16 +291,15 @@ class SemanticMapFusion(nn.Module):
 
     def __init__(self, in_dims, dim, heads, depth=1):
         super().__init__()
-        self.dim = dim
         self.in_proj = nn.ModuleList(nn.Conv3d(c, dim, 1, bias=False) for c in in_dims)
         self.fusion = TransformerBlock(dim, depth, heads, dim // heads, dim)
         self.out_proj = nn.ModuleList(nn.Conv3d(dim, c, 1, bias=False) for c in in_dims)
 
     def forward(self, maps):
-        B, _, D, H, W = maps[0].shape
-        toks = torch.cat([_conv(m, p).flatten(2).transpose(1, 2) for m, p in zip(maps, self.in_proj)], 1)
+        shape = maps[0].shape[:4]
+        toks = torch.cat([pointwise(m, p).flatten(1, 3) for m, p in zip(maps, self.in_proj)], 1)
         outs = self.fusion(toks).chunk(len(maps), 1)
-        return [_conv(o.transpose(1, 2).reshape(B, self.dim, D, H, W), p) for o, p in zip(outs, self.out_proj)]
+        return [pointwise(o.reshape(*shape, -1), p) for o, p in zip(outs, self.out_proj)]
 
 
 class inconv(nn.Module):
@@ -332,13 +338,13 @@ class down_block(nn.Module):
         self.trans_blocks = BasicLayer(out_ch, out_ch, out_ch, trans_num, heads, dim_head, expansion)
 
     def forward(self, feat, dtype):
-        out = Feat(t=self.patch_merging(feat.t()))
+        out = Feat(g=self.patch_merging(feat.g()))
         if len(self.conv_blocks):
             out = _run_blocks(self.conv_blocks, out, dtype)
         smap = self.map_gen(out, dtype) if self.map_generate else None
         if len(self.trans_blocks.blocks):
-            t, smap = self.trans_blocks(out.t(), smap)
-            out = Feat(t=t)
+            g, smap = self.trans_blocks(out.g(), smap)
+            out = Feat(g=g)
         return out, smap
 
 
@@ -354,14 +360,14 @@ class up_block(nn.Module):
         """x1: coarse features, x2: encoder skip; cat([up(x1), x2]) (medformer_utils.py:377-378)."""
         smap = map1
         if not isinstance(self.map_reduction, nn.Identity) and map2 is not None:
-            smap = _conv(torch.cat([map1, map2], 1), self.map_reduction)
+            smap = pointwise(torch.cat([map1, map2], -1), self.map_reduction)
         has_trans, has_conv = len(self.trans_blocks.blocks) > 0, len(self.conv_blocks) > 0
         if has_trans or not has_conv:
-            up = upsample_trilinear(x1.t(), x2.t().shape[-3:])
-            out = Feat(t=torch.cat([up, x2.t()], 1))
+            skip = x2.g()
+            out = Feat(g=torch.cat([upsample_trilinear(x1.g(), skip.shape[1:4]), skip], -1))
             if has_trans:
-                t, smap = self.trans_blocks(out.t(), smap)
-                out = Feat(t=t)
+                g, smap = self.trans_blocks(out.g(), smap)
+                out = Feat(g=g)
             if has_conv:
                 out = _run_blocks(self.conv_blocks, out, dtype)
             return out, smap

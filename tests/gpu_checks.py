@@ -408,6 +408,23 @@ def check_unet_tiny(mode):
 
 
 # ================================================================================================ losses
+def check_cnorm(C, dims, relu, N=2, seed=95):
+    """Stand-alone InstanceNorm [+ ReLU] (csrc/instnorm.hip) forward / backward against F.instance_norm (+ F.relu) on the CPU."""
+    from rsuper_amd.hip import ops
+    D, H, W = dims
+    x = (_rng_t(seed, (N, C, D, H, W)) * 1.7 + 0.3).requires_grad_(True)
+    y_ref = F.instance_norm(x, eps=1e-5)
+    y_ref = F.relu(y_ref) if relu else y_ref
+    go = _rng_t(seed + 1, tuple(y_ref.shape))
+    y_ref.backward(go)
+    xd = x.detach().permute(0, 2, 3, 4, 1).contiguous().to(DEV).requires_grad_(True)
+    y = ops.ChannelNormFn.apply(xd, 1e-5, relu)
+    y.backward(go.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
+    torch.cuda.synchronize()
+    e = max(relerr(y.detach().cpu().permute(0, 4, 1, 2, 3), y_ref.detach()), relerr(xd.grad.cpu().permute(0, 4, 1, 2, 3), x.grad))
+    return result(f'cnorm C{C} {dims} relu{int(relu)}', e, 2e-5)
+
+
 def check_depthwise(C, dims, N=2, seed=91):
     """Depthwise 3x3x3 convolution (csrc/depthwise.hip) forward, data gradient and weight gradient against F.conv3d(groups=C) on the
     CPU (fp32; 1e-5 of max: pure fp32 multiply-adds in a different summation order)."""
@@ -777,6 +794,8 @@ def all_checks(quick=False):
            (check_seg_from_sums, (1, 300, True, 3)), (check_dilate, ()), (check_isolate_tumor, ()), (check_gwrp, ()), (check_optimizer, ())]
     cs += [(check_calculate_loss, c) for c in LOSS_CASES]
     cs += [(check_train_steps, ('f32',)), (check_train_steps, ('bf16',))]
+    cs += [(check_cnorm, (8, (6, 7, 9), True)), (check_cnorm, (72, (5, 4, 11), False, 1)), (check_cnorm, (1280, (3, 3, 3), True)),
+           (check_cnorm, (256, (24, 24, 24), True, 1))]
     cs += [(check_depthwise, (8, (6, 7, 9))), (check_depthwise, (72, (5, 4, 11), 1)), (check_depthwise, (256, (12, 12, 12))),
            (check_depthwise, (1280, (3, 3, 3)))]
     cs += [(check_medformer_tiny, ('f32',)), (check_medformer_tiny, ('bf16',))]
