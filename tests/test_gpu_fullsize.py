@@ -224,3 +224,44 @@ def test_config5_mixed_batch_128_42_classes():
         torch.cuda.empty_cache()
     assert runs[0][-1] < runs[0][0], runs[0]
     assert runs[1] == runs[0][:2], (runs[0][:2], runs[1])
+
+
+def test_medformer_shipped_config_128_42_classes():
+    """The network and configuration R-Super actually trains (config/abdomenatlas_ufo/medformer_3d.yaml: MedFormer, 42 classes, 128^3 crops,
+    deep supervision, `ball_dice_last` with report weight 0.1) for a few optimiser steps on one GPU with a 50/50 mask / report batch:
+    every loss key finite, the loss decreases, two runs from the same initial weights give identical values, and the step fits well inside
+    the reference's "> 30 GB at 128^3" (rsuper_train/Merlin_demo.md:152)."""
+    import os
+    import yaml
+    from rsuper_amd.model.utils import get_model
+    from rsuper_amd.train_ddp import train_step, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, 'r-super_amd', 'config', 'abdomenatlas_ufo', 'medformer_3d.yaml')))
+    margs = argparse.Namespace(model='medformer', dimension='3d', classification_branch=False, **cfg)
+    classes = synth.MASK42_CLASSES
+    S5 = 128
+    bt = synth.batch(2, S5, classes, ['mask', 'report'], seed=11, diam_range=(5.0, 40.0), max_tumors=3)
+    batch = dict(image=torch.from_numpy(synth.image(2, S5, seed=99)).to(DEV), **{k: torch.from_numpy(v).to(DEV) for k, v in bt.items()})
+    args = _args(loss='ball_dice_last', report_volume_loss_basic=0.1)
+    runs = []
+    torch.cuda.reset_peak_memory_stats()
+    for rep in range(2):
+        torch.manual_seed(0)
+        net = get_model(margs, classes=classes).to(DEV)
+        assert net.aux_loss and net.outc.weight.shape[0] == 42
+        ema = make_ema(net)
+        opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        losses = []
+        for step in range(4 if rep == 0 else 2):
+            la, gn = train_step(net, ema, opt, batch, args, classes, step)
+            vals = {k: float(v.detach()) for k, v in la.items()}
+            assert all(math.isfinite(v) for v in vals.values()) and math.isfinite(float(gn)), vals
+            assert {'segmentation', 'ball_loss_bce', 'ball_loss_dice', 'overall'} <= set(vals), vals
+            losses.append(vals['overall'])
+        runs.append(losses)
+        del net, ema, opt
+        torch.cuda.empty_cache()
+    assert runs[0][-1] < runs[0][0], runs[0]
+    assert runs[1] == runs[0][:2], (runs[0][:2], runs[1])
+    assert torch.cuda.max_memory_allocated() < 30 * 2 ** 30
