@@ -179,6 +179,10 @@ int rsuper_window_normalize(float* acc, const float* cd, const float* ch, const 
  * apply: mode 0 out = x_hat (max(x_hat, 0) when relu); mode 1 out = rstd * (g - gm0 - x_hat * gm1).
  * ------------------------------------------------------------------------------------------------ */
 int rsuper_cnorm_rows(long vox);
+/* one-launch variant for small volumes (statistics + finalize + apply in a block per (sample, 64 channels)):
+ * mode 0: out = norm(x) [+ relu], mr_out = (mean, rstd);  mode 1: out = dx from (x, dy, mr). */
+int rsuper_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps,
+                       int mode, void* stream);
 int rsuper_cnorm_stats(const float* x, const float* dy, const float* mr, float* part, int N, long vox, int C, int relu, int mode, void* stream);
 int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode,
                        void* stream);

@@ -293,6 +293,12 @@ int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const f
     if (!x || !mr || !out || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || (mode != 0 && mode != 1) || (mode == 1 && (!dy || !gm))) return RS_ERR_ARG;
     return rs_launch_cnorm_apply(x, dy, mr, gm, out, N, vox, C, relu ? 1 : 0, mode, ST(stream));
 }
+int rsuper_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps,
+                       int mode, void* stream) {
+    if (!x || !out || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || (mode != 0 && mode != 1) || (mode == 0 && !mr_out) || (mode == 1 && (!dy || !mr)))
+        return RS_ERR_ARG;
+    return rs_launch_cnorm_small(x, dy, mr, out, mr_out, N, vox, C, relu ? 1 : 0, eps, mode, ST(stream));
+}
 int rsuper_depthwise3_rows(long vox) { return rs_depthwise_rows(vox); }
 int rsuper_depthwise3_fwd(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, void* stream) {
     if (!x || !w || !y || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (flip != 0 && flip != 1)) return RS_ERR_ARG;

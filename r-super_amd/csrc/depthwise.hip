@@ -43,32 +43,29 @@ __global__ __launch_bounds__(256) void depthwise_fwd_kernel(DwParams p) {
 #pragma unroll
     for (int t = 0; t < 27; ++t) wr[t] = *(const float4*)&wl[t][cv * 4];
     const long vox = (long)p.N * p.D * p.H * p.W;
+    // tap offsets in elements, once per thread (the launcher keeps tensors below 2^31 elements): the per-tap 64-bit products were
+    // 4x the arithmetic of the 108 multiply-adds they fed
+    int toff[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) toff[t] = (((t / 9 - 1) * p.H + ((t / 3) % 3 - 1)) * p.W + (t % 3 - 1)) * p.C;
     for (long v = (long)blockIdx.x * DW_VPB + vl; v < vox; v += (long)gridDim.x * DW_VPB) {
         const int xw = (int)(v % p.W);
         long t2 = v / p.W;
         const int yh = (int)(t2 % p.H); t2 /= p.H;
         const int zd = (int)(t2 % p.D);
         const float* base = p.x + (size_t)v * p.C + c;
+        const bool okd[3] = {zd > 0, true, zd + 1 < p.D}, okh[3] = {yh > 0, true, yh + 1 < p.H}, okw[3] = {xw > 0, true, xw + 1 < p.W};
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int kd = 0; kd < 3; ++kd) {
-            const bool okd = (unsigned)(zd + kd - 1) < (unsigned)p.D;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const bool okh = okd && (unsigned)(yh + kh - 1) < (unsigned)p.H;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const bool ok = okh && (unsigned)(xw + kw - 1) < (unsigned)p.W;
-                    const long off = (((long)(kd - 1) * p.H + (kh - 1)) * p.W + (kw - 1)) * p.C;
-                    // clamp the address instead of branching around the load; the value is masked by the select below
-                    const float4 q = *(const float4*)(ok ? base + off : base);
-                    const float4 wv = wr[(kd * 3 + kh) * 3 + kw];
-                    acc.x = fmaf(ok ? q.x : 0.f, wv.x, acc.x);
-                    acc.y = fmaf(ok ? q.y : 0.f, wv.y, acc.y);
-                    acc.z = fmaf(ok ? q.z : 0.f, wv.z, acc.z);
-                    acc.w = fmaf(ok ? q.w : 0.f, wv.w, acc.w);
-                }
-            }
+        for (int t = 0; t < 27; ++t) {
+            const bool ok = okd[t / 9] && okh[(t / 3) % 3] && okw[t % 3];
+            // clamp the address instead of branching around the load; the value is masked by the select below
+            const float4 q = *(const float4*)(base + (ok ? toff[t] : 0));
+            const float4 wv = wr[t];
+            acc.x = fmaf(ok ? q.x : 0.f, wv.x, acc.x);
+            acc.y = fmaf(ok ? q.y : 0.f, wv.y, acc.y);
+            acc.z = fmaf(ok ? q.z : 0.f, wv.z, acc.z);
+            acc.w = fmaf(ok ? q.w : 0.f, wv.w, acc.w);
         }
         *(float4*)(p.y + (size_t)v * p.C + c) = acc;
     }
@@ -93,6 +90,9 @@ __global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwWgParams p) {
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     const long vox = (long)p.N * p.D * p.H * p.W;
+    int toff[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) toff[t] = (((t / 9 - 1) * p.H + ((t / 3) % 3 - 1)) * p.W + (t % 3 - 1)) * p.C;
     if (cok)
         for (long v = (long)blockIdx.x * DW_VPB + vl; v < vox; v += (long)gridDim.x * DW_VPB) {
             const int xw = (int)(v % p.W);
@@ -101,24 +101,16 @@ __global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwWgParams p) {
             const int zd = (int)(t2 % p.D);
             const float4 g = *(const float4*)(p.dy + (size_t)v * p.C + c);
             const float* base = p.x + (size_t)v * p.C + c;
+            const bool okd[3] = {zd > 0, true, zd + 1 < p.D}, okh[3] = {yh > 0, true, yh + 1 < p.H}, okw[3] = {xw > 0, true, xw + 1 < p.W};
 #pragma unroll
-            for (int kd = 0; kd < 3; ++kd) {
-                const bool okd = (unsigned)(zd + kd - 1) < (unsigned)p.D;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const bool okh = okd && (unsigned)(yh + kh - 1) < (unsigned)p.H;
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const bool ok = okh && (unsigned)(xw + kw - 1) < (unsigned)p.W;
-                        const long off = (((long)(kd - 1) * p.H + (kh - 1)) * p.W + (kw - 1)) * p.C;
-                        const float4 q = *(const float4*)(ok ? base + off : base);
-                        float4& a = acc[(kd * 3 + kh) * 3 + kw];
-                        a.x = fmaf(ok ? q.x : 0.f, g.x, a.x);
-                        a.y = fmaf(ok ? q.y : 0.f, g.y, a.y);
-                        a.z = fmaf(ok ? q.z : 0.f, g.z, a.z);
-                        a.w = fmaf(ok ? q.w : 0.f, g.w, a.w);
-                    }
-                }
+            for (int t = 0; t < 27; ++t) {
+                const bool ok = okd[t / 9] && okh[(t / 3) % 3] && okw[t % 3];
+                const float4 q = *(const float4*)(base + (ok ? toff[t] : 0));
+                float4& a = acc[t];
+                a.x = fmaf(ok ? q.x : 0.f, g.x, a.x);
+                a.y = fmaf(ok ? q.y : 0.f, g.y, a.y);
+                a.z = fmaf(ok ? q.z : 0.f, g.z, a.z);
+                a.w = fmaf(ok ? q.w : 0.f, g.w, a.w);
             }
         }
     // the four voxel lanes of a wave that share a channel vector sit 16 and 32 lanes apart: two butterfly steps, fixed order
@@ -161,6 +153,7 @@ int rs_depthwise_rows(long vox) {
 }
 
 int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, hipStream_t st) {
+    if ((long)N * D * H * W * C >= (1L << 31)) return RS_ERR_UNSUPPORTED;       // 32-bit tap offsets
     DwParams p = {x, w, y, N, D, H, W, C, flip};
     const long vox = (long)N * D * H * W;
     long bx = (vox + DW_VPB - 1) / DW_VPB;
@@ -170,6 +163,7 @@ int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, 
 }
 
 int rs_launch_depthwise_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int D, int H, int W, int C, hipStream_t st) {
+    if ((long)N * D * H * W * C >= (1L << 31)) return RS_ERR_UNSUPPORTED;
     const int rows = rs_depthwise_rows((long)N * D * H * W);
     DwWgParams p = {x, dy, part, N, D, H, W, C};
     hipLaunchKernelGGL(depthwise_wgrad_kernel, dim3(rows, (C + DW_CG - 1) / DW_CG), dim3(256), 0, st, p);

@@ -104,6 +104,86 @@ __global__ __launch_bounds__(256) void cnorm_apply_kernel(CnParams p) {
     }
 }
 
+// Small volumes (the 12^3 / 6^3 stages and the 27-token semantic maps: most of MedFormer's norm calls): one block per
+// (sample, 64-channel group) does statistics, finalize and apply in ONE launch -- the three-launch path is pure launch latency there.
+// Same arithmetic: f32 partial sums per thread, fixed-order f64 combination, mean / rstd (or m1 / m2) in f32.
+template <int MODE>
+__global__ __launch_bounds__(256) void cnorm_small_kernel(CnParams p, float eps, float* mr_out) {
+    __shared__ double red[4][2][CN_CG];
+    __shared__ float fin[2][CN_CG];
+    const int n = blockIdx.y;
+    const int cv = threadIdx.x & 15, vl = threadIdx.x >> 4;
+    const int c = blockIdx.x * CN_CG + cv * 4;
+    const bool cok = c < p.C;
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu;
+    if (MODE == 1 && cok) {
+        const float* m = p.mr + ((size_t)n * p.C + c) * 2;
+        mu = make_float4(m[0], m[2], m[4], m[6]); rs = make_float4(m[1], m[3], m[5], m[7]);
+    }
+    const float* xb = p.x + (size_t)n * p.vox * p.C + c;
+    const float* gb = MODE == 1 ? p.dy + (size_t)n * p.vox * p.C + c : nullptr;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (cok)
+        for (long v = vl; v < p.vox; v += CN_VPB) {
+            const float4 q = *(const float4*)(xb + (size_t)v * p.C);
+            if (MODE == 0) {
+                s1.x += q.x; s1.y += q.y; s1.z += q.z; s1.w += q.w;
+                s2.x += q.x * q.x; s2.y += q.y * q.y; s2.z += q.z * q.z; s2.w += q.w * q.w;
+            } else {
+                float4 g = *(const float4*)(gb + (size_t)v * p.C);
+                const float4 xh = make_float4((q.x - mu.x) * rs.x, (q.y - mu.y) * rs.y, (q.z - mu.z) * rs.z, (q.w - mu.w) * rs.w);
+                if (p.relu) { g.x = xh.x > 0.f ? g.x : 0.f; g.y = xh.y > 0.f ? g.y : 0.f; g.z = xh.z > 0.f ? g.z : 0.f; g.w = xh.w > 0.f ? g.w : 0.f; }
+                s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+                s2.x += g.x * xh.x; s2.y += g.y * xh.y; s2.z += g.z * xh.z; s2.w += g.w * xh.w;
+            }
+        }
+    double d1[4] = {s1.x, s1.y, s1.z, s1.w}, d2[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d1[j] += __shfl_xor(d1[j], o, 64); d2[j] += __shfl_xor(d2[j], o, 64); }
+    if ((threadIdx.x & 63) < 16)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[threadIdx.x >> 6][0][cv * 4 + j] = d1[j]; red[threadIdx.x >> 6][1][cv * 4 + j] = d2[j]; }
+    __syncthreads();
+    if (threadIdx.x < CN_CG) {
+        const int cc = threadIdx.x;
+        const double a = (red[0][0][cc] + red[1][0][cc]) + (red[2][0][cc] + red[3][0][cc]);
+        const double b = (red[0][1][cc] + red[1][1][cc]) + (red[2][1][cc] + red[3][1][cc]);
+        const double cnt = (double)p.vox;
+        float f0, f1;
+        if (MODE == 0) {
+            const double mean = a / cnt;
+            double var = b / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            f0 = (float)mean; f1 = (float)(1.0 / sqrt(var + (double)eps));
+            if (blockIdx.x * CN_CG + cc < p.C) { float* o = mr_out + ((size_t)n * p.C + blockIdx.x * CN_CG + cc) * 2; o[0] = f0; o[1] = f1; }
+        } else {
+            f0 = (float)(a / cnt); f1 = (float)(b / cnt);
+        }
+        fin[0][cc] = f0; fin[1][cc] = f1;
+    }
+    __syncthreads();
+    if (!cok) return;
+    const float4 a0 = *(const float4*)&fin[0][cv * 4], a1 = *(const float4*)&fin[1][cv * 4];
+    if (MODE == 0) { mu = a0; rs = a1; }
+    float* ob = p.out + (size_t)n * p.vox * p.C + c;
+    for (long v = vl; v < p.vox; v += CN_VPB) {
+        const float4 q = *(const float4*)(xb + (size_t)v * p.C);
+        const float4 xh = make_float4((q.x - mu.x) * rs.x, (q.y - mu.y) * rs.y, (q.z - mu.z) * rs.z, (q.w - mu.w) * rs.w);
+        float4 o;
+        if (MODE == 0) {
+            o = p.relu ? make_float4(fmaxf(xh.x, 0.f), fmaxf(xh.y, 0.f), fmaxf(xh.z, 0.f), fmaxf(xh.w, 0.f)) : xh;
+        } else {
+            float4 g = *(const float4*)(gb + (size_t)v * p.C);
+            if (p.relu) { g.x = xh.x > 0.f ? g.x : 0.f; g.y = xh.y > 0.f ? g.y : 0.f; g.z = xh.z > 0.f ? g.z : 0.f; g.w = xh.w > 0.f ? g.w : 0.f; }
+            o = make_float4(rs.x * (g.x - a0.x - xh.x * a1.x), rs.y * (g.y - a0.y - xh.y * a1.y), rs.z * (g.z - a0.z - xh.z * a1.z),
+                            rs.w * (g.w - a0.w - xh.w * a1.w));
+        }
+        *(float4*)(ob + (size_t)v * p.C) = o;
+    }
+}
+
 }  // namespace
 
 int rs_cnorm_rows(long vox) {
@@ -128,5 +208,15 @@ int rs_launch_cnorm_apply(const float* x, const float* dy, const float* mr, cons
     dim3 grid((unsigned)bx, (C + CN_CG - 1) / CN_CG, N);
     if (mode == 0) hipLaunchKernelGGL(cnorm_apply_kernel<0>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(cnorm_apply_kernel<1>, grid, dim3(256), 0, st, p);
+    return rs_check_launch();
+}
+
+// One-launch path for small volumes.  mode 0: out = norm(x) (+relu), mr_out = (mean, rstd); mode 1: out = dx from (x, dy, mr).
+int rs_launch_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps,
+                          int mode, hipStream_t st) {
+    CnParams p = {x, dy, mr, nullptr, out, nullptr, vox, C, relu, 0};
+    dim3 grid((C + CN_CG - 1) / CN_CG, N);
+    if (mode == 0) hipLaunchKernelGGL(cnorm_small_kernel<0>, grid, dim3(256), 0, st, p, eps, mr_out);
+    else hipLaunchKernelGGL(cnorm_small_kernel<1>, grid, dim3(256), 0, st, p, eps, mr_out);
     return rs_check_launch();
 }

@@ -51,6 +51,7 @@ struct HeadParams {
 };
 
 int rs_cnorm_rows(long vox);
+int rs_launch_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps, int mode, hipStream_t st);
 int rs_launch_cnorm_stats(const float* x, const float* dy, const float* mr, float* part, int N, long vox, int C, int relu, int mode, hipStream_t st);
 int rs_launch_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode, hipStream_t st);
 int rs_depthwise_rows(long vox);

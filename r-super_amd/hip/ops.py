@@ -714,6 +714,9 @@ class Conv3Fn(torch.autograd.Function):
         return dx, dw
 
 
+CNORM_SMALL_VOX = int(os.environ.get('RSUPER_CNORM_SMALL_VOX', '512'))
+
+
 class ChannelNormFn(torch.autograd.Function):
     """InstanceNorm3d(affine=False, eps) [+ ReLU] of a channels-last fp32 tensor (N, D, H, W, C), forward and backward on
     csrc/instnorm.hip (per-block partial sums + the deterministic f64 finalize shared with the conv epilogues)."""
@@ -726,16 +729,20 @@ class ChannelNormFn(torch.autograd.Function):
         assert x.dim() == 5 and x.dtype == torch.float32 and x.shape[-1] % 4 == 0, (tuple(x.shape), x.dtype)
         N, C = x.shape[0], x.shape[-1]
         vox = x.shape[1] * x.shape[2] * x.shape[3]
-        rows = _L().rsuper_cnorm_rows(vox)
-        part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
         mr = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
         y = torch.empty_like(x)
         st = _stream()
+        ctx.relu = bool(relu)
+        if vox <= CNORM_SMALL_VOX:               # low-resolution stages / semantic maps: one launch
+            _l.check(_L().rsuper_cnorm_small(_ptr(x), None, None, _ptr(y), _ptr(mr), N, vox, C, int(relu), float(eps), 0, st), 'cnorm_small')
+            ctx.save_for_backward(x, mr)
+            return y
+        rows = _L().rsuper_cnorm_rows(vox)
+        part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
         _l.check(_L().rsuper_cnorm_stats(_ptr(x), None, None, _ptr(part), N, vox, C, int(relu), 0, st), 'cnorm_stats')
         _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), float(eps), 0, 0, _ptr(mr), st), 'stats_finalize')
         _l.check(_L().rsuper_cnorm_apply(_ptr(x), None, _ptr(mr), None, _ptr(y), N, vox, C, int(relu), 0, st), 'cnorm_apply')
         ctx.save_for_backward(x, mr)
-        ctx.relu = bool(relu)
         return y
 
     @staticmethod
@@ -744,6 +751,10 @@ class ChannelNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         N, C = x.shape[0], x.shape[-1]
         vox = x.shape[1] * x.shape[2] * x.shape[3]
+        if vox <= CNORM_SMALL_VOX:
+            dx = torch.empty_like(x)
+            _l.check(_L().rsuper_cnorm_small(_ptr(x), _ptr(dy), _ptr(mr), _ptr(dx), None, N, vox, C, int(ctx.relu), 0.0, 1, _stream()), 'cnorm_small_bwd')
+            return dx, None, None
         rows = _L().rsuper_cnorm_rows(vox)
         part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
         gm = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
