@@ -151,12 +151,21 @@ class Leg:
         self.step = 0
         self.world = world
         self.last = None
+        self.graphed = None
 
     def run(self, n):
         from rsuper_amd.train_ddp import train_step
         for _ in range(n):
-            self.last = train_step(self.model, self.ema, self.opt, self.batch, self.largs, self.classes, self.step)
+            if self.graphed is not None:
+                self.last = self.graphed(self.batch, self.step)
+            else:
+                self.last = train_step(self.model, self.ema, self.opt, self.batch, self.largs, self.classes, self.step)
             self.step += 1
+
+    def use_graph(self):
+        """Replay the step from a hipGraph (rsuper_amd.graph): same kernels, one host launch per step."""
+        from rsuper_amd.graph import GraphedTrainStep
+        self.graphed = GraphedTrainStep(self.net, self.ema, self.opt, self.largs, self.classes, warmup=3)
 
     def sync(self):
         if self.world > 1:
@@ -294,7 +303,24 @@ def main():
             sec['config3_workload'] = 'same UNet + Volume + Ball report losses (ball_dice_both, weight 0.1, 50/50 mask/report batch), BASELINE configs[2]'
             l3.close()
             del l3
+        if not args.report:
+            # the same step replayed from a hipGraph (one host launch per step instead of ~330); results are bit-identical to the eager step
+            # (tests/test_gpu_edge.py::test_graphed_step_matches_eager)
+            lg = Leg(args, args.dtype, False, rank, world, local, False, classes, B, S)
+            lg.use_graph()
+            sec['graph_ms_per_step'] = lg.timed(n2, w2 + 4) / n2 * 1e3
+            sec['graph_final_loss'] = lg.loss()
+            lg.close()
+            del lg
+            torch.cuda.empty_cache()
         if not args.report and args.base == 32:
+            lmg = Leg(args, args.dtype, False, rank, world, local, False, classes, B, S, medformer=True)
+            lmg.use_graph()
+            nm = min(n2, 10)
+            sec['medformer_graph_ms_per_step'] = lmg.timed(nm, 7) / nm * 1e3
+            lmg.close()
+            del lmg
+            torch.cuda.empty_cache()
             lm = Leg(args, args.dtype, False, rank, world, local, False, classes, B, S, medformer=True)
             nm = min(n2, 10)
             sec['medformer_ms_per_step'] = lm.timed(nm, 3) / nm * 1e3

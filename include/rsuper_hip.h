@@ -248,6 +248,11 @@ int rsuper_clip_scale(int n, void* const* host_g, const size_t* host_numel, floa
 int rsuper_adamw_ema_step(int n, void* const* host_p, void* const* host_g, void* const* host_m, void* const* host_v,
                           void* const* host_ema, const size_t* host_numel, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int step, float ema_alpha, float max_norm, const double* total_sq, void* stream);
+/* Same update with the step-dependent scalars read on the device: dyn = [lr, lr / (1 - beta1^t), sqrt(1 - beta2^t), ema_alpha] (f32).
+ * A training step captured in a hipGraph replays this launch unchanged while the host refreshes the four floats before each replay. */
+int rsuper_adamw_ema_step_dyn(int n, void* const* host_p, void* const* host_g, void* const* host_m, void* const* host_v,
+                              void* const* host_ema, const size_t* host_numel, float beta1, float beta2, float eps, float weight_decay,
+                              float max_norm, const double* total_sq, const float* dyn, void* stream);
 
 #ifdef __cplusplus
 }

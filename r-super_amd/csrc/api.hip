@@ -419,7 +419,16 @@ int rsuper_adamw_ema_step(int n, void* const* host_p, void* const* host_g, void*
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
     a.sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    a.ema_alpha = ema_alpha; a.max_norm = max_norm;
+    a.ema_alpha = ema_alpha; a.max_norm = max_norm; a.dyn = nullptr;
+    return for_chunks(n, host_p, host_g, host_m, host_v, host_ema, host_numel, [&](const MTChunk& c) { return rs_launch_adamw_ema(c, a, total_sq, ST(stream)); });
+}
+int rsuper_adamw_ema_step_dyn(int n, void* const* host_p, void* const* host_g, void* const* host_m, void* const* host_v,
+                              void* const* host_ema, const size_t* host_numel, float beta1, float beta2, float eps, float weight_decay,
+                              float max_norm, const double* total_sq, const float* dyn, void* stream) {
+    if (n <= 0 || !host_p || !host_g || !host_m || !host_v || !host_numel || !dyn) return RS_ERR_ARG;
+    AdamParams a;
+    a.lr = 0.f; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.step_size = 0.f; a.sqrt_bc2 = 1.f; a.ema_alpha = 0.f; a.max_norm = max_norm; a.dyn = dyn;
     return for_chunks(n, host_p, host_g, host_m, host_v, host_ema, host_numel, [&](const MTChunk& c) { return rs_launch_adamw_ema(c, a, total_sq, ST(stream)); });
 }
 

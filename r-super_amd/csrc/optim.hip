@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(MTChunk c, AdamParams a,
     float* p = (float*)c.p[ti]; const float* g = (const float*)c.g[ti];
     float* m = (float*)c.m[ti]; float* v = (float*)c.v[ti]; float* e = (float*)c.ema[ti];
     const size_t n = c.numel[ti], base = (size_t)local * MT_ELEMS;
+    if (a.dyn) { a.lr = a.dyn[0]; a.step_size = a.dyn[1]; a.sqrt_bc2 = a.dyn[2]; a.ema_alpha = a.dyn[3]; }   // step-dependent scalars of a captured step
     float coef = 1.f;
     if (total_sq) {                                              // clip_grad_norm_: max_norm / (norm + 1e-6), clamped to 1
         const float norm = (float)sqrt(*total_sq);

@@ -17,6 +17,7 @@ struct AdamParams {
     float sqrt_bc2;      // sqrt(1 - beta2^t)
     float ema_alpha;     // min(1 - 1/(step+1), ema_alpha)
     float max_norm;
+    const float* dyn;    // optional device array [lr, step_size, sqrt_bc2, ema_alpha] overriding the fields above (hipGraph replay)
 };
 int rs_mt_blocks(size_t numel);
 int rs_launch_sqnorm(const MTChunk& c, double* total, hipStream_t st);

@@ -1,0 +1,114 @@
+"""hipGraph replay of the training step (SURVEY 8 rows a/b; the "HIP graphs instead of a tracing compiler" idiom of the MI355X port).
+
+One iteration of train_epoch (rsuper_train/train_ddp.py:308-357: zero_grad -> net(img) -> calculate_loss -> backward -> clip ->
+AdamW -> EMA) is captured ONCE into a hipGraph (torch.cuda.CUDAGraph records the raw-stream launches of the ctypes kernels like any
+other stream work) and replayed for every later batch of the same shape: the host enqueues one graph launch instead of 330 (UNet) /
+3000 (MedFormer) kernel launches.  What keeps a replay equal to an eager step:
+
+  * the batch is copied into static device buffers before the replay;
+  * the step-dependent scalars of the optimiser -- lr (epoch schedule), the two Adam bias corrections, the EMA alpha ramp
+    (training/utils.py:135-140) -- live in a 4-float device buffer the host refreshes before each replay
+    (`rsuper_adamw_ema_step_dyn`); the optimiser's Python-side step counters are advanced after the replay;
+  * `ops.WEIGHTS_EPOCH` is bumped after each replay (the graph rewrites the parameters behind the caches' back).
+
+Only steps without host-side control flow can be captured: segmentation-only supervision (`report_volume_loss_basic == 0`, the
+headline configuration).  The ball search of the report losses reads device flags on the host (losses_foundation.py:1423-1492), so
+batches with report supervision, DDP-wrapped modules and the sanity-check asserts take the eager `train_step`.
+The first `warmup` calls run eagerly (they are real training steps: allocator pools, lazily created optimiser state and kernel
+attributes are settled before capture).
+"""
+import math
+
+import torch
+
+from .hip import ops
+from .train_ddp import train_step
+from .training import losses_foundation as lf
+from .training.utils import FusedAdamWEMA, ema_alpha_for_step
+
+
+class GraphedTrainStep:
+    def __init__(self, net, ema_net, optimizer, args, classes, warmup=3):
+        if not isinstance(optimizer, FusedAdamWEMA) or len(optimizer.param_groups) != 1:
+            raise ValueError('GraphedTrainStep needs the fused AdamW+EMA optimiser with one parameter group')
+        if getattr(net, '_rsuper_reducer', None) is not None or hasattr(net, 'module'):
+            raise ValueError('data-parallel modules take the eager step (the gradient exchange is not captured)')
+        if float(getattr(args, 'report_volume_loss_basic', 0.0)) > 0:
+            raise ValueError('report supervision has host-side control flow (ball search): use the eager train_step')
+        self.net, self.ema, self.opt, self.args, self.classes = net, ema_net, optimizer, args, list(classes)
+        self.warmup, self.calls = int(warmup), 0
+        self.graph, self.static, self.out = None, None, None
+        self.dyn = None
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _scalars(self, step):
+        g = self.opt.param_groups[0]
+        # the eager entry point receives lr / betas as C floats and forms the bias corrections in double from those (csrc/api.hip
+        # rsuper_adamw_ema_step): the same roundings here keep a replay bit-identical to an eager step
+        f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))
+        lr, b1, b2 = f32(g['lr']), f32(g['betas'][0]), f32(g['betas'][1])
+        t = self._opt_step() + 1
+        ema_on = self.ema is not None and getattr(self.args, 'ema', True)
+        return [lr, lr / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t),
+                float(ema_alpha_for_step(getattr(self.args, 'ema_alpha', 0.99), step)) if ema_on else 0.0]
+
+    def _opt_step(self):
+        for p in self.opt.param_groups[0]['params']:
+            st = self.opt.state.get(p)
+            if st and 'step' in st:
+                return int(st['step'])
+        return 0
+
+    def _set_opt_step(self, t):
+        for p in self.opt.param_groups[0]['params']:
+            st = self.opt.state.get(p)
+            if st is not None and 'step' in st:
+                st['step'] = t
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def __call__(self, batch, step):
+        """Same contract as train_step(net, ema, opt, batch, args, classes, step): returns (loss dict, pre-clip gradient norm).  The
+        returned tensors are static buffers of the graph -- read them before the next call."""
+        self.calls += 1
+        if self.calls <= self.warmup:
+            # detached: a loss tensor kept by the caller would keep this step's autograd graph -- and its AccumulateGrad nodes, which are
+            # bound to the default stream -- alive into the capture, where the engine would then synchronise the default stream with the
+            # capturing one (hipStreamEndCapture crashes on that join)
+            loss, gnorm = train_step(self.net, self.ema, self.opt, batch, self.args, self.classes, step)
+            return {k: v.detach() for k, v in loss.items()}, gnorm
+        if self.graph is None:
+            self._capture(batch, step)
+        else:
+            for k, v in batch.items():
+                dst = self.static[k]
+                if dst.shape != v.shape or dst.dtype != v.dtype:
+                    raise ValueError(f'batch entry {k!r} changed shape / dtype: {tuple(v.shape)} {v.dtype} vs captured {tuple(dst.shape)} {dst.dtype}')
+                dst.copy_(v, non_blocking=True)
+        self.dyn_host.copy_(torch.tensor(self._scalars(step), dtype=torch.float32))
+        self.dyn.copy_(self.dyn_host, non_blocking=True)
+        t = self._opt_step() + 1
+        self.graph.replay()
+        self._set_opt_step(t)
+        ops.WEIGHTS_EPOCH += 1
+        return self.out
+
+    def _capture(self, batch, step):
+        dev = next(self.net.parameters()).device
+        self.static = {k: v.to(dev).clone() for k, v in batch.items()}
+        self.dyn = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.dyn_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self.dyn.copy_(torch.tensor(self._scalars(step), dtype=torch.float32))
+        sanity = lf.SANITY_CHECKS
+        lf.SANITY_CHECKS = False                     # its asserts read device flags on the host: not capturable (train_epoch keeps its own)
+        t0 = self._opt_step()
+        self.opt.dyn = self.dyn
+        try:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                loss, gnorm = train_step(self.net, self.ema, self.opt, self.static, self.args, self.classes, step)
+            self.out = ({k: v.detach() for k, v in loss.items()}, gnorm)
+        finally:
+            lf.SANITY_CHECKS = sanity
+            self.opt.dyn = None
+            self._set_opt_step(t0)                   # capture only records: the counters advance when the graph is replayed

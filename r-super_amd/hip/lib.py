@@ -71,6 +71,7 @@ _SIGS = {
     'rsuper_grad_sqnorm': (c_int, [c_int, P, P, P, P]),
     'rsuper_clip_scale': (c_int, [c_int, P, P, c_float, P, P]),
     'rsuper_adamw_ema_step': (c_int, [c_int, P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_float, P, P]),
+    'rsuper_adamw_ema_step_dyn': (c_int, [c_int, P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P]),
 }
 
 ERR = {1: 'RSUPER_ERR_ARG', 2: 'RSUPER_ERR_LAUNCH', 3: 'RSUPER_ERR_UNSUPPORTED', 4: 'RSUPER_ERR_NO_DEVICE'}

@@ -82,6 +82,14 @@ class FusedAdamWEMA(torch.optim.Optimizer):
             b1, b2 = group['betas']
             emas = [ema_of[id(p)] for p in ps] if ema_params is not None else None
             numel = (ctypes.c_size_t * len(ps))(*[p.numel() for p in ps])
+            dyn = getattr(self, 'dyn', None)
+            if dyn is not None:      # captured step (rsuper_amd.graph): lr / bias corrections / EMA alpha are read from device memory
+                assert len(self.param_groups) == 1 and max_norm is not None
+                _l.check(_l.lib().rsuper_adamw_ema_step_dyn(
+                    len(ps), _ptr_array(ps), _ptr_array([p.grad for p in ps]), _ptr_array([st['exp_avg'] for st in sts]),
+                    _ptr_array([st['exp_avg_sq'] for st in sts]), _ptr_array(emas) if emas is not None else None, numel,
+                    b1, b2, group['eps'], group['weight_decay'], float(max_norm), total.data_ptr(), dyn.data_ptr(), _stream()), 'adamw_ema_step_dyn')
+                continue
             _l.check(_l.lib().rsuper_adamw_ema_step(
                 len(ps), _ptr_array(ps), _ptr_array([p.grad for p in ps]), _ptr_array([st['exp_avg'] for st in sts]),
                 _ptr_array([st['exp_avg_sq'] for st in sts]), _ptr_array(emas) if emas is not None else None, numel,

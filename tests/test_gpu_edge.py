@@ -509,3 +509,61 @@ def test_medformer_train_steps_deep_supervision():
         assert moved > 0                                    # EMA lags the weights
         sd = net.state_dict()
         assert 'down2.trans_blocks.blocks.0.attn.feat_qv.depthwise.weight' in sd and 'map_fusion.fusion.layers.0.0.fn.to_qkv.weight' in sd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model', ['unet', 'medformer'])
+def test_graphed_step_matches_eager(model):
+    """rsuper_amd.graph.GraphedTrainStep: the training step captured in a hipGraph and replayed gives exactly the losses and parameters of
+    the eager train_step, including a learning-rate change between replays (the lr, the Adam bias corrections and the EMA alpha are
+    read from device memory), different batches (static input buffers) and the EMA ramp."""
+    import argparse
+    import synth
+    from rsuper_amd.graph import GraphedTrainStep
+    from rsuper_amd.train_ddp import train_step, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    classes = synth.TINY_CLASSES
+    largs = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.0, volume_loss_tolerance=0.2,
+                               ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                               classification_branch=False, ema=True, ema_alpha=0.99)
+    dev = 'cuda'
+    batches = []
+    for i in range(2):
+        bt = synth.batch(2, 32, classes, ['mask', 'mask'], seed=11 + i)
+        batches.append(dict(image=torch.from_numpy(synth.image(2, 32, seed=5 + i)).to(dev), label=torch.from_numpy(bt['label']).to(dev),
+                            unk_channels=torch.from_numpy(bt['unk_channels']).to(dev), mask=torch.from_numpy(bt['mask']).to(dev),
+                            volumes=torch.from_numpy(bt['volumes']).to(dev), diameters=torch.from_numpy(bt['diameters']).to(dev)))
+
+    def build():
+        torch.manual_seed(0)
+        if model == 'unet':
+            from rsuper_amd.model.dim3.unet import UNet
+            net = UNet(1, 8, num_classes=len(classes), compute_dtype='bf16').to(dev)
+        else:
+            from rsuper_amd.model.dim3.medformer import MedFormer
+            net = MedFormer(1, len(classes), compute_dtype='bf16', **{k: v for k, v in synth.MEDFORMER_TINY.items() if k not in ('size', 'seed')}).to(dev)
+        ema = make_ema(net)
+        return net, ema, FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+
+    def run(graphed):
+        net, ema, opt = build()
+        stepper = GraphedTrainStep(net, ema, opt, largs, classes, warmup=2) if graphed else None
+        hist = []
+        for i in range(7):
+            if i == 4:
+                opt.param_groups[0]['lr'] = 2e-4                      # epoch boundary of the LR schedule
+            b = batches[i % 2]
+            loss, gn = stepper(b, i) if graphed else train_step(net, ema, opt, b, largs, classes, i)
+            hist.append((float(loss['overall'].detach()), float(gn)))
+        if graphed:
+            assert stepper.graph is not None and stepper.calls == 7
+        return hist, [p.detach().clone() for p in net.parameters()], [p.detach().clone() for p in ema.parameters()], opt
+
+    h_e, p_e, e_e, opt_e = run(False)
+    h_g, p_g, e_g, opt_g = run(True)
+    assert h_e == h_g, (h_e, h_g)
+    assert all(torch.equal(a, b) for a, b in zip(p_e, p_g)) and all(torch.equal(a, b) for a, b in zip(e_e, e_g))
+    st_e, st_g = next(iter(opt_e.state.values())), next(iter(opt_g.state.values()))
+    assert int(st_e['step']) == int(st_g['step']) == 7
+    with pytest.raises(ValueError):
+        GraphedTrainStep(*build(), argparse.Namespace(**{**vars(largs), 'report_volume_loss_basic': 0.1}), classes)
