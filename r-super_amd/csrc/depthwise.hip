@@ -27,6 +27,11 @@ struct DwParams {
     int flip;              // 1: use w[c][26 - tap] (data gradient)
 };
 
+// Each thread produces DW_R consecutive outputs along W for its 4 channels: a (kd, kh) row of the halo is DW_R + 2 vectors that feed
+// 3 * DW_R multiply-adds each, i.e. 9 * (DW_R + 2) loads per DW_R outputs instead of 27 per output (2x fewer at DW_R = 4) -- the kernel
+// is bound by L1 / L2 transactions, not by HBM.
+constexpr int DW_R = 4;
+
 __global__ __launch_bounds__(256) void depthwise_fwd_kernel(DwParams p) {
     __shared__ float wl[27][DW_CG];
     const int c0 = blockIdx.y * DW_CG;
@@ -39,35 +44,49 @@ __global__ __launch_bounds__(256) void depthwise_fwd_kernel(DwParams p) {
     const int cv = threadIdx.x & 15, vl = threadIdx.x >> 4;
     const int c = c0 + cv * 4;
     if (c >= p.C) return;
-    float4 wr[27];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) wr[t] = *(const float4*)&wl[t][cv * 4];
-    const long vox = (long)p.N * p.D * p.H * p.W;
-    // tap offsets in elements, once per thread (the launcher keeps tensors below 2^31 elements): the per-tap 64-bit products were
-    // 4x the arithmetic of the 108 multiply-adds they fed
-    int toff[27];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) toff[t] = (((t / 9 - 1) * p.H + ((t / 3) % 3 - 1)) * p.W + (t % 3 - 1)) * p.C;
-    for (long v = (long)blockIdx.x * DW_VPB + vl; v < vox; v += (long)gridDim.x * DW_VPB) {
-        const int xw = (int)(v % p.W);
-        long t2 = v / p.W;
+    const int WR = (p.W + DW_R - 1) / DW_R;                           // runs per row
+    const long runs = (long)p.N * p.D * p.H * WR;
+    for (long r = (long)blockIdx.x * DW_VPB + vl; r < runs; r += (long)gridDim.x * DW_VPB) {
+        const int xr = (int)(r % WR);
+        long t2 = r / WR;
         const int yh = (int)(t2 % p.H); t2 /= p.H;
         const int zd = (int)(t2 % p.D);
-        const float* base = p.x + (size_t)v * p.C + c;
-        const bool okd[3] = {zd > 0, true, zd + 1 < p.D}, okh[3] = {yh > 0, true, yh + 1 < p.H}, okw[3] = {xw > 0, true, xw + 1 < p.W};
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int x0 = xr * DW_R;
+        const long v0 = (t2 * p.H + yh) * p.W + x0;                   // t2 = n * D + zd
+        const float* base = p.x + (size_t)v0 * p.C + c;
+        float4 acc[DW_R];
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            const bool ok = okd[t / 9] && okh[(t / 3) % 3] && okw[t % 3];
-            // clamp the address instead of branching around the load; the value is masked by the select below
-            const float4 q = *(const float4*)(base + (ok ? toff[t] : 0));
-            const float4 wv = wr[t];
-            acc.x = fmaf(ok ? q.x : 0.f, wv.x, acc.x);
-            acc.y = fmaf(ok ? q.y : 0.f, wv.y, acc.y);
-            acc.z = fmaf(ok ? q.z : 0.f, wv.z, acc.z);
-            acc.w = fmaf(ok ? q.w : 0.f, wv.w, acc.w);
+        for (int j = 0; j < DW_R; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const bool okd = (unsigned)(zd + kd - 1) < (unsigned)p.D;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const bool okr = okd && (unsigned)(yh + kh - 1) < (unsigned)p.H;
+                const int roff = ((kd - 1) * p.H + (kh - 1)) * p.W * p.C;
+                float4 q[DW_R + 2];
+#pragma unroll
+                for (int j = 0; j < DW_R + 2; ++j) {
+                    const bool ok = okr && (unsigned)(x0 + j - 1) < (unsigned)p.W;
+                    const float4 t = *(const float4*)(base + (ok ? roff + (j - 1) * p.C : 0));   // address clamped, value masked
+                    q[j] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float4 wv = *(const float4*)&wl[(kd * 3 + kh) * 3 + kw][cv * 4];
+#pragma unroll
+                    for (int j = 0; j < DW_R; ++j) {
+                        acc[j].x = fmaf(q[j + kw].x, wv.x, acc[j].x);
+                        acc[j].y = fmaf(q[j + kw].y, wv.y, acc[j].y);
+                        acc[j].z = fmaf(q[j + kw].z, wv.z, acc[j].z);
+                        acc[j].w = fmaf(q[j + kw].w, wv.w, acc[j].w);
+                    }
+                }
+            }
         }
-        *(float4*)(p.y + (size_t)v * p.C + c) = acc;
+#pragma unroll
+        for (int j = 0; j < DW_R; ++j)
+            if (x0 + j < p.W) *(float4*)(p.y + (size_t)(v0 + j) * p.C + c) = acc[j];
     }
 }
 
@@ -89,28 +108,47 @@ __global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwWgParams p) {
     float4 acc[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const long vox = (long)p.N * p.D * p.H * p.W;
-    int toff[27];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) toff[t] = (((t / 9 - 1) * p.H + ((t / 3) % 3 - 1)) * p.W + (t % 3 - 1)) * p.C;
+    const int WR = (p.W + DW_R - 1) / DW_R;
+    const long runs = (long)p.N * p.D * p.H * WR;
     if (cok)
-        for (long v = (long)blockIdx.x * DW_VPB + vl; v < vox; v += (long)gridDim.x * DW_VPB) {
-            const int xw = (int)(v % p.W);
-            long t2 = v / p.W;
+        for (long r = (long)blockIdx.x * DW_VPB + vl; r < runs; r += (long)gridDim.x * DW_VPB) {
+            const int xr = (int)(r % WR);
+            long t2 = r / WR;
             const int yh = (int)(t2 % p.H); t2 /= p.H;
             const int zd = (int)(t2 % p.D);
-            const float4 g = *(const float4*)(p.dy + (size_t)v * p.C + c);
-            const float* base = p.x + (size_t)v * p.C + c;
-            const bool okd[3] = {zd > 0, true, zd + 1 < p.D}, okh[3] = {yh > 0, true, yh + 1 < p.H}, okw[3] = {xw > 0, true, xw + 1 < p.W};
+            const int x0 = xr * DW_R;
+            const long v0 = (t2 * p.H + yh) * p.W + x0;
+            const float* base = p.x + (size_t)v0 * p.C + c;
+            float4 g[DW_R];
 #pragma unroll
-            for (int t = 0; t < 27; ++t) {
-                const bool ok = okd[t / 9] && okh[(t / 3) % 3] && okw[t % 3];
-                const float4 q = *(const float4*)(base + (ok ? toff[t] : 0));
-                float4& a = acc[t];
-                a.x = fmaf(ok ? q.x : 0.f, g.x, a.x);
-                a.y = fmaf(ok ? q.y : 0.f, g.y, a.y);
-                a.z = fmaf(ok ? q.z : 0.f, g.z, a.z);
-                a.w = fmaf(ok ? q.w : 0.f, g.w, a.w);
+            for (int j = 0; j < DW_R; ++j)
+                g[j] = x0 + j < p.W ? *(const float4*)(p.dy + (size_t)(v0 + j) * p.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const bool okd = (unsigned)(zd + kd - 1) < (unsigned)p.D;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const bool okr = okd && (unsigned)(yh + kh - 1) < (unsigned)p.H;
+                    const int roff = ((kd - 1) * p.H + (kh - 1)) * p.W * p.C;
+                    float4 q[DW_R + 2];
+#pragma unroll
+                    for (int j = 0; j < DW_R + 2; ++j) {
+                        const bool ok = okr && (unsigned)(x0 + j - 1) < (unsigned)p.W;
+                        const float4 t = *(const float4*)(base + (ok ? roff + (j - 1) * p.C : 0));
+                        q[j] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        float4& a = acc[(kd * 3 + kh) * 3 + kw];
+#pragma unroll
+                        for (int j = 0; j < DW_R; ++j) {
+                            a.x = fmaf(q[j + kw].x, g[j].x, a.x);
+                            a.y = fmaf(q[j + kw].y, g[j].y, a.y);
+                            a.z = fmaf(q[j + kw].z, g[j].z, a.z);
+                            a.w = fmaf(q[j + kw].w, g[j].w, a.w);
+                        }
+                    }
+                }
             }
         }
     // the four voxel lanes of a wave that share a channel vector sit 16 and 32 lanes apart: two butterfly steps, fixed order
@@ -156,8 +194,13 @@ int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, 
     if ((long)N * D * H * W * C >= (1L << 31)) return RS_ERR_UNSUPPORTED;       // 32-bit tap offsets
     DwParams p = {x, w, y, N, D, H, W, C, flip};
     const long vox = (long)N * D * H * W;
-    long bx = (vox + DW_VPB - 1) / DW_VPB;
-    if (bx > 4096) bx = 4096;
+    const long runs = (long)N * D * H * ((W + DW_R - 1) / DW_R);
+    // the LDS weight staging is per block: aim at >= 8 passes per block, but never below ~1024 blocks in flight (small volumes)
+    const long groups = (C + DW_CG - 1) / DW_CG, all = (runs + DW_VPB - 1) / DW_VPB;
+    long bx = (runs + DW_VPB * 8 - 1) / (DW_VPB * 8);
+    if (bx * groups < 1024) bx = (1024 + groups - 1) / groups;
+    if (bx > all) bx = all;
+    if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(depthwise_fwd_kernel, dim3((unsigned)bx, (C + DW_CG - 1) / DW_CG), dim3(256), 0, st, p);
     return rs_check_launch();
 }
