@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import medformer_utils as _mu
 from .medformer_utils import Feat, inconv, down_block, up_block, SemanticMapFusion, pointwise, upsample_trilinear
 from ...hip import ops, lib as _lib
 
@@ -67,6 +68,9 @@ class MedFormer(nn.Module):
             raise _lib.RSuperHipError('rsuper_amd MedFormer runs on MI355X only (no CPU fallback); move the input to cuda')
         _lib.require_device()
         dt = self._dtype()
+        # operand dtype of the 1x1x1 GEMMs in the attention stages: fp32 (RSUPER_MF_GEMM_BF16=1 rounds the operands to bf16 in the bf16 mode --
+        # measured SLOWER, 47-53 vs 44 ms/step: the casts around every GEMM cost more than the faster MFMA rate saves at these sizes)
+        _mu.GEMM_DTYPE = dt if os.environ.get('RSUPER_MF_GEMM_BF16') == '1' else torch.float32
         x0 = self.inc(x, dt)
         x1, _ = self.down1(x0, dt)
         x2, m2 = self.down2(x1, dt)

@@ -71,10 +71,17 @@ def upsample_trilinear(x, size):
     return y[..., :C] if pad else y
 
 
+GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 operands for the 1x1x1 GEMMs, see medformer.py)
+
+
 def pointwise(x, conv):
-    """Conv3d(k=1) as a GEMM over the channel axis (rocBLAS / hipBLASLt through F.linear, forward and both gradients)."""
-    w = conv.weight
-    return F.linear(x, w.reshape(w.shape[0], w.shape[1]), conv.bias)
+    """Conv3d(k=1) as a GEMM over the channel axis (rocBLAS / hipBLASLt through F.linear, forward and both gradients); fp32 unless
+    GEMM_DTYPE says bf16 (opt-in experiment)."""
+    w = conv.weight.reshape(conv.weight.shape[0], conv.weight.shape[1])
+    if GEMM_DTYPE != torch.float32 and x.numel() // x.shape[-1] >= 64:
+        y = F.linear(x.to(GEMM_DTYPE), w.to(GEMM_DTYPE)).float()
+        return y if conv.bias is None else y + conv.bias
+    return F.linear(x, w, conv.bias)
 
 
 def depthwise(x, conv):
