@@ -50,3 +50,28 @@ def test_conv_fuzz_f32(case):
     assert r['ok'], (r['name'], r['err'], r['note'])
     r = gc.check_conv_bwd('f32', N, S, Ca, Cb, Cout, sc)
     assert r['ok'], (r['name'], r['err'], r['note'])
+
+
+def _glue_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        dims = (int(rng.integers(1, 10)), int(rng.integers(1, 10)), int(rng.integers(1, 23)))
+        out.append((int(rng.choice([4, 8, 60, 64, 68, 132, 320])), dims, int(rng.integers(1, 3)), bool(rng.integers(0, 2))))
+    return out
+
+
+GLUE_CASES = _glue_cases(12, 77)
+
+
+@pytest.mark.parametrize('case', GLUE_CASES, ids=[f'C{c[0]}_{"x".join(map(str, c[1]))}_N{c[2]}_r{int(c[3])}' for c in GLUE_CASES])
+def test_attention_stage_kernels_fuzz(case):
+    """Depthwise 3x3x3 (forward / data gradient / weight gradient) and stand-alone InstanceNorm [+ ReLU] (forward / backward) on ragged
+    volumes: widths that are not multiples of the 4-voxel run, 1-voxel axes, channel counts that leave a partial 64-channel group, and
+    both the one-launch (<= 512 voxels) and the three-launch InstanceNorm paths."""
+    C, dims, N, relu = case
+    r = gc.check_depthwise(C, dims, N)
+    assert r['ok'], f"{r['name']}: err {r['err']:.3e} > tol {r['tol']:.1e}"
+    if dims[0] * dims[1] * dims[2] > 1:                     # InstanceNorm of a single voxel is 0 / 0 in the reference too
+        r = gc.check_cnorm(C, dims, relu, N)
+        assert r['ok'], f"{r['name']}: err {r['err']:.3e} > tol {r['tol']:.1e}"
