@@ -119,3 +119,27 @@ def test_inference_pack_cache_follows_fused_optimizer_updates():
     with torch.no_grad():
         y2 = fresh(x)['segmentation']
     assert not torch.equal(y1, y0) and torch.equal(y1, y2)
+
+
+def test_sliding_window_with_medformer_matches_oracle():
+    """The inference mirror drives any network with the {'segmentation': ...} contract: MedFormer with deep supervision (only the final head
+    is used, inference3d.py:85-90).  Probabilities of the f32 HIP path against the window-by-window CPU evaluation of the MedFormer oracle."""
+    from rsuper_amd.inference import inference_sliding_window
+    from rsuper_amd.model.dim3.medformer import MedFormer
+    from oracle import medformer_oracle as mo
+    cfg = synth.MEDFORMER_TINY
+    net = MedFormer(1, len(synth.TINY_CLASSES), compute_dtype='f32', **{k: v for k, v in cfg.items() if k not in ('size', 'seed')})
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sdn = synth.fill_state_dict(shapes, cfg['seed'])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()})
+    net = net.to(DEV).eval()
+    img = torch.from_numpy(synth.volume((32, 48, 32), 21))
+    args = argparse.Namespace(window_size=[32, 32, 32], classes=len(synth.TINY_CLASSES))
+    pred = inference_sliding_window(net, img, args)
+    assert tuple(pred.shape) == (1, len(synth.TINY_CLASSES), 32, 48, 32) and bool(torch.isfinite(pred).all())
+    # expected: the inference oracle (window schedule pinned by tests/golden/inference.npz) driving the MedFormer oracle window by window
+    from oracle import inference_oracle as io
+    sd = {k: torch.from_numpy(v) for k, v in sdn.items()}
+    with torch.no_grad():
+        ref = io.inference_sliding_window(lambda x: mo.medformer_forward(sd, x, cfg), img, [32, 32, 32], len(synth.TINY_CLASSES))
+    np.testing.assert_allclose(pred.numpy(), ref.numpy(), atol=1e-4)
