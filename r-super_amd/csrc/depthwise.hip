@@ -32,7 +32,25 @@ struct DwParams {
 // is bound by L1 / L2 transactions, not by HBM.
 constexpr int DW_R = 4;
 
-__global__ __launch_bounds__(256) void depthwise_fwd_kernel(DwParams p) {
+// XCD-aware work order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2): with a plain grid-stride loop the
+// blocks of one XCD touch every 8th group of runs, so each L2 holds its own copy of every halo plane (measured 6x the algorithmic
+// bytes on the L2 -> fabric side, rocprofv3 FETCH_SIZE).  Here XCD x owns a contiguous slab of run groups and its blocks sweep that slab
+// together, so the d-1 / d+1 planes a block needs were just fetched by its neighbours on the same XCD.
+struct DwSweep { long first, step, end; };
+__device__ __forceinline__ DwSweep dw_sweep(long runs) {
+    const long G = (runs + DW_VPB - 1) / DW_VPB;                  // groups of 16 runs (one block pass)
+    const long Gx = (G + 7) / 8;                                  // groups per XCD
+    const long x = blockIdx.x & 7, idx = blockIdx.x >> 3, Bx = (gridDim.x + 7 - x) / 8;
+    DwSweep s;
+    if (gridDim.x < 8) { s.first = blockIdx.x; s.step = gridDim.x; s.end = G; return s; }   // small launches: plain grid stride
+    s.first = x * Gx + idx;
+    s.step = Bx > 0 ? Bx : 1;
+    s.end = min((x + 1) * Gx, G);
+    return s;
+}
+
+
+__global__ __launch_bounds__(256, 2) void depthwise_fwd_kernel(DwParams p) {
     __shared__ float wl[27][DW_CG];
     const int c0 = blockIdx.y * DW_CG;
     const int ncl = min(DW_CG, p.C - c0);
@@ -46,14 +64,18 @@ __global__ __launch_bounds__(256) void depthwise_fwd_kernel(DwParams p) {
     if (c >= p.C) return;
     const int WR = (p.W + DW_R - 1) / DW_R;                           // runs per row
     const long runs = (long)p.N * p.D * p.H * WR;
-    for (long r = (long)blockIdx.x * DW_VPB + vl; r < runs; r += (long)gridDim.x * DW_VPB) {
+    const DwSweep sw = dw_sweep(runs);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)((size_t)p.N * p.D * p.H * p.W * p.C * 4), 0x00020000);
+    for (long gidx = sw.first; gidx < sw.end; gidx += sw.step) {
+        const long r = gidx * DW_VPB + vl;
+        if (r >= runs) break;
         const int xr = (int)(r % WR);
         long t2 = r / WR;
         const int yh = (int)(t2 % p.H); t2 /= p.H;
         const int zd = (int)(t2 % p.D);
         const int x0 = xr * DW_R;
         const long v0 = (t2 * p.H + yh) * p.W + x0;                   // t2 = n * D + zd
-        const float* base = p.x + (size_t)v0 * p.C + c;
+        const uint32_t boff = (uint32_t)(((size_t)v0 * p.C + c) * 4);
         float4 acc[DW_R];
 #pragma unroll
         for (int j = 0; j < DW_R; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -63,13 +85,15 @@ __global__ __launch_bounds__(256) void depthwise_fwd_kernel(DwParams p) {
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const bool okr = okd && (unsigned)(yh + kh - 1) < (unsigned)p.H;
-                const int roff = ((kd - 1) * p.H + (kh - 1)) * p.W * p.C;
+                const uint32_t roff = boff + (uint32_t)(((kd - 1) * p.H + (kh - 1)) * p.W * p.C * 4);
                 float4 q[DW_R + 2];
 #pragma unroll
                 for (int j = 0; j < DW_R + 2; ++j) {
+                    // buffer load with a 32-bit byte offset: out-of-volume taps get an out-of-range offset and read as zeros -- no
+                    // select, no branch, and no 64-bit address per load (54 of those were 108 VGPRs)
                     const bool ok = okr && (unsigned)(x0 + j - 1) < (unsigned)p.W;
-                    const float4 t = *(const float4*)(base + (ok ? roff + (j - 1) * p.C : 0));   // address clamped, value masked
-                    q[j] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? roff + (uint32_t)((j - 1) * p.C * 4) : 0xFFFFFFFFu, 0, 0);
+                    q[j] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
                 }
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
@@ -82,6 +106,12 @@ __global__ __launch_bounds__(256) void depthwise_fwd_kernel(DwParams p) {
                         acc[j].w = fmaf(q[j + kw].w, wv.w, acc[j].w);
                     }
                 }
+                // Fence per halo row, with the accumulators as in/out operands so that the multiply-adds of this row cannot sink below it: otherwise
+                // the scheduler issues all 54 loads of the run first and keeps them live (350 VGPRs, one wave per SIMD; a register cap alone
+                // only turns that into scratch spills).
+#pragma unroll
+                for (int j = 0; j < DW_R; ++j)
+                    asm volatile("" : "+v"(acc[j].x), "+v"(acc[j].y), "+v"(acc[j].z), "+v"(acc[j].w) :: "memory");
             }
         }
 #pragma unroll
@@ -99,7 +129,7 @@ struct DwWgParams {
     int N, D, H, W, C;
 };
 
-__global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwWgParams p) {
+__global__ __launch_bounds__(256, 2) void depthwise_wgrad_kernel(DwWgParams p) {
     __shared__ float red[4][27][DW_CG + 4];                        // one partial per wave (29 KB)
     const int c0 = blockIdx.y * DW_CG;
     const int cv = threadIdx.x & 15, vl = threadIdx.x >> 4;
@@ -110,15 +140,19 @@ __global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwWgParams p) {
     for (int t = 0; t < 27; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int WR = (p.W + DW_R - 1) / DW_R;
     const long runs = (long)p.N * p.D * p.H * WR;
+    const DwSweep sw = dw_sweep(runs);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)((size_t)p.N * p.D * p.H * p.W * p.C * 4), 0x00020000);
     if (cok)
-        for (long r = (long)blockIdx.x * DW_VPB + vl; r < runs; r += (long)gridDim.x * DW_VPB) {
+        for (long gidx = sw.first; gidx < sw.end; gidx += sw.step) {
+            const long r = gidx * DW_VPB + vl;
+            if (r >= runs) break;
             const int xr = (int)(r % WR);
             long t2 = r / WR;
             const int yh = (int)(t2 % p.H); t2 /= p.H;
             const int zd = (int)(t2 % p.D);
             const int x0 = xr * DW_R;
             const long v0 = (t2 * p.H + yh) * p.W + x0;
-            const float* base = p.x + (size_t)v0 * p.C + c;
+            const uint32_t boff = (uint32_t)(((size_t)v0 * p.C + c) * 4);
             float4 g[DW_R];
 #pragma unroll
             for (int j = 0; j < DW_R; ++j)
@@ -129,13 +163,13 @@ __global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwWgParams p) {
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const bool okr = okd && (unsigned)(yh + kh - 1) < (unsigned)p.H;
-                    const int roff = ((kd - 1) * p.H + (kh - 1)) * p.W * p.C;
+                    const uint32_t roff = boff + (uint32_t)(((kd - 1) * p.H + (kh - 1)) * p.W * p.C * 4);
                     float4 q[DW_R + 2];
 #pragma unroll
                     for (int j = 0; j < DW_R + 2; ++j) {
                         const bool ok = okr && (unsigned)(x0 + j - 1) < (unsigned)p.W;
-                        const float4 t = *(const float4*)(base + (ok ? roff + (j - 1) * p.C : 0));
-                        q[j] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? roff + (uint32_t)((j - 1) * p.C * 4) : 0xFFFFFFFFu, 0, 0);
+                        q[j] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
                     }
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
@@ -147,6 +181,11 @@ __global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwWgParams p) {
                             a.z = fmaf(q[j + kw].z, g[j].z, a.z);
                             a.w = fmaf(q[j + kw].w, g[j].w, a.w);
                         }
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {                 // fence: one row of loads live at a time (see the forward kernel)
+                        float4& a = acc[(kd * 3 + kh) * 3 + kw];
+                        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) :: "memory");
                     }
                 }
             }
@@ -191,7 +230,7 @@ int rs_depthwise_rows(long vox) {
 }
 
 int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, hipStream_t st) {
-    if ((long)N * D * H * W * C >= (1L << 31)) return RS_ERR_UNSUPPORTED;       // 32-bit tap offsets
+    if ((long)N * D * H * W * C >= (1L << 30)) return RS_ERR_UNSUPPORTED;       // 32-bit byte offsets of the buffer loads (< 4 GiB)
     DwParams p = {x, w, y, N, D, H, W, C, flip};
     const long vox = (long)N * D * H * W;
     const long runs = (long)N * D * H * ((W + DW_R - 1) / DW_R);
@@ -206,7 +245,7 @@ int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, 
 }
 
 int rs_launch_depthwise_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int D, int H, int W, int C, hipStream_t st) {
-    if ((long)N * D * H * W * C >= (1L << 31)) return RS_ERR_UNSUPPORTED;
+    if ((long)N * D * H * W * C >= (1L << 30)) return RS_ERR_UNSUPPORTED;
     const int rows = rs_depthwise_rows((long)N * D * H * W);
     DwWgParams p = {x, dy, part, N, D, H, W, C};
     hipLaunchKernelGGL(depthwise_wgrad_kernel, dim3(rows, (C + DW_CG - 1) / DW_CG), dim3(256), 0, st, p);
