@@ -714,6 +714,19 @@ class Conv3Fn(torch.autograd.Function):
         return dx, dw
 
 
+def channel_stats(x, eps):
+    """(mean, rstd) per (sample, channel) of a channels-last fp32 tensor -> (N, C, 2) f32 (csrc/instnorm.hip + stats_finalize)."""
+    N, C = x.shape[0], x.shape[-1]
+    vox = x.numel() // (N * C)
+    rows = _L().rsuper_cnorm_rows(vox)
+    part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
+    mr = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
+    st = _stream()
+    _l.check(_L().rsuper_cnorm_stats(_ptr(x), None, None, _ptr(part), N, vox, C, 0, 0, st), 'cnorm_stats')
+    _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), float(eps), 0, 0, _ptr(mr), st), 'stats_finalize')
+    return mr
+
+
 CNORM_SMALL_VOX = int(os.environ.get('RSUPER_CNORM_SMALL_VOX', '512'))
 
 
