@@ -41,3 +41,26 @@ for i in range(10):
     ts.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
 print(f'host enqueue with empty queue: {1e3 * sorted(ts)[len(ts) // 2]:.2f} ms/step')
+
+# hipGraph replay (rsuper_amd/graph.py): host cost of one step = a few small copies + one graph launch
+from rsuper_amd.graph import GraphedTrainStep
+stepper = GraphedTrainStep(net, ema, opt, largs, classes, warmup=3)
+for i in range(6):
+    stepper(batch, 200 + i)
+torch.cuda.synchronize()
+K = 20
+t0 = time.perf_counter()
+for i in range(K):
+    stepper(batch, 300 + i)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f'hipGraph replay: host enqueue {1e3 * (t1 - t0) / K:.2f} ms/step, total {1e3 * (t2 - t0) / K:.2f} ms/step')
+ts = []
+for i in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stepper(batch, 400 + i)
+    ts.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+print(f'hipGraph replay, host enqueue with empty queue: {1e3 * sorted(ts)[len(ts) // 2]:.3f} ms/step')
