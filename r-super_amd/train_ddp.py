@@ -175,6 +175,15 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
     dev = next(net.parameters()).device
     classes = trainLoader.dataset.classes
     packed = getattr(trainLoader.dataset, 'packed', False)
+    # rsuper_amd extension (--hip_graph): replay the step from a hipGraph where that is possible -- segmentation-only supervision, one process,
+    # the fused optimiser (rsuper_amd/graph.py); the stepper lives on the optimiser so that it survives across epochs
+    stepper = None
+    if getattr(args, 'hip_graph', False) and float(getattr(args, 'report_volume_loss_basic', 0.0)) == 0 and not getattr(args, 'distributed', False) \
+            and isinstance(optimizer, FusedAdamWEMA) and getattr(net, '_rsuper_reducer', None) is None:
+        from .graph import GraphedTrainStep
+        stepper = getattr(optimizer, '_graphed_step', None)
+        if stepper is None or stepper.net is not net:
+            stepper = optimizer._graphed_step = GraphedTrainStep(net, ema_net, optimizer, args, classes)
     for i, inputs in enumerate(trainLoader):
         batch = dict(image=inputs['image'], label=inputs['label'], unk_channels=inputs['unk_channels'],
                      volumes=inputs['volumes'].float(), mask=inputs['mask'], diameters=inputs['diameters'].float())
@@ -190,12 +199,18 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
             assert not torch.isnan(img).any(), 'Input is nan'
             assert torch.max(img) <= 100, f'Input is bigger than 100: {torch.max(img)}'
             assert torch.min(img) >= -100, f'Input is smaller than -100: {torch.min(img)}'
-        loss_all, _ = train_step(net, ema_net, optimizer, batch, args, classes, step, matcher=matcher)
+        if stepper is not None:
+            loss_all, _ = stepper(batch, step)
+        else:
+            loss_all, _ = train_step(net, ema_net, optimizer, batch, args, classes, step, matcher=matcher)
         if len(loss_meters) == 0:
             loss_meters = OrderedDict((k, AverageMeter(k, ':6.4f')) for k in loss_all.keys())
             loss_meters['Elapsed Time'] = AverageMeter('Elapsed Time', ':6.2f')
         for k, v in loss_all.items():
-            loss_meters[k].update(v.item(), img.shape[0])
+            val = v.item()
+            if k == 'overall' and val != val:            # the NaN guard of calculate_loss (:1070-1071) also for replayed steps
+                raise ValueError('loss is nan, propagating this can destroy the network weights, STOP!')
+            loss_meters[k].update(val, img.shape[0])
         loss_meters['Elapsed Time'].update(time.time() - start, n=1)
         if progress is None:
             progress = ProgressMeter(len(trainLoader) if args.dimension == '2d' else args.iter_per_epoch, list(loss_meters.values()),
@@ -263,6 +278,7 @@ def get_parser(argv=None, config_root=None):
     parser.add_argument('--crop_size', default=None, type=int)
     parser.add_argument('--load_augmented', action='store_true', help='Loads pre-saved crops for training (:414)')
     parser.add_argument('--save_destination', type=str, default=None, help='directory of the pre-saved crops (:415)')
+    parser.add_argument('--hip_graph', action='store_true', help='rsuper_amd extension: replay eligible training steps from a hipGraph')
     parser.add_argument('--synthetic', type=int, default=0, help='rsuper_amd extension: train on N synthetic samples (no dataset on disk)')
     args = parser.parse_args(argv)
 
