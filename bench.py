@@ -196,6 +196,96 @@ class Leg:
             red.remove()
 
 
+def secondary_legs(args, rank, world, local, classes, B, S):
+    """The workloads / modes the headline does not show (N = 1 only): config 3, hipGraph replay, MedFormer, the f32 parity mode and the
+    cost of bf16.  Runs in a child process (`--secondary-only`): a failure here must never take the headline JSON line down with it;
+    inside, every leg is guarded separately."""
+    sec = {}
+    n2, w2 = min(args.steps, 20), min(args.warmup, 5)
+    headline_steps = args.steps + args.warmup + args.roofline_steps
+
+    def leg_of(*a, **kw):
+        return Leg(args, *a, rank, world, local, False, classes, B, S, **kw)
+
+    def guarded(name, fn):
+        try:
+            fn()
+        except Exception as e:                           # noqa: BLE001
+            sec[name + '_error'] = repr(e)[:300]
+        torch.cuda.empty_cache()
+
+    def config3():
+        l3 = leg_of(args.dtype, True)
+        sec['config3_ms_per_step'] = l3.timed(n2, w2) / n2 * 1e3
+        sec['config3_final_loss'] = l3.loss()
+        sec['config3_workload'] = 'same UNet + Volume + Ball report losses (ball_dice_both, weight 0.1, 50/50 mask/report batch), BASELINE configs[2]'
+        l3.close()
+
+    def graph():
+        # the same step replayed from a hipGraph (one host launch per step instead of ~330); results are bit-identical to the eager step
+        # (tests/test_gpu_edge.py::test_graphed_step_matches_eager)
+        lg = leg_of(args.dtype, False)
+        lg.use_graph()
+        sec['graph_ms_per_step'] = lg.timed(n2, w2 + 4) / n2 * 1e3
+        sec['graph_final_loss'] = lg.loss()
+        lg.close()
+
+    def medformer_graph():
+        lmg = leg_of(args.dtype, False, medformer=True)
+        lmg.use_graph()
+        nm = min(n2, 10)
+        sec['medformer_graph_ms_per_step'] = lmg.timed(nm, 7) / nm * 1e3
+        lmg.close()
+
+    def medformer():
+        lm = leg_of(args.dtype, False, medformer=True)
+        nm = min(n2, 10)
+        sec['medformer_ms_per_step'] = lm.timed(nm, 3) / nm * 1e3
+        sec['medformer_final_loss'] = lm.loss()
+        sec['medformer_workload'] = ('MedFormer of config/abdomenatlas_ufo/medformer_3d.yaml (37.9 M parameters, deep supervision), same batch and '
+                                     'segmentation loss: conv stem / BasicBlock stages / up-sampling / head / depthwise / InstanceNorm on the HIP kernels, '
+                                     '1x1x1 convolutions and attention products as library GEMMs (SURVEY 8f-1)')
+        lm.close()
+
+    def f32():
+        ref_logits = bf16_last_loss = None
+        if not args.report:
+            # the bf16 run the f32 leg is compared with: the same number of optimiser steps as the headline run, from the same initial weights
+            lb = leg_of('bf16', False)
+            lb.run(headline_steps)
+            lb.sync()
+            ref_logits, bf16_last_loss = lb.logits(), lb.loss()
+            lb.close()
+            del lb
+            torch.cuda.empty_cache()
+        lf32 = leg_of('f32', args.report)
+        n3 = min(n2, 10)
+        sec['f32_ms_per_step'] = lf32.timed(n3, 2) / n3 * 1e3
+        if ref_logits is not None:
+            lf32.run(headline_steps - lf32.step)
+            lf32.sync()
+            f32_logits = lf32.logits()
+            sec['bf16_vs_f32'] = {
+                'steps': headline_steps,
+                'abs_delta_overall_loss': abs(lf32.loss() - bf16_last_loss),
+                'bf16_overall_loss': bf16_last_loss, 'f32_overall_loss': lf32.loss(),
+                'logits_rel_l2': float(((ref_logits - f32_logits).double().norm() / f32_logits.double().norm()).item()),
+                'note': 'identical init and batch, same number of optimiser steps in both arithmetic modes (full size); loss of the last step, '
+                        'logits of the trained weights on the training batch',
+            }
+        lf32.close()
+
+    if not args.report:
+        guarded('config3', config3)
+        guarded('graph', graph)
+        if args.base == 32:
+            guarded('medformer_graph', medformer_graph)
+            guarded('medformer', medformer)
+    if args.dtype == 'bf16':
+        guarded('f32', f32)
+    return sec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -209,6 +299,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the config-3 / f32 / bf16-vs-f32 legs')
     ap.add_argument('--roofline-steps', type=int, default=10, help='steps of the separate HIP-event pass after the timed region')
+    ap.add_argument('--secondary-only', action='store_true', help='(internal) run only the secondary legs and print their JSON')
     ap.add_argument('--force-ddp', action='store_true', help='wrap in the data-parallel reducer even with one rank (exercises the RCCL path)')
     args = ap.parse_args()
 
@@ -233,6 +324,9 @@ def main():
     classes = synth.PANTS_CLASSES
     B, S = args.batch, args.size
 
+    if args.secondary_only:
+        print(json.dumps(secondary_legs(args, rank, world, local, classes, B, S)))
+        return
     leg = Leg(args, args.dtype, args.report, rank, world, local, args.force_ddp, classes, B, S)
     dt = leg.timed(args.steps, args.warmup)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -287,71 +381,17 @@ def main():
                                             'tflops': d['flops'] / (d['ms'] * 1e-3) / 1e12} for k, d in ksum.items()}},
         }
     if world == 1 and not args.no_secondary and not args.force_ddp:
-        # ---- secondary legs (N = 1 only): the workloads / modes the headline does not show
-        sec = {}
-        n2, w2 = min(args.steps, 20), min(args.warmup, 5)
-        ref_logits = leg.logits() if not args.report and args.dtype == 'bf16' else None
-        headline_steps = leg.step
-        bf16_last_loss = leg.loss()
+        # ---- secondary legs in a child process: whatever happens there (exception, hard crash), the headline line is still printed
         leg.close()
         del leg
         torch.cuda.empty_cache()
-        if not args.report:
-            l3 = Leg(args, args.dtype, True, rank, world, local, False, classes, B, S)
-            sec['config3_ms_per_step'] = l3.timed(n2, w2) / n2 * 1e3
-            sec['config3_final_loss'] = l3.loss()
-            sec['config3_workload'] = 'same UNet + Volume + Ball report losses (ball_dice_both, weight 0.1, 50/50 mask/report batch), BASELINE configs[2]'
-            l3.close()
-            del l3
-        if not args.report:
-            # the same step replayed from a hipGraph (one host launch per step instead of ~330); results are bit-identical to the eager step
-            # (tests/test_gpu_edge.py::test_graphed_step_matches_eager)
-            lg = Leg(args, args.dtype, False, rank, world, local, False, classes, B, S)
-            lg.use_graph()
-            sec['graph_ms_per_step'] = lg.timed(n2, w2 + 4) / n2 * 1e3
-            sec['graph_final_loss'] = lg.loss()
-            lg.close()
-            del lg
-            torch.cuda.empty_cache()
-        if not args.report and args.base == 32:
-            lmg = Leg(args, args.dtype, False, rank, world, local, False, classes, B, S, medformer=True)
-            lmg.use_graph()
-            nm = min(n2, 10)
-            sec['medformer_graph_ms_per_step'] = lmg.timed(nm, 7) / nm * 1e3
-            lmg.close()
-            del lmg
-            torch.cuda.empty_cache()
-            lm = Leg(args, args.dtype, False, rank, world, local, False, classes, B, S, medformer=True)
-            nm = min(n2, 10)
-            sec['medformer_ms_per_step'] = lm.timed(nm, 3) / nm * 1e3
-            sec['medformer_final_loss'] = lm.loss()
-            sec['medformer_workload'] = ('MedFormer of config/abdomenatlas_ufo/medformer_3d.yaml (37.9 M parameters, deep supervision), same batch and '
-                                         'segmentation loss: conv stem / BasicBlock stages / up-sampling / head on the HIP kernels, attention stages as '
-                                         'fp32 PyTorch-ROCm ops (first version, SURVEY 8f-1)')
-            lm.close()
-            del lm
-            torch.cuda.empty_cache()
-        if args.dtype == 'bf16':
-            lf32 = Leg(args, 'f32', args.report, rank, world, local, False, classes, B, S)
-            n3 = min(n2, 10)
-            sec['f32_ms_per_step'] = lf32.timed(n3, 2) / n3 * 1e3
-            if ref_logits is not None:
-                # same init, same batch, same number of optimiser steps in both arithmetic modes
-                lf32.run(headline_steps - lf32.step)
-                lf32.sync()
-                f32_logits = lf32.logits()
-                sec['bf16_vs_f32'] = {
-                    'steps': headline_steps,
-                    'abs_delta_overall_loss': abs(lf32.loss() - bf16_last_loss),
-                    'bf16_overall_loss': bf16_last_loss, 'f32_overall_loss': lf32.loss(),
-                    'logits_rel_l2': float(((ref_logits - f32_logits).double().norm() / f32_logits.double().norm()).item()),
-                    'note': 'identical init and batch, same number of optimiser steps in both arithmetic modes (full size); loss of the last step, '
-                            'logits of the trained weights on the training batch',
-                }
-            lf32.close()
-            del lf32
-        torch.cuda.empty_cache()
-        out['secondary'] = sec
+        cmd = [sys.executable, os.path.abspath(__file__), '--secondary-only'] + [a for a in sys.argv[1:] if a != '--secondary-only']
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+            out['secondary'] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {'error': f'rc {r.returncode}: ' + r.stderr.strip()[-300:]}
+        except Exception as e:                           # noqa: BLE001 -- includes the timeout
+            out['secondary'] = {'error': repr(e)[:300]}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args, classes)
     if world > 1 or args.force_ddp:
