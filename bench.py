@@ -393,7 +393,10 @@ def main():
         except Exception as e:                           # noqa: BLE001 -- includes the timeout
             out['secondary'] = {'error': repr(e)[:300]}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        out['cpu_baseline'] = cpu_baseline(args, classes)
+        try:
+            out['cpu_baseline'] = cpu_baseline(args, classes)
+        except Exception as e:                           # noqa: BLE001 -- a reported baseline must not cost the headline line
+            out['cpu_baseline'] = {'error': repr(e)[:300]}
     if world > 1 or args.force_ddp:
         dist.barrier()
         dist.destroy_process_group()
