@@ -56,6 +56,12 @@ class Feat:
             self._mr = channel_stats(self._cl)
         return self._cl, self._mr
 
+    def tensor(self, dtype):
+        """The activation in `dtype` without the statistics (inputs of the up-sampling kernel, which produces its own)."""
+        if self._cl is not None and self._cl.dtype == dtype:
+            return self._cl
+        return (self._g if self._g is not None else self._cl).contiguous().to(dtype)
+
     def g(self):
         if self._g is None:
             self._g = self._cl.float()
@@ -385,7 +391,5 @@ class up_block(nn.Module):
                 out = _run_blocks(self.conv_blocks, out, dtype)
             return out, smap
         # convolution-only stage: HIP trilinear up-sampling (it also produces the statistics) feeding a two-source first block
-        xl, _ = x1.cl(dtype)
-        xs, _ = x2.cl(dtype)
-        up, mru = ops.UpsampleFn.apply(xl, tuple(xs.shape[1:4]))
+        up, mru = ops.UpsampleFn.apply(x1.tensor(dtype), tuple(x2.tensor(dtype).shape[1:4]))
         return _run_blocks(self.conv_blocks, Feat(up, mru), dtype, second=x2), smap
