@@ -412,21 +412,33 @@ __global__ void compact_kernel(const float* x, const uint8_t* pm, long V, float*
         if (pm[i]) { const unsigned int p = atomicAdd(n, 1u); vals[p] = x[i]; idx[p] = (uint32_t)i; }
 }
 
+// Order key: larger value first, ties by lower index -> "j precedes i" is ONE unsigned 64-bit compare (the float is mapped to its
+// order-preserving unsigned image, the index complemented).  Each thread ranks two candidates per LDS tile element read.
+__device__ __forceinline__ unsigned long long rank_key(float v, uint32_t id) {
+    const uint32_t b = __float_as_uint(v);
+    const uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // monotone: larger float -> larger unsigned
+    return ((unsigned long long)ord << 32) | (unsigned long long)(~id);
+}
+
 __global__ __launch_bounds__(256) void rank_weight_kernel(const float* vals, const uint32_t* idx, unsigned int n, float dlog2, float scale, float* w) {
-    __shared__ float sv[256];
-    __shared__ uint32_t si[256];
-    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
-    const float v = i < n ? vals[i] : 0.f;
-    const uint32_t id = i < n ? idx[i] : 0u;
-    unsigned int rank = 0;
+    __shared__ unsigned long long sk[256];
+    const unsigned int i0 = blockIdx.x * 512 + threadIdx.x, i1 = i0 + 256;
+    const uint32_t id0 = i0 < n ? idx[i0] : 0u, id1 = i1 < n ? idx[i1] : 0u;
+    const unsigned long long k0 = i0 < n ? rank_key(vals[i0], id0) : 0ull, k1 = i1 < n ? rank_key(vals[i1], id1) : 0ull;
+    unsigned int r0 = 0, r1 = 0;
     for (unsigned int j0 = 0; j0 < n; j0 += 256) {
         __syncthreads();
-        if (j0 + threadIdx.x < n) { sv[threadIdx.x] = vals[j0 + threadIdx.x]; si[threadIdx.x] = idx[j0 + threadIdx.x]; }
+        sk[threadIdx.x] = j0 + threadIdx.x < n ? rank_key(vals[j0 + threadIdx.x], idx[j0 + threadIdx.x]) : 0ull;
         __syncthreads();
         const unsigned int lim = min(256u, n - j0);
-        for (unsigned int j = 0; j < lim; ++j) rank += (sv[j] > v) || (sv[j] == v && si[j] < id);
+        for (unsigned int j = 0; j < lim; ++j) {
+            const unsigned long long kj = sk[j];
+            r0 += kj > k0;
+            r1 += kj > k1;
+        }
     }
-    if (i < n) w[id] = exp2f((float)rank * dlog2) * scale;       // d^rank * N / sum_{r<N} d^r
+    if (i0 < n) w[id0] = exp2f((float)r0 * dlog2) * scale;       // d^rank * N / sum_{r<N} d^r
+    if (i1 < n) w[id1] = exp2f((float)r1 * dlog2) * scale;
 }
 
 __global__ void mask_op_kernel(uint8_t* a, const uint8_t* b, long V, int op) {
@@ -512,7 +524,7 @@ int rs_launch_compact(const float* x, const uint8_t* pm, long V, float* vals, ui
 
 int rs_launch_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float dlog2, float scale, float* w, hipStream_t st) {
     if (!n) return RS_OK;
-    hipLaunchKernelGGL(rank_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, st, vals, idx, n, dlog2, scale, w);
+    hipLaunchKernelGGL(rank_weight_kernel, dim3((n + 511) / 512), dim3(256), 0, st, vals, idx, n, dlog2, scale, w);
     return rs_check_launch();
 }
 
