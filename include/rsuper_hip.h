@@ -177,6 +177,7 @@ int rsuper_window_normalize(float* acc, const float* cd, const float* ch, const 
  * stats: part [N][rsuper_cnorm_rows(vox)][C][2]; mode 0 (sum x, sum x^2) -> rsuper_stats_finalize(mode 0) gives mr = (mean, rstd);
  *        mode 1 (sum g, sum g * x_hat) with g = dy * [x_hat > 0 when relu] -> rsuper_stats_finalize(mode 1) gives gm.
  * apply: mode 0 out = x_hat (max(x_hat, 0) when relu); mode 1 out = rstd * (g - gm0 - x_hat * gm1).
+ *        mode 2 out = x * mr[1] + mr[0]: a per-(sample, channel) affine map (SEBlock scaling x * s and its gradient, conv_layers.py:159-174).
  * ------------------------------------------------------------------------------------------------ */
 int rsuper_cnorm_rows(long vox);
 /* one-launch variant for small volumes (statistics + finalize + apply in a block per (sample, 64 channels)):
@@ -186,6 +187,25 @@ int rsuper_cnorm_small(const float* x, const float* dy, const float* mr, float* 
 int rsuper_cnorm_stats(const float* x, const float* dy, const float* mr, float* part, int N, long vox, int C, int relu, int mode, void* stream);
 int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode,
                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bidirectional attention between the L voxels of a stage and its T semantic-map tokens, f32 channels-last -- the score / soft-max /
+ * mixing core of BidirectionAttention (model/dim3/medformer_utils.py:13-99: the two einsums 'bhid,bhjd->bhij', the soft-max
+ * over either axis, 'bhij,bhjd->bhid' / 'bhji,bhjd->bhid' and the head rearranges around them):
+ *   S[t,l] = scale * <mq[t], fq[l]>;  f_out[l] = sum_t softmax_t(S[:,l])[t] mv[t];  m_out[t] = sum_l softmax_l(S[t,:])[l] fv[l]
+ * fqv [B][L][2*inner], mqv [B][T][2*inner]: q in channels [0, inner), v in [inner, 2*inner), inner = heads * dim_head, channel =
+ * dim_head_index * heads + head ('b (dim_head heads) ...'); f_out [B][L][inner], m_out [B][T][inner] in the same channel order.
+ * lse [B][heads][T][2] = (max, sum) of the voxel-axis soft-max (saved for backward).
+ * Workspaces (n = rsuper_battn_chunks(L, heads)): fwd part B*n*T*inner floats, pms B*n*heads*T*2 floats; bwd part B*n*T*2*inner.
+ * Built for (T, dim_head) in {(27, 32), (8, 16)}, heads <= 10 (rsuper_battn_supported); anything else -> RS_ERR_UNSUPPORTED.
+ * Deterministic (fixed-order merges, no atomics).
+ * ------------------------------------------------------------------------------------------------ */
+int rsuper_battn_supported(int T, int dim_head, int heads);
+int rsuper_battn_chunks(int L, int heads);
+int rsuper_battn_fwd(const float* fqv, const float* mqv, float* f_out, float* m_out, float* lse, float* part, float* pms, int B, int L, int T,
+                     int heads, int dim_head, float scale, void* stream);
+int rsuper_battn_bwd(const float* fqv, const float* mqv, const float* m_out, const float* lse, const float* d_f_out, const float* d_m_out,
+                     float* d_fqv, float* d_mqv, float* part, int B, int L, int T, int heads, int dim_head, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Depthwise 3x3x3 convolution (groups = C, stride 1, padding 1, no bias), channels-last f32 [N][D][H][W][C], C % 4 == 0 --

@@ -290,7 +290,7 @@ int rsuper_cnorm_stats(const float* x, const float* dy, const float* mr, float* 
 }
 int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode,
                        void* stream) {
-    if (!x || !mr || !out || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || (mode != 0 && mode != 1) || (mode == 1 && (!dy || !gm))) return RS_ERR_ARG;
+    if (!x || !mr || !out || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || mode < 0 || mode > 2 || (mode == 1 && (!dy || !gm))) return RS_ERR_ARG;
     return rs_launch_cnorm_apply(x, dy, mr, gm, out, N, vox, C, relu ? 1 : 0, mode, ST(stream));
 }
 int rsuper_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps,
@@ -298,6 +298,20 @@ int rsuper_cnorm_small(const float* x, const float* dy, const float* mr, float* 
     if (!x || !out || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || (mode != 0 && mode != 1) || (mode == 0 && !mr_out) || (mode == 1 && (!dy || !mr)))
         return RS_ERR_ARG;
     return rs_launch_cnorm_small(x, dy, mr, out, mr_out, N, vox, C, relu ? 1 : 0, eps, mode, ST(stream));
+}
+int rsuper_battn_supported(int T, int dim_head, int heads) { return rs_battn_supported(T, dim_head, heads); }
+int rsuper_battn_chunks(int L, int heads) { return rs_battn_chunks(L, heads); }
+int rsuper_battn_fwd(const float* fqv, const float* mqv, float* f_out, float* m_out, float* lse, float* part, float* pms, int B, int L, int T,
+                     int heads, int dim_head, float scale, void* stream) {
+    if (!fqv || !mqv || !f_out || !m_out || !lse || !part || !pms || B <= 0 || L <= 0 || T <= 0 || heads <= 0 || dim_head <= 0) return RS_ERR_ARG;
+    return rs_launch_battn(fqv, mqv, f_out, m_out, lse, nullptr, nullptr, nullptr, nullptr, part, pms, B, L, T, heads, dim_head, scale, 0, ST(stream));
+}
+int rsuper_battn_bwd(const float* fqv, const float* mqv, const float* m_out, const float* lse, const float* d_f_out, const float* d_m_out,
+                     float* d_fqv, float* d_mqv, float* part, int B, int L, int T, int heads, int dim_head, float scale, void* stream) {
+    if (!fqv || !mqv || !m_out || !lse || !d_f_out || !d_m_out || !d_fqv || !d_mqv || !part || B <= 0 || L <= 0 || T <= 0 || heads <= 0 || dim_head <= 0)
+        return RS_ERR_ARG;
+    return rs_launch_battn(fqv, mqv, nullptr, (float*)m_out, (float*)lse, d_f_out, d_m_out, d_fqv, d_mqv, part, nullptr, B, L, T, heads, dim_head,
+                           scale, 1, ST(stream));
 }
 int rsuper_depthwise3_rows(long vox) { return rs_depthwise_rows(vox); }
 int rsuper_depthwise3_fwd(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, void* stream) {

@@ -7,6 +7,7 @@
 //          mode 1: part[n][row][c] = (sum g, sum g * x_hat),  g = dy * [x_hat > 0 if relu]   -> mode 1 -> (m1, m2)
 //   apply  mode 0: y  = x_hat, or max(x_hat, 0) with relu                          x_hat = (x - mean) * rstd
 //          mode 1: dx = rstd * (g - m1 - x_hat * m2)
+//          mode 2: y  = x * mr[1] + mr[0]        (per-(sample, channel) affine map: the squeeze-excite scaling and its gradient)
 // Thread = (voxel, 4 consecutive channels); a block owns 64 channels (blockIdx.y) of one sample (blockIdx.z) and walks voxels
 // with stride rows * 16; per-block partial rows + the existing fixed-order f64 finalize keep the reduction deterministic.
 // ATen's reductions over the middle axes of a channels-last tensor ran at ~100 us per call (21 ms per MedFormer step).
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(256) void cnorm_apply_kernel(CnParams p) {
         const float4 q = *(const float4*)(xb + (size_t)v * p.C);
         const float4 xh = make_float4((q.x - mu.x) * rs.x, (q.y - mu.y) * rs.y, (q.z - mu.z) * rs.z, (q.w - mu.w) * rs.w);
         float4 o;
-        if (MODE == 0) {
+        if (MODE == 2) {                                     // per-(sample, channel) affine map: out = x * mr[1] + mr[0]
+            o = make_float4(fmaf(q.x, rs.x, mu.x), fmaf(q.y, rs.y, mu.y), fmaf(q.z, rs.z, mu.z), fmaf(q.w, rs.w, mu.w));
+        } else if (MODE == 0) {
             o = p.relu ? make_float4(fmaxf(xh.x, 0.f), fmaxf(xh.y, 0.f), fmaxf(xh.z, 0.f), fmaxf(xh.w, 0.f)) : xh;
         } else {
             float4 g = *(const float4*)(gb + (size_t)v * p.C);
@@ -207,7 +210,8 @@ int rs_launch_cnorm_apply(const float* x, const float* dy, const float* mr, cons
     if (bx > 2048) bx = 2048;
     dim3 grid((unsigned)bx, (C + CN_CG - 1) / CN_CG, N);
     if (mode == 0) hipLaunchKernelGGL(cnorm_apply_kernel<0>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(cnorm_apply_kernel<1>, grid, dim3(256), 0, st, p);
+    else if (mode == 1) hipLaunchKernelGGL(cnorm_apply_kernel<1>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(cnorm_apply_kernel<2>, grid, dim3(256), 0, st, p);
     return rs_check_launch();
 }
 

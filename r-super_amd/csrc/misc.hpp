@@ -54,6 +54,11 @@ int rs_cnorm_rows(long vox);
 int rs_launch_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps, int mode, hipStream_t st);
 int rs_launch_cnorm_stats(const float* x, const float* dy, const float* mr, float* part, int N, long vox, int C, int relu, int mode, hipStream_t st);
 int rs_launch_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode, hipStream_t st);
+int rs_battn_supported(int T, int dh, int heads);
+int rs_battn_chunks(int L, int heads);
+int rs_launch_battn(const float* fqv, const float* mqv, float* fout, float* mout, float* lse, const float* dfo, const float* dmo,
+                    float* dfqv, float* dmqv, float* part, float* pms, int B, int L, int T, int heads, int dh, float scale, int bwd,
+                    hipStream_t st);
 int rs_depthwise_rows(long vox);
 int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, hipStream_t st);
 int rs_launch_depthwise_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int D, int H, int W, int C, hipStream_t st);

@@ -8,6 +8,7 @@ producing kernel's epilogue (model/dim3/conv_layers.py:40-42: eps=1e-4, affine=F
 import os
 
 import torch
+import torch.nn.functional as F
 
 from . import lib as _l
 
@@ -712,6 +713,114 @@ class Conv3Fn(torch.autograd.Function):
             dw = torch.empty_like(w)
             wgrad(Src(x), None, Src(dout), None, dw, None, dims)
         return dx, dw
+
+
+class SqueezeExciteFn(torch.autograd.Function):
+    """SEBlock (model/dim3/conv_layers.py:159-174) on a channels-last fp32 tensor: y = x * sigmoid(W2 relu(W1 mean(x) + b1) + b2).
+    Two passes over x in each direction on csrc/instnorm.hip (per-channel sums + the affine apply); the two-layer excitation acts on one
+    (N, C) vector and stays in ATen, differentiated by a nested autograd call in backward."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = x.contiguous()
+        assert x.is_cuda and x.dim() == 5 and x.dtype == torch.float32 and x.shape[-1] % 4 == 0
+        N, C = x.shape[0], x.shape[-1]
+        vox = x.shape[1] * x.shape[2] * x.shape[3]
+        rows = _L().rsuper_cnorm_rows(vox)
+        st = _stream()
+        part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
+        ms = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
+        _l.check(_L().rsuper_cnorm_stats(_ptr(x), None, None, _ptr(part), N, vox, C, 0, 0, st), 'se_stats')
+        _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), 0.0, 1, 0, _ptr(ms), st), 'stats_finalize')
+        with torch.enable_grad():
+            leaves = [t.detach().requires_grad_(True) for t in (ms[..., 0], w1, b1, w2, b2)]
+            m, a1, c1, a2, c2 = leaves
+            s = torch.sigmoid(F.linear(F.relu(F.linear(m, a1.flatten(1), c1)), a2.flatten(1), c2))
+        tab = torch.stack([torch.zeros_like(s), s.detach()], -1)
+        y = torch.empty_like(x)
+        _l.check(_L().rsuper_cnorm_apply(_ptr(x), None, _ptr(tab), None, _ptr(y), N, vox, C, 0, 2, st), 'se_apply')
+        ctx.save_for_backward(x)
+        ctx.leaves, ctx.s = leaves, s
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, C = x.shape[0], x.shape[-1]
+        vox = x.shape[1] * x.shape[2] * x.shape[3]
+        rows = _L().rsuper_cnorm_rows(vox)
+        st = _stream()
+        part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
+        gm = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
+        ident = _se_identity(N, C, x.device)
+        # (sum dy, sum dy * x) / vox: the backward statistics kernel with (mean, rstd) = (0, 1)
+        _l.check(_L().rsuper_cnorm_stats(_ptr(x), _ptr(dy), _ptr(ident), _ptr(part), N, vox, C, 0, 1, st), 'se_bwd_stats')
+        _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), 0.0, 1, 0, _ptr(gm), st), 'stats_finalize')
+        s = ctx.s
+        grads = torch.autograd.grad(s, ctx.leaves, gm[..., 1] * float(vox))
+        ctx.leaves = ctx.s = None
+        tab = torch.stack([grads[0] / float(vox), s.detach()], -1)          # dx = dy * s + d mean / vox
+        dx = torch.empty_like(x)
+        _l.check(_L().rsuper_cnorm_apply(_ptr(dy), None, _ptr(tab), None, _ptr(dx), N, vox, C, 0, 2, st), 'se_bwd_apply')
+        return (dx,) + tuple(grads[1:])
+
+
+_SE_IDENT = {}
+
+
+def _se_identity(N, C, device):
+    k = (N, C, str(device))
+    if k not in _SE_IDENT:
+        t = torch.zeros((N, C, 2), device=device, dtype=torch.float32)
+        t[..., 1] = 1.0
+        _SE_IDENT[k] = t
+    return _SE_IDENT[k]
+
+
+def battn_supported(T, dim_head, heads):
+    return bool(_L().rsuper_battn_supported(int(T), int(dim_head), int(heads)))
+
+
+class BidirAttnFn(torch.autograd.Function):
+    """Score / soft-max / mixing core of MedFormer's BidirectionAttention (model/dim3/medformer_utils.py:13-99) in two launches per
+    direction (csrc/battn.hip).  fqv (B, L, 2 * inner), mqv (B, T, 2 * inner) f32: q | v halves, channel = dim_head_index * heads + head.
+    Returns f_out (B, L, inner), m_out (B, T, inner) in the same channel order."""
+
+    @staticmethod
+    def forward(ctx, fqv, mqv, heads, scale):
+        fqv, mqv = fqv.contiguous(), mqv.contiguous()
+        assert fqv.dtype == torch.float32 and mqv.dtype == torch.float32
+        B, L, c2 = fqv.shape
+        T = mqv.shape[1]
+        inner = c2 // 2
+        dh = inner // heads
+        dev = fqv.device
+        n = _L().rsuper_battn_chunks(L, heads)
+        f_out = torch.empty((B, L, inner), device=dev, dtype=torch.float32)
+        m_out = torch.empty((B, T, inner), device=dev, dtype=torch.float32)
+        lse = torch.empty((B, heads, T, 2), device=dev, dtype=torch.float32)
+        part = torch.empty(B * n * T * inner + B * n * heads * T * 2, device=dev, dtype=torch.float32)
+        pms = part[B * n * T * inner:]
+        _l.check(_L().rsuper_battn_fwd(_ptr(fqv), _ptr(mqv), _ptr(f_out), _ptr(m_out), _ptr(lse), _ptr(part), _ptr(pms), B, L, T, heads, dh,
+                                       float(scale), _stream()), 'battn_fwd')
+        ctx.save_for_backward(fqv, mqv, m_out, lse)
+        ctx.heads, ctx.scale = heads, float(scale)
+        return f_out, m_out
+
+    @staticmethod
+    def backward(ctx, df, dm):
+        fqv, mqv, m_out, lse = ctx.saved_tensors
+        B, L, c2 = fqv.shape
+        T, heads = mqv.shape[1], ctx.heads
+        inner = c2 // 2
+        df, dm = df.contiguous(), dm.contiguous()
+        n = _L().rsuper_battn_chunks(L, heads)
+        d_fqv, d_mqv = torch.empty_like(fqv), torch.empty_like(mqv)
+        part = torch.empty(B * n * T * c2, device=fqv.device, dtype=torch.float32)
+        _l.check(_L().rsuper_battn_bwd(_ptr(fqv), _ptr(mqv), _ptr(m_out), _ptr(lse), _ptr(df), _ptr(dm), _ptr(d_fqv), _ptr(d_mqv), _ptr(part),
+                                       B, L, T, heads, inner // heads, ctx.scale, _stream()), 'battn_bwd')
+        return d_fqv, d_mqv, None, None
 
 
 def channel_stats(x, eps):

@@ -14,6 +14,8 @@ the head split of the attention is a reshape of that axis, no NCDHW tensor is ev
 between the two worlds: in the compute dtype together with the InstanceNorm statistics the fused conv prologue needs (HIP
 BasicBlocks), or as fp32 (attention stages).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -83,6 +85,8 @@ def upsample_trilinear(x, size):
     return y[..., :C] if pad else y
 
 
+# RSUPER_MF_ATEN_ATTENTION=1: the ATen composition of the attention core instead of csrc/battn.hip (A/B switch; same results to fp32 rounding)
+FUSED_ATTENTION = os.environ.get('RSUPER_MF_ATEN_ATTENTION') != '1'
 GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 operands for the 1x1x1 GEMMs, see medformer.py)
 
 
@@ -137,9 +141,8 @@ class SEBlock(nn.Module):
         self.excitation = nn.Sequential(nn.Conv3d(ch, ch // ratio, 1), nn.ReLU(), nn.Conv3d(ch // ratio, ch, 1), nn.Sigmoid())
 
     def forward(self, x):
-        s = x.mean((1, 2, 3), keepdim=True)
-        s = torch.sigmoid(pointwise(F.relu(pointwise(s, self.excitation[0])), self.excitation[2]))
-        return x * s
+        e0, e2 = self.excitation[0], self.excitation[2]
+        return ops.SqueezeExciteFn.apply(x, e0.weight, e0.bias, e2.weight, e2.bias)
 
 
 class MBConv(nn.Module):
@@ -184,6 +187,15 @@ class BidirectionAttention(nn.Module):
         self.map_out = nn.Identity() if no_map_out else nn.Conv3d(inner, map_dim, 1, bias=False)
 
     def forward(self, feat, smap):
+        dim_head = self.map_qv.weight.shape[0] // (2 * self.heads)
+        tokens = smap.shape[1] * smap.shape[2] * smap.shape[3]
+        if FUSED_ATTENTION and ops.battn_supported(tokens, dim_head, self.heads):
+            # one HIP op for scores, both soft-maxes and both mixes, reading the projections' (q | v) channel layout as it is
+            f_out, m_out = ops.BidirAttnFn.apply(self.feat_qv(feat).flatten(1, 3), pointwise(smap, self.map_qv).flatten(1, 3), self.heads,
+                                                 self.scale)
+            f_out, m_out = f_out.reshape(*feat.shape[:4], -1), m_out.reshape(*smap.shape[:4], -1)
+            m_out = m_out if isinstance(self.map_out, nn.Identity) else pointwise(m_out, self.map_out)
+            return self.feat_out(f_out), m_out
         fq, fv = self.feat_qv(feat).chunk(2, -1)
         mq, mv = pointwise(smap, self.map_qv).chunk(2, -1)
         fq, fv, mq, mv = (_split_heads(t, self.heads) for t in (fq, fv, mq, mv))
@@ -229,8 +241,14 @@ class PatchMerging(nn.Module):
         self.norm = nn.Identity()                          # InstanceNorm3d(affine=False) has no state; applied functionally below
 
     def forward(self, x):
-        parts = [x[:, i::2, j::2, k::2, :] for i in range(2) for j in range(2) for k in range(2)]
-        return self.reduction(instance_norm(torch.cat(parts, -1), IN_EPS))
+        B, D, H, W, C = x.shape
+        if (D | H | W) & 1:
+            # the reference's torch.cat of the eight parity sub-lattices (medformer_utils.py:167-174) fails on an odd axis as well
+            raise ValueError(f'PatchMerging needs even spatial sizes, got {(D, H, W)}')
+        # space-to-depth as ONE strided copy (and one for its gradient) instead of eight strided slices + cat, whose backward is eight
+        # zero-fills, eight scatters and seven accumulations of a full-resolution tensor
+        merged = x.reshape(B, D // 2, 2, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(B, D // 2, H // 2, W // 2, 8 * C)
+        return self.reduction(instance_norm(merged, IN_EPS))
 
 
 class SemanticMapGeneration(nn.Module):

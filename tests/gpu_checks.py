@@ -445,6 +445,56 @@ def check_depthwise(C, dims, N=2, seed=91):
     return result(f'depthwise3 C{C} {dims}', e, 1e-5)
 
 
+def check_squeeze_excite(C, dims, N=2, seed=93):
+    """SEBlock (csrc/instnorm.hip statistics + affine apply around the ATen excitation) forward and all five gradients against the
+    float64 composition x * sigmoid(W2 relu(W1 mean(x) + b1) + b2) on the CPU."""
+    from rsuper_amd.hip import ops
+    r = C // 4
+    x = _rng_t(seed, (N, *dims, C)).requires_grad_(True)
+    ws = [_rng_t(seed + 1, (r, C, 1, 1, 1), 0.3), _rng_t(seed + 2, (r,), 0.3), _rng_t(seed + 3, (C, r, 1, 1, 1), 0.3), _rng_t(seed + 4, (C,), 0.3)]
+    ws = [w.requires_grad_(True) for w in ws]
+    go = _rng_t(seed + 5, (N, *dims, C))
+    xd, wd = x.double(), [w.double() for w in ws]
+    sc = torch.sigmoid(F.linear(F.relu(F.linear(xd.mean((1, 2, 3)), wd[0].flatten(1), wd[1])), wd[2].flatten(1), wd[3]))
+    y_ref = xd * sc[:, None, None, None, :]
+    (y_ref * go.double()).sum().backward()
+    xg = x.detach().to(DEV).requires_grad_(True)
+    wg = [w.detach().to(DEV).requires_grad_(True) for w in ws]
+    y = ops.SqueezeExciteFn.apply(xg, *wg)
+    (y * go.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    e = max([relerr(y.detach().cpu(), y_ref.detach().float()), relerr(xg.grad.cpu(), x.grad)] + [relerr(a.grad.cpu(), b.grad) for a, b in zip(wg, ws)])
+    return result(f'squeeze_excite C{C} {dims}', e, 2e-5)
+
+
+def check_battn(B, L, T, heads, dh, seed=97):
+    """Bidirectional attention core (csrc/battn.hip) forward + backward against the einsum / soft-max composition of the reference
+    (medformer_utils.py:66-86) evaluated in float64 on the CPU.  fp32 kernels with a different summation order: 2e-5 of max."""
+    from rsuper_amd.hip import ops
+    inner = heads * dh
+    fqv = _rng_t(seed, (B, L, 2 * inner)).requires_grad_(True)
+    mqv = _rng_t(seed + 1, (B, T, 2 * inner)).requires_grad_(True)
+    gf, gm = _rng_t(seed + 2, (B, L, inner)), _rng_t(seed + 3, (B, T, inner))
+    scale = dh ** -0.5
+
+    def split(t):                                           # 'b (dim_head heads) l -> b heads l dim_head' on channels-last rows
+        return t.reshape(B, -1, dh, heads).permute(0, 3, 1, 2)
+
+    fq, fv = (split(t) for t in fqv.double().chunk(2, -1))
+    mq, mv = (split(t) for t in mqv.double().chunk(2, -1))
+    attn = torch.einsum('bhid,bhjd->bhij', fq, mq) * scale                       # voxels x tokens
+    f_ref = torch.einsum('bhij,bhjd->bhid', F.softmax(attn, -1), mv).permute(0, 2, 3, 1).reshape(B, L, inner)
+    m_ref = torch.einsum('bhji,bhjd->bhid', F.softmax(attn, -2), fv).permute(0, 2, 3, 1).reshape(B, T, inner)
+    ((f_ref * gf.double()).sum() + (m_ref * gm.double()).sum()).backward()
+    a, b = fqv.detach().to(DEV).requires_grad_(True), mqv.detach().to(DEV).requires_grad_(True)
+    f, m = ops.BidirAttnFn.apply(a, b, heads, scale)
+    ((f * gf.to(DEV)).sum() + (m * gm.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    e = max(relerr(f.detach().cpu(), f_ref.detach().float()), relerr(m.detach().cpu(), m_ref.detach().float()),
+            relerr(a.grad.cpu(), fqv.grad), relerr(b.grad.cpu(), mqv.grad))
+    return result(f'battn B{B} L{L} T{T} h{heads} dh{dh}', e, 2e-5)
+
+
 def check_medformer_tiny(mode):
     """MedFormer forward + backward against the fixture of the reference class (tests/golden/medformer.npz): both heads,
     encoder features / semantic maps (summaries) and a strided sample of every parameter gradient."""
@@ -796,6 +846,9 @@ def all_checks(quick=False):
     cs += [(check_train_steps, ('f32',)), (check_train_steps, ('bf16',))]
     cs += [(check_cnorm, (8, (6, 7, 9), True)), (check_cnorm, (72, (5, 4, 11), False, 1)), (check_cnorm, (1280, (3, 3, 3), True)),
            (check_cnorm, (256, (24, 24, 24), True, 1))]
+    cs += [(check_squeeze_excite, (8, (6, 7, 9))), (check_squeeze_excite, (1024, (12, 12, 12))), (check_squeeze_excite, (72, (5, 4, 3), 1))]
+    cs += [(check_battn, (2, 1728, 27, 8, 32)), (check_battn, (1, 216, 27, 10, 32)), (check_battn, (2, 13824, 27, 4, 32)),
+           (check_battn, (2, 100, 27, 1, 32)), (check_battn, (1, 512, 8, 2, 16)), (check_battn, (2, 61, 8, 5, 16)), (check_battn, (1, 8, 8, 4, 16))]
     cs += [(check_depthwise, (8, (6, 7, 9))), (check_depthwise, (72, (5, 4, 11), 1)), (check_depthwise, (256, (12, 12, 12))),
            (check_depthwise, (1280, (3, 3, 3)))]
     cs += [(check_medformer_tiny, ('f32',)), (check_medformer_tiny, ('bf16',))]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which lines of this package still launch ATen kernels inside one training step?  Runs a few config-2 steps under
 torch.profiler (with_stack) and prints, per (aten op, innermost rsuper_amd source line), the launches per step and the device
-time -- the work list for VERDICT item 4 ("kill the ATen leftovers").  Usage: python tools/aten_trace.py [--report] [--steps 3]"""
+time -- the work list for VERDICT item 4 ("kill the ATen leftovers").  Usage: python tools/aten_trace.py [--report] [--medformer] [--steps 3]"""
 import argparse, collections, os, sys
 import torch
 from torch.profiler import profile, ProfilerActivity
@@ -16,10 +16,17 @@ from rsuper_amd.training import losses_foundation as lf
 ap = argparse.ArgumentParser()
 ap.add_argument('--report', action='store_true')
 ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--medformer', action='store_true', help='the shipped MedFormer configuration instead of the UNet')
 a = ap.parse_args()
 lf.SANITY_CHECKS = False
 dev = 'cuda'; B, S = 2, 96; classes = synth.PANTS_CLASSES
-net = UNet(1, 32, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype='bf16').to(dev)
+if a.medformer:
+    from rsuper_amd.model.dim3.medformer import MedFormer
+    net = MedFormer(1, len(classes), base_chan=32, map_size=[3, 3, 3], conv_num=[2, 0, 0, 0, 0, 0, 2, 2], trans_num=[0, 2, 4, 6, 4, 2, 0, 0],
+                    num_heads=[1, 4, 8, 10, 8, 4, 1, 1], fusion_depth=2, fusion_dim=320, fusion_heads=10, expansion=4, aux_loss=True,
+                    compute_dtype='bf16').to(dev)
+else:
+    net = UNet(1, 32, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype='bf16').to(dev)
 ema = make_ema(net); opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
 kinds = (['mask', 'report'] * B)[:B] if a.report else ['mask'] * B
 bt = synth.batch(B, S, classes, kinds, seed=7, diam_range=(5.0, 40.0), max_tumors=3)
@@ -65,7 +72,7 @@ print('# dispatcher view: ops per step on device tensors (views/allocations skip
 for (name, where, shape), n in sorted(calls.items(), key=lambda kv: (kv[0][1], kv[0][0])):
     print(f'{n / a.steps:6.1f}  {name:34s} {str(shape):28s} {where}')
 
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     for i in range(a.steps):
         train_step(net, ema, opt, batch, largs, classes, 4 + i)
     torch.cuda.synchronize()
@@ -89,3 +96,20 @@ print(f'# ATen launches / step: {tot_l:.1f}, device time {tot_t:.1f} us / step (
 print(f'{"op":28s} {"launch/step":>11s} {"us/step":>9s}  where')
 for (name, where), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f'{name:28s} {n / a.steps:11.1f} {t / a.steps:9.1f}  {where}')
+
+# in-place / internal ops (copy_, fill_, add_ ...) never reach the dispatcher hook above with a Python frame: name them by the chain of
+# enclosing profiler ranges (autograd node / parent aten op) and their input shapes
+chains = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.name not in ('aten::copy_', 'aten::fill_', 'aten::add_', 'aten::zero_') or ev.device_time_total <= 0 or not ev.kernels:
+        continue
+    names, q = [], ev.cpu_parent
+    while q is not None and len(names) < 4:
+        names.append(q.name)
+        q = q.cpu_parent
+    k = (ev.name, ' < '.join(names), str(ev.input_shapes[:2]))
+    chains[k][0] += len(ev.kernels)
+    chains[k][1] += sum(kk.duration for kk in ev.kernels)
+print('# in-place leaves by enclosing range')
+for (name, chain, shp), (n, t) in sorted(chains.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f'{name:14s} {n / a.steps:7.1f} {t / a.steps:9.1f} us  {shp:40s} {chain}')

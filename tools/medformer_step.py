@@ -32,5 +32,5 @@ t0 = time.perf_counter()
 for i in range(steps):
     loss, _ = train_step(net, ema, opt, batch, largs, classes, 2 + i)
 torch.cuda.synchronize()
-print(f'medformer {dtype}: {1e3 * (time.perf_counter() - t0) / steps:.1f} ms/step, loss {float(loss["overall"]):.4f}, '
+print(f'medformer {dtype}: {1e3 * (time.perf_counter() - t0) / steps:.1f} ms/step, loss {float(loss["overall"]):.6f}, '
       f'peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
