@@ -90,14 +90,54 @@ FUSED_ATTENTION = os.environ.get('RSUPER_MF_ATEN_ATTENTION') != '1'
 GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 operands for the 1x1x1 GEMMs, see medformer.py)
 
 
+SPLITK_MIN_ROWS = 8192          # weight gradients over more voxels than this are split along the voxel axis
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """F.linear whose weight gradient dW = dy^T x is a batched GEMM over slabs of the voxel axis followed by a sum.  The library runs
+    dy^T x as ONE GEMM with (Cout / 32) x (Cin / 128) workgroups however long the reduction is: at 24^3 x 2 voxels that is 16 workgroups
+    on 256 CUs, 186 us for a 128 x 27648 x 512 product (3.4 ms per MedFormer step over all such layers); split 16-way it takes ~15 us."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, w).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            rows = x2.shape[0]
+            slabs = next((s for s in (32, 16, 8) if rows % s == 0 and rows // s >= 1024), 0)
+            if slabs:
+                dw = torch.bmm(dy2.reshape(slabs, rows // slabs, -1).transpose(1, 2), x2.reshape(slabs, rows // slabs, -1)).sum(0)
+            else:
+                dw = torch.mm(dy2.t(), x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    rows = x.numel() // x.shape[-1]
+    if rows >= SPLITK_MIN_ROWS and x.dtype == torch.float32:
+        return _LinearSplitK.apply(x, w, b)
+    return F.linear(x, w, b)
+
+
 def pointwise(x, conv):
-    """Conv3d(k=1) as a GEMM over the channel axis (rocBLAS / hipBLASLt through F.linear, forward and both gradients); fp32 unless
-    GEMM_DTYPE says bf16 (opt-in experiment)."""
+    """Conv3d(k=1) as a GEMM over the channel axis (rocBLAS / hipBLASLt, forward and both gradients; the weight gradient of the
+    high-resolution stages split along the voxel axis); fp32 unless GEMM_DTYPE says bf16 (opt-in experiment)."""
     w = conv.weight.reshape(conv.weight.shape[0], conv.weight.shape[1])
     if GEMM_DTYPE != torch.float32 and x.numel() // x.shape[-1] >= 64:
         y = F.linear(x.to(GEMM_DTYPE), w.to(GEMM_DTYPE)).float()
         return y if conv.bias is None else y + conv.bias
-    return F.linear(x, w, conv.bias)
+    return linear(x, w, conv.bias)
 
 
 def depthwise(x, conv):

@@ -467,6 +467,28 @@ def check_squeeze_excite(C, dims, N=2, seed=93):
     return result(f'squeeze_excite C{C} {dims}', e, 2e-5)
 
 
+def check_linear_splitk(rows, cin, cout, bias, seed=99):
+    """1x1x1 convolution of the attention stages with the voxel-split weight gradient (model/dim3/medformer_utils.py linear) against
+    F.linear in float64 on the CPU: output and the three gradients."""
+    from rsuper_amd.model.dim3 import medformer_utils as mu
+    x = _rng_t(seed, (2, rows // 2, cin)).requires_grad_(True)
+    w = _rng_t(seed + 1, (cout, cin), 0.2).requires_grad_(True)
+    b = _rng_t(seed + 2, (cout,)).requires_grad_(True) if bias else None
+    go = _rng_t(seed + 3, (2, rows // 2, cout))
+    y_ref = F.linear(x.double(), w.double(), None if b is None else b.double())
+    (y_ref * go.double()).sum().backward()
+    xd, wd = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    bd = b.detach().to(DEV).requires_grad_(True) if bias else None
+    assert rows >= mu.SPLITK_MIN_ROWS
+    y = mu.linear(xd, wd, bd)
+    (y * go.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    errs = [relerr(y.detach().cpu(), y_ref.detach().float()), relerr(xd.grad.cpu(), x.grad), relerr(wd.grad.cpu(), w.grad)]
+    if bias:
+        errs.append(relerr(bd.grad.cpu(), b.grad))
+    return result(f'linear_splitk rows{rows} {cin}->{cout} bias{int(bias)}', max(errs), 2e-5)
+
+
 def check_battn(B, L, T, heads, dh, seed=97):
     """Bidirectional attention core (csrc/battn.hip) forward + backward against the einsum / soft-max composition of the reference
     (medformer_utils.py:66-86) evaluated in float64 on the CPU.  fp32 kernels with a different summation order: 2e-5 of max."""
@@ -846,6 +868,7 @@ def all_checks(quick=False):
     cs += [(check_train_steps, ('f32',)), (check_train_steps, ('bf16',))]
     cs += [(check_cnorm, (8, (6, 7, 9), True)), (check_cnorm, (72, (5, 4, 11), False, 1)), (check_cnorm, (1280, (3, 3, 3), True)),
            (check_cnorm, (256, (24, 24, 24), True, 1))]
+    cs += [(check_linear_splitk, (27648, 128, 512, False)), (check_linear_splitk, (8192, 72, 24, True)), (check_linear_splitk, (10000, 16, 8, True))]
     cs += [(check_squeeze_excite, (8, (6, 7, 9))), (check_squeeze_excite, (1024, (12, 12, 12))), (check_squeeze_excite, (72, (5, 4, 3), 1))]
     cs += [(check_battn, (2, 1728, 27, 8, 32)), (check_battn, (1, 216, 27, 10, 32)), (check_battn, (2, 13824, 27, 4, 32)),
            (check_battn, (2, 100, 27, 1, 32)), (check_battn, (1, 512, 8, 2, 16)), (check_battn, (2, 61, 8, 5, 16)), (check_battn, (1, 8, 8, 4, 16))]

@@ -113,3 +113,14 @@ for ev in prof.events():
 print('# in-place leaves by enclosing range')
 for (name, chain, shp), (n, t) in sorted(chains.items(), key=lambda kv: -kv[1][1])[:60]:
     print(f'{name:14s} {n / a.steps:7.1f} {t / a.steps:9.1f} us  {shp:40s} {chain}')
+
+# library GEMMs by operand shapes (which 1x1x1 convolutions / weight gradients are slow?)
+gemm = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.name in ('aten::mm', 'aten::addmm', 'aten::bmm') and ev.device_time_total > 0 and ev.kernels:
+        k = (ev.name, str(ev.input_shapes[:3]))
+        gemm[k][0] += 1
+        gemm[k][1] += sum(kk.duration for kk in ev.kernels)
+print('# GEMMs by shape')
+for (name, shp), (n, t) in sorted(gemm.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f'{name:12s} {n / a.steps:6.1f} calls {t / a.steps:9.1f} us/step {t / n:8.1f} us each  {shp}')

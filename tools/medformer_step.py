@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few MedFormer training steps (config/abdomenatlas_ufo/medformer_3d.yaml at 96^3, B = 2, 26 classes) -- the target of
-`rocprofv3 --kernel-trace` runs for SURVEY 8f-1.  Usage: python tools/medformer_step.py [steps] [dtype]"""
+`rocprofv3 --kernel-trace` runs for SURVEY 8f-1.  Usage: python tools/medformer_step.py [steps] [dtype] [graph]"""
 import argparse, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,12 +25,17 @@ batch = dict(image=torch.from_numpy(synth.image(B, S, seed=1234)).to(dev), label
 largs = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.0, volume_loss_tolerance=0.2,
                            ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
                            classification_branch=False, ema=True, ema_alpha=0.99)
-for i in range(2):
-    train_step(net, ema, opt, batch, largs, classes, i)
+step_fn = lambda b, i: train_step(net, ema, opt, b, largs, classes, i)
+if len(sys.argv) > 3 and sys.argv[3] == 'graph':                  # hipGraph replay: the GPU-side time of the step without the host's launch cost
+    from rsuper_amd.graph import GraphedTrainStep
+    step_fn = GraphedTrainStep(net, ema, opt, largs, classes, warmup=2)
+    dtype += ' graph'
+for i in range(4):
+    step_fn(batch, i)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(steps):
-    loss, _ = train_step(net, ema, opt, batch, largs, classes, 2 + i)
+    loss, _ = step_fn(batch, 4 + i)
 torch.cuda.synchronize()
 print(f'medformer {dtype}: {1e3 * (time.perf_counter() - t0) / steps:.1f} ms/step, loss {float(loss["overall"]):.6f}, '
       f'peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
