@@ -34,19 +34,29 @@ struct BaCfg {
     static constexpr int HS = T * DH + 4;                 // pitch of one head's token table: heads land on disjoint banks
 };
 
+// Token rows (T, ld) -> per-head tables [head][t][d] in LDS.  Four channels per thread and iteration as one 16-byte load; the loop is
+// unrolled so the loads of several iterations are in flight together (one load per iteration was pure latency: 70 us per block).
+template <int T, int DH>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int ld, int c0, int nc, int heads, float* __restrict__ dst, float mul) {
+    constexpr int HS = BaCfg<T, DH>::HS;
+    const int nq = nc >> 2, total = T * nq;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int t = i / nq, c = (i - t * nq) * 4;
+        const float4 x = *(const float4*)(src + (size_t)t * ld + c0 + c);
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = c + k, d = cc / heads, h = cc - d * heads;
+            dst[h * HS + t * DH + d] = xs[k] * mul;
+        }
+    }
+}
+
 template <int T, int DH>
 __device__ __forceinline__ void stage_tokens(const BaParams& p, const float* __restrict__ src, float* q, float* v, float qscale) {
-    constexpr int HS = BaCfg<T, DH>::HS;
-    const int ld = 2 * p.inner;
-    for (int i = threadIdx.x; i < T * ld; i += 256) {
-        const int t = i / ld, c = i - t * ld;
-        const bool isv = c >= p.inner;
-        const int cc = isv ? c - p.inner : c;
-        const int d = cc / p.heads, h = cc - d * p.heads;
-        const float x = src[i];
-        if (isv) { if (v) v[h * HS + t * DH + d] = x; }
-        else if (q) q[h * HS + t * DH + d] = x * qscale;
-    }
+    stage_rows<T, DH>(src, 2 * p.inner, 0, p.inner, p.heads, q, qscale);
+    stage_rows<T, DH>(src, 2 * p.inner, p.inner, p.inner, p.heads, v, 1.f);
 }
 
 template <int T, int DH>
@@ -240,11 +250,7 @@ __global__ __launch_bounds__(256) void battn_bwd_kernel(BaParams p) {
 #pragma unroll
     for (int d = 0; d < DH; ++d) a[d] = frow[d * heads];
     stage_tokens<T, DH>(p, p.mqv + (size_t)b * T * ld, mq, mv, p.scale);
-    for (int i = tid; i < T * inner; i += 256) {            // dM (B, T, inner) -> [head][t][d]
-        const int t = i / inner, c = i - t * inner;
-        const int d = c / heads, hh = c - d * heads;
-        dm[hh * HS + t * DH + d] = p.dmo[(size_t)b * T * inner + i];
-    }
+    stage_rows<T, DH>(p.dmo + (size_t)b * T * inner, inner, 0, inner, heads, dm, 1.f);   // dM (B, T, inner) -> [head][t][d]
     __syncthreads();
     for (int i = tid; i < heads * T; i += 256) {
         const int hh = i / T, t = i - hh * T;
@@ -318,14 +324,20 @@ __global__ __launch_bounds__(256) void battn_bwd_kernel(BaParams p) {
 }
 
 __global__ __launch_bounds__(256) void battn_bwd_merge_kernel(BaParams p, int T) {
-    const int t = blockIdx.x, b = blockIdx.y, ld = 2 * p.inner;
-    for (int c = threadIdx.x; c < ld; c += 256) {
-        const float* pr = p.part + ((size_t)b * p.chunks * T + t) * ld + c;
-        float s0 = 0.f, s1 = 0.f;
-        int k = 0;
-        for (; k + 1 < p.chunks; k += 2) { s0 += pr[(size_t)k * T * ld]; s1 += pr[(size_t)(k + 1) * T * ld]; }
-        if (k < p.chunks) s0 += pr[(size_t)k * T * ld];
-        const float s = s0 + s1;
+    __shared__ float red[4][64];
+    const int t = blockIdx.x, b = blockIdx.y, ld = 2 * p.inner, cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int c = blockIdx.z * 64 + cl;
+    const bool ok = c < ld;
+    const float* pr = p.part + ((size_t)b * p.chunks * T + t) * ld + (ok ? c : 0);
+    const size_t step = (size_t)T * ld;
+    float s0 = 0.f, s1 = 0.f;
+    int k = kg;
+    for (; k + 4 < p.chunks; k += 8) { s0 += pr[k * step]; s1 += pr[(k + 4) * step]; }
+    if (k < p.chunks) s0 += pr[k * step];
+    red[kg][cl] = s0 + s1;
+    __syncthreads();
+    if (kg == 0 && ok) {
+        const float s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
         p.dmqv[((size_t)b * T + t) * ld + c] = c < p.inner ? s * p.scale : s;
     }
 }
@@ -339,7 +351,7 @@ template <int T, int DH>
 int launch(const BaParams& p, int bwd, hipStream_t st) {
     const size_t smem = ba_smem<T, DH>(p.heads, bwd);
     if (smem > 160 * 1024) return RS_ERR_UNSUPPORTED;
-    dim3 grid(p.chunks, p.B), mgrid(T, p.B);
+    dim3 grid(p.chunks, p.B);
     if (!bwd) {
         auto k = battn_fwd_kernel<T, DH>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -349,7 +361,7 @@ int launch(const BaParams& p, int bwd, hipStream_t st) {
         auto k = battn_bwd_kernel<T, DH>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, p);
-        hipLaunchKernelGGL(battn_bwd_merge_kernel, mgrid, dim3(256), 0, st, p, T);
+        hipLaunchKernelGGL(battn_bwd_merge_kernel, dim3(T, p.B, (2 * p.inner + 63) / 64), dim3(256), 0, st, p, T);
     }
     return rs_check_launch();
 }
