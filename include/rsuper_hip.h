@@ -188,6 +188,12 @@ int rsuper_cnorm_stats(const float* x, const float* dy, const float* mr, float* 
 int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode,
                        void* stream);
 
+/* Re-layout of a logits-like f32 tensor between channels-last [N][vox][C] (C % 4 == 0, C <= 64, the first K channels real) and
+ * planar [N][K][vox] -- the `permute(0, 4, 1, 2, 3)` between MedFormer's channels-last deep-supervision head and the (N, K, D, H, W)
+ * planes the loss reads (model/dim3/medformer.py:190-194).  to_channels_last = 0: dst planar <- src channels-last;
+ * 1: dst channels-last <- src planar, padding channels K..C-1 written as zero (the gradient direction). */
+int rsuper_cl_planar(const float* src, float* dst, int N, long vox, int C, int K, int to_channels_last, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Bidirectional attention between the L voxels of a stage and its T semantic-map tokens, f32 channels-last -- the score / soft-max /
  * mixing core of BidirectionAttention (model/dim3/medformer_utils.py:13-99: the two einsums 'bhid,bhjd->bhij', the soft-max

@@ -313,6 +313,10 @@ int rsuper_battn_bwd(const float* fqv, const float* mqv, const float* m_out, con
     return rs_launch_battn(fqv, mqv, nullptr, (float*)m_out, (float*)lse, d_f_out, d_m_out, d_fqv, d_mqv, part, nullptr, B, L, T, heads, dim_head,
                            scale, 1, ST(stream));
 }
+int rsuper_cl_planar(const float* src, float* dst, int N, long vox, int C, int K, int to_channels_last, void* stream) {
+    if (!src || !dst || N <= 0 || vox <= 0 || C <= 0 || K <= 0) return RS_ERR_ARG;
+    return rs_launch_cl_planar(src, dst, N, vox, C, K, to_channels_last ? 1 : 0, ST(stream));
+}
 int rsuper_depthwise3_rows(long vox) { return rs_depthwise_rows(vox); }
 int rsuper_depthwise3_fwd(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, void* stream) {
     if (!x || !w || !y || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (flip != 0 && flip != 1)) return RS_ERR_ARG;

@@ -215,6 +215,57 @@ int rs_launch_cnorm_apply(const float* x, const float* dy, const float* mr, cons
     return rs_check_launch();
 }
 
+namespace {
+
+// Channels-last <-> planar re-layout of a logits-like f32 tensor: [N][vox][C] (C % 4 == 0, C <= 64, the first K channels real) <->
+// [N][K][vox].  The deep-supervision head of MedFormer up-samples channels-last and hands (N, K, D, H, W) planes to the loss
+// (medformer.py:190-194); ATen's permute copy ran this at 0.45 TB/s.  A block moves 128 voxels x C channels through LDS: 16-byte row
+// accesses on the channels-last side, 256-byte plane runs on the planar side.  dir 0: planar <- channels-last; dir 1: channels-last
+// <- planar with the C - K padding channels written as zero.
+__global__ __launch_bounds__(256) void cl_planar_kernel(const float* __restrict__ src, float* __restrict__ dst, long vox, int C, int K, int dir) {
+    __shared__ float tile[128][65];
+    const int n = blockIdx.y;
+    const long v0 = (long)blockIdx.x * 128;
+    const int nv = (int)min((long)128, vox - v0);
+    const int CV = C >> 2;
+    const float* cl_src = src + ((size_t)n * vox + v0) * C;
+    float* cl_dst = dst + ((size_t)n * vox + v0) * C;
+    if (dir == 0) {
+        for (int i = threadIdx.x; i < nv * CV; i += 256) {
+            const int v = i / CV, c = (i - v * CV) * 4;
+            const float4 q = *(const float4*)(cl_src + (size_t)v * C + c);
+            tile[v][c] = q.x; tile[v][c + 1] = q.y; tile[v][c + 2] = q.z; tile[v][c + 3] = q.w;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < K * 128; i += 256) {
+            const int k = i >> 7, v = i & 127;
+            if (v < nv) dst[((size_t)n * K + k) * vox + v0 + v] = tile[v][k];
+        }
+    } else {
+        for (int i = threadIdx.x; i < K * 128; i += 256) {
+            const int k = i >> 7, v = i & 127;
+            if (v < nv) tile[v][k] = src[((size_t)n * K + k) * vox + v0 + v];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nv * CV; i += 256) {
+            const int v = i / CV, c = (i - v * CV) * 4;
+            const float4 q = make_float4(c < K ? tile[v][c] : 0.f, c + 1 < K ? tile[v][c + 1] : 0.f, c + 2 < K ? tile[v][c + 2] : 0.f,
+                                         c + 3 < K ? tile[v][c + 3] : 0.f);
+            *(float4*)(cl_dst + (size_t)v * C + c) = q;
+        }
+    }
+}
+
+}  // namespace
+
+int rs_launch_cl_planar(const float* src, float* dst, int N, long vox, int C, int K, int dir, hipStream_t st) {
+    if (C > 64 || (C & 3) || K > C || K < 1) return RS_ERR_UNSUPPORTED;
+    const long bx = (vox + 127) / 128;
+    if (bx > 0x7FFFFFFFL) return RS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cl_planar_kernel, dim3((unsigned)bx, N), dim3(256), 0, st, src, dst, vox, C, K, dir);
+    return rs_check_launch();
+}
+
 // One-launch path for small volumes.  mode 0: out = norm(x) (+relu), mr_out = (mean, rstd); mode 1: out = dx from (x, dy, mr).
 int rs_launch_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps,
                           int mode, hipStream_t st) {

@@ -59,6 +59,7 @@ int rs_battn_chunks(int L, int heads);
 int rs_launch_battn(const float* fqv, const float* mqv, float* fout, float* mout, float* lse, const float* dfo, const float* dmo,
                     float* dfqv, float* dmqv, float* part, float* pms, int B, int L, int T, int heads, int dh, float scale, int bwd,
                     hipStream_t st);
+int rs_launch_cl_planar(const float* src, float* dst, int N, long vox, int C, int K, int dir, hipStream_t st);
 int rs_depthwise_rows(long vox);
 int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, hipStream_t st);
 int rs_launch_depthwise_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int D, int H, int W, int C, hipStream_t st);

@@ -715,6 +715,29 @@ class Conv3Fn(torch.autograd.Function):
         return dx, dw
 
 
+class PlanarFn(torch.autograd.Function):
+    """(N, D, H, W, C) channels-last f32, first K channels real -> (N, K, D, H, W) contiguous, and the padded channels-last gradient
+    back (csrc/instnorm.hip cl_planar_kernel) -- `x[..., :K].permute(0, 4, 1, 2, 3).contiguous()` in one pass each way."""
+
+    @staticmethod
+    def forward(ctx, x, K):
+        x = x.contiguous()
+        assert x.is_cuda and x.dim() == 5 and x.dtype == torch.float32
+        N, D, H, W, C = x.shape
+        y = torch.empty((N, K, D, H, W), device=x.device, dtype=torch.float32)
+        _l.check(_L().rsuper_cl_planar(_ptr(x), _ptr(y), N, D * H * W, C, K, 0, _stream()), 'cl_planar')
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        N, K, D, H, W = dy.shape
+        dx = torch.empty((N, D, H, W, ctx.C), device=dy.device, dtype=torch.float32)
+        _l.check(_L().rsuper_cl_planar(_ptr(dy), _ptr(dx), N, D * H * W, ctx.C, K, 1, _stream()), 'cl_planar_bwd')
+        return dx, None
+
+
 class SqueezeExciteFn(torch.autograd.Function):
     """SEBlock (model/dim3/conv_layers.py:159-174) on a channels-last fp32 tensor: y = x * sigmoid(W2 relu(W1 mean(x) + b1) + b2).
     Two passes over x in each direction on csrc/instnorm.hip (per-channel sums + the affine apply); the two-layer excitation acts on one

@@ -81,7 +81,7 @@ class MedFormer(nn.Module):
         out, smap = self.up2(out, x2, smap, maps[0], dt)
         aux = None
         if self.aux_loss:                                      # deep supervision head at 1/4 resolution, up-sampled (medformer.py:190-194)
-            aux = upsample_trilinear(pointwise(out.g(), self.aux_out), x.shape[-3:]).permute(0, 4, 1, 2, 3).contiguous()
+            aux = upsample_trilinear(pointwise(out.g(), self.aux_out), x.shape[-3:], planar=True)
         out, smap = self.up3(out, x1, smap, None, dt)
         out, smap = self.up4(out, x0, smap, None, dt)
         feat, _ = out.cl(dt)

@@ -75,13 +75,15 @@ def instance_norm(x, eps, relu=False):
     return ops.ChannelNormFn.apply(x, eps, relu)
 
 
-def upsample_trilinear(x, size):
+def upsample_trilinear(x, size, planar=False):
     """F.interpolate(size, mode='trilinear', align_corners=True) of a channels-last fp32 tensor on the HIP kernels (hip/ops.py
     UpsampleFn): deterministic backward (ATen's uses atomics).  Channels are zero-padded to the multiple of 8 the activation kernels
     work in."""
     C = x.shape[-1]
     pad = (-C) % 8
     y, _ = ops.UpsampleFn.apply((F.pad(x, (0, pad)) if pad else x).contiguous().float(), tuple(size))
+    if planar:                                   # (N, C, D, H, W) planes for the loss: one re-layout pass instead of slice + permute copy
+        return ops.PlanarFn.apply(y, C) if y.shape[-1] <= 64 else y[..., :C].permute(0, 4, 1, 2, 3).contiguous()
     return y[..., :C] if pad else y
 
 

@@ -489,6 +489,21 @@ def check_linear_splitk(rows, cin, cout, bias, seed=99):
     return result(f'linear_splitk rows{rows} {cin}->{cout} bias{int(bias)}', max(errs), 2e-5)
 
 
+def check_cl_planar(N, dims, C, K, seed=101):
+    """Channels-last -> planar re-layout (csrc/instnorm.hip cl_planar_kernel) and its gradient: pure data movement, bit-exact against
+    x[..., :K].permute(0, 4, 1, 2, 3) and the zero-padded inverse."""
+    from rsuper_amd.hip import ops
+    x = _rng_t(seed, (N, *dims, C)).to(DEV).requires_grad_(True)
+    go = _rng_t(seed + 1, (N, K, *dims)).to(DEV)
+    y = ops.PlanarFn.apply(x, K)
+    y.backward(go)
+    torch.cuda.synchronize()
+    y_ref = x.detach()[..., :K].permute(0, 4, 1, 2, 3)
+    g_ref = F.pad(go.permute(0, 2, 3, 4, 1), (0, C - K))
+    exact = bool(torch.equal(y.detach(), y_ref)) and bool(torch.equal(x.grad, g_ref))
+    return result(f'cl_planar N{N} {dims} C{C} K{K}', 0.0 if exact else 1.0, 0.5)
+
+
 def check_battn(B, L, T, heads, dh, seed=97):
     """Bidirectional attention core (csrc/battn.hip) forward + backward against the einsum / soft-max composition of the reference
     (medformer_utils.py:66-86) evaluated in float64 on the CPU.  fp32 kernels with a different summation order: 2e-5 of max."""
@@ -869,6 +884,7 @@ def all_checks(quick=False):
     cs += [(check_cnorm, (8, (6, 7, 9), True)), (check_cnorm, (72, (5, 4, 11), False, 1)), (check_cnorm, (1280, (3, 3, 3), True)),
            (check_cnorm, (256, (24, 24, 24), True, 1))]
     cs += [(check_linear_splitk, (27648, 128, 512, False)), (check_linear_splitk, (8192, 72, 24, True)), (check_linear_splitk, (10000, 16, 8, True))]
+    cs += [(check_cl_planar, (2, (24, 24, 24), 32, 26)), (check_cl_planar, (1, (5, 7, 9), 8, 3)), (check_cl_planar, (2, (4, 4, 33), 64, 64))]
     cs += [(check_squeeze_excite, (8, (6, 7, 9))), (check_squeeze_excite, (1024, (12, 12, 12))), (check_squeeze_excite, (72, (5, 4, 3), 1))]
     cs += [(check_battn, (2, 1728, 27, 8, 32)), (check_battn, (1, 216, 27, 10, 32)), (check_battn, (2, 13824, 27, 4, 32)),
            (check_battn, (2, 100, 27, 1, 32)), (check_battn, (1, 512, 8, 2, 16)), (check_battn, (2, 61, 8, 5, 16)), (check_battn, (1, 8, 8, 4, 16))]
