@@ -236,8 +236,11 @@ int rsuper_dilate_volume_sparse(const uint8_t* in, uint8_t* out, uint8_t* tmp, c
                                 int kernel_size, void* stream);
 /* isolate_tumor :1423-1445: Gaussian-ball correlation (odd diameter d_odd, std) and first-maximum argmax.
  * best: device u64, pre-zeroed; key = (f32 bits << 32) | (0xFFFFFFFF - linear index). conv_out optional (debug).
- * workspace: (d_odd/2 + 1) * D*H*W floats -> separable two-stage form (row sums per half width, then a k^2 gather per
- * voxel instead of k^3 taps); NULL -> direct form.  Both are f32; they differ only in summation order. */
+ * workspace: rsuper_ball_workspace_floats(D, H, W, d_odd) floats ((d_odd/2 + 1) * D*H*W row sums + one occupancy bit per (z, y)
+ * row) -> separable two-stage form (row sums per half width, then a k^2 gather per voxel instead of k^3 taps, over the rows of x
+ * that hold a non-zero only: x is zero outside the report's organ segment); NULL -> direct form.  Both are f32; they differ
+ * only in summation order. */
+long rsuper_ball_workspace_floats(int D, int H, int W, int d_odd);
 int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, float* workspace,
                             void* stream);
 /* insert_ball :1336-1385; count (device u32, pre-zeroed) += voxels set. */

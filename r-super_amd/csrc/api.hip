@@ -370,6 +370,7 @@ int rsuper_dilate_volume_sparse(const uint8_t* in, uint8_t* out, uint8_t* tmp, c
     return RS_OK;
 }
 
+long rsuper_ball_workspace_floats(int D, int H, int W, int d_odd) { return rs_ball_workspace_floats(D, H, W, d_odd); }
 int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, float* workspace,
                             void* stream) {
     if (!x || !best || d_odd < 1 || !(d_odd & 1) || std <= 0) return RS_ERR_ARG;

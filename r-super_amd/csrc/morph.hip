@@ -199,8 +199,26 @@ __global__ __launch_bounds__(256) void ball_rowsum_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void ball_gather_argmax_kernel(const float* __restrict__ ws, int D, int H, int W, int d_odd, float inv2s2,
-                                                                 unsigned long long* best, float* conv_out) {
+// One bit per (z, y) row of x: set when the row holds a non-zero.  x = sigmoid(logit) * segment mask is zero outside the report's organ
+// segment, F_L of an all-zero row is all zero, and adding exact zeros changes no partial sum: stage 2 visits the set bits only.
+// Block = one z plane; a wave ballots one row at a time.
+__global__ __launch_bounds__(256) void ball_row_bits_kernel(const float* __restrict__ x, int H, int W, int HW, uint32_t* __restrict__ bits) {
+    __shared__ uint32_t wb[64];
+    const int z = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < HW; i += 256) wb[i] = 0u;
+    __syncthreads();
+    for (int y = wv; y < H; y += 4) {
+        const float* row = x + ((long)z * H + y) * W;
+        bool nz = false;
+        for (int xx = lane; xx < W; xx += 64) nz |= row[xx] != 0.f;
+        if (__ballot(nz) != 0ull && lane == 0) atomicOr(&wb[y >> 5], 1u << (y & 31));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW; i += 256) bits[(long)z * HW + i] = wb[i];
+}
+
+__global__ __launch_bounds__(256) void ball_gather_argmax_kernel(const float* __restrict__ ws, const uint32_t* __restrict__ bits, int HW, int D, int H, int W,
+                                                                 int d_odd, float inv2s2, unsigned long long* best, float* conv_out) {
     __shared__ float g1[64];
     __shared__ signed char Lt[64 * 64];                          // row half width per (|dz|, |dy|), -1 outside the ball
     __shared__ unsigned long long wbest[4];
@@ -212,18 +230,27 @@ __global__ __launch_bounds__(256) void ball_gather_argmax_kernel(const float* __
     unsigned long long mine = 0ull;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long)gridDim.x * 256) {
         const int xx = (int)(i % W), yy = (int)((i / W) % H), zz = (int)(i / ((long)W * H));
+        const int ylo = max(yy - R, 0), yhi = min(yy + R, H - 1);
         float acc = 0.f;
         for (int dz = -R; dz <= R; ++dz) {
             const int z = zz + dz;
             if (z < 0 || z >= D) continue;
             const int az = dz < 0 ? -dz : dz;
             float part = 0.f;
-            for (int dy = -R; dy <= R; ++dy) {
-                const int y = yy + dy;
-                const int ay = dy < 0 ? -dy : dy;
-                const int L = Lt[az * 64 + ay];
-                if (L < 0 || y < 0 || y >= H) continue;
-                part += g1[ay] * ws[(long)L * V + ((long)z * H + y) * W + xx];
+            // rows y in [ylo, yhi] of plane z in ascending order (the order of the dense loop), non-empty ones only
+            for (int w = ylo >> 5; w <= (yhi >> 5); ++w) {
+                uint32_t m = bits[(long)z * HW + w];
+                const int base = w << 5;
+                if (base < ylo) m &= 0xFFFFFFFFu << (ylo - base);
+                if (base + 31 > yhi) m &= 0xFFFFFFFFu >> (base + 31 - yhi);
+                while (m) {
+                    const int y = base + __builtin_ctz(m);
+                    m &= m - 1;
+                    const int ay = y < yy ? yy - y : y - yy;
+                    const int L = Lt[az * 64 + ay];
+                    if (L < 0) continue;
+                    part += g1[ay] * ws[(long)L * V + ((long)z * H + y) * W + xx];
+                }
             }
             acc += g1[az] * part;
         }
@@ -474,14 +501,23 @@ int rs_launch_dilate_pass(const uint8_t* in, uint8_t* out, const uint8_t* flags,
     return rs_check_launch();
 }
 
+long rs_ball_workspace_floats(int D, int H, int W, int d_odd) {
+    return (long)((d_odd >> 1) + 1) * D * H * W + (long)D * ((H + 31) / 32);
+}
+
 int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, float* ws,
                                hipStream_t st) {
     if ((d_odd >> 1) >= 64) return RS_ERR_UNSUPPORTED;
     const long V = (long)D * H * W;
     int blocks = (int)((V + 255) / 256);
     if (ws) {
+        const int HW = (H + 31) / 32;
+        if (HW > 64) return RS_ERR_UNSUPPORTED;
+        uint32_t* bits = (uint32_t*)(ws + (size_t)((d_odd >> 1) + 1) * V);          // row-occupancy bits behind the row sums
+        hipLaunchKernelGGL(ball_row_bits_kernel, dim3(D), dim3(256), 0, st, x, H, W, HW, bits);
         hipLaunchKernelGGL(ball_rowsum_kernel, dim3(blocks), dim3(256), 0, st, x, D, H, W, d_odd >> 1, 1.f / (2.f * std * std), ws);
-        hipLaunchKernelGGL(ball_gather_argmax_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, D, H, W, d_odd, 1.f / (2.f * std * std), best, conv_out);
+        hipLaunchKernelGGL(ball_gather_argmax_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, (const uint32_t*)bits, HW, D, H, W, d_odd,
+                           1.f / (2.f * std * std), best, conv_out);
         return rs_check_launch();
     }
     hipLaunchKernelGGL(ball_conv_argmax_kernel, dim3(blocks), dim3(256), 0, st, x, D, H, W, d_odd, 1.f / (2.f * std * std), best, conv_out);

@@ -3,6 +3,7 @@
 #include <stddef.h>
 #include <stdint.h>
 int rs_launch_dilate_pass(const uint8_t* in, uint8_t* out, const uint8_t* flags, long nvol, int D, int H, int W, int k, hipStream_t st);
+long rs_ball_workspace_floats(int D, int H, int W, int d_odd);
 int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, float std, unsigned long long* best, float* conv_out, float* ws,
                                hipStream_t st);
 int rs_launch_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, hipStream_t st);

@@ -61,6 +61,7 @@ _SIGS = {
     'rsuper_window_normalize': (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, P]),
     'rsuper_dilate_volume': (c_int, [P, P, P, c_long, c_int, c_int, c_int, c_int, P]),
     'rsuper_dilate_volume_sparse': (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, c_int, P]),
+    'rsuper_ball_workspace_floats': (c_long, [c_int, c_int, c_int, c_int]),
     'rsuper_ball_conv_argmax': (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, P, P, P]),
     'rsuper_insert_ball': (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     'rsuper_radix_hist': (c_int, [P, P, c_long, c_uint32, c_int, P, P]),

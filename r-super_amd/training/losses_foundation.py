@@ -105,30 +105,39 @@ class _Term:
 
 class _PartialsFn(torch.autograd.Function):
     """sums[planes, 6] = (S, A, B, Cn, F1, F2) per term (csrc/loss.hip); backward writes d(logits) once:
-    term 0 must cover every plane (segmentation term), later terms accumulate on their planes."""
+    term 0 must cover every plane (segmentation term), later terms accumulate on their planes.
+    Returns (sums of term 0, sums of all later terms stacked along the plane axis or an empty (0, 6) tensor): one accumulator buffer and
+    one f64 -> f32 conversion per call."""
 
     @staticmethod
     def forward(ctx, logits, terms):
         assert logits.is_contiguous() and logits.dtype == torch.float32
         V = logits[0, 0].numel()
-        outs = []
+        total = sum(tm.planes for tm in terms)
+        acc = torch.zeros((total, 6), device=logits.device, dtype=torch.float64)
+        row = 0
         for tm in terms:
-            sums = torch.zeros((tm.planes, 6), device=logits.device, dtype=torch.float64)
             _l.check(_L().rsuper_plane_partials_fwd(_ptr(logits, tm.x_off), tm.xstride, _ptr(tm.t), _ptr(tm.k), _ptr(tm.w1), _ptr(tm.w2),
-                                                    _ptr(sums), 2 if tm.kinv else 0, tm.planes, V, _stream()), 'plane_partials_fwd')
-            outs.append(sums.to(torch.float32))
+                                                    _ptr(acc, row * 6), 2 if tm.kinv else 0, tm.planes, V, _stream()), 'plane_partials_fwd')
+            row += tm.planes
+        out = acc.to(torch.float32)
         ctx.terms = terms
         ctx.save_for_backward(logits)
-        return tuple(outs)
+        return out[:terms[0].planes], out[terms[0].planes:]
 
     @staticmethod
-    def backward(ctx, *gs):
+    def backward(ctx, g0, grest):
         (logits,) = ctx.saved_tensors
         V = logits[0, 0].numel()
         B, C = logits.shape[:2]
         assert ctx.terms[0].planes == B * C and ctx.terms[0].x_off == 0
         dl = torch.empty_like(logits)
-        for i, (tm, g) in enumerate(zip(ctx.terms, gs)):
+        grest = None if grest is None else grest.contiguous().float()
+        row = 0
+        for i, tm in enumerate(ctx.terms):
+            g = g0 if i == 0 else (None if grest is None else grest[row:row + tm.planes])
+            if i > 0:
+                row += tm.planes
             if g is None:
                 if i == 0:
                     dl.zero_()
@@ -161,6 +170,9 @@ class _SegFromSums(torch.autograd.Function):
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
         return d * g, None, None, None, None, None
+
+
+HOST_REPORT_ALGEBRA = os.environ.get('RSUPER_REPORT_ALGEBRA_DEVICE') != '1'
 
 
 def _dice_from_sums(A, Bs, Cn, w=None):
@@ -252,7 +264,8 @@ def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_ma
         vol, f32 = nnz - 1, True
     best = torch.zeros(1, device=x.device, dtype=torch.int64)
     # separable two-stage correlation (k^2 gathers per voxel instead of k^3 taps); direct form for tiny balls
-    ws = torch.empty(((diameter // 2 + 1) * V,), device=x.device, dtype=torch.float32) if (diameter >= 5 and os.environ.get('RSUPER_BALL_DIRECT', '0') != '1') else None
+    ws = (torch.empty((_L().rsuper_ball_workspace_floats(D, H, W, diameter),), device=x.device, dtype=torch.float32)
+          if (diameter >= 5 and os.environ.get('RSUPER_BALL_DIRECT', '0') != '1') else None)
     _l.check(_L().rsuper_ball_conv_argmax(_ptr(x), D, H, W, diameter, float(gaussian_std * (diameter / 2.0)), _ptr(best), None, _ptr(ws), _stream()),
               'ball_conv_argmax')
     key = int(best.item()) & 0xFFFFFFFFFFFFFFFF
@@ -529,23 +542,32 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
                         terms.append(_Term((p.b * C + c) * V, 0, 1, k=p.pens[li].contiguous()))
                 else:
                     terms.append(_Term((p.b * C + p.c) * V, 0, 1, t=p.pm, k=p.penal, w1=p.fw, w2=p.big))
-        sums = _PartialsFn.apply(r, terms)
-        ti = 0
+        seg_sums, rest = _PartialsFn.apply(r, terms)
         # ---- segmentation: masked BCE mean + adaptive-Tversky Dice (:945-956)
-        seg = _SegFromSums.apply(sums[ti], cw, B, C, V, aw * args.seg_loss); ti += 1
+        seg = _SegFromSums.apply(seg_sums, cw, B, C, V, aw * args.seg_loss)
         loss_seg_total = seg if loss_seg_total is None else loss_seg_total + seg
         loss_r = {}
+        # The report terms are a few dozen scalars per sample: their algebra (~100 forward and ~100 backward one-element ATen launches, each
+        # costing the host ~10 us while the queue is empty behind the ball search's synchronisations) runs on the HOST through torch's CPU
+        # autograd; the sums come over in one copy, the gradient goes back in one (HOST_REPORT_ALGEBRA = False keeps it on the device).
+        host = HOST_REPORT_ALGEBRA and rest.shape[0] > 0
+        sums = rest.cpu() if host else rest
+        cwx = None if cw is None else (cw.float().cpu() if host else cw)
+        ti = 0
         # ---- volume loss (:250-349)
         if use_vol and L > 0:
-            vhat = torch.stack([sums[ti + li][:, 1] for li in range(L)], dim=1)          # (B, L) sum sig * M
-            ti += L
-            lab_any = torch.stack([_plane_any(label_u8[:, c], 1) for c in chs], 1).float()        # per-voxel annotated tumour (:313)
-            gate = torch.stack([_plane_any(m, 1) for m in mseg31], 1).float()                      # :335
+            vhat = torch.stack([sums[ti + li * B:ti + (li + 1) * B, 1] for li in range(L)], dim=1)      # (B, L) sum sig * M
+            ti += L * B
+            flags = torch.stack([_plane_any(label_u8[:, c], 1) for c in chs] + [_plane_any(m, 1) for m in mseg31], 1).float()   # (B, 2L)
+            rvol = tumor_volumes_report.float().sum(-1, keepdim=True)
+            if host:
+                flags, rvol = flags.cpu(), rvol.cpu()
+            lab_any, gate = flags[:, :L], flags[:, L:]                     # per-voxel annotated tumour (:313) / segment present (:335)
             vhat = vhat * (1 - lab_any)
-            rv = tumor_volumes_report.float().sum(-1, keepdim=True).expand(B, L) * gate
+            rv = rvol.expand(B, L) * gate
             lv = dice_based_volume_loss(vhat, rv, tolerance=args.volume_loss_tolerance, E=500)
-            if cw is not None:
-                lv = lv * cw[:, chs]
+            if cwx is not None:
+                lv = lv * cwx[:, chs]
             loss_r['dice_volume_loss'] = lv.mean()
         # ---- ball loss (:1537-1864)
         if use_ball and L > 0:
@@ -553,16 +575,16 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
             l_bce, l_dice = [], []
             for p in plans:
                 if p.kind == 'none':                                      # :1625-1661
-                    ss = torch.stack([sums[ti + li][0] for li in range(L)], 0)   # (L, 6)
+                    ss = sums[ti:ti + L]                                  # (L, 6)
                     ti += L
-                    wl = cw[p.b, chs] if cw is not None else None
+                    wl = cwx[p.b, chs] if cwx is not None else None
                     Sb = ss[:, 0] * wl if wl is not None else ss[:, 0]
                     l_bce.append(Sb.sum() / float(L * V))
                     if apply_dice:
                         l_dice.append(_dice_from_sums(ss[None, :, 1], ss[None, :, 2], ss[None, :, 3], None if wl is None else wl[None]))
                 else:
-                    ss = sums[ti][0]; ti += 1
-                    wc = cw[p.b, p.c] if cw is not None else None
+                    ss = sums[ti]; ti += 1
+                    wc = cwx[p.b, p.c] if cwx is not None else None
                     if getattr(args, 'stardard_ce_ball', False):
                         lb = ss[0] / float(V)
                     else:
@@ -573,6 +595,7 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
                                                       None if wc is None else wc.view(1, 1)))
             loss_r['ball_loss_bce'] = torch.stack(l_bce).mean()
             loss_r['ball_loss_dice'] = torch.stack(l_dice).mean() if apply_dice else torch.zeros_like(loss_r['ball_loss_bce'])
+        assert ti == rest.shape[0]
         if not loss_r and rep_scalar is None:
             rep_scalar = torch.zeros((), device=r.device)                   # aw * rw * 0 for every head
         for k, v in loss_r.items():
@@ -585,7 +608,7 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         # key order of the reference: ball keys first, then volume
         for k in ('ball_loss_bce', 'ball_loss_dice', 'dice_volume_loss'):
             if k in rep:
-                loss[k] = rep[k]
+                loss[k] = rep[k].to(loss_seg_total.device)
     else:
         loss['report'] = rep_scalar
     overall = None

@@ -181,25 +181,37 @@ def test_packed_batch_gives_same_loss():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('fill', ['dense', 'segment', 'empty'])
 @pytest.mark.parametrize('d_odd', [5, 9, 21])
-def test_ball_conv_two_stage_equals_direct(d_odd):
-    """The separable two-stage correlation gives the direct kernel's values (f32 summation-order tolerance) and argmax."""
+def test_ball_conv_two_stage_equals_direct(d_odd, fill):
+    """The separable two-stage correlation gives the direct kernel's values (f32 summation-order tolerance) and argmax -- on a dense
+    volume, on one that is zero outside an organ-like segment (the second stage then visits the occupied (z, y) rows only) and on an
+    all-zero volume (first index wins)."""
     from rsuper_amd.hip import lib
     L = lib.lib()
-    D, H, W = 24, 20, 28
+    D, H, W = 24, 40, 28
     g = torch.Generator(device=DEV).manual_seed(d_odd)
     x = torch.rand((D, H, W), device=DEV, generator=g)
+    if fill == 'segment':
+        m = torch.zeros_like(x)
+        m[5:17, 3:37:2, 4:20] = 1.0                      # every other row empty inside the box, rows on both sides of a 32-row word
+        m[20, 33, 7] = 1.0
+        x = x * m
+    elif fill == 'empty':
+        x = torch.zeros_like(x)
     outs, keys = [], []
     for two_stage in (False, True):
         best = torch.zeros(1, device=DEV, dtype=torch.int64)
         conv = torch.empty((D, H, W), device=DEV)
-        ws = torch.empty(((d_odd // 2 + 1) * D * H * W,), device=DEV) if two_stage else None
+        ws = torch.empty((L.rsuper_ball_workspace_floats(D, H, W, d_odd),), device=DEV) if two_stage else None
         rc = L.rsuper_ball_conv_argmax(x.data_ptr(), D, H, W, d_odd, 1.5 * d_odd / 2.0, best.data_ptr(), conv.data_ptr(),
                                        ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
         assert rc == 0
         outs.append(conv.cpu()); keys.append(int(best.item()) & 0xFFFFFFFF)
     assert torch.allclose(outs[0], outs[1], rtol=2e-5, atol=1e-5)
     assert keys[0] == keys[1]
+    if fill == 'empty':
+        assert 0xFFFFFFFF - keys[1] == 0 and float(outs[1].abs().max()) == 0.0
 
 
 @pytest.mark.gpu
