@@ -253,6 +253,11 @@ int rsuper_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr_bits
  * need four device->host reads per mask).  workspace: 260 u32 on the device.  out[i] = 1 for the k largest of x*m
  * (x >= 0), ties -> lower index first.  1 <= k <= V. */
 int rsuper_topk_select(const float* x, const uint8_t* m, long V, unsigned int k, uint8_t* out, unsigned int* workspace, void* stream);
+/* nk <= 4 selections over the same (x, m) in one pass sequence (isolate_tumor's t / t_small / t_big masks, :1483-1507): k is a HOST
+ * array of nk counts, out holds nk volumes, workspace nk * 260 u32.  clip_to_mask != 0 ANDs every selection with m (voxels outside m
+ * rank with value 0 as in the dense top-k but are never marked: the "no tumor_mask value outside the ball" step). */
+int rsuper_topk_select_multi(const float* x, const uint8_t* m, long V, const unsigned int* k, int nk, uint8_t* out, unsigned int* workspace,
+                             int clip_to_mask, void* stream);
 /* GlobalWeightedRankPooling(return_weights, hard_cutoff) :442-535 restricted to the pseudo mask. */
 int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream);
 int rsuper_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float log2_d, float scale, float* w, void* stream);

@@ -390,7 +390,14 @@ int rsuper_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr_bits
 }
 int rsuper_topk_select(const float* x, const uint8_t* m, long V, unsigned int k, uint8_t* out, unsigned int* workspace, void* stream) {
     if (!x || !out || !workspace || V <= 0 || k == 0 || (long)k > V) return RS_ERR_ARG;
-    return rs_launch_topk_select(x, m, V, k, out, workspace, ST(stream));
+    return rs_launch_topk_select(x, m, V, &k, 1, out, workspace, 0, ST(stream));
+}
+int rsuper_topk_select_multi(const float* x, const uint8_t* m, long V, const unsigned int* k, int nk, uint8_t* out, unsigned int* workspace,
+                             int clip_to_mask, void* stream) {
+    if (!x || !out || !workspace || !k || V <= 0 || nk < 1 || nk > 4) return RS_ERR_ARG;
+    for (int i = 0; i < nk; ++i)
+        if (k[i] == 0 || (long)k[i] > V) return RS_ERR_ARG;
+    return rs_launch_topk_select(x, m, V, k, nk, out, workspace, clip_to_mask ? 1 : 0, ST(stream));
 }
 int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream) {
     if (!x || !pm || !vals || !idx || !n) return RS_ERR_ARG;

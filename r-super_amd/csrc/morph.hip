@@ -343,10 +343,12 @@ __global__ void topk_mark_all_kernel(const float* x, const uint8_t* m, long V, u
 //   per pass:  hist (as above, prefix read from the state)  ->  scan (one block: pick the digit, update the state)
 //   then:      mark (parallel: bits > thr, and every tie when all ties are wanted)  +  ordered tie pass (single block; exits
 //              immediately unless only some of the elements equal to the threshold are wanted)
+// blockIdx.y = which of the batched selections (k values) of one call: its state / histogram sit 260 words apart
 __global__ __launch_bounds__(256) void radix_hist_dev_kernel(const float* x, const uint8_t* m, long V, const unsigned int* state, int shift, unsigned int* hist) {
     __shared__ unsigned int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
+    state += blockIdx.y * 260; hist += blockIdx.y * 260;
     const uint32_t prefix = state[0];
     const uint32_t hmask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long)gridDim.x * 256) {
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(256) void radix_hist_dev_kernel(const float* x, con
 // inclusive wave scan of the per-lane sums locates the lane, the lane walks its four digits.  Clears the histogram.
 __global__ __launch_bounds__(64) void radix_scan_kernel(unsigned int* hist, unsigned int* state, int shift) {
     const int lane = threadIdx.x;
+    hist += blockIdx.x * 260; state += blockIdx.x * 260;
     unsigned int h[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { h[j] = hist[255 - 4 * lane - j]; hist[255 - 4 * lane - j] = 0; }
@@ -390,18 +393,23 @@ __global__ __launch_bounds__(64) void radix_scan_kernel(unsigned int* hist, unsi
     }
 }
 
-__global__ void topk_mark_dev_kernel(const float* x, const uint8_t* m, long V, const unsigned int* state, uint8_t* out) {
+// clip: the selection is AND-ed with the mask m (voxels outside m take part in the ranking with value 0, as in the dense top-k, but are
+// never marked -- the reference's "no tumor_mask value outside the ball" step folded in)
+__global__ void topk_mark_dev_kernel(const float* x, const uint8_t* m, long V, const unsigned int* state, uint8_t* out, int clip) {
+    state += blockIdx.y * 260; out += (size_t)blockIdx.y * V;
     const uint32_t thr = state[0];
     const bool all_ties = state[3] == 0xFFFFFFFFu;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) {
-        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
-        out[i] = all_ties ? (b >= thr) : (b > thr);
+        const bool in = !m || m[i];
+        const uint32_t b = in ? __float_as_uint(x[i]) : 0u;
+        out[i] = (all_ties ? (b >= thr) : (b > thr)) && (in || !clip);
     }
 }
 
 // ties in index order (lower index first): only runs when some but not all elements equal to the threshold are wanted
-__global__ __launch_bounds__(1024) void topk_ties_dev_kernel(const float* x, const uint8_t* m, long V, const unsigned int* state, uint8_t* out) {
+__global__ __launch_bounds__(1024) void topk_ties_dev_kernel(const float* x, const uint8_t* m, long V, const unsigned int* state, uint8_t* out, int clip) {
     __shared__ unsigned int cnt[1024];
+    state += blockIdx.x * 260; out += (size_t)blockIdx.x * V;
     const unsigned int need_eq = state[3];
     if (need_eq == 0xFFFFFFFFu) return;
     const uint32_t thr = state[0];
@@ -422,14 +430,17 @@ __global__ __launch_bounds__(1024) void topk_ties_dev_kernel(const float* x, con
     }
     unsigned int before = cnt[threadIdx.x] - c;
     for (long i = b0; i < b1; ++i) {
-        const uint32_t b = (!m || m[i]) ? __float_as_uint(x[i]) : 0u;
-        if (b == thr) { out[i] = before < need_eq; ++before; }
+        const bool in = !m || m[i];
+        const uint32_t b = in ? __float_as_uint(x[i]) : 0u;
+        if (b == thr) { out[i] = before < need_eq && (in || !clip); ++before; }
     }
 }
 
-__global__ void topk_state_init_kernel(unsigned int* ws, unsigned int k) {
+struct TopkKs { unsigned int k[4]; };
+__global__ void topk_state_init_kernel(unsigned int* ws, TopkKs ks) {
+    ws += blockIdx.x * 260;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) ws[4 + i] = 0;      // histogram
-    if (threadIdx.x == 0) { ws[0] = 0; ws[1] = k; ws[2] = 0; ws[3] = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) { ws[0] = 0; ws[1] = ks.k[blockIdx.x]; ws[2] = 0; ws[3] = 0xFFFFFFFFu; }
 }
 
 // ------------------------------------------------------------------------------------------------ GWRP rank weights
@@ -540,16 +551,19 @@ int rs_launch_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr, 
     return rs_check_launch();
 }
 
-// workspace: 260 u32 on the device = {prefix, remaining, ties, need, hist[256]}
-int rs_launch_topk_select(const float* x, const uint8_t* m, long V, unsigned int k, uint8_t* out, unsigned int* ws, hipStream_t st) {
+// workspace: nk * 260 u32 on the device = {prefix, remaining, ties, need, hist[256]} per selection; out: nk volumes
+int rs_launch_topk_select(const float* x, const uint8_t* m, long V, const unsigned int* k, int nk, uint8_t* out, unsigned int* ws, int clip, hipStream_t st) {
+    if (nk < 1 || nk > 4) return RS_ERR_ARG;
     const int hb = rs_elem_blocks((size_t)V) > 512 ? 512 : rs_elem_blocks((size_t)V);
-    hipLaunchKernelGGL(topk_state_init_kernel, dim3(1), dim3(256), 0, st, ws, k);
+    TopkKs ks = {{0, 0, 0, 0}};
+    for (int i = 0; i < nk; ++i) ks.k[i] = k[i];
+    hipLaunchKernelGGL(topk_state_init_kernel, dim3(nk), dim3(256), 0, st, ws, ks);
     for (int shift = 24; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(radix_hist_dev_kernel, dim3(hb), dim3(256), 0, st, x, m, V, (const unsigned int*)ws, shift, ws + 4);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(64), 0, st, ws + 4, ws, shift);
+        hipLaunchKernelGGL(radix_hist_dev_kernel, dim3(hb, nk), dim3(256), 0, st, x, m, V, (const unsigned int*)ws, shift, ws + 4);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(nk), dim3(64), 0, st, ws + 4, ws, shift);
     }
-    hipLaunchKernelGGL(topk_mark_dev_kernel, dim3(rs_elem_blocks((size_t)V)), dim3(256), 0, st, x, m, V, (const unsigned int*)ws, out);
-    hipLaunchKernelGGL(topk_ties_dev_kernel, dim3(1), dim3(1024), 0, st, x, m, V, (const unsigned int*)ws, out);
+    hipLaunchKernelGGL(topk_mark_dev_kernel, dim3(rs_elem_blocks((size_t)V), nk), dim3(256), 0, st, x, m, V, (const unsigned int*)ws, out, clip);
+    hipLaunchKernelGGL(topk_ties_dev_kernel, dim3(nk), dim3(1024), 0, st, x, m, V, (const unsigned int*)ws, out, clip);
     return rs_check_launch();
 }
 

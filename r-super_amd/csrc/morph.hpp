@@ -9,7 +9,7 @@ int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, f
 int rs_launch_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, hipStream_t st);
 int rs_launch_radix_hist(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist, hipStream_t st);
 int rs_launch_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr, unsigned int need_eq, uint8_t* out, hipStream_t st);
-int rs_launch_topk_select(const float* x, const uint8_t* m, long V, unsigned int k, uint8_t* out, unsigned int* ws, hipStream_t st);
+int rs_launch_topk_select(const float* x, const uint8_t* m, long V, const unsigned int* k, int nk, uint8_t* out, unsigned int* ws, int clip, hipStream_t st);
 int rs_launch_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, hipStream_t st);
 int rs_launch_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float dlog2, float scale, float* w, hipStream_t st);
 int rs_launch_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, hipStream_t st);

@@ -69,6 +69,7 @@ _SIGS = {
     'rsuper_compact': (c_int, [P, P, c_long, P, P, P, P]),
     'rsuper_rank_weights': (c_int, [P, P, c_uint, c_float, c_float, P, P]),
     'rsuper_topk_select': (c_int, [P, P, c_long, c_uint, P, P, P]),
+    'rsuper_topk_select_multi': (c_int, [P, P, c_long, P, c_int, P, P, c_int, P]),
     'rsuper_plane_any': (c_int, [P, c_long, c_long, P, P]),
     'rsuper_mask_op': (c_int, [P, P, c_long, c_int, P]),
     'rsuper_unpack_bits': (c_int, [P, P, c_int, c_int, c_int, c_long, P]),

@@ -288,9 +288,19 @@ def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_ma
     t_small = int(np.float32(t) * np.float32(1 - ms)) if f32 else int(t * (1 - ms))
     t_small = max(t_small, min(100, vol))
     t_big = min(V - 1, int(np.float32(vol) * np.float32(1 + volume_margin)) if f32 else int(vol * (1 + volume_margin)))
-    masks = [_topk_mask(x, ball, k) for k in (t, t_small, t_big)]
-    for m in masks:                       # "ensure no tumor_mask value is outside the ball" (:1504-1507)
-        _l.check(_L().rsuper_mask_op(_ptr(m), _ptr(ball), V, 0, _stream()), 'mask_and')
+    ks = (t, t_small, t_big)
+    if min(ks) > 0 and os.environ.get('RSUPER_TOPK_HOST', '0') != '1':
+        # the three selections share x and the ball: one batched radix select, AND with the ball folded into the marking (:1504-1507)
+        import ctypes
+        out3 = torch.empty((3,) + tuple(x.shape), device=x.device, dtype=torch.uint8)
+        ws3 = torch.empty(3 * 260, device=x.device, dtype=torch.int32)
+        _l.check(_L().rsuper_topk_select_multi(_ptr(x), _ptr(ball), V, (ctypes.c_uint * 3)(*ks), 3, _ptr(out3), _ptr(ws3), 1, _stream()),
+                 'topk_select_multi')
+        masks = [out3[0], out3[1], out3[2]]
+    else:
+        masks = [_topk_mask(x, ball, k) for k in ks]
+        for m in masks:                       # "ensure no tumor_mask value is outside the ball" (:1504-1507)
+            _l.check(_L().rsuper_mask_op(_ptr(m), _ptr(ball), V, 0, _stream()), 'mask_and')
     iters = 0
     while vol < 50 ** 3 and _count(masks[0]) < vol * 0.7:     # :1513-1522
         if iters > 5:

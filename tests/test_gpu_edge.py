@@ -340,6 +340,38 @@ def test_topk_select_device_matches_oracle(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', ['plain', 'ties', 'sparse_positive'])
+def test_topk_select_multi_equals_three_selections_and_mask(case):
+    """rsuper_topk_select_multi (three counts over one (x, ball) in one pass sequence, clipped to the ball) == three oracle top-k masks
+    of x * ball AND-ed with the ball, bit-exact -- incl. the case where k exceeds the number of positive values (threshold 0: the dense
+    top-k then picks zeros by index, inside and outside the ball; only the inside ones survive the clip)."""
+    import ctypes
+    from rsuper_amd.hip import lib
+    from oracle import morph as om
+    L = lib.lib()
+    rng = np.random.default_rng(11)
+    V = 24 * 20 * 28
+    x = rng.random(V).astype(np.float32)
+    if case == 'ties':
+        x = (rng.integers(0, 30, V) / 30.0).astype(np.float32)
+    ball = (rng.random(V) < 0.3).astype(np.uint8)
+    if case == 'sparse_positive':
+        x = x * (rng.random(V) < 0.05)                            # ~200 positive values inside the ball, k up to 3000
+    ks = (1500, 1200, 3000)
+    xm = np.ascontiguousarray((x * ball).astype(np.float32))
+    want = [om.topk_mask(xm, k) & ball for k in ks]
+    xd, bd = torch.from_numpy(x.astype(np.float32)).to(DEV), torch.from_numpy(ball).to(DEV)
+    out = torch.empty((3, V), device=DEV, dtype=torch.uint8)
+    ws = torch.empty(3 * 260, device=DEV, dtype=torch.int32)
+    rc = L.rsuper_topk_select_multi(xd.data_ptr(), bd.data_ptr(), V, (ctypes.c_uint * 3)(*ks), 3, out.data_ptr(), ws.data_ptr(), 1,
+                                    torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    got = out.cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], want[i]), (case, i, int(got[i].sum()), int(want[i].sum()))
+
+
+@pytest.mark.gpu
 def test_plane_any_matches_torch():
     from rsuper_amd.training.losses_foundation import _plane_any
     g = torch.Generator(device=DEV).manual_seed(3)
