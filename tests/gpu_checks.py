@@ -590,14 +590,14 @@ def check_plane_partials():
     (ref * gs).sum().backward()
     xd = x.to(DEV).requires_grad_(True)
     term = lf._Term(0, V, B * C, t=t.to(DEV), k=k.to(DEV), w1=w1.to(DEV), w2=w2.to(DEV))
-    (sums,) = lf._PartialsFn.apply(xd, [term])
+    sums, _ = lf._PartialsFn.apply(xd, [term])
     (sums * gs.to(DEV)).sum().backward()
     torch.cuda.synchronize()
     e1 = relerr(sums.detach().cpu(), ref.detach())
     e2 = relerr(xd.grad.cpu(), xr.grad)
     # the same term given the complementary ("unknown") mask with the inverted-k flag must give identical results
     xi = x.to(DEV).requires_grad_(True)
-    (sums_i,) = lf._PartialsFn.apply(xi, [lf._Term(0, V, B * C, t=t.to(DEV), k=(1 - k).to(DEV), w1=w1.to(DEV), w2=w2.to(DEV), kinv=True)])
+    sums_i, _ = lf._PartialsFn.apply(xi, [lf._Term(0, V, B * C, t=t.to(DEV), k=(1 - k).to(DEV), w1=w1.to(DEV), w2=w2.to(DEV), kinv=True)])
     (sums_i * gs.to(DEV)).sum().backward()
     e3 = max(relerr(sums_i.detach().cpu(), sums.detach().cpu()), relerr(xi.grad.cpu(), xd.grad.cpu()))
     return result('plane_partials', max(e1, e2, e3), 2e-5, f'sums {e1:.2e} grad {e2:.2e} inverted-k {e3:.2e}')
