@@ -92,7 +92,9 @@ FUSED_ATTENTION = os.environ.get('RSUPER_MF_ATEN_ATTENTION') != '1'
 GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 operands for the 1x1x1 GEMMs, see medformer.py)
 
 
-SPLITK_MIN_ROWS = 8192          # weight gradients over more voxels than this are split along the voxel axis
+# weight gradients over at least MIN_ROWS voxels are split into slabs of at least MIN_SLAB voxels (measured: splitting the 12^3 stages too,
+# 3456 rows, or thinner slabs is slower -- 31.3 / 30.7 vs 30.1 ms per replayed step)
+SPLITK_MIN_ROWS, SPLITK_MIN_SLAB = 8192, 1024
 
 
 class _LinearSplitK(torch.autograd.Function):
@@ -115,7 +117,7 @@ class _LinearSplitK(torch.autograd.Function):
             dx = torch.mm(dy2, w).reshape(x.shape)
         if ctx.needs_input_grad[1]:
             rows = x2.shape[0]
-            slabs = next((s for s in (32, 16, 8) if rows % s == 0 and rows // s >= 1024), 0)
+            slabs = next((s for s in (32, 16, 8, 4) if rows % s == 0 and rows // s >= SPLITK_MIN_SLAB), 0)
             if slabs:
                 dw = torch.bmm(dy2.reshape(slabs, rows // slabs, -1).transpose(1, 2), x2.reshape(slabs, rows // slabs, -1)).sum(0)
             else:
