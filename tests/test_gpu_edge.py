@@ -512,6 +512,75 @@ def test_augmented_loader_feeds_packed_ingest(tmp_path):
 
 
 @pytest.mark.gpu
+def test_medformer_fused_attention_matches_aten_composition():
+    """The HIP attention core (csrc/battn.hip) against the ATen composition it replaces (einsum / soft-max / head rearranges), through
+    the whole tiny MedFormer in f32: logits and every parameter gradient.  Same mathematics in a different summation order on an
+    ill-conditioned tiny net: 2e-3 of the largest gradient."""
+    import synth
+    from rsuper_amd.model.dim3.medformer import MedFormer
+    from rsuper_amd.model.dim3 import medformer_utils as mu
+    cfg = {k: v for k, v in synth.MEDFORMER_TINY.items() if k not in ('size', 'seed')}
+    x = torch.from_numpy(synth.image(1, 32, seed=3)).to('cuda')
+
+    def run(fused):
+        old = mu.FUSED_ATTENTION
+        mu.FUSED_ATTENTION = fused
+        try:
+            torch.manual_seed(0)
+            net = MedFormer(1, len(synth.TINY_CLASSES), compute_dtype='f32', **cfg).to('cuda')
+            y, aux = net(x)['segmentation']
+            (y.square().mean() + aux.square().mean()).backward()
+            return y.detach(), aux.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        finally:
+            mu.FUSED_ATTENTION = old
+
+    y1, a1, g1 = run(True)
+    y0, a0, g0 = run(False)
+    assert float((y1 - y0).abs().max() / y0.abs().max()) < 1e-4 and float((a1 - a0).abs().max() / a0.abs().max()) < 1e-4
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    worst = max(float((g1[k] - g0[k]).abs().max()) for k in g0) / gmax
+    assert worst < 2e-3, worst
+
+
+@pytest.mark.gpu
+def test_report_algebra_on_host_matches_device():
+    """The Volume / Ball scalar algebra through CPU autograd (default) against the same algebra on the device
+    (RSUPER_REPORT_ALGEBRA_DEVICE=1): loss entries and d(logits)."""
+    import argparse
+    import synth
+    from rsuper_amd.training import losses_foundation as lf
+    classes = synth.TINY_CLASSES
+    largs = argparse.Namespace(loss='ball_dice_both', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1, volume_loss_tolerance=0.2,
+                               ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                               classification_branch=False)
+    bt = synth.batch(3, 32, classes, ['mask', 'report', 'report'], seed=13, diam_range=(4.0, 9.0), max_tumors=2)
+    b = {k: torch.from_numpy(bt[k]).to('cuda') for k in ('label', 'unk_channels', 'mask', 'volumes', 'diameters')}
+    g = torch.Generator(device='cuda').manual_seed(5)
+    logits = torch.randn((3, len(classes), 32, 32, 32), device='cuda', generator=g) * 2
+    weights = torch.rand((3, len(classes)), device='cuda', generator=g) + 0.5
+
+    def run(host):
+        old = lf.HOST_REPORT_ALGEBRA
+        lf.HOST_REPORT_ALGEBRA = host
+        try:
+            x = logits.clone().requires_grad_(True)
+            loss = lf.calculate_loss(model_output={'segmentation': x}, label=b['label'], unk_voxels=b['unk_channels'], args=largs, matcher=None,
+                                     chosen_segment_mask=b['mask'], tumor_volumes_report=b['volumes'], tumor_diameters=b['diameters'],
+                                     classes=classes, class_weights=weights)
+            loss['overall'].backward()
+            return {k: float(v.detach()) for k, v in loss.items()}, x.grad.clone()
+        finally:
+            lf.HOST_REPORT_ALGEBRA = old
+
+    lh, gh = run(True)
+    ld, gd = run(False)
+    assert lh.keys() == ld.keys() and len(lh) >= 4
+    for k in lh:
+        assert abs(lh[k] - ld[k]) <= 1e-6 * max(1.0, abs(ld[k])), (k, lh[k], ld[k])
+    assert float((gh - gd).abs().max()) <= 1e-6 * float(gd.abs().max())
+
+
+@pytest.mark.gpu
 def test_medformer_train_steps_deep_supervision():
     """MedFormer (8f-1) through the training step: deep-supervision output [final, aux] (medformer.py:205-222) into calculate_loss with
     aux_weight (losses_foundation.py:905-930), backward through the HIP conv stages and the attention stages, clip + fused AdamW + EMA over
