@@ -167,6 +167,12 @@ class Leg:
         from rsuper_amd.graph import GraphedTrainStep
         self.graphed = GraphedTrainStep(self.net, self.ema, self.opt, self.largs, self.classes, warmup=3)
 
+    def use_net_graphs(self):
+        """Forward and backward of the network from two hipGraphs around the eager loss / optimiser: the form that also covers report
+        supervision (host-synchronous ball search in the loss)."""
+        from rsuper_amd.graph import GraphedNetwork
+        self.model = GraphedNetwork(self.net, warmup=3)
+
     def sync(self):
         if self.world > 1:
             dist.barrier()
@@ -247,6 +253,20 @@ def secondary_legs(args, rank, world, local, classes, B, S):
                                      '1x1x1 convolutions and attention products as library GEMMs (SURVEY 8f-1)')
         lm.close()
 
+    def medformer_report():
+        # the R-Super use proper: MedFormer with report supervision (one mask + one report sample); eager, then with the network's forward
+        # and backward replayed from two hipGraphs around the eager loss (losses identical: tests/test_gpu_edge.py)
+        nm = min(n2, 10)
+        lr_ = leg_of(args.dtype, True, medformer=True)
+        sec['medformer_report_ms_per_step'] = lr_.timed(nm, 3) / nm * 1e3
+        lr_.close()
+        del lr_
+        torch.cuda.empty_cache()
+        lg = leg_of(args.dtype, True, medformer=True)
+        lg.use_net_graphs()
+        sec['medformer_report_netgraph_ms_per_step'] = lg.timed(nm, 5) / nm * 1e3
+        lg.close()
+
     def f32():
         ref_logits = bf16_last_loss = None
         if not args.report:
@@ -281,6 +301,7 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         if args.base == 32:
             guarded('medformer_graph', medformer_graph)
             guarded('medformer', medformer)
+            guarded('medformer_report', medformer_report)
     if args.dtype == 'bf16':
         guarded('f32', f32)
     return sec

@@ -177,13 +177,21 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
     packed = getattr(trainLoader.dataset, 'packed', False)
     # rsuper_amd extension (--hip_graph): replay the step from a hipGraph where that is possible -- segmentation-only supervision, one process,
     # the fused optimiser (rsuper_amd/graph.py); the stepper lives on the optimiser so that it survives across epochs
-    stepper = None
-    if getattr(args, 'hip_graph', False) and float(getattr(args, 'report_volume_loss_basic', 0.0)) == 0 and not getattr(args, 'distributed', False) \
-            and isinstance(optimizer, FusedAdamWEMA) and getattr(net, '_rsuper_reducer', None) is None:
-        from .graph import GraphedTrainStep
-        stepper = getattr(optimizer, '_graphed_step', None)
-        if stepper is None or stepper.net is not net:
-            stepper = optimizer._graphed_step = GraphedTrainStep(net, ema_net, optimizer, args, classes)
+    # With report supervision (host-synchronous ball search in the loss) the network's forward and backward are replayed from two graphs
+    # around the eager loss and optimiser (graph.GraphedNetwork); a batch of another shape (last batch of an epoch) takes the eager path.
+    stepper, fwd_net = None, net
+    if getattr(args, 'hip_graph', False) and not getattr(args, 'distributed', False) and getattr(net, '_rsuper_reducer', None) is None \
+            and not hasattr(net, 'module'):
+        if float(getattr(args, 'report_volume_loss_basic', 0.0)) == 0 and isinstance(optimizer, FusedAdamWEMA):
+            from .graph import GraphedTrainStep
+            stepper = getattr(optimizer, '_graphed_step', None)
+            if stepper is None or stepper.net is not net:
+                stepper = optimizer._graphed_step = GraphedTrainStep(net, ema_net, optimizer, args, classes)
+        else:
+            from .graph import GraphedNetwork
+            fwd_net = getattr(optimizer, '_graphed_net', None)
+            if fwd_net is None or fwd_net.net is not net:
+                fwd_net = optimizer._graphed_net = GraphedNetwork(net)
     for i, inputs in enumerate(trainLoader):
         batch = dict(image=inputs['image'], label=inputs['label'], unk_channels=inputs['unk_channels'],
                      volumes=inputs['volumes'].float(), mask=inputs['mask'], diameters=inputs['diameters'].float())
@@ -202,7 +210,8 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
         if stepper is not None:
             loss_all, _ = stepper(batch, step)
         else:
-            loss_all, _ = train_step(net, ema_net, optimizer, batch, args, classes, step, matcher=matcher)
+            use = fwd_net if (fwd_net is net or fwd_net.accepts(img)) else net
+            loss_all, _ = train_step(use, ema_net, optimizer, batch, args, classes, step, matcher=matcher)
         if len(loss_meters) == 0:
             loss_meters = OrderedDict((k, AverageMeter(k, ':6.4f')) for k in loss_all.keys())
             loss_meters['Elapsed Time'] = AverageMeter('Elapsed Time', ':6.2f')
@@ -278,7 +287,7 @@ def get_parser(argv=None, config_root=None):
     parser.add_argument('--crop_size', default=None, type=int)
     parser.add_argument('--load_augmented', action='store_true', help='Loads pre-saved crops for training (:414)')
     parser.add_argument('--save_destination', type=str, default=None, help='directory of the pre-saved crops (:415)')
-    parser.add_argument('--hip_graph', action='store_true', help='rsuper_amd extension: replay eligible training steps from a hipGraph')
+    parser.add_argument('--hip_graph', action='store_true', help='rsuper_amd extension: replay the training step from a hipGraph (segmentation-only supervision) or the network forward / backward from two graphs around the eager loss (report supervision)')
     parser.add_argument('--synthetic', type=int, default=0, help='rsuper_amd extension: train on N synthetic samples (no dataset on disk)')
     args = parser.parse_args(argv)
 

@@ -683,9 +683,64 @@ def test_graphed_step_matches_eager(model):
 
 
 @pytest.mark.gpu
-def test_train_epoch_with_hip_graph_matches_eager(tmp_path):
-    """train_net / train_epoch with --hip_graph (segmentation-only supervision): the epochs replayed from the captured step give the same meter
-    averages and the same final checkpointed weights as the eager driver."""
+@pytest.mark.parametrize('model', ['unet', 'medformer'])
+def test_graphed_network_with_report_supervision_matches_eager(model):
+    """rsuper_amd.graph.GraphedNetwork: forward and backward of the network replayed from two hipGraphs around an EAGER report-supervised
+    loss (ball search with host reads) and the eager fused optimiser: exactly the losses, gradient norms, parameters and EMA of the eager
+    train_step over different batches; evaluation calls and state_dict fall through to the module."""
+    import argparse
+    import synth
+    from rsuper_amd.graph import GraphedNetwork
+    from rsuper_amd.train_ddp import train_step, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    classes = synth.TINY_CLASSES
+    largs = argparse.Namespace(loss='ball_dice_both', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1, volume_loss_tolerance=0.2,
+                               ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                               classification_branch=False, ema=True, ema_alpha=0.99)
+    dev = 'cuda'
+    batches = []
+    for i in range(2):
+        bt = synth.batch(2, 32, classes, ['mask', 'report'], seed=21 + i, diam_range=(4.0, 8.0), max_tumors=2)
+        batches.append(dict(image=torch.from_numpy(synth.image(2, 32, seed=7 + i)).to(dev), label=torch.from_numpy(bt['label']).to(dev),
+                            unk_channels=torch.from_numpy(bt['unk_channels']).to(dev), mask=torch.from_numpy(bt['mask']).to(dev),
+                            volumes=torch.from_numpy(bt['volumes']).to(dev), diameters=torch.from_numpy(bt['diameters']).to(dev)))
+
+    def run(graphed):
+        torch.manual_seed(0)
+        if model == 'unet':
+            from rsuper_amd.model.dim3.unet import UNet
+            net = UNet(1, 8, num_classes=len(classes), compute_dtype='bf16').to(dev)
+        else:
+            from rsuper_amd.model.dim3.medformer import MedFormer
+            net = MedFormer(1, len(classes), compute_dtype='bf16', **{k: v for k, v in synth.MEDFORMER_TINY.items() if k not in ('size', 'seed')}).to(dev)
+        ema = make_ema(net)
+        opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        fwd = GraphedNetwork(net, warmup=2) if graphed else net
+        hist = []
+        for i in range(6):
+            loss, gn = train_step(fwd, ema, opt, batches[i % 2], largs, classes, i)
+            hist.append(({k: float(v.detach()) for k, v in loss.items()}, float(gn)))
+        if graphed:
+            assert fwd.fwd_graph is not None and set(fwd.state_dict().keys()) == set(net.state_dict().keys())
+            net.eval()
+            with torch.no_grad():
+                y = fwd(batches[0]['image'])['segmentation']          # evaluation falls through to the module
+            net.train()
+            assert torch.isfinite(y[0] if isinstance(y, (list, tuple)) else y).all()
+        return hist, [p.detach().clone() for p in net.parameters()], [p.detach().clone() for p in ema.parameters()]
+
+    h_e, p_e, e_e = run(False)
+    h_g, p_g, e_g = run(True)
+    assert h_e == h_g, (h_e, h_g)
+    assert all(torch.equal(a, b) for a, b in zip(p_e, p_g)) and all(torch.equal(a, b) for a, b in zip(e_e, e_g))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('report', ['0', '0.1'])
+def test_train_epoch_with_hip_graph_matches_eager(tmp_path, report):
+    """train_net / train_epoch with --hip_graph: the epochs replayed from the captured step (segmentation-only supervision) or with the network
+    forward / backward replayed from two graphs around the eager report-supervised loss give the same meter averages and the same final
+    checkpointed weights as the eager driver."""
     import os
     from rsuper_amd.train_ddp import get_parser, main_worker
     from rsuper_amd.training.dataset import SyntheticUFODataset
@@ -694,7 +749,7 @@ def test_train_epoch_with_hip_graph_matches_eager(tmp_path):
     for tag, extra in (('eager', []), ('graph', ['--hip_graph'])):
         ds = SyntheticUFODataset(classes, size=32, length=16, seed=3)
         args = get_parser(['--epochs', '2', '--batch_size', '2', '--cp_path', str(tmp_path) + '/', '--unique_name', tag, '--loss', 'ball_dice_last',
-                           '--report_volume_loss_basic', '0'] + extra)
+                           '--report_volume_loss_basic', report] + extra)
         args.base_chan, args.iter_per_epoch, args.print_freq, args.compute_dtype = 8, 4, 100, 'bf16'
         torch.manual_seed(0)
         hist = main_worker(0, 1, 0, args, trainset=ds)
