@@ -154,10 +154,10 @@ class _ReplayFn(torch.autograd.Function):
         for p, g in zip(o.params, o.static_grads):
             if g is None:
                 continue
-            if p.grad is None:
+            if p.grad is None or p.grad is g:       # `is g`: zero_grad(set_to_none=False) zeroed the static buffer, the replay refilled it
                 p.grad = g
             else:
-                p.grad.add_(g)                      # gradient accumulation over micro-batches
+                p.grad.add_(g)                      # gradient accumulation into a tensor of the caller's
         return None, None, None
 
 
