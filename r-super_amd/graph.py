@@ -148,6 +148,11 @@ class _ReplayFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         o = ctx.owner
+        probe = next((i for i, g in enumerate(o.static_grads) if g is not None), None)
+        if probe is not None and o.params[probe].grad is o.static_grads[probe] and o.static_grads[probe]._version == o._grad_version:
+            # .grad still points at the static buffer and nothing reset it since the last backward: a second backward before the optimiser
+            # step (micro-batch accumulation) would be overwritten by this replay
+            raise RuntimeError('GraphedNetwork: one backward per zero_grad / optimiser step (gradient accumulation needs the eager module)')
         for dst, g in zip(o.static_gouts, gouts):
             dst.copy_(g) if g is not None else dst.zero_()
         o.bwd_graph.replay()
@@ -158,6 +163,7 @@ class _ReplayFn(torch.autograd.Function):
                 p.grad = g
             else:
                 p.grad.add_(g)                      # gradient accumulation into a tensor of the caller's
+        o._grad_version = o.static_grads[probe]._version if probe is not None else -1
         return None, None, None
 
 
@@ -207,6 +213,7 @@ class GraphedNetwork:
         for p, g in zip(self.params, saved):
             p.grad = g
         self._anchor = torch.zeros(1, device=img.device, requires_grad=True)
+        self._grad_version = -1
         self._shape = (tuple(img.shape), img.dtype)
         ops.WEIGHTS_EPOCH += 1                         # fragment caches filled during capture belong to the graphs' replays
 

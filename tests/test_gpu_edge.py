@@ -722,6 +722,11 @@ def test_graphed_network_with_report_supervision_matches_eager(model):
             hist.append(({k: float(v.detach()) for k, v in loss.items()}, float(gn)))
         if graphed:
             assert fwd.fwd_graph is not None and set(fwd.state_dict().keys()) == set(net.state_dict().keys())
+            # a second backward without zero_grad / optimiser step in between would overwrite the static gradient buffers: refused
+            y2 = fwd(batches[0]['image'])['segmentation']
+            with pytest.raises(RuntimeError):
+                (y2[0] if isinstance(y2, (list, tuple)) else y2).sum().backward()
+            opt.zero_grad(set_to_none=True)
             net.eval()
             with torch.no_grad():
                 y = fwd(batches[0]['image'])['segmentation']          # evaluation falls through to the module
