@@ -185,6 +185,11 @@ int rsuper_cnorm_rows(long vox);
 int rsuper_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps,
                        int mode, void* stream);
 int rsuper_cnorm_stats(const float* x, const float* dy, const float* mr, float* part, int N, long vox, int C, int relu, int mode, void* stream);
+/* stats -> rsuper_stats_finalize -> apply in one host call (same three launches; part / mr / gm as above): forward writes mr and
+ * y = norm(x) [+ relu]; backward writes gm and dx. */
+int rsuper_cnorm_forward(const float* x, float* part, float* mr, float* y, int N, long vox, int C, int relu, float eps, void* stream);
+int rsuper_cnorm_backward(const float* x, const float* dy, const float* mr, float* part, float* gm, float* dx, int N, long vox, int C, int relu,
+                          void* stream);
 int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode,
                        void* stream);
 

@@ -293,6 +293,27 @@ int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const f
     if (!x || !mr || !out || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || mode < 0 || mode > 2 || (mode == 1 && (!dy || !gm))) return RS_ERR_ARG;
     return rs_launch_cnorm_apply(x, dy, mr, gm, out, N, vox, C, relu ? 1 : 0, mode, ST(stream));
 }
+/* statistics -> finalize -> apply as ONE host call (three launches): the eager training step of MedFormer is bound by the host's
+ * per-call cost (230 norm calls per step), not by these kernels */
+int rsuper_cnorm_forward(const float* x, float* part, float* mr, float* y, int N, long vox, int C, int relu, float eps, void* stream) {
+    if (!x || !part || !mr || !y || N <= 0 || vox <= 0 || C <= 0 || (C & 3)) return RS_ERR_ARG;
+    const int rows = rs_cnorm_rows(vox);
+    int rc = rs_launch_cnorm_stats(x, nullptr, nullptr, part, N, vox, C, relu ? 1 : 0, 0, ST(stream));
+    if (rc != RS_OK) return rc;
+    rc = rs_launch_stats_finalize(part, N, rows, C, (double)vox, eps, 0, 0, mr, ST(stream));
+    if (rc != RS_OK) return rc;
+    return rs_launch_cnorm_apply(x, nullptr, mr, nullptr, y, N, vox, C, relu ? 1 : 0, 0, ST(stream));
+}
+int rsuper_cnorm_backward(const float* x, const float* dy, const float* mr, float* part, float* gm, float* dx, int N, long vox, int C, int relu,
+                          void* stream) {
+    if (!x || !dy || !mr || !part || !gm || !dx || N <= 0 || vox <= 0 || C <= 0 || (C & 3)) return RS_ERR_ARG;
+    const int rows = rs_cnorm_rows(vox);
+    int rc = rs_launch_cnorm_stats(x, dy, mr, part, N, vox, C, relu ? 1 : 0, 1, ST(stream));
+    if (rc != RS_OK) return rc;
+    rc = rs_launch_stats_finalize(part, N, rows, C, (double)vox, 0.f, 1, 0, gm, ST(stream));
+    if (rc != RS_OK) return rc;
+    return rs_launch_cnorm_apply(x, dy, mr, gm, dx, N, vox, C, relu ? 1 : 0, 1, ST(stream));
+}
 int rsuper_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps,
                        int mode, void* stream) {
     if (!x || !out || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || (mode != 0 && mode != 1) || (mode == 0 && !mr_out) || (mode == 1 && (!dy || !mr)))

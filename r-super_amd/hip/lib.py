@@ -44,6 +44,8 @@ _SIGS = {
     'rsuper_plane_partials_fwd': (c_int, [P, c_size_t, P, P, P, P, P, c_int, c_int, c_size_t, P]),
     'rsuper_cnorm_rows': (c_int, [c_long]),
     'rsuper_cnorm_small': (c_int, [P, P, P, P, P, c_int, c_long, c_int, c_int, c_float, c_int, P]),
+    'rsuper_cnorm_forward': (c_int, [P, P, P, P, c_int, c_long, c_int, c_int, c_float, P]),
+    'rsuper_cnorm_backward': (c_int, [P, P, P, P, P, P, c_int, c_long, c_int, c_int, P]),
     'rsuper_cnorm_stats': (c_int, [P, P, P, P, c_int, c_long, c_int, c_int, c_int, P]),
     'rsuper_cnorm_apply': (c_int, [P, P, P, P, P, c_int, c_long, c_int, c_int, c_int, P]),
     'rsuper_battn_supported': (c_int, [c_int, c_int, c_int]),

@@ -884,9 +884,7 @@ class ChannelNormFn(torch.autograd.Function):
             return y
         rows = _L().rsuper_cnorm_rows(vox)
         part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
-        _l.check(_L().rsuper_cnorm_stats(_ptr(x), None, None, _ptr(part), N, vox, C, int(relu), 0, st), 'cnorm_stats')
-        _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), float(eps), 0, 0, _ptr(mr), st), 'stats_finalize')
-        _l.check(_L().rsuper_cnorm_apply(_ptr(x), None, _ptr(mr), None, _ptr(y), N, vox, C, int(relu), 0, st), 'cnorm_apply')
+        _l.check(_L().rsuper_cnorm_forward(_ptr(x), _ptr(part), _ptr(mr), _ptr(y), N, vox, C, int(relu), float(eps), st), 'cnorm_forward')
         ctx.save_for_backward(x, mr)
         return y
 
@@ -905,9 +903,7 @@ class ChannelNormFn(torch.autograd.Function):
         gm = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
         dx = torch.empty_like(x)
         st = _stream()
-        _l.check(_L().rsuper_cnorm_stats(_ptr(x), _ptr(dy), _ptr(mr), _ptr(part), N, vox, C, int(ctx.relu), 1, st), 'cnorm_bwd_stats')
-        _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), 0.0, 1, 0, _ptr(gm), st), 'stats_finalize')
-        _l.check(_L().rsuper_cnorm_apply(_ptr(x), _ptr(dy), _ptr(mr), _ptr(gm), _ptr(dx), N, vox, C, int(ctx.relu), 1, st), 'cnorm_bwd_apply')
+        _l.check(_L().rsuper_cnorm_backward(_ptr(x), _ptr(dy), _ptr(mr), _ptr(part), _ptr(gm), _ptr(dx), N, vox, C, int(ctx.relu), st), 'cnorm_backward')
         return dx, None, None
 
 
