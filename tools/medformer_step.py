@@ -11,6 +11,8 @@ from rsuper_amd.train_ddp import train_step, make_ema
 from rsuper_amd.training.utils import FusedAdamWEMA
 from rsuper_amd.training import losses_foundation as lf
 lf.SANITY_CHECKS = False
+if os.environ.get('MF_BLAS'):
+    torch.backends.cuda.preferred_blas_library(os.environ['MF_BLAS'])
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dtype = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
 dev = 'cuda'; B, S = 2, 96; classes = synth.PANTS_CLASSES
