@@ -49,7 +49,12 @@ def train_step(net, ema_net, optimizer, batch, args, classes, step, matcher=None
         reducer.finish()                 # gradients are now the mean over ranks (what DDP's reducer leaves in p.grad)
     gnorm = None
     if isinstance(optimizer, FusedAdamWEMA):
-        ema_params = list(ema_net.parameters()) if (ema_net is not None and getattr(args, 'ema', True)) else None
+        ema_params = None
+        if ema_net is not None and getattr(args, 'ema', True):
+            # the module-tree walk of .parameters() costs ~1 ms per step on MedFormer's 300 modules: keep the list on the module
+            ema_params = ema_net.__dict__.get('_rsuper_param_list')
+            if ema_params is None:
+                ema_params = ema_net.__dict__['_rsuper_param_list'] = list(ema_net.parameters())
         gnorm = optimizer.fused_step(max_norm=1.0, ema_params=ema_params,
                                      ema_alpha=ema_alpha_for_step(getattr(args, 'ema_alpha', 0.99), step))
     else:
