@@ -65,6 +65,7 @@ class MedFormer(nn.Module):
         blas = os.environ.get('RSUPER_MF_BLAS', 'cublas')
         if blas != 'default' and torch.cuda.is_available():
             torch.backends.cuda.preferred_blas_library(blas)
+            _mu.gemm_library.active = blas == 'cublas'      # long reductions switch back to hipBLASLt per call (medformer_utils.gemm_library)
 
     def _dtype(self):
         return {'bf16': torch.bfloat16, 'f32': torch.float32}[self.compute_dtype]

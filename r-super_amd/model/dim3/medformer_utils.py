@@ -97,16 +97,43 @@ GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 oper
 SPLITK_MIN_ROWS, SPLITK_MIN_SLAB = 8192, 1024
 
 
-class _LinearSplitK(torch.autograd.Function):
-    """F.linear whose weight gradient dW = dy^T x is a batched GEMM over slabs of the voxel axis followed by a sum.  The library runs
+LT_MIN_K = 1024         # reductions at least this long go to hipBLASLt (see `gemm_library`; 512: 28.7, 2048: 28.7, 256: 29.7 vs 28.5 ms/step)
+
+
+class gemm_library:
+    """Per-call choice between the two GEMM libraries behind torch.mm / bmm.  MedFormer makes rocBLAS the process default (medformer.py:
+    7.5 vs 18.5 us of host time per call, faster kernels for the 54-row products and the wide-output expansions), but rocBLAS is slower on
+    long reductions with small outputs: 57 vs 25 us for the 1024 x 3456 x 256 weight gradients of the 12^3 stages, 47 vs 36 us for the
+    voxel-split weight gradients, 772 vs ~50 us for the semantic-map product (27 x 13824 x 128).  `with gemm_library(k):` switches to
+    hipBLASLt for the calls inside when the reduction length k reaches LT_MIN_K -- and only if MedFormer's default is active."""
+
+    active = False                                       # set by MedFormer when it selected rocBLAS as the default
+
+    def __init__(self, k):
+        self.on = gemm_library.active and k >= LT_MIN_K
+
+    def __enter__(self):
+        if self.on:
+            torch.backends.cuda.preferred_blas_library('cublaslt')
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.backends.cuda.preferred_blas_library('cublas')
+        return False
+
+
+class _LinearFn(torch.autograd.Function):
+    """F.linear with the three GEMMs issued explicitly: each through the faster library for its shape (`gemm_library`), and the weight
+    gradient dW = dy^T x of the high-resolution stages as a batched GEMM over slabs of the voxel axis followed by a sum.  The library runs
     dy^T x as ONE GEMM with (Cout / 32) x (Cin / 128) workgroups however long the reduction is: at 24^3 x 2 voxels that is 16 workgroups
-    on 256 CUs, 186 us for a 128 x 27648 x 512 product (3.4 ms per MedFormer step over all such layers); split 16-way it takes ~15 us."""
+    on 256 CUs, 186 us for a 128 x 27648 x 512 product (3.4 ms per MedFormer step over all such layers); split 16-way it takes ~35 us."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return F.linear(x, w, b)
+        with gemm_library(w.shape[1]):
+            return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
@@ -114,14 +141,17 @@ class _LinearSplitK(torch.autograd.Function):
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dy2, w).reshape(x.shape)
+            with gemm_library(w.shape[0]):
+                dx = torch.mm(dy2, w).reshape(x.shape)
         if ctx.needs_input_grad[1]:
             rows = x2.shape[0]
-            slabs = next((s for s in (32, 16, 8, 4) if rows % s == 0 and rows // s >= SPLITK_MIN_SLAB), 0)
+            slabs = next((s for s in (32, 16, 8, 4) if rows % s == 0 and rows // s >= SPLITK_MIN_SLAB), 0) if rows >= SPLITK_MIN_ROWS else 0
             if slabs:
-                dw = torch.bmm(dy2.reshape(slabs, rows // slabs, -1).transpose(1, 2), x2.reshape(slabs, rows // slabs, -1)).sum(0)
+                with gemm_library(rows // slabs):
+                    dw = torch.bmm(dy2.reshape(slabs, rows // slabs, -1).transpose(1, 2), x2.reshape(slabs, rows // slabs, -1)).sum(0)
             else:
-                dw = torch.mm(dy2.t(), x2)
+                with gemm_library(rows):
+                    dw = torch.mm(dy2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(0)
         return dx, dw, db
@@ -129,8 +159,8 @@ class _LinearSplitK(torch.autograd.Function):
 
 def linear(x, w, b=None):
     rows = x.numel() // x.shape[-1]
-    if rows >= SPLITK_MIN_ROWS and x.dtype == torch.float32:
-        return _LinearSplitK.apply(x, w, b)
+    if x.dtype == torch.float32 and (rows >= SPLITK_MIN_ROWS or (gemm_library.active and max(rows, w.shape[0], w.shape[1]) >= LT_MIN_K)):
+        return _LinearFn.apply(x, w, b)
     return F.linear(x, w, b)
 
 
@@ -316,7 +346,8 @@ class SemanticMapGeneration(nn.Module):
             w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
         y = ops.Conv3Fn.apply(x, w).float().flatten(1, 3)                       # (B, voxels, md + codes + pad)
         weight = F.softmax(y[..., md:md + codes].transpose(1, 2), dim=-1)       # (B, codes, voxels): softmax over the voxels of a code
-        return torch.matmul(weight, y[..., :md]).reshape(x.shape[0], *self.map_size, md)
+        with gemm_library(weight.shape[-1]):                                    # 27 x voxels x map_dim: a long reduction into a tiny output
+            return torch.matmul(weight, y[..., :md]).reshape(x.shape[0], *self.map_size, md)
 
 
 class _PreNorm(nn.Module):

@@ -480,6 +480,8 @@ def check_linear_splitk(rows, cin, cout, bias, seed=99):
     xd, wd = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
     bd = b.detach().to(DEV).requires_grad_(True) if bias else None
     assert rows >= mu.SPLITK_MIN_ROWS
+    mu.gemm_library.active = True                       # the per-call library switch of the MedFormer default
+    torch.backends.cuda.preferred_blas_library('cublas')
     y = mu.linear(xd, wd, bd)
     (y * go.to(DEV)).sum().backward()
     torch.cuda.synchronize()
