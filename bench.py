@@ -232,7 +232,7 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         # (tests/test_gpu_edge.py::test_graphed_step_matches_eager)
         lg = leg_of(args.dtype, False)
         lg.use_graph()
-        sec['graph_ms_per_step'] = lg.timed(n2, w2 + 4) / n2 * 1e3
+        sec['graph_ms_per_step'] = lg.timed(n2, w2 + 24) / n2 * 1e3
         sec['graph_final_loss'] = lg.loss()
         lg.close()
 
