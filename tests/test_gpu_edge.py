@@ -512,6 +512,36 @@ def test_augmented_loader_feeds_packed_ingest(tmp_path):
 
 
 @pytest.mark.gpu
+def test_gemm_library_switch_is_scoped():
+    """medformer_utils.gemm_library: hipBLASLt for the calls inside the block when the reduction is long and MedFormer's rocBLAS default is
+    active, the default restored afterwards (also on an exception); inactive -> never touches the process setting."""
+    from rsuper_amd.model.dim3 import medformer_utils as mu
+    get = torch.backends.cuda.preferred_blas_library
+    before, was_active = get(), mu.gemm_library.active
+    try:
+        mu.gemm_library.active = True
+        get('cublas')
+        with mu.gemm_library(mu.LT_MIN_K):
+            assert 'lt' in str(get()).lower()
+            y = torch.mm(torch.ones(8, mu.LT_MIN_K, device='cuda'), torch.ones(mu.LT_MIN_K, 8, device='cuda'))
+        assert 'lt' not in str(get()).lower() and float(y[0, 0]) == mu.LT_MIN_K
+        with mu.gemm_library(mu.LT_MIN_K - 1):
+            assert 'lt' not in str(get()).lower()
+        with pytest.raises(ZeroDivisionError):
+            with mu.gemm_library(4 * mu.LT_MIN_K):
+                1 / 0
+        assert 'lt' not in str(get()).lower()
+        mu.gemm_library.active = False
+        get('cublaslt')
+        with mu.gemm_library(4 * mu.LT_MIN_K):
+            pass
+        assert 'lt' in str(get()).lower()
+    finally:
+        mu.gemm_library.active = was_active
+        get(before)
+
+
+@pytest.mark.gpu
 def test_medformer_fused_attention_matches_aten_composition():
     """The HIP attention core (csrc/battn.hip) against the ATen composition it replaces (einsum / soft-max / head rearranges), through
     the whole tiny MedFormer in f32: logits and every parameter gradient.  Same mathematics in a different summation order on an

@@ -75,3 +75,28 @@ def test_attention_stage_kernels_fuzz(case):
     if dims[0] * dims[1] * dims[2] > 1:                     # InstanceNorm of a single voxel is 0 / 0 in the reference too
         r = gc.check_cnorm(C, dims, relu, N)
         assert r['ok'], f"{r['name']}: err {r['err']:.3e} > tol {r['tol']:.1e}"
+
+
+def _attn_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        T, dh = ((27, 32), (8, 16))[int(rng.integers(0, 2))]
+        out.append((int(rng.integers(1, 4)), int(rng.choice([1, 7, 63, 64, 65, 200, 513, 1728])), T, int(rng.integers(1, 11)), dh))
+    return out
+
+
+ATTN_CASES = _attn_cases(10, 91)
+
+
+@pytest.mark.parametrize('case', ATTN_CASES, ids=[f'B{c[0]}_L{c[1]}_T{c[2]}_h{c[3]}' for c in ATTN_CASES])
+def test_bidirectional_attention_core_fuzz(case):
+    """csrc/battn.hip forward + backward on ragged problems: voxel counts around the block's voxel capacity (256 / heads), a single voxel,
+    every head count the kernel is built for (1..10: head x token tables beyond 256 entries at 10 heads x 27 tokens), both token / head-width
+    builds; plus the squeeze-excite op on a ragged volume with the same seed."""
+    B, L, T, heads, dh = case
+    r = gc.check_battn(B, L, T, heads, dh, seed=100 + L)
+    assert r['ok'], f"{r['name']}: err {r['err']:.3e} > tol {r['tol']:.1e}"
+    C = 4 * heads * 2
+    r = gc.check_squeeze_excite(C, (1 + L % 5, 2 + L % 3, 3), B)
+    assert r['ok'], f"{r['name']}: err {r['err']:.3e} > tol {r['tol']:.1e}"
