@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the MFMA conv kernels on the layer shapes of the full UNet (B=2, 96^3, base 32).
-Usage: python tools/bench_conv.py [bf16|f32]"""
+Usage: python tools/bench_conv.py [bf16|f32] [variant|-] [batch]"""
 import os, sys, math
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,11 +8,11 @@ sys.path.insert(0, ROOT)
 from rsuper_amd.hip import ops
 
 mode = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and sys.argv[2] != '-':
     ops._L().rsuper_conv3_variant(int(sys.argv[2]))      # force an igemm kernel variant
 dt = {'bf16': torch.bfloat16, 'f32': torch.float32}[mode]
 dev = 'cuda'
-N = 2
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # per-GPU batch (the layer times at a larger batch show the under-fill of the low levels)
 # (name, S, Ca, Cb, Cout, fused_sc)
 LAYERS = [('inc 32->32', 96, 32, 0, 32, False), ('up4.0 96->32+sc', 96, 32, 64, 32, True), ('down1.0 32->64+sc', 48, 32, 0, 64, True),
           ('64->64', 48, 64, 0, 64, False), ('up3.0 192->64+sc', 48, 64, 128, 64, True), ('128->128', 24, 128, 0, 128, False),
