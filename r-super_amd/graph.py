@@ -20,7 +20,8 @@ attributes are settled before capture).
 `GraphedNetwork` is the form for everything else -- report supervision, the actual R-Super use: the network's forward and its backward
 are captured as TWO hipGraphs (static input / output / gradient buffers, both recorded on one capture stream), the loss between them -- with the ball search's host reads -- runs eagerly on the graph's static logits, and so do
 clip / AdamW / EMA.  The host then enqueues 2 graph launches + the loss + the optimiser instead of every kernel of the network
-(MedFormer: ~2000 of its 2170 launches).
+(MedFormer: ~2000 of its 2170 launches).  Under torch.distributed it also averages the gradients over the ranks after the backward replay
+(`exchange_gradients`: flat buckets, one RCCL all-reduce each), so it replaces the DDP wrapper rather than sitting inside it.
 """
 import math
 
@@ -120,6 +121,34 @@ class GraphedTrainStep:
             self._set_opt_step(t0)                   # capture only records: the counters advance when the graph is replayed
 
 
+def exchange_gradients(grads, group=None, bucket_bytes=64 << 20, force=False):
+    """Mean of `grads` (list of tensors, modified in place) over the ranks of `group`: the gradient exchange of DistributedDataParallel
+    (train_ddp.py:663) for gradients that already sit in their final buffers -- flatten a bucket, ONE all-reduce per bucket (launched
+    asynchronously, all buckets in flight together), copy back.  RCCL averages in the collective; gloo (CPU tests) sums and divides."""
+    import torch.distributed as dist
+    from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+    world = dist.get_world_size(group)
+    if (world == 1 and not force) or not grads:           # force: run the collectives on a one-rank group too (tests)
+        return
+    avg = dist.get_backend(group) == 'nccl'
+    buckets, cur, n = [], [], 0
+    for g in grads:
+        if cur and n + g.numel() * g.element_size() > bucket_bytes:
+            buckets.append(cur); cur, n = [], 0
+        cur.append(g); n += g.numel() * g.element_size()
+    if cur:
+        buckets.append(cur)
+    work = []
+    for b in buckets:
+        flat = _flatten_dense_tensors(b)
+        work.append((b, flat, dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True)))
+    for b, flat, h in work:
+        h.wait()
+        if not avg:
+            flat.div_(world)
+        torch._foreach_copy_(b, list(_unflatten_dense_tensors(flat, b)))
+
+
 class _TupleOut(nn.Module):
     """The network with a tuple of tensors as output (what make_graphed_callables can hold in static buffers)."""
 
@@ -156,6 +185,8 @@ class _ReplayFn(torch.autograd.Function):
         for dst, g in zip(o.static_gouts, gouts):
             dst.copy_(g) if g is not None else dst.zero_()
         o.bwd_graph.replay()
+        if o.exchange:
+            exchange_gradients([g for g in o.static_grads if g is not None], o.group, force=True)
         for p, g in zip(o.params, o.static_grads):
             if g is None:
                 continue
@@ -174,10 +205,24 @@ class GraphedNetwork:
     capture stream (real kernels, but no optimiser step: parameters are untouched).  Gradients land in static buffers that the
     parameters' .grad point at after every backward (`zero_grad(set_to_none=True)` only drops the reference)."""
 
-    def __init__(self, net, warmup=3):
+    def __init__(self, net, warmup=3, exchange=None, process_group=None):
+        """exchange: average the gradients over the ranks of `process_group` after every backward replay (None: whenever torch.distributed
+        is initialised with more than one rank).  The module must be the bare network -- not wrapped by DistributedDataParallel or
+        `wrap_ddp`: the exchange happens here, on the static gradient buffers, after the backward graph (no overlap with backward, but the
+        host no longer enqueues the network's launches one by one); parameters are broadcast from rank 0 like DDP does at construction."""
         if getattr(net, '_rsuper_reducer', None) is not None or hasattr(net, 'module'):
-            raise ValueError('data-parallel modules take the eager path (the gradient exchange is not captured)')
+            raise ValueError('GraphedNetwork takes the bare module (it exchanges the gradients itself when torch.distributed is initialised)')
+        import torch.distributed as dist
         self.net, self.warmup = net, int(warmup)
+        self.group = process_group
+        if exchange is None:
+            exchange = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.exchange = bool(exchange)
+        if self.exchange:
+            with torch.no_grad():
+                for t in list(net.parameters()) + list(net.buffers()):
+                    dist.broadcast(t, 0, group=process_group)
+            ops.WEIGHTS_EPOCH += 1
         self.fwd_graph = None
         self._shape = None
         self._anchor = None
@@ -227,6 +272,7 @@ class GraphedNetwork:
         if self.fwd_graph is None:
             self._capture(img)
         if (tuple(img.shape), img.dtype) != self._shape:
-            raise ValueError(f'GraphedNetwork was captured for input {self._shape}, got {(tuple(img.shape), img.dtype)}')
+            raise ValueError(f'GraphedNetwork was captured for input {self._shape}, got {(tuple(img.shape), img.dtype)}'
+                             + (' (with the gradient exchange on there is no eager fall-back: keep the batch shape fixed, drop_last)' if self.exchange else ''))
         out = _ReplayFn.apply(self._anchor, self, img)
         return {'segmentation': list(out) if len(out) > 1 else out[0]}

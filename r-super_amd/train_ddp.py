@@ -185,9 +185,9 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
     # With report supervision (host-synchronous ball search in the loss) the network's forward and backward are replayed from two graphs
     # around the eager loss and optimiser (graph.GraphedNetwork); a batch of another shape (last batch of an epoch) takes the eager path.
     stepper, fwd_net = None, net
-    if getattr(args, 'hip_graph', False) and not getattr(args, 'distributed', False) and getattr(net, '_rsuper_reducer', None) is None \
-            and not hasattr(net, 'module'):
-        if float(getattr(args, 'report_volume_loss_basic', 0.0)) == 0 and isinstance(optimizer, FusedAdamWEMA):
+    if getattr(args, 'hip_graph', False) and getattr(net, '_rsuper_reducer', None) is None and not hasattr(net, 'module'):
+        if float(getattr(args, 'report_volume_loss_basic', 0.0)) == 0 and isinstance(optimizer, FusedAdamWEMA) \
+                and not getattr(args, 'distributed', False):
             from .graph import GraphedTrainStep
             stepper = getattr(optimizer, '_graphed_step', None)
             if stepper is None or stepper.net is not net:
@@ -215,7 +215,8 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
         if stepper is not None:
             loss_all, _ = stepper(batch, step)
         else:
-            use = fwd_net if (fwd_net is net or fwd_net.accepts(img)) else net
+            # another batch shape: eager module -- unless the graphed network also carries the gradient exchange (then it refuses loudly)
+            use = fwd_net if (fwd_net is net or fwd_net.accepts(img) or fwd_net.exchange) else net
             loss_all, _ = train_step(use, ema_net, optimizer, batch, args, classes, step, matcher=matcher)
         if len(loss_meters) == 0:
             loss_meters = OrderedDict((k, AverageMeter(k, ':6.4f')) for k in loss_all.keys())
@@ -384,7 +385,8 @@ def main_worker(proc_idx, ngpus_per_node, fold_idx, args, result_dict=None, trai
     args.classes = len(trainset.classes)
     net = get_model(args, pretrain=args.pretrain, classes=trainset.classes).to('cuda')
     ema_net = make_ema(net) if args.ema else None
-    model = wrap_ddp(net, proc_idx) if args.distributed else net
+    # --hip_graph in a distributed run: the bare module goes to train_epoch, whose GraphedNetwork averages the gradients itself
+    model = wrap_ddp(net, proc_idx) if (args.distributed and not getattr(args, 'hip_graph', False)) else net
     return train_net(model, trainset, testset, args, ema_net, fold_idx=fold_idx)
 
 

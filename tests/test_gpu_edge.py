@@ -713,6 +713,58 @@ def test_graphed_step_matches_eager(model):
 
 
 @pytest.mark.gpu
+def test_graphed_network_gradient_exchange_single_rank_nccl():
+    """GraphedNetwork with the gradient exchange on, on a 1-rank RCCL group: parameter broadcast at construction, flat-bucket all-reduce
+    (AVG over one rank = identity) on the static gradient buffers after every backward replay -- exactly the parameters of the plain eager
+    run; a batch of another shape is refused (no silent un-exchanged fall-back); a DDP-wrapped module is refused."""
+    import os
+    import torch.distributed as dist
+    from rsuper_amd.graph import GraphedNetwork
+    from rsuper_amd.model.dim3.unet import UNet
+    from rsuper_amd.train_ddp import train_step, make_ema, wrap_ddp
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    from rsuper_amd.hip import ops
+    classes = synth.TINY_CLASSES
+    bt = synth.batch(2, 32, classes, ['mask', 'report'], seed=5, diam_range=(4.0, 8.0), max_tumors=2)
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in bt.items() if k in ('label', 'unk_channels', 'mask', 'volumes', 'diameters')}
+    batch['image'] = torch.from_numpy(synth.image(2, 32, seed=3)).to(DEV)
+    la = argparse.Namespace(loss='ball_dice_both', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1, volume_loss_tolerance=0.2,
+                            ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                            classification_branch=False, ema=True, ema_alpha=0.99)
+
+    def run(graphed):
+        torch.manual_seed(0)
+        net = UNet(1, 8, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype='bf16').to(DEV)
+        ema = make_ema(net)
+        opt = FusedAdamWEMA(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        f = GraphedNetwork(net, warmup=2, exchange=True) if graphed else net
+        for step in range(4):
+            train_step(f, ema, opt, batch, la, classes, step)
+        if graphed:
+            assert f.exchange and f.fwd_graph is not None
+            with pytest.raises(ValueError):
+                f(batch['image'][:1])
+        return [p.detach().clone() for p in net.parameters()]
+
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29543')
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        a = run(True)
+        wrapped = wrap_ddp(UNet(1, 8, num_classes=len(classes), compute_dtype='bf16').to(DEV), 0)
+        with pytest.raises(ValueError):
+            GraphedNetwork(wrapped)
+        red = getattr(wrapped, '_rsuper_reducer', None)
+        if red is not None:
+            red.remove()
+    finally:
+        dist.destroy_process_group()
+        ops.GRAD_DEST = None
+    b = run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('model', ['unet', 'medformer'])
 def test_graphed_network_with_report_supervision_matches_eager(model):
     """rsuper_amd.graph.GraphedNetwork: forward and backward of the network replayed from two hipGraphs around an EAGER report-supervised

@@ -221,3 +221,14 @@ def test_grad_reducer_world2_gloo_cpu():
                         '--master-port', '29537', script], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'REDUCER_OK' in r.stdout
+
+
+def test_graph_gradient_exchange_world2_gloo_cpu():
+    """rsuper_amd.graph.exchange_gradients (what GraphedNetwork runs after its backward replay in a distributed run) on two gloo ranks:
+    in-place mean over several flat buckets."""
+    script = os.path.join(ROOT, 'tests', 'exchange_gloo_worker.py')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29541', script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'EXCHANGE_OK' in r.stdout
