@@ -120,6 +120,125 @@ __global__ __launch_bounds__(256, 2) void depthwise_fwd_kernel(DwParams p) {
     }
 }
 
+// LDS-tiled forward / data gradient for the large volumes.  The register-run kernel above re-reads every input vector 13.5 times
+// through L1 / L2 and is bound by that traffic (2.2 TB/s effective on 48^3 x 256 channels; fewer loads per output ran faster in
+// proportion).  Here a block owns an 8 x 8 (H x W) column of voxels x 32 channels and marches along D with a ring of three halo planes
+// (10 x 10 voxels) in LDS: every input vector is fetched from L2 once per block (1.56x the unique bytes with the halo), the 27-tap
+// stencil reads LDS.  Thread = (4 outputs along W, 4 channels), 128 threads per block; global loads run two planes ahead of the
+// stencil in registers and land in LDS when their slot is free (two barriers per plane).  Row layout in LDS: one pad voxel after every
+// four, so the two 4-voxel runs of a row that a 16-lane group reads together start 640 bytes apart and use disjoint banks.
+constexpr int DL_T = 8;                                  // tile edge in H and W
+constexpr int DL_C = 32;                                 // channels per block
+constexpr int DL_ROW = 12;                               // LDS slots per halo row: 10 voxels + a pad slot after every 4
+constexpr int DL_PLANE = (DL_T + 2) * DL_ROW;            // slots per halo plane
+
+__global__ __launch_bounds__(128) void depthwise_lds_kernel(DwParams p, int dsegs, int tiles_w, int tiles_h) {
+    __shared__ float4 ring[3][DL_PLANE][DL_C / 4];       // 46 KB
+    __shared__ float wl[27][DL_C];
+    const int c0 = blockIdx.y * DL_C;
+    const int n = blockIdx.z;
+    int bx = blockIdx.x;
+    const int tw = bx % tiles_w; bx /= tiles_w;
+    const int th = bx % tiles_h; bx /= tiles_h;
+    const int seg = bx;
+    const int dlen = (p.D + dsegs - 1) / dsegs;
+    const int d0 = seg * dlen, d1 = min(p.D, d0 + dlen);
+    const int h0 = th * DL_T, w0 = tw * DL_T;
+    for (int i = threadIdx.x; i < 27 * DL_C; i += 128) {
+        const int c = i / 27, tap = i - c * 27;
+        wl[p.flip ? 26 - tap : tap][c] = c0 + c < p.C ? p.w[(size_t)(c0 + c) * 27 + tap] : 0.f;
+    }
+    if (d0 >= d1) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)((size_t)p.N * p.D * p.H * p.W * p.C * 4), 0x00020000);
+    // staging map: element i of a halo plane = (voxel v = i / 8 in 10 x 10, channel vector i % 8); at most 7 per thread
+    constexpr int NST = ((DL_T + 2) * (DL_T + 2) * (DL_C / 4) + 127) / 128;
+    uint32_t goff[NST]; int lslot[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = threadIdx.x + k * 128;
+        const int v = i >> 3, c4 = i & 7;
+        const int hy = v / (DL_T + 2), wx = v - hy * (DL_T + 2);
+        const int hh = h0 - 1 + hy, ww = w0 - 1 + wx;
+        const bool ok = v < (DL_T + 2) * (DL_T + 2) && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W && c0 + c4 * 4 < p.C;
+        goff[k] = ok ? (uint32_t)((((size_t)hh * p.W + ww) * p.C + c0 + c4 * 4) * 4) : 0xFFFFFFFFu;      // offset inside one depth plane
+        lslot[k] = v < (DL_T + 2) * (DL_T + 2) ? (hy * DL_ROW + wx + (wx >> 2)) * (DL_C / 4) + c4 : -1;
+    }
+    const uint32_t plane_bytes = (uint32_t)((size_t)p.H * p.W * p.C * 4);
+    auto load_plane = [&](int d, float4 (&q)[NST]) {
+        const bool okd = (unsigned)d < (unsigned)p.D;
+        const uint32_t base = (uint32_t)(n * p.D + (okd ? d : 0)) * plane_bytes;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (okd && goff[k] != 0xFFFFFFFFu) ? base + goff[k] : 0xFFFFFFFFu, 0, 0);
+            q[k] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+        }
+    };
+    auto store_plane = [&](int slot, const float4 (&q)[NST]) {
+        float4* dst = &ring[slot][0][0];
+#pragma unroll
+        for (int k = 0; k < NST; ++k)
+            if (lslot[k] >= 0) dst[lslot[k]] = q[k];
+    };
+    float4 q[NST], qn[NST];                                          // plane d + 2 (arrived, waiting for its slot) and plane d + 3 (in flight)
+    // ring slot of plane d: (d - (d0 - 1)) % 3
+    load_plane(d0 - 1, q); store_plane(0, q);
+    load_plane(d0, q); store_plane(1, q);
+    load_plane(d0 + 1, q); store_plane(2, q);
+    if (d0 + 2 <= d1) load_plane(d0 + 2, q);
+    __syncthreads();
+    const int cv = threadIdx.x & 7, pos = threadIdx.x >> 3;          // pos 0..15: row = pos / 2, run = pos % 2
+    const int row = pos >> 1, x0 = (pos & 1) * 4;
+    const int c = c0 + cv * 4;
+    const int xs = x0 + (x0 >> 2);                                   // first LDS slot of the run's halo (voxel x0 of the 10-wide row)
+    for (int d = d0; d < d1; ++d) {
+        const int rel = d - d0;                                      // planes d-1, d, d+1 sit in slots rel % 3, (rel + 1) % 3, (rel + 2) % 3
+        if (d + 3 <= d1) load_plane(d + 3, qn);                      // two planes ahead: in flight during two stencils (plane d1 + 1 is never needed)
+        float4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const float4* pl = &ring[(rel + kd) % 3][0][0];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                float4 v[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int xv = x0 + j;                           // voxel index in the 10-wide halo row
+                    v[j] = pl[((row + kh) * DL_ROW + xv + (xv >> 2)) * (DL_C / 4) + cv];
+                }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float4 wv = *(const float4*)&wl[(kd * 3 + kh) * 3 + kw][cv * 4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j].x = fmaf(v[j + kw].x, wv.x, acc[j].x);
+                        acc[j].y = fmaf(v[j + kw].y, wv.y, acc[j].y);
+                        acc[j].z = fmaf(v[j + kw].z, wv.z, acc[j].z);
+                        acc[j].w = fmaf(v[j + kw].w, wv.w, acc[j].w);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("" : "+v"(acc[j].x), "+v"(acc[j].y), "+v"(acc[j].z), "+v"(acc[j].w));
+            }
+        }
+        const int hh = h0 + row;
+        if (hh < p.H && c < p.C) {
+            float* yo = p.y + ((((size_t)n * p.D + d) * p.H + hh) * p.W + w0 + x0) * p.C + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w0 + x0 + j < p.W) *(float4*)(yo + (size_t)j * p.C) = acc[j];
+        }
+        __syncthreads();                                             // every read of plane d - 1's slot is done
+        if (d + 2 <= d1) store_plane(rel % 3, q);                    // plane d + 2 takes the slot of plane d - 1
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NST; ++k) q[k] = qn[k];
+    }
+    (void)xs;
+}
+
 // Weight gradient, stage 1: block (bx, channel group) accumulates dw over its voxels in registers (27 taps x 4 channels per
 // thread), then the 16 voxel lanes of each channel vector are summed through LDS in a fixed order and the block writes one
 // row part[bx][tap][c].  Stage 2 sums the rows (fixed order: deterministic) into (C, 1, 3, 3, 3).
@@ -233,6 +352,17 @@ int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, 
     if ((long)N * D * H * W * C >= (1L << 30)) return RS_ERR_UNSUPPORTED;       // 32-bit byte offsets of the buffer loads (< 4 GiB)
     DwParams p = {x, w, y, N, D, H, W, C, flip};
     const long vox = (long)N * D * H * W;
+    static const bool no_lds = getenv("RSUPER_DW_NO_LDS") != nullptr;          // A/B switch: the register-run kernel for every shape
+    // measured (B = 2): 48^3 x 256 ch 209 -> 149 us; 24^3 x 512 41 -> 40, 24^3 x 384 33 -> 37, 24^3 x 128 14 -> 20 us (the halo planes of the
+    // short D segments and 6 waves per CU cost more than the L2 re-reads there): the LDS kernel takes the 32^2-and-larger planes only
+    if (!no_lds && H >= 32 && W >= 32 && D >= 6 && (C % 4) == 0 && (size_t)H * W * C * 4 < 0x40000000ull) {
+        const int th = (H + DL_T - 1) / DL_T, tw = (W + DL_T - 1) / DL_T, groups = (C + DL_C - 1) / DL_C;
+        // split D so that >= ~1500 blocks are in flight (3 per CU), but keep >= 6 planes per segment (2 halo planes are re-read per segment)
+        int dsegs = 1;
+        while ((long)th * tw * groups * N * dsegs < 1536 && D / (dsegs + 1) >= 6) ++dsegs;
+        hipLaunchKernelGGL(depthwise_lds_kernel, dim3((unsigned)(th * tw * dsegs), groups, N), dim3(128), 0, st, p, dsegs, tw, th);
+        return rs_check_launch();
+    }
     const long runs = (long)N * D * H * ((W + DW_R - 1) / DW_R);
     // the LDS weight staging is per block: aim at >= 8 passes per block, but never below ~1024 blocks in flight (small volumes)
     const long groups = (C + DW_CG - 1) / DW_CG, all = (runs + DW_VPB - 1) / DW_VPB;

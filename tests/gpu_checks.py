@@ -901,6 +901,7 @@ def all_checks(quick=False):
     cs += [(check_squeeze_excite, (8, (6, 7, 9))), (check_squeeze_excite, (1024, (12, 12, 12))), (check_squeeze_excite, (72, (5, 4, 3), 1))]
     cs += [(check_battn, (2, 1728, 27, 8, 32)), (check_battn, (1, 216, 27, 10, 32)), (check_battn, (2, 13824, 27, 4, 32)),
            (check_battn, (2, 100, 27, 1, 32)), (check_battn, (1, 512, 8, 2, 16)), (check_battn, (2, 61, 8, 5, 16)), (check_battn, (1, 8, 8, 4, 16))]
+    cs += [(check_depthwise, (36, (6, 32, 40), 1)), (check_depthwise, (8, (7, 33, 35))), (check_depthwise, (64, (13, 48, 32), 1))]     # LDS-tiled kernel (planes >= 32 x 32)
     cs += [(check_depthwise, (8, (6, 7, 9))), (check_depthwise, (72, (5, 4, 11), 1)), (check_depthwise, (256, (12, 12, 12))),
            (check_depthwise, (1280, (3, 3, 3)))]
     cs += [(check_medformer_tiny, ('f32',)), (check_medformer_tiny, ('bf16',))]
