@@ -91,8 +91,11 @@ class GraphedTrainStep:
                 if dst.shape != v.shape or dst.dtype != v.dtype:
                     raise ValueError(f'batch entry {k!r} changed shape / dtype: {tuple(v.shape)} {v.dtype} vs captured {tuple(dst.shape)} {dst.dtype}')
                 dst.copy_(v, non_blocking=True)
-        self.dyn_host.copy_(torch.tensor(self._scalars(step), dtype=torch.float32))
-        self.dyn.copy_(self.dyn_host, non_blocking=True)
+        # a FRESH pinned staging tensor per step: with one reused pinned buffer a host that runs ahead (no per-step synchronisation) overwrote
+        # the scalars of step i with those of step i + 1 before the asynchronous copy of step i had executed -- the replay then used the next
+        # step's bias corrections (losses drifted from the eager run after a few dozen steps).  The pinned allocator only recycles a block
+        # once the copies recorded on it have completed.
+        self.dyn.copy_(torch.tensor(self._scalars(step), dtype=torch.float32).pin_memory(), non_blocking=True)
         t = self._opt_step() + 1
         self.graph.replay()
         self._set_opt_step(t)
@@ -103,7 +106,6 @@ class GraphedTrainStep:
         dev = next(self.net.parameters()).device
         self.static = {k: v.to(dev).clone() for k, v in batch.items()}
         self.dyn = torch.zeros(4, device=dev, dtype=torch.float32)
-        self.dyn_host = torch.zeros(4, dtype=torch.float32).pin_memory()
         self.dyn.copy_(torch.tensor(self._scalars(step), dtype=torch.float32))
         sanity = lf.SANITY_CHECKS
         lf.SANITY_CHECKS = False                     # its asserts read device flags on the host: not capturable (train_epoch keeps its own)

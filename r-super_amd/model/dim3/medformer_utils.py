@@ -153,8 +153,26 @@ class _LinearFn(torch.autograd.Function):
                 with gemm_library(rows):
                     dw = torch.mm(dy2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0)
+            if dy2.shape[0] >= 4096:
+                # Column sums of a tall matrix as a 1 x rows GEMM, NOT `dy2.sum(0)`: ATen's multi-block reduction (global partials + semaphores)
+                # returned garbage from the 12th replay on when captured in a hipGraph on this ROCm (the aux head's bias gradient, 27648 x 26:
+                # ~-2e-10 instead of ~2e-3, every later replay too; eager and the first 11 replays correct) -- found by comparing eager and
+                # replayed training runs gradient by gradient (tests/test_gpu_edge.py::test_graphed_network_many_replays_match_eager).
+                with gemm_library(dy2.shape[0]):
+                    db = torch.mm(_ones_row(dy2.shape[0], dy2.device), dy2).reshape(-1)
+            else:
+                db = dy2.sum(0)
         return dx, dw, db
+
+
+_ONES = {}
+
+
+def _ones_row(n, device):
+    k = (n, str(device))
+    if k not in _ONES:
+        _ONES[k] = torch.ones((1, n), device=device, dtype=torch.float32)
+    return _ONES[k]
 
 
 def linear(x, w, b=None):

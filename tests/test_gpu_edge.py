@@ -713,6 +713,84 @@ def test_graphed_step_matches_eager(model):
 
 
 @pytest.mark.gpu
+def test_graphed_step_without_per_step_sync_matches_eager():
+    """GraphedTrainStep driven the way a training loop drives it -- no host read between steps, so the host runs many replays ahead of the
+    GPU -- ends with exactly the parameters of the eager run.  Regression test: the step-dependent optimiser scalars (Adam bias
+    corrections, EMA alpha) used to be staged through ONE reused pinned buffer, which a host running ahead overwrote before the
+    asynchronous copy of the previous step had executed."""
+    import argparse
+    import synth
+    from rsuper_amd.graph import GraphedTrainStep
+    from rsuper_amd.model.dim3.unet import UNet
+    from rsuper_amd.train_ddp import train_step, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    classes = synth.TINY_CLASSES
+    largs = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.0, volume_loss_tolerance=0.2,
+                               ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                               classification_branch=False, ema=True, ema_alpha=0.99)
+    S = 64                                                    # ~ms of GPU work per step against ~0.1 ms of host work per replay
+    bt = synth.batch(2, S, classes, ['mask', 'mask'], seed=41)
+    batch = dict(image=torch.from_numpy(synth.image(2, S, seed=17)).to('cuda'), label=torch.from_numpy(bt['label']).to('cuda'),
+                 unk_channels=torch.from_numpy(bt['unk_channels']).to('cuda'), mask=torch.from_numpy(bt['mask']).to('cuda'),
+                 volumes=torch.from_numpy(bt['volumes']).to('cuda'), diameters=torch.from_numpy(bt['diameters']).to('cuda'))
+
+    def run(graphed):
+        torch.manual_seed(0)
+        net = UNet(1, 16, num_classes=len(classes), compute_dtype='bf16').to('cuda')
+        ema = make_ema(net)
+        opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        st = GraphedTrainStep(net, ema, opt, largs, classes, warmup=2) if graphed else None
+        for i in range(40):
+            st(batch, i) if graphed else train_step(net, ema, opt, batch, largs, classes, i)      # nothing read back: the host runs ahead
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in net.parameters()], [p.detach().clone() for p in ema.parameters()]
+
+    (p_e, e_e), (p_g, e_g) = run(False), run(True)
+    assert all(torch.equal(a, b) for a, b in zip(p_e, p_g)) and all(torch.equal(a, b) for a, b in zip(e_e, e_g))
+
+
+@pytest.mark.gpu
+def test_graphed_network_many_replays_match_eager():
+    """More than a dozen replays of the forward / backward graphs of a MedFormer whose deep-supervision head is tall enough (8192 rows)
+    for the GEMM form of its bias gradient: losses and gradient norms equal to the eager run at EVERY step.  Regression test for a defect
+    of captured ATen multi-block reductions on this ROCm -- `dy.sum(0)` over 27648 rows returned garbage from the 12th replay of a hipGraph
+    on (eager and the first 11 replays were right), found by comparing an eager and a replayed full-size run gradient by gradient; the tall
+    bias gradients are now a 1 x rows GEMM (model/dim3/medformer_utils.py _LinearFn)."""
+    import argparse
+    import synth
+    from rsuper_amd.graph import GraphedNetwork
+    from rsuper_amd.model.dim3.medformer import MedFormer
+    from rsuper_amd.model.dim3 import medformer_utils as mu
+    from rsuper_amd.train_ddp import train_step, make_ema
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    classes = synth.TINY_CLASSES
+    largs = argparse.Namespace(loss='ball_dice_last', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.0, volume_loss_tolerance=0.2,
+                               ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                               classification_branch=False, ema=True, ema_alpha=0.99)
+    S = 64
+    bt = synth.batch(2, S, classes, ['mask', 'mask'], seed=31)
+    batch = dict(image=torch.from_numpy(synth.image(2, S, seed=9)).to('cuda'), label=torch.from_numpy(bt['label']).to('cuda'),
+                 unk_channels=torch.from_numpy(bt['unk_channels']).to('cuda'), mask=torch.from_numpy(bt['mask']).to('cuda'),
+                 volumes=torch.from_numpy(bt['volumes']).to('cuda'), diameters=torch.from_numpy(bt['diameters']).to('cuda'))
+    assert 2 * (S // 4) ** 3 >= 4096 >= 1 and mu.SPLITK_MIN_ROWS <= 2 * (S // 4) ** 3      # the aux head takes _LinearFn with the GEMM bias gradient
+
+    def run(graphed):
+        torch.manual_seed(0)
+        net = MedFormer(1, len(classes), compute_dtype='bf16', **{k: v for k, v in synth.MEDFORMER_TINY.items() if k not in ('size', 'seed')}).to('cuda')
+        ema = make_ema(net)
+        opt = FusedAdamWEMA(net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+        f = GraphedNetwork(net, warmup=2) if graphed else net
+        hist = []
+        for i in range(16):
+            loss, gn = train_step(f, ema, opt, batch, largs, classes, i)
+            hist.append((float(loss['overall'].detach()), float(gn)))
+        return hist
+
+    h_e, h_g = run(False), run(True)
+    assert h_e == h_g, [(i, a, b) for i, (a, b) in enumerate(zip(h_e, h_g)) if a != b][:3]
+
+
+@pytest.mark.gpu
 def test_graphed_network_gradient_exchange_single_rank_nccl():
     """GraphedNetwork with the gradient exchange on, on a 1-rank RCCL group: parameter broadcast at construction, flat-bucket all-reduce
     (AVG over one rank = identity) on the static gradient buffers after every backward replay -- exactly the parameters of the plain eager
