@@ -193,6 +193,17 @@ int rsuper_cnorm_backward(const float* x, const float* dy, const float* mr, floa
 int rsuper_cnorm_apply(const float* x, const float* dy, const float* mr, const float* gm, float* out, int N, long vox, int C, int relu, int mode,
                        void* stream);
 
+/* SEBlock (model/dim3/conv_layers.py:159-174) on a channels-last f32 tensor [N][vox][C]: y = x * sigmoid(W2 relu(W1 mean(x) + b1) + b2), w1 (r, C),
+ * w2 (C, r) as in the state_dict of the two 1x1x1 convolutions.  One host call per direction (channel statistics + finalize, the excitation on the
+ * (N, C) vector in one block per sample, the per-(sample, channel) affine apply).  Scratch kept by the caller from forward to backward: ms [N][C][2]
+ * (channel means), tab [N][C][2] = (0, s), hbuf [N][r] (hidden activations).  part: rsuper_cnorm_rows(vox) * N * C * 2 floats of workspace.
+ * backward: ident = [N][C][2] table of (0, 1); gm, dz1 [N][r], tab2 [N][C][2] are workspaces; dw1 / db1 / dw2 / db2 are overwritten. */
+int rsuper_se_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* part, float* ms, float* tab,
+                      float* hbuf, float* y, int N, long vox, int C, int r, void* stream);
+int rsuper_se_backward(const float* x, const float* dy, const float* ident, const float* w1, const float* w2, const float* ms, const float* tab,
+                       const float* hbuf, float* part, float* gm, float* dz1, float* tab2, float* dx, float* dw1, float* db1, float* dw2, float* db2,
+                       int N, long vox, int C, int r, void* stream);
+
 /* Re-layout of a logits-like f32 tensor between channels-last [N][vox][C] (C % 4 == 0, C <= 64, the first K channels real) and
  * planar [N][K][vox] -- the `permute(0, 4, 1, 2, 3)` between MedFormer's channels-last deep-supervision head and the (N, K, D, H, W)
  * planes the loss reads (model/dim3/medformer.py:190-194).  to_channels_last = 0: dst planar <- src channels-last;

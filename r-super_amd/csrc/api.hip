@@ -334,6 +334,19 @@ int rsuper_battn_bwd(const float* fqv, const float* mqv, const float* m_out, con
     return rs_launch_battn(fqv, mqv, nullptr, (float*)m_out, (float*)lse, d_f_out, d_m_out, d_fqv, d_mqv, part, nullptr, B, L, T, heads, dim_head,
                            scale, 1, ST(stream));
 }
+int rsuper_se_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* part, float* ms, float* tab,
+                      float* hbuf, float* y, int N, long vox, int C, int r, void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !part || !ms || !tab || !hbuf || !y || N <= 0 || vox <= 0 || C <= 0 || (C & 3) || r <= 0) return RS_ERR_ARG;
+    return rs_launch_se_forward(x, w1, b1, w2, b2, part, ms, tab, hbuf, y, N, vox, C, r, ST(stream));
+}
+int rsuper_se_backward(const float* x, const float* dy, const float* ident, const float* w1, const float* w2, const float* ms, const float* tab,
+                       const float* hbuf, float* part, float* gm, float* dz1, float* tab2, float* dx, float* dw1, float* db1, float* dw2, float* db2,
+                       int N, long vox, int C, int r, void* stream) {
+    if (!x || !dy || !ident || !w1 || !w2 || !ms || !tab || !hbuf || !part || !gm || !dz1 || !tab2 || !dx || !dw1 || !db1 || !dw2 || !db2 ||
+        N <= 0 || vox <= 0 || C <= 0 || (C & 3) || r <= 0)
+        return RS_ERR_ARG;
+    return rs_launch_se_backward(x, dy, ident, w1, w2, ms, tab, hbuf, part, gm, dz1, tab2, dx, dw1, db1, dw2, db2, N, vox, C, r, ST(stream));
+}
 int rsuper_cl_planar(const float* src, float* dst, int N, long vox, int C, int K, int to_channels_last, void* stream) {
     if (!src || !dst || N <= 0 || vox <= 0 || C <= 0 || K <= 0) return RS_ERR_ARG;
     return rs_launch_cl_planar(src, dst, N, vox, C, K, to_channels_last ? 1 : 0, ST(stream));

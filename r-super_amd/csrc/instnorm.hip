@@ -217,6 +217,131 @@ int rs_launch_cnorm_apply(const float* x, const float* dy, const float* mr, cons
 
 namespace {
 
+// Squeeze-excite excitation (conv_layers.py:159-174) on one (N, C) vector of channel means: s = sigmoid(W2 relu(W1 m + b1) + b2), r = C / ratio
+// hidden units.  Two small kernels, a wave per output with the lanes striding the reduction (coalesced weight rows, shuffle reduce) -- a
+// single block per sample took 269 us (one memory latency per output, 80 outputs in sequence per wave); spread over 32-40 blocks it takes a few us.
+// The ATen form was ~8 forward and ~14 backward one-element-sized launches per block of the network (36 blocks per step).
+// Writes the affine table (0, s) that `cnorm_apply_kernel<2>` scales x with, and the hidden activations for the backward pass.
+__global__ __launch_bounds__(1024) void se_hidden_fwd_kernel(const float* __restrict__ ms, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             float* __restrict__ hbuf, int C, int r) {
+    // grid (N, r / 16): one hidden unit per wave, lanes stride the C-long reduction (coalesced W1 row)
+    const int n = blockIdx.x, lane = threadIdx.x & 63, j = blockIdx.y * 16 + (threadIdx.x >> 6);
+    if (j >= r) return;
+    const float* row = w1 + (size_t)j * C;
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(row[c], ms[((size_t)n * C + c) * 2], a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) hbuf[(size_t)n * r + j] = fmaxf(a + b1[j], 0.f);
+}
+
+__global__ __launch_bounds__(1024) void se_gate_fwd_kernel(const float* __restrict__ hbuf, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           float* __restrict__ tab, int C, int r) {
+    // grid (N, C / 64): four gates per wave, lanes stride the r-long reduction (coalesced W2 row); writes the affine table (0, s)
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = blockIdx.y * 64 + wv * 4 + k;
+        if (c >= C) return;
+        const float* row = w2 + (size_t)c * r;
+        float a = 0.f;
+        for (int jj = lane; jj < r; jj += 64) a = fmaf(row[jj], hbuf[(size_t)n * r + jj], a);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) {
+            float* t = tab + ((size_t)n * C + c) * 2;
+            t[0] = 0.f; t[1] = 1.f / (1.f + expf(-(a + b2[c])));
+        }
+    }
+}
+
+// Backward, stage 1: dz2 = ds * s (1 - s) with ds = vox * gm[., 1] (gm = per-channel means of (dy, dy * x) from the statistics kernel),
+// dh = dz2 W2, dz1 = dh [h > 0].  Grid (N, r / 32): a block owns 32 hidden units; its 1024 threads are 32 units x 32 slices of the C-long
+// reduction (the lanes of a unit row read 128 contiguous bytes of a W2 row), slices summed through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void se_excite_bwd_hidden_kernel(const float* __restrict__ gm, const float* __restrict__ stab,
+                                                                    const float* __restrict__ hbuf, const float* __restrict__ w2, float vox,
+                                                                    float* __restrict__ dz1buf, int C, int r) {
+    extern __shared__ float se_sm[];
+    float* dz2 = se_sm;                 // [C]
+    float* red = se_sm + C;             // [32][33]
+    const int n = blockIdx.x, j0 = blockIdx.y * 32;
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        const float sv = stab[((size_t)n * C + c) * 2 + 1];
+        dz2[c] = gm[((size_t)n * C + c) * 2 + 1] * vox * sv * (1.f - sv);
+    }
+    __syncthreads();
+    const int jl = threadIdx.x & 31, sl = threadIdx.x >> 5, j = j0 + jl;
+    float a = 0.f;
+    if (j < r)
+        for (int c = sl; c < C; c += 32) a = fmaf(dz2[c], w2[(size_t)c * r + j], a);
+    red[sl * 33 + jl] = a;
+    __syncthreads();
+    if (threadIdx.x < 32 && j0 + threadIdx.x < r) {
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += red[k * 33 + threadIdx.x];
+        dz1buf[(size_t)n * r + j0 + threadIdx.x] = hbuf[(size_t)n * r + j0 + threadIdx.x] > 0.f ? t : 0.f;
+    }
+}
+
+// Backward: dm[n][c] = sum_j dz1[n][j] W1[j][c] into the affine table (dm / vox, s) of dx = dy * s + dm / vox.  Grid (N, C / 32): 32 channels x 32
+// slices of the r-long reduction per block, slices summed through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void se_dm_kernel(const float* __restrict__ dz1buf, const float* __restrict__ w1, const float* __restrict__ stab, float vox,
+                                                     float* __restrict__ tab, int C, int r) {
+    __shared__ float red[32 * 33];
+    const int n = blockIdx.x, cl = threadIdx.x & 31, sl = threadIdx.x >> 5, c = blockIdx.y * 32 + cl;
+    float a = 0.f;
+    if (c < C)
+        for (int jj = sl; jj < r; jj += 32) a = fmaf(dz1buf[(size_t)n * r + jj], w1[(size_t)jj * C + c], a);
+    red[sl * 33 + cl] = a;
+    __syncthreads();
+    if (threadIdx.x < 32 && blockIdx.y * 32 + threadIdx.x < C) {
+        const int cc = blockIdx.y * 32 + threadIdx.x;
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += red[k * 33 + threadIdx.x];
+        float* o = tab + ((size_t)n * C + cc) * 2;
+        o[0] = t / vox; o[1] = stab[((size_t)n * C + cc) * 2 + 1];
+    }
+}
+
+// Backward, stage 2: weight / bias gradients summed over the samples in a fixed order -- dW2[c][j] = sum_n dz2[n][c] h[n][j],
+// dW1[j][c] = sum_n dz1[n][j] m[n][c], db2 = sum_n dz2, db1 = sum_n dz1.  Element-parallel (threads walk the contiguous axis of each output).
+__global__ __launch_bounds__(256) void se_excite_wgrad_kernel(const float* __restrict__ gm, const float* __restrict__ stab, const float* __restrict__ hbuf,
+                                                              const float* __restrict__ ms, const float* __restrict__ dz1buf,
+                                                              float vox, int N, int C, int r, float* __restrict__ dw1, float* __restrict__ db1,
+                                                              float* __restrict__ dw2, float* __restrict__ db2) {
+    const long total = (long)C * r;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        {   // dW2 (C, r)
+            const int c = (int)(i / r), j = (int)(i - (long)c * r);
+            float a = 0.f;
+            for (int n = 0; n < N; ++n) {
+                const float sv = stab[((size_t)n * C + c) * 2 + 1];
+                a = fmaf(gm[((size_t)n * C + c) * 2 + 1] * vox * sv * (1.f - sv), hbuf[(size_t)n * r + j], a);
+            }
+            dw2[i] = a;
+        }
+        {   // dW1 (r, C)
+            const int j = (int)(i / C), c = (int)(i - (long)j * C);
+            float a = 0.f;
+            for (int n = 0; n < N; ++n) a = fmaf(dz1buf[(size_t)n * r + j], ms[((size_t)n * C + c) * 2], a);
+            dw1[i] = a;
+        }
+        if (i < C) {
+            float a = 0.f;
+            for (int n = 0; n < N; ++n) {
+                const float sv = stab[((size_t)n * C + i) * 2 + 1];
+                a += gm[((size_t)n * C + i) * 2 + 1] * vox * sv * (1.f - sv);
+            }
+            db2[i] = a;
+        }
+        if (i < r) {
+            float a = 0.f;
+            for (int n = 0; n < N; ++n) a += dz1buf[(size_t)n * r + i];
+            db1[i] = a;
+        }
+    }
+}
+
 // Channels-last <-> planar re-layout of a logits-like f32 tensor: [N][vox][C] (C % 4 == 0, C <= 64, the first K channels real) <->
 // [N][K][vox].  The deep-supervision head of MedFormer up-samples channels-last and hands (N, K, D, H, W) planes to the loss
 // (medformer.py:190-194); ATen's permute copy ran this at 0.45 TB/s.  A block moves 128 voxels x C channels through LDS: 16-byte row
@@ -257,6 +382,44 @@ __global__ __launch_bounds__(256) void cl_planar_kernel(const float* __restrict_
 }
 
 }  // namespace
+
+// SEBlock forward in one host call: channel means (statistics + finalize), excitation, y = x * s.  scratch: part (cnorm rows), ms (N, C, 2),
+// tab (N, C, 2) = (0, s) and hbuf (N, r) are kept by the caller for the backward pass.
+int rs_launch_se_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* part, float* ms, float* tab,
+                         float* hbuf, float* y, int N, long vox, int C, int r, hipStream_t st) {
+    if (C > 8192 || r > 8192 || r < 1) return RS_ERR_UNSUPPORTED;
+    const int rows = rs_cnorm_rows(vox);
+    int rc = rs_launch_cnorm_stats(x, nullptr, nullptr, part, N, vox, C, 0, 0, st);
+    if (rc != RS_OK) return rc;
+    rc = rs_launch_stats_finalize(part, N, rows, C, (double)vox, 0.f, 1, 0, ms, st);
+    if (rc != RS_OK) return rc;
+    hipLaunchKernelGGL(se_hidden_fwd_kernel, dim3(N, (r + 15) / 16), dim3(1024), 0, st, (const float*)ms, w1, b1, hbuf, C, r);
+    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(N, (C + 63) / 64), dim3(1024), 0, st, (const float*)hbuf, w2, b2, tab, C, r);
+    rc = rs_check_launch();
+    if (rc != RS_OK) return rc;
+    return rs_launch_cnorm_apply(x, nullptr, tab, nullptr, y, N, vox, C, 0, 2, st);
+}
+
+// SEBlock backward in one host call.  ident: (N, C, 2) table of (0, 1) (the statistics kernel then yields the means of (dy, dy * x)).
+int rs_launch_se_backward(const float* x, const float* dy, const float* ident, const float* w1, const float* w2, const float* ms, const float* tab,
+                          const float* hbuf, float* part, float* gm, float* dz1buf, float* tab2, float* dx, float* dw1, float* db1, float* dw2,
+                          float* db2, int N, long vox, int C, int r, hipStream_t st) {
+    if (C > 8192 || r > 8192 || r < 1) return RS_ERR_UNSUPPORTED;
+    const int rows = rs_cnorm_rows(vox);
+    int rc = rs_launch_cnorm_stats(x, dy, ident, part, N, vox, C, 0, 1, st);
+    if (rc != RS_OK) return rc;
+    rc = rs_launch_stats_finalize(part, N, rows, C, (double)vox, 0.f, 1, 0, gm, st);
+    if (rc != RS_OK) return rc;
+    hipLaunchKernelGGL(se_excite_bwd_hidden_kernel, dim3(N, (r + 31) / 32), dim3(1024), (size_t)(C + 32 * 33) * sizeof(float), st, (const float*)gm, tab,
+                       hbuf, w2, (float)vox, dz1buf, C, r);
+    const long total = (long)C * r;
+    hipLaunchKernelGGL(se_excite_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)gm, tab, hbuf, ms,
+                       (const float*)dz1buf, (float)vox, N, C, r, dw1, db1, dw2, db2);
+    hipLaunchKernelGGL(se_dm_kernel, dim3(N, (C + 31) / 32), dim3(1024), 0, st, (const float*)dz1buf, w1, tab, (float)vox, tab2, C, r);
+    rc = rs_check_launch();
+    if (rc != RS_OK) return rc;
+    return rs_launch_cnorm_apply(dy, nullptr, tab2, nullptr, dx, N, vox, C, 0, 2, st);
+}
 
 int rs_launch_cl_planar(const float* src, float* dst, int N, long vox, int C, int K, int dir, hipStream_t st) {
     if (C > 64 || (C & 3) || K > C || K < 1) return RS_ERR_UNSUPPORTED;

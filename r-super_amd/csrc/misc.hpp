@@ -59,6 +59,11 @@ int rs_battn_chunks(int L, int heads);
 int rs_launch_battn(const float* fqv, const float* mqv, float* fout, float* mout, float* lse, const float* dfo, const float* dmo,
                     float* dfqv, float* dmqv, float* part, float* pms, int B, int L, int T, int heads, int dh, float scale, int bwd,
                     hipStream_t st);
+int rs_launch_se_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* part, float* ms, float* tab,
+                         float* hbuf, float* y, int N, long vox, int C, int r, hipStream_t st);
+int rs_launch_se_backward(const float* x, const float* dy, const float* ident, const float* w1, const float* w2, const float* ms, const float* tab,
+                          const float* hbuf, float* part, float* gm, float* dz1buf, float* tab2, float* dx, float* dw1, float* db1, float* dw2,
+                          float* db2, int N, long vox, int C, int r, hipStream_t st);
 int rs_launch_cl_planar(const float* src, float* dst, int N, long vox, int C, int K, int dir, hipStream_t st);
 int rs_depthwise_rows(long vox);
 int rs_launch_depthwise(const float* x, const float* w, float* y, int N, int D, int H, int W, int C, int flip, hipStream_t st);

@@ -52,6 +52,8 @@ _SIGS = {
     'rsuper_battn_chunks': (c_int, [c_int, c_int]),
     'rsuper_battn_fwd': (c_int, [P] * 7 + [c_int] * 5 + [c_float, P]),
     'rsuper_battn_bwd': (c_int, [P] * 9 + [c_int] * 5 + [c_float, P]),
+    'rsuper_se_forward': (c_int, [P] * 10 + [c_int, c_long, c_int, c_int, P]),
+    'rsuper_se_backward': (c_int, [P] * 17 + [c_int, c_long, c_int, c_int, P]),
     'rsuper_cl_planar': (c_int, [P, P, c_int, c_long, c_int, c_int, c_int, P]),
     'rsuper_depthwise3_rows': (c_int, [c_long]),
     'rsuper_depthwise3_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

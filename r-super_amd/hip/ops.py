@@ -740,8 +740,9 @@ class PlanarFn(torch.autograd.Function):
 
 class SqueezeExciteFn(torch.autograd.Function):
     """SEBlock (model/dim3/conv_layers.py:159-174) on a channels-last fp32 tensor: y = x * sigmoid(W2 relu(W1 mean(x) + b1) + b2).
-    Two passes over x in each direction on csrc/instnorm.hip (per-channel sums + the affine apply); the two-layer excitation acts on one
-    (N, C) vector and stays in ATen, differentiated by a nested autograd call in backward."""
+    ONE host call per direction (csrc/instnorm.hip: channel statistics + finalize, the excitation of the (N, C) mean vector in a block per
+    sample, the per-(sample, channel) affine apply; backward adds the weight-gradient kernel).  The first version kept the excitation
+    in ATen with a nested autograd call: 110 us of host time forward and ~200 us backward per block (18 blocks per MedFormer step)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -749,44 +750,38 @@ class SqueezeExciteFn(torch.autograd.Function):
         assert x.is_cuda and x.dim() == 5 and x.dtype == torch.float32 and x.shape[-1] % 4 == 0
         N, C = x.shape[0], x.shape[-1]
         vox = x.shape[1] * x.shape[2] * x.shape[3]
-        rows = _L().rsuper_cnorm_rows(vox)
-        st = _stream()
-        part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
-        ms = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
-        _l.check(_L().rsuper_cnorm_stats(_ptr(x), None, None, _ptr(part), N, vox, C, 0, 0, st), 'se_stats')
-        _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), 0.0, 1, 0, _ptr(ms), st), 'stats_finalize')
-        with torch.enable_grad():
-            leaves = [t.detach().requires_grad_(True) for t in (ms[..., 0], w1, b1, w2, b2)]
-            m, a1, c1, a2, c2 = leaves
-            s = torch.sigmoid(F.linear(F.relu(F.linear(m, a1.flatten(1), c1)), a2.flatten(1), c2))
-        tab = torch.stack([torch.zeros_like(s), s.detach()], -1)
+        r = w1.shape[0]
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        dev = x.device
+        part = torch.empty((N, _L().rsuper_cnorm_rows(vox), C, 2), device=dev, dtype=torch.float32)
+        ms = torch.empty((N, C, 2), device=dev, dtype=torch.float32)
+        tab = torch.empty((N, C, 2), device=dev, dtype=torch.float32)
+        hbuf = torch.empty((N, r), device=dev, dtype=torch.float32)
         y = torch.empty_like(x)
-        _l.check(_L().rsuper_cnorm_apply(_ptr(x), None, _ptr(tab), None, _ptr(y), N, vox, C, 0, 2, st), 'se_apply')
-        ctx.save_for_backward(x)
-        ctx.leaves, ctx.s = leaves, s
+        _l.check(_L().rsuper_se_forward(_ptr(x), _ptr(w1c), _ptr(b1), _ptr(w2c), _ptr(b2), _ptr(part), _ptr(ms), _ptr(tab), _ptr(hbuf), _ptr(y),
+                                        N, vox, C, r, _stream()), 'se_forward')
+        ctx.save_for_backward(x, w1c, w2c, ms, tab, hbuf)
+        ctx.wshapes = (tuple(w1.shape), tuple(w2.shape))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, = ctx.saved_tensors
+        x, w1, w2, ms, tab, hbuf = ctx.saved_tensors
         dy = dy.contiguous()
         N, C = x.shape[0], x.shape[-1]
         vox = x.shape[1] * x.shape[2] * x.shape[3]
-        rows = _L().rsuper_cnorm_rows(vox)
-        st = _stream()
-        part = torch.empty((N, rows, C, 2), device=x.device, dtype=torch.float32)
-        gm = torch.empty((N, C, 2), device=x.device, dtype=torch.float32)
-        ident = _se_identity(N, C, x.device)
-        # (sum dy, sum dy * x) / vox: the backward statistics kernel with (mean, rstd) = (0, 1)
-        _l.check(_L().rsuper_cnorm_stats(_ptr(x), _ptr(dy), _ptr(ident), _ptr(part), N, vox, C, 0, 1, st), 'se_bwd_stats')
-        _l.check(_L().rsuper_stats_finalize(_ptr(part), N, rows, C, float(vox), 0.0, 1, 0, _ptr(gm), st), 'stats_finalize')
-        s = ctx.s
-        grads = torch.autograd.grad(s, ctx.leaves, gm[..., 1] * float(vox))
-        ctx.leaves = ctx.s = None
-        tab = torch.stack([grads[0] / float(vox), s.detach()], -1)          # dx = dy * s + d mean / vox
+        r = w1.shape[0]
+        dev = x.device
+        part = torch.empty((N, _L().rsuper_cnorm_rows(vox), C, 2), device=dev, dtype=torch.float32)
+        scratch = torch.empty(N * C * 4 + N * r, device=dev, dtype=torch.float32)          # gm | tab2 | dz1
+        gm, tab2, dz1 = scratch[:N * C * 2], scratch[N * C * 2:N * C * 4], scratch[N * C * 4:]
         dx = torch.empty_like(x)
-        _l.check(_L().rsuper_cnorm_apply(_ptr(dy), None, _ptr(tab), None, _ptr(dx), N, vox, C, 0, 2, st), 'se_bwd_apply')
-        return (dx,) + tuple(grads[1:])
+        dw1, dw2 = torch.empty(ctx.wshapes[0], device=dev, dtype=torch.float32), torch.empty(ctx.wshapes[1], device=dev, dtype=torch.float32)
+        db1, db2 = torch.empty(r, device=dev, dtype=torch.float32), torch.empty(C, device=dev, dtype=torch.float32)
+        _l.check(_L().rsuper_se_backward(_ptr(x), _ptr(dy), _ptr(_se_identity(N, C, dev)), _ptr(w1), _ptr(w2), _ptr(ms), _ptr(tab), _ptr(hbuf),
+                                         _ptr(part), _ptr(gm), _ptr(dz1), _ptr(tab2), _ptr(dx), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+                                         N, vox, C, r, _stream()), 'se_backward')
+        return dx, dw1, db1, dw2, db2
 
 
 _SE_IDENT = {}
