@@ -24,6 +24,7 @@ clip / AdamW / EMA.  The host then enqueues 2 graph launches + the loss + the op
 (`exchange_gradients`: flat buckets, one RCCL all-reduce each), so it replaces the DDP wrapper rather than sitting inside it.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -187,6 +188,9 @@ class _ReplayFn(torch.autograd.Function):
         for dst, g in zip(o.static_gouts, gouts):
             dst.copy_(g) if g is not None else dst.zero_()
         o.bwd_graph.replay()
+        o._replays += 1
+        if o._replays in o.verify_at or (o.verify_every and o._replays % o.verify_every == 0):
+            o._verify()
         if o.exchange:
             exchange_gradients([g for g in o.static_grads if g is not None], o.group, force=True)
         for p, g in zip(o.params, o.static_grads):
@@ -228,12 +232,36 @@ class GraphedNetwork:
         self.fwd_graph = None
         self._shape = None
         self._anchor = None
+        self._replays = 0
+        on = os.environ.get('RSUPER_GRAPH_VERIFY', '1') != '0'
+        self.verify_at, self.verify_every = ((1, 12, 50) if on else ()), (1000 if on else 0)
 
     def __getattr__(self, name):                       # parameters(), named_parameters(), state_dict(), train(), eval(), ...
         return getattr(self.__dict__['net'], name)
 
+    def _verify(self):
+        """Recompute this step's gradients eagerly (same input buffer, same output gradients) and compare them with what the backward graph
+        left in the static buffers.  The step is bit-reproducible across eager and replayed execution, so anything beyond summation-order
+        noise is a defect of the replay -- like the captured ATen reduction that returned garbage from the 12th replay on,
+        which this check reports at replay 12 instead of letting one bias train on noise.  Runs at replays 1, 12, 50 and every 1000th
+        (one extra eager forward + backward each); RSUPER_GRAPH_VERIFY=0 turns it off."""
+        with torch.enable_grad():
+            outs = self._wrapped(self.static_img)
+            ref = torch.autograd.grad(outs, self.params, self.static_gouts, allow_unused=True)
+        names = {id(p): k for k, p in self.net.named_parameters()}
+        for p, g, r in zip(self.params, self.static_grads, ref):
+            if g is None or r is None:
+                continue
+            scale = float(r.abs().max())
+            err = float((g - r).abs().max())
+            if err > 1e-3 * max(scale, 1e-30) and err > 1e-12:
+                raise RuntimeError(f'GraphedNetwork: replay {self._replays} disagrees with the eager step on the gradient of '
+                                   f'{names.get(id(p), "?")} (max difference {err:.3e}, largest entry {scale:.3e}); '
+                                   'run without --hip_graph and report the kernel (tools/mode_consistency.py narrows it down)')
+        ops.WEIGHTS_EPOCH += 1
+
     def _capture(self, img):
-        wrapped = _TupleOut(self.net)
+        wrapped = self._wrapped = _TupleOut(self.net)
         self.params = [p for p in self.net.parameters() if p.requires_grad]
         saved = [p.grad for p in self.params]
         self.static_img = img.detach().clone()

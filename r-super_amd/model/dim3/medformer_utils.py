@@ -153,7 +153,7 @@ class _LinearFn(torch.autograd.Function):
                 with gemm_library(rows):
                     dw = torch.mm(dy2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            if dy2.shape[0] >= 4096:
+            if dy2.shape[0] >= 4096 and not _ATEN_BIAS_SUM:
                 # Column sums of a tall matrix as a 1 x rows GEMM, NOT `dy2.sum(0)`: ATen's multi-block reduction (global partials + semaphores)
                 # returned garbage from the 12th replay on when captured in a hipGraph on this ROCm (the aux head's bias gradient, 27648 x 26:
                 # ~-2e-10 instead of ~2e-3, every later replay too; eager and the first 11 replays correct) -- found by comparing eager and
@@ -166,6 +166,7 @@ class _LinearFn(torch.autograd.Function):
 
 
 _ONES = {}
+_ATEN_BIAS_SUM = os.environ.get('RSUPER_DEBUG_ATEN_BIAS_SUM') == '1'      # reproduce the captured-reduction defect (see _LinearFn.backward)
 
 
 def _ones_row(n, device):

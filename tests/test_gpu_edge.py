@@ -713,6 +713,42 @@ def test_graphed_step_matches_eager(model):
 
 
 @pytest.mark.gpu
+def test_graphed_network_self_verification_reports_a_wrong_replay():
+    """GraphedNetwork recomputes the gradients eagerly at replays 1, 12, 50, ... and compares them with the backward graph's static buffers.
+    A healthy run passes silently (every other graph test runs with the check on); here the backward graph is wrapped so that one static
+    gradient buffer is scribbled on after the replay -- what a defective replay looks like from the outside: RuntimeError naming the
+    gradient.  With RSUPER_GRAPH_VERIFY=0 semantics (verify_at = ()) the same sequence goes through."""
+    import synth
+    from rsuper_amd.graph import GraphedNetwork
+    from rsuper_amd.model.dim3.unet import UNet
+    classes = synth.TINY_CLASSES
+    img = torch.from_numpy(synth.image(1, 32, seed=3)).to('cuda')
+    for check in (True, False):
+        torch.manual_seed(0)
+        net = UNet(1, 8, num_classes=len(classes), compute_dtype='f32').to('cuda')
+        g = GraphedNetwork(net, warmup=1)
+        if not check:
+            g.verify_at, g.verify_every = (), 0
+        y = g(img)['segmentation']
+
+        class Scribbling:
+            def __init__(self, graph):
+                self.graph = graph
+
+            def replay(self):
+                self.graph.replay()
+                g.static_grads[-1].add_(1.0)           # outc.bias
+
+        g.bwd_graph = Scribbling(g.bwd_graph)
+        if check:
+            with pytest.raises(RuntimeError, match='disagrees with the eager step'):
+                y.square().mean().backward()
+        else:
+            y.square().mean().backward()
+            assert net.outc.weight.grad is not None
+
+
+@pytest.mark.gpu
 def test_graphed_step_without_per_step_sync_matches_eager():
     """GraphedTrainStep driven the way a training loop drives it -- no host read between steps, so the host runs many replays ahead of the
     GPU -- ends with exactly the parameters of the eager run.  Regression test: the step-dependent optimiser scalars (Adam bias
