@@ -63,7 +63,7 @@ class MedFormer(nn.Module):
         # 18.5 us of host time against 7.5 us, and the 54-row map-token products run 21 us kernels against < 8 us (measured per call;
         # MedFormer step 41.0 -> 36.6 ms eager, 30.55 -> 30.15 ms replayed).  Process-wide torch setting; RSUPER_MF_BLAS=default keeps torch's.
         blas = os.environ.get('RSUPER_MF_BLAS', 'cublas')
-        if blas != 'default' and torch.cuda.is_available():
+        if blas != 'default' and torch.cuda.is_available() and hasattr(torch.backends.cuda, 'preferred_blas_library'):
             torch.backends.cuda.preferred_blas_library(blas)
             _mu.gemm_library.active = blas == 'cublas'      # long reductions switch back to hipBLASLt per call (medformer_utils.gemm_library)
 
