@@ -23,13 +23,13 @@ def dur(d):
 
 
 fetch, write, durs = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE'), dur(sys.argv[1])
-names = ['depthwise_fwd_kernel', 'depthwise_wgrad_kernel', 'cnorm_stats_kernel<0>', 'cnorm_apply_kernel<0>', 'cnorm_stats_kernel<1>', 'cnorm_apply_kernel<1>']
+names = ['depthwise_lds_kernel', 'depthwise_fwd_kernel', 'depthwise_wgrad_kernel', 'cnorm_stats_kernel<0>', 'cnorm_apply_kernel<0>', 'cnorm_stats_kernel<1>', 'cnorm_apply_kernel<1>']
 MB = {48: 2 * 48 ** 3 * 256 * 4 / 1e6, 24: 2 * 24 ** 3 * 512 * 4 / 1e6}
-alg = {'depthwise_fwd_kernel': 2, 'depthwise_wgrad_kernel': 2, 'cnorm_stats_kernel<0>': 1, 'cnorm_apply_kernel<0>': 2, 'cnorm_stats_kernel<1>': 2,
+alg = {'depthwise_lds_kernel': 2, 'depthwise_fwd_kernel': 2, 'depthwise_wgrad_kernel': 2, 'cnorm_stats_kernel<0>': 1, 'cnorm_apply_kernel<0>': 2, 'cnorm_stats_kernel<1>': 2,
        'cnorm_apply_kernel<1>': 3}
 print('# rocprofv3 PMC, attention-stage kernels (tools/pmc_glue.sh): HBM-side bytes per launch vs algorithmic bytes\n')
 print('FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-byte requests at 64 B); KB -> MB.  Shapes (2,48,48,48,256) = 226 MB and '
-      '(2,24,24,24,512) = 57 MB per tensor, fp32.  depthwise_fwd_kernel is also the data-gradient kernel (every second launch).\n')
+      '(2,24,24,24,512) = 57 MB per tensor, fp32.  depthwise_lds_kernel (48^3) / depthwise_fwd_kernel (24^3) are also the data-gradient kernels (every second launch).\n')
 print('| kernel | tensor MB | algorithmic MB | FETCH x2 MB | WRITE MB | us | achieved GB/s (algorithmic) |')
 print('|---|---|---|---|---|---|---|')
 for n in names:
@@ -39,7 +39,8 @@ for n in names:
     if not f:
         continue
     half = len(f) // 2
-    for tag, sl in ((48, slice(0, half)), (24, slice(half, None))):
+    only = {'depthwise_lds_kernel': 48, 'depthwise_fwd_kernel': 24}.get(n) if any('depthwise_lds_kernel' in r[1] for r in fetch) else None
+    for tag, sl in (((only, slice(0, None)),) if only else ((48, slice(0, half)), (24, slice(half, None)))):
         ff, ww, dd = f[sl], w[sl], d[sl]
         if not ff:
             continue
