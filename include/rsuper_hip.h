@@ -63,8 +63,18 @@ int rsuper_conv3_tiles(int D, int H, int W);
  * producer/consumer persistent kernel (bf16), 2 = per-launch choice between the two (round-1 default), 3 (default) = as 2,
  * with the weight-stationary 8-wave kernel (weights in registers, activation fragments re-used across taps, epilogue
  * straight from the accumulators) for 32-column launches over a single 32-channel K chunk, 4 = weight-stationary kernel
- * for every bf16 32-column launch.  v < 0 queries.  Returns the variant in effect. */
+ * for every bf16 32-column launch, 5 = second-generation producer/consumer kernel for bn <= 64, 6 / 7 = the volume-fitted
+ * K-split kernel (rsuper_conv3_box_bn) forced for every bf16 64-column launch (6: box shape per volume, 7: the 4x4x4 box).
+ * v < 0 queries.  Returns the variant in effect. */
 int rsuper_conv3_variant(int v);
+
+/* Launches whose volume cannot fill the chip with 4x4x16-voxel tiles (the 24^3 / 12^3 levels of the UNet at batch 2:
+ * model/dim3/unet.py:49-58 after three / four poolings) run a volume-fitted kernel under the default variant: boxes of
+ * 4x4x8 or 4x4x4 voxels that divide the volume, GEMM rows = flat voxel index of the box, the block's four waves split the
+ * reduction (taps x k-steps) and reduce-scatter their partial tiles through LDS before the same fused epilogue.  It works
+ * on 64-column blocks: returns 64 when rsuper_conv3_igemm(dtype, ..., n_cols, bn = 64, N, D, H, W) would take that kernel
+ * (pack the weights with bn = 64 then), else 0. */
+int rsuper_conv3_box_bn(int dtype, int N, int D, int H, int W, int n_cols);
 
 /* Rows per sample of the `part` buffer rsuper_conv3_igemm(dtype, epi, ..., n_cols, bn, N, D, H, W) writes under the
  * current variant (classic: one row per tile; producer/consumer: one row per (persistent block, consumer wave row)). */

@@ -1,6 +1,7 @@
 // extern "C" entry points declared in include/rsuper_hip.h: argument checking + kernel launches.
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 #include "common.hpp"
 #include "kernels.hpp"
 #include "misc.hpp"
@@ -106,7 +107,7 @@ int rsuper_conv3_tiles(int D, int H, int W) { return ((D + 3) / 4) * ((H + 3) / 
 
 static int g_variant = 3;
 int rsuper_conv3_variant(int v) {
-    if (v >= 0 && v <= 5) g_variant = v;
+    if (v >= 0 && v <= 7) g_variant = v;
     return g_variant;
 }
 // variant 2 (auto, default): producer/consumer kernel where it measured faster on MI355X -- data-gradient launches with
@@ -123,7 +124,26 @@ static bool use_pc(int dtype, int epi, int bn, int tiles_total) {
     return g_variant == 1;
 }
 
+// Volume-fitted K-split kernel (conv3d_igemm_box.hip) for launches that cannot fill the chip with 4x4x16-voxel tiles: bf16, 64-column
+// blocks, more than 32 columns, and fewer than 512 classic work items (the 24^3 / 12^3 / 6^3 levels at batch 2).  Variants 6 / 7 force
+// it for every eligible dtype / column count (6: shape chosen per volume, 7: the 4x4x4 box) -- test paths.
+static int box_for(int dtype, int bn, int N, int D, int H, int W, int n_cols) {
+    if (dtype != RS_BF16 || bn != 64) return 0;
+    if (g_variant == 6) return rs_box_config(N, D, H, W, n_cols);
+    if (g_variant == 7) return 2;
+    if (g_variant != 3 || n_cols <= 32) return 0;
+    static const int off = getenv("RSUPER_NO_BOX") ? atoi(getenv("RSUPER_NO_BOX")) : 0;
+    if (off) return 0;
+    if ((long)N * rsuper_conv3_tiles(D, H, W) * ((n_cols + 127) / 128) >= 512) return 0;
+    return rs_box_config(N, D, H, W, n_cols);
+}
+
+int rsuper_conv3_box_bn(int dtype, int N, int D, int H, int W, int n_cols) {
+    return box_for(dtype, 64, N, D, H, W, n_cols) ? 64 : 0;
+}
+
 int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn) {
+    if (const int cfg = box_for(dtype, bn, N, D, H, W, n_cols)) return rs_box_part_rows(cfg, D, H, W);
     return rs_igemm_part_rows(bn, use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0, rsuper_conv3_tiles(D, H, W), n_cols, N);
 }
 
@@ -154,6 +174,7 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     p.out = out; p.ldo = ldo; p.res = res; p.ldr = ldr; p.part = part;
     p.ea = {exa, elda, eCa, emra};
     p.eb = {exb, eldb, eCb, emrb};
+    p.box = box_for(dtype, bn, N, D, H, W, n_cols);
     p.pc = use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0;
     if (p.pc && g_variant == 5) p.pc = 3;
     if (p.pc && bn == 32 && (g_variant == 4 || (g_variant == 3 && (Ca + 31) / 32 + (Cb + 31) / 32 == 1))) p.pc = 2;

@@ -43,11 +43,19 @@ def _L():
     return _l.lib()
 
 
-def pick_bn(n_cols, dtype, tiles_total=None):
+def pick_bn(n_cols, dtype, tiles_total=None, dims=None):
     """Block N tile of the implicit GEMM (32/64/128 output columns); f32 parity mode is limited to 64.
     tiles_total (spatial tiles x batch): on small volumes prefer the largest tile that still yields >= 512 workgroups
-    (24^3 and below would otherwise leave most of the 256 CUs idle; the narrower tiles also run on the persistent kernel)."""
+    (24^3 and below would otherwise leave most of the 256 CUs idle; the narrower tiles also run on the persistent kernel).
+    dims = (N, D, H, W): launches the library would hand to the volume-fitted K-split kernel (rsuper_conv3_box_bn: low-resolution
+    levels that cannot fill the chip with 4x4x16 tiles) take its 64-column blocks."""
     cands = (32, 64) if dtype == torch.float32 else (32, 64, 128)
+    if dtype != torch.float32 and _L().rsuper_conv3_variant(-1) in (6, 7):
+        return 64         # forced volume-fitted kernel (tests): 64-column blocks whatever the column count
+    if dims is not None and dtype != torch.float32:
+        bn = _L().rsuper_conv3_box_bn(_DT[dtype], *dims, n_cols)
+        if bn:
+            return bn
     if n_cols <= 32:
         return 32
     if dtype != torch.float32 and _L().rsuper_conv3_variant(-1) == 4:
@@ -122,17 +130,17 @@ def pack_weights_batch(dtype, specs):
     return [buf[offs[i]:offs[i + 1]] for i in range(n)]
 
 
-def block_pack_specs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward):
+def block_pack_specs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims=None):
     """The (up to) four fragment buffers a BasicBlock needs: forward conv1(+shortcut), forward conv2, data-gradient
     conv2, data-gradient conv1(+shortcut).  Returns (specs, bns) in that order."""
     Cout, Cin = w1.shape[0], Ca + Cb
     has_sc = ws is not None
     nc1 = Cout * (2 if has_sc else 1)
-    bn1, bn2 = pick_bn(nc1, dtype, tiles_total), pick_bn(Cout, dtype, tiles_total)
+    bn1, bn2 = pick_bn(nc1, dtype, tiles_total, dims), pick_bn(Cout, dtype, tiles_total, dims)
     specs = [(0, w1, ws, Ca, Cb, Cout, Cout if has_sc else 0, bn1), (0, w2, None, Cout, 0, Cout, 0, bn2)]
     bns = [bn1, bn2]
     if with_backward:
-        bnd2, bnd1 = pick_bn(Cout, dtype, tiles_total), pick_bn(Cin, dtype, tiles_total)
+        bnd2, bnd1 = pick_bn(Cout, dtype, tiles_total, dims), pick_bn(Cin, dtype, tiles_total, dims)
         specs += [(1, w2, None, Cout, 0, Cout, 0, bnd2), (1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bnd1)]
         bns += [bnd2, bnd1]
     return specs, bns
@@ -388,7 +396,7 @@ class BasicBlockFn(torch.autograd.Function):
             # with gradients wanted, the data-gradient fragments are packed by the same launch (one pack launch per block instead of
             # two; they are read once, much later, so being cold in L2 by then costs nothing measurable)
             both = os.environ.get('RSUPER_PACK_BOTH', '1') == '1' and any(ctx.needs_input_grad)
-            specs, bns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, both)
+            specs, bns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, both, dims)
             packs = (pack_weights_batch(dt, specs), bns)
         bn1, wp1 = packs[1][0], packs[0][0]
         ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
@@ -419,7 +427,7 @@ class BasicBlockFn(torch.autograd.Function):
         tiles = _L().rsuper_conv3_tiles(D, H, W)
         sa = Src(xa, mr=mra)
         nc1 = 2 * Cout
-        specs, bns = block_pack_specs(w1, w2, ws, Ca, 0, dt, tiles * N, False)
+        specs, bns = block_pack_specs(w1, w2, ws, Ca, 0, dt, tiles * N, False, dims)
         wp = pack_weights_batch(dt, specs)
         full = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
         igemm(0, sa, None, wp[0], nc1, bns[0], dims, full)                       # [conv1 | shortcut] at stride 1, no statistics
@@ -429,7 +437,7 @@ class BasicBlockFn(torch.autograd.Function):
         dims2 = (N, OD, OH, OW)
         mr_y1 = mr_ys[:, :Cout].contiguous()
         tiles2 = _L().rsuper_conv3_tiles(OD, OH, OW)
-        bn2 = pick_bn(Cout, dt, tiles2 * N)
+        bn2 = pick_bn(Cout, dt, tiles2 * N, dims2)
         wp2 = pack_weights(dt, 0, w2, None, Cout, 0, Cout, 0, bn2)
         out = torch.empty((N, OD, OH, OW, Cout), device=dev, dtype=dt)
         part2 = part_buffer(dt, dims2, Cout, bn2, dev)
@@ -455,7 +463,7 @@ class BasicBlockFn(torch.autograd.Function):
         sdo = Src(dout)
         # conv2 at the half resolution: as in the stride-1 block
         tiles2 = _L().rsuper_conv3_tiles(OD, OH, OW)
-        bn = pick_bn(Cout, dt, tiles2 * N)
+        bn = pick_bn(Cout, dt, tiles2 * N, dims2)
         wpd2 = pack_weights(dt, 1, w2, None, Cout, 0, Cout, 0, bn)
         g1 = torch.empty((N, OD, OH, OW, Cout), device=dev, dtype=dt)
         part = part_buffer(dt, dims2, Cout, bn, dev, epi=1)
@@ -470,7 +478,7 @@ class BasicBlockFn(torch.autograd.Function):
         subsample2_scatter(dout, dfull, Cout, dims)
         sa = Src(xa, mr=mra)
         tiles = _L().rsuper_conv3_tiles(D, H, W)
-        bnd = pick_bn(Ca, dt, tiles * N)
+        bnd = pick_bn(Ca, dt, tiles * N, dims)
         wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, bnd)
         g0 = torch.empty((N, D, H, W, Ca), device=dev, dtype=dt)
         part0 = part_buffer(dt, dims, Ca, bnd, dev, epi=1)
@@ -501,7 +509,7 @@ class BasicBlockFn(torch.autograd.Function):
         if ctx.packs is not None:
             bpk = (ctx.packs[0][2:], ctx.packs[1][2:])
         else:
-            bspecs, bbns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, True)
+            bspecs, bbns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, True, dims)
             bpk = (pack_weights_batch(dt, bspecs[2:]), bbns[2:])
         bn, wpd2 = bpk[1][0], bpk[0][0]
         g1 = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
@@ -690,7 +698,7 @@ class Conv3Fn(torch.autograd.Function):
         assert tuple(w.shape[1:]) == (Cin, 3, 3, 3) and Cout % 8 == 0 and w.dtype == torch.float32
         dt, dims = x.dtype, (N, D, H, W)
         tiles = _L().rsuper_conv3_tiles(D, H, W) * N
-        bn = pick_bn(Cout, dt, tiles)
+        bn = pick_bn(Cout, dt, tiles, dims)
         wc = w.contiguous()
         out = torch.empty((N, D, H, W, Cout), device=x.device, dtype=dt)
         igemm(0, Src(x), None, pack_weights(dt, 0, wc, None, Cin, 0, Cout, 0, bn), Cout, bn, dims, out)
@@ -706,7 +714,7 @@ class Conv3Fn(torch.autograd.Function):
         dout = dout.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            bn = pick_bn(Cin, dt, _L().rsuper_conv3_tiles(D, H, W) * N)
+            bn = pick_bn(Cin, dt, _L().rsuper_conv3_tiles(D, H, W) * N, dims)
             dx = torch.empty_like(x)
             igemm(0, Src(dout), None, pack_weights(dt, 1, w, None, Cout, 0, Cin, 0, bn), Cin, bn, dims, dx)
         if ctx.needs_input_grad[1]:

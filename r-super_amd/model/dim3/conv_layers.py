@@ -60,7 +60,7 @@ class BasicBlock(nn.Module):
         hit = getattr(self, '_pack_cache', None)
         if hit is not None and hit[0] == key:
             return hit[1]
-        specs, bns = ops.block_pack_specs(w1, w2, ws, Ca, Cb, xa.dtype, tiles_total, False)
+        specs, bns = ops.block_pack_specs(w1, w2, ws, Ca, Cb, xa.dtype, tiles_total, False, (N, D, H, W))
         packs = (ops.pack_weights_batch(xa.dtype, specs), bns)
         self._pack_cache = (key, packs)
         return packs

@@ -84,7 +84,7 @@ class UNet(nn.Module):
         for blk, Ca, Cb, (D, H, W) in self._blocks_with_geometry(shape):
             tiles_total = ops._L().rsuper_conv3_tiles(D, H, W) * N
             w1, w2, ws = blk.weights()
-            sp, bns = ops.block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles_total, with_bwd)
+            sp, bns = ops.block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles_total, with_bwd, (N, D, H, W))
             meta.append((blk, len(specs), len(sp), bns))
             specs += sp
         with torch.no_grad():

@@ -28,7 +28,7 @@ def _conv(ops, x, w, dt, mr=None, res=None):
     N, D, H, W, Ci = x.shape
     Co = w.shape[0]
     tiles = ops._L().rsuper_conv3_tiles(D, H, W)
-    bn = ops.pick_bn(Co, dt, tiles * N)
+    bn = ops.pick_bn(Co, dt, tiles * N, (N, D, H, W))
     wp = ops.pack_weights(dt, 0, w, None, Ci, 0, Co, 0, bn)
     out = torch.empty((N, D, H, W, Co), device=DEV, dtype=dt)
     ops.igemm(0, ops.Src(x, mr=mr), None, wp, Co, bn, (N, D, H, W), out)
