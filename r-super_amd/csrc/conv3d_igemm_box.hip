@@ -20,6 +20,9 @@
 // per voxel ACROSS row and plane boundaries, so any 16 consecutive flat rows (one ds_read_b128 lane group) hit 16 distinct
 // 16-byte bank groups -- conflict-free for every box shape.
 #include <type_traits>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -42,6 +45,12 @@ template <int TD_, int TH_, int TW_> struct Box {
 };
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#ifdef RS_BOX_PROF
+__device__ unsigned long long g_box_prof[64 * 32];        // [block slot][stamp]
+#define BOX_STAMP(k) do { if (lane == 0 && wave == 0 && blockIdx.x % 16 == 0 && blockIdx.x / 16 < 64) g_box_prof[(blockIdx.x / 16) * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BOX_STAMP(k)
+#endif
 
 // EPI: 0 forward (optional residual, statistics of the output), 1 data gradient (ReLU mask, InstanceNorm-backward sums)
 template <typename B, int NFR, int EPI>
@@ -75,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     const int th = t % bh; t /= bh;
     const int d0 = t * B::TD, h0 = th * B::TH, w0 = tw * B::TW;
 
+    BOX_STAMP(0);
     const int nchA = (p.a.C + KC - 1) / KC, nchB = (p.b.C + KC - 1) / KC;
     const int nch = nchA + nchB;
     const bool normA = p.a.mr != nullptr, normB = p.b.mr != nullptr;
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
 #pragma unroll
         for (int i = 0; i < NVEC; ++i) dmask |= (d0 - 1 + i >= 0 && d0 - 1 + i < p.D) ? (1u << i) : 0u;
     }
-    const int plane = p.H * p.W;
+    int plane = p.H * p.W;
     // The NVEC planes of a chunk travel in two groups (planes [0, NH) and [NH, NVEC)) that share the NH registers of `pre`:
     // group 0 of chunk c + 1 is issued in the middle of chunk c - 1's MFMA phase and written to LDS at the start of chunk c's,
     // group 1 is issued there and written in the middle of chunk c's -- half a chunk of MFMAs covers the load latency, and only
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     constexpr int NH = (NVEC + 1) / 2;
     uint4 pre[NH];
     const uint32_t nvox_total = (uint32_t)(p.N * p.D * p.H * p.W);
-    auto issue_one = [&](int ch, int i) {                    // out-of-volume voxels / channel slots past C: hardware zeros
+    auto issue_to = [&](int ch, int i, uint4& dst) {         // out-of-volume voxels / channel slots past C: hardware zeros
         const bool isB = ch >= nchA;
         const ConvSrc& src = isB ? p.b : p.a;
         const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
@@ -114,17 +124,18 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src.x, 0, nvox_total * rowb, 0x00020000);
         const bool ok = hw_ok && ((dmask >> i) & 1u) && c < src.C;
         const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (uint32_t)(vox0 + i * plane) * rowb + (uint32_t)c * 2u : 0xFFFFFFFFu, 0, 0);
-        pre[i % NH] = make_uint4(q[0], q[1], q[2], q[3]);
+        dst = make_uint4(q[0], q[1], q[2], q[3]);
     };
+    auto issue_one = [&](int ch, int i) { issue_to(ch, i, pre[i % NH]); };
     auto issue_group = [&](int ch, int g) {
 #pragma unroll
         for (int i = g * NH; i < (g ? NVEC : NH); ++i) issue_one(ch, i);
     };
-    auto commit = [&](int ch, int g) {                       // group g of chunk ch (held in pre) -> halo buffer ch & 1
+    auto commit_from = [&](int ch, int i0, int i1, const uint4* src_q) {   // planes [i0, i1) of chunk ch (src_q[i - i0]) -> halo buffer ch & 1
         const bool isB = ch >= nchA;
         const ConvSrc& src = isB ? p.b : p.a;
         const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
-        const bool norm = (isB ? normB : normA) && c < src.C && hw_ok;
+        const bool norm = src.mr != nullptr && c < src.C && hw_ok;      // (a cached flag ends up in a spilled VGPR)
         float sc_[KP], nb_[KP];
         if (norm) {
             const float* mr = mr_lds + 2 * ((isB ? p.a.C : 0) + c);
@@ -133,12 +144,13 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
         }
         char* buf = smem + (ch & 1) * B::HALO + lbase;
 #pragma unroll
-        for (int i = g * NH; i < (g ? NVEC : NH); ++i) {
-            uint4 q = pre[i % NH];
+        for (int i = i0; i < i1; ++i) {
+            uint4 q = src_q[i - i0];
             if (norm && ((dmask >> i) & 1u)) q = norm_relu16<T>(q, sc_, nb_);     // padding stays zero AFTER the activation
             if (lbase >= 0) *(uint4*)(buf + i * B::SD) = q;
         }
     };
+    auto commit = [&](int ch, int g) { commit_from(ch, g * NH, g ? NVEC : NH, pre); };   // group g of chunk ch (held in pre)
 
     // ---- A-fragment bases: lane l holds flat row 32 mf + row_hw_packed(l & 31) (lane groups of ds_read_b128 = runs of 16
     //      consecutive flat rows), k half l >> 5; rows past the box clamp to row 0 (their results are never stored)
@@ -152,16 +164,10 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     }
 
     f32x16_t acc[MFR][NFR];
-#pragma unroll
-    for (int mf = 0; mf < MFR; ++mf)
-#pragma unroll
-        for (int nf = 0; nf < NFR; ++nf)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
 
     // ---- weight fragments: buffer loads, per-lane VGPR offset (lane * 16 + nf KiB), wave-uniform SGPR step offsets
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7FFFFFFF, 0x00020000);
-    const uint32_t wstep16 = (uint32_t)__builtin_amdgcn_readfirstlane(p.ntiles * 64 * 16);   // bytes per (chunk, tap, k-step)
+    uint32_t wstep16 = (uint32_t)__builtin_amdgcn_readfirstlane(p.ntiles * 64 * 16);   // bytes per (chunk, tap, k-step)
     const uint32_t wn_off = (uint32_t)__builtin_amdgcn_readfirstlane(ng * NFR * 1024) + (uint32_t)ks * wstep16;
     const uint32_t lane16 = (uint32_t)lane * 16u;
     constexpr int RB = 3;                                    // weight ring depth (k-steps); 14 + 13 steps per chunk pair = 0 (mod 3)
@@ -184,6 +190,16 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     auto chunk = [&](auto T0c, auto Q0c, int ch) {
         constexpr int T0 = decltype(T0c)::value, Q0 = decltype(Q0c)::value;
         constexpr int NJ = T0 ? 13 : 14;
+        // LLVM hoists every per-plane voxel offset and every per-step weight offset (a multiply each) out of the chunk loop and then
+        // spills them -- a spill reload waits for vmcnt(0), i.e. for the whole weight ring.  Opaque copies keep them in the loop.
+        // (inline-asm results count as divergent: the wave-uniform values are re-derived with readfirstlane, or every weight load
+        // turns into a waterfall loop.)
+        {
+            int pv = plane, wv = (int)wstep16;
+            asm volatile("" : "+v"(vox0), "+v"(lbase), "+v"(pv), "+v"(wv));
+            plane = __builtin_amdgcn_readfirstlane(pv);
+            wstep16 = (uint32_t)__builtin_amdgcn_readfirstlane(wv);
+        }
         const int nx = ch + 1 < nch ? ch + 1 : 0;            // weight prefetch past the last chunk wraps (harmless re-load)
         if (ch + 1 < nch) { commit(ch + 1, 0); issue_group(ch + 1, 1); }
         // MFMA phase in units of AU activation fragments: the fragments of unit u + 1 are read from LDS while unit u's MFMAs issue
@@ -222,92 +238,56 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     auto run = [&](auto Hc) {
         constexpr int H = decltype(Hc)::value;               // tap parity of this wave in even chunks
         constexpr int QB = (H ? 13 : 14) % RB;               // ring phase at the second chunk of a pair
-#pragma unroll
-        for (int r = 0; r < RB; ++r) load_b(0, H + 2 * r, bq[r]);
         for (int ch = 0; ch < nch; ch += 2) {
             chunk(std::integral_constant<int, H>{}, std::integral_constant<int, 0>{}, ch);
             if (ch + 1 < nch) chunk(std::integral_constant<int, 1 - H>{}, std::integral_constant<int, QB>{}, ch + 1);
         }
     };
 
-    // ---- prologue: chunk 0 staged synchronously, group 0 of chunk 1 in flight
-    issue_group(0, 0);
-    __syncthreads();                                         // mr_lds visible
-    commit(0, 0);
-    issue_group(0, 1);
-    commit(0, 1);
+    // ---- prologue: the first weight fragments go out before anything else (L2 latency under the halo staging), then chunk 0 is
+    //      staged synchronously with group 0 of chunk 1 in flight
+#pragma unroll
+    for (int r = 0; r < RB; ++r) load_b(0, hsel + 2 * r, bq[r]);
+    {
+        uint4 p0[NVEC];                                      // the accumulators are not live yet: all planes of chunk 0 at once
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) issue_to(0, i, p0[i]);
+        __syncthreads();                                     // mr_lds visible
+        commit_from(0, 0, NVEC, p0);
+    }
     if (nch > 1) issue_group(1, 0);
     __syncthreads();
+#pragma unroll
+    for (int mf = 0; mf < MFR; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+    BOX_STAMP(1);
     if (hsel == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+    BOX_STAMP(2);
 
-    // ------------------------------------------------------------------ reduce-scatter of the four K-partial tiles
-    // fragment f = mf * NFR + nf is owned by wave f & 3; per round of four fragments every wave publishes the three it does
-    // not own (48 KB per round), the owner adds them.  (The halo buffers are dead: the last chunk ended with a barrier.)
-    constexpr int ROUNDS = (F + 3) / 4;
-#pragma unroll
-    for (int q = 0; q < ROUNDS; ++q) {
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int f = 4 * q + o;
-            if (f < F && wave != o) {
-                const int sub = wave < o ? wave : wave - 1;
-                char* dst = smem + (o * 3 + sub) * 4096 + lane * 16;
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const f32x16_t& a = acc[f / NFR][f % NFR];
-                    *(float4*)(dst + r4 * 1024) = make_float4(a[r4 * 4], a[r4 * 4 + 1], a[r4 * 4 + 2], a[r4 * 4 + 3]);
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int f = 4 * q + o;
-            if (f < F && wave == o) {
-#pragma unroll
-                for (int sub = 0; sub < 3; ++sub) {
-                    const char* src = smem + (o * 3 + sub) * 4096 + lane * 16;
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const float4 v = *(const float4*)(src + r4 * 1024);
-                        f32x16_t& a = acc[f / NFR][f % NFR];
-                        a[r4 * 4] += v.x; a[r4 * 4 + 1] += v.y; a[r4 * 4 + 2] += v.z; a[r4 * 4 + 3] += v.w;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ------------------------------------------------------------------ cooperative epilogue through LDS
-    // owners write their summed fragments voxel-major as f32 ([flat row][BN] + 16 B pad); all 256 threads then walk the box with
-    // 16-byte vectors: coalesced residual / forward-input loads and output stores, per-column partial sums for InstanceNorm.
+    // ------------------------------------------------------------------ K-partial reduction fused into the epilogue
+    // Per group of GM row fragments: every wave writes ITS partial sums voxel-major as f32 ([wave][flat row][BN] + 16 B pad),
+    // then all 256 threads walk the rows with 16-byte vectors, add the four partials in wave order (deterministic), apply
+    // residual / ReLU mask, round, accumulate the InstanceNorm partial sums and store.  The residual / forward-input vectors of
+    // a group are requested before its scratch is written, so their latency hides behind the LDS round trip.
+    // (The halo buffers are dead: the last chunk ended with a barrier.)
     constexpr int EPF = BN + 4;
     constexpr int CG = BN / KP;                              // 16-byte column groups per voxel
     constexpr int RPT = 256 / CG;                            // row stride between a thread's vectors
-    constexpr int NV = (MFR * 32 + RPT - 1) / RPT;
+    constexpr int GM = MFR >= 2 ? 2 : 1;                     // row fragments per group: 4 x 64 x EPF floats = 68 KB at BN = 64
+    constexpr int NGRP = (MFR + GM - 1) / GM;
+    constexpr int GROWS = GM * 32;
+    constexpr int NV = GROWS / RPT;
+    static_assert(GROWS % RPT == 0, "a group is a whole number of thread passes");
     float* sc2 = (float*)smem;
-    {
-        const int col_l = lane & 31, hi = lane >> 5;
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            if (wave == (f & 3)) {
-                const int mf = f / NFR, nf = f % NFR;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i0 = (r & 3) + 8 * (r >> 2);
-                    const int row = 32 * mf + (hi ? row_hw_packed(i0 + 4) : row_hw_packed(i0));
-                    sc2[row * EPF + nf * 32 + col_l] = acc[mf][nf][r];
-                }
-            }
-        }
-    }
-    __syncthreads();
     const int cg = tid % CG, pr0 = tid / CG;
     const int col0 = ng * BN + cg * KP;
     const bool cok = col0 < p.Cout;
-    const ConvSrc& es = (EPI == 1 && col0 >= p.ea.C) ? p.eb : p.ea;
-    const int ecol0 = (EPI == 1 && col0 >= p.ea.C) ? col0 - p.ea.C : col0;
+    const bool useb = EPI == 1 && cok && col0 >= p.ea.C;      // columns past Cout keep source a (never loaded from: ok[] is false)
+    const ConvSrc& es = useb ? p.eb : p.ea;
+    const int ecol0 = useb ? col0 - p.ea.C : (cok ? col0 : 0);
     float emu[KP], ers[KP];
     if (EPI == 1 && cok) {
 #pragma unroll
@@ -316,39 +296,81 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     float s1[KP], s2[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const bool need_ld = EPI == 1 || p.res != nullptr;
+    const T* ld_base = EPI == 1 ? (const T*)es.x + ecol0 : (const T*)p.res + (cok ? col0 : 0);
+    const uint32_t ld_ld = EPI == 1 ? (uint32_t)es.ld : (uint32_t)p.ldr;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int pr = pr0 + j * RPT;                        // flat row of the box
-        const int dd = pr / (B::TH * B::TW), hh = (pr / B::TW) % B::TH, ww = pr % B::TW;
-        const int d = d0 + dd, h = h0 + hh, w = w0 + ww;
-        if (cok && pr < B::ROWS && d < p.D && h < p.H && w < p.W) {
-            float v[KP];
-            const float4* sp = (const float4*)(sc2 + pr * EPF + cg * KP);
+    for (int gq = 0; gq < NGRP; ++gq) {
+        uint32_t vox[NV];
+        bool ok[NV];
+        uint4 ev[NV];
 #pragma unroll
-            for (int k4 = 0; k4 < KP / 4; ++k4) { const float4 t4 = sp[k4]; v[k4 * 4] = t4.x; v[k4 * 4 + 1] = t4.y; v[k4 * 4 + 2] = t4.z; v[k4 * 4 + 3] = t4.w; }
-            const uint32_t vox = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
-            if (EPI == 0) {
-                if (p.res) {
-                    float rr[KP];
-                    unpack16<T>(*(const uint4*)((const T*)p.res + (size_t)(vox * (uint32_t)p.ldr + (uint32_t)col0)), rr);
+        for (int j = 0; j < NV; ++j) {
+            const int pr = gq * GROWS + pr0 + j * RPT;       // flat row of the box
+            const int dd = pr / (B::TH * B::TW), hh = (pr / B::TW) % B::TH, ww = pr % B::TW;
+            const int d = d0 + dd, h = h0 + hh, w = w0 + ww;
+            ok[j] = cok && pr < B::ROWS && d < p.D && h < p.H && w < p.W;
+            vox[j] = (uint32_t)(((n * p.D + d) * p.H + h) * p.W + w);
+            ev[j] = make_uint4(0, 0, 0, 0);
+            if (need_ld) ev[j] = *(const uint4*)(ok[j] ? ld_base + (size_t)(vox[j] * ld_ld) : ld_base);     // address select, no branch
+        }
+        if (gq) __syncthreads();                             // previous group's scratch consumed
+        {
+            const int col_l = lane & 31, hi = lane >> 5;
+            float* dst = sc2 + wave * (GROWS * EPF);
 #pragma unroll
-                    for (int k = 0; k < KP; ++k) v[k] += rr[k];
-                }
+            for (int m = 0; m < GM; ++m) {
+                const int mf = gq * GM + m;
+                if (mf < MFR) {
 #pragma unroll
-                for (int k = 0; k < KP; ++k) { v[k] = Elem<T>::rnd(v[k]); s1[k] += v[k]; s2[k] += v[k] * v[k]; }
-            } else {
-                float xx[KP];
-                unpack16<T>(*(const uint4*)((const T*)es.x + (size_t)(vox * (uint32_t)es.ld + (uint32_t)ecol0)), xx);
+                    for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
-                for (int k = 0; k < KP; ++k) {
-                    const float xn = (xx[k] - emu[k]) * ers[k];
-                    v[k] = Elem<T>::rnd(xn > 0.f ? v[k] : 0.f);
-                    s1[k] += v[k]; s2[k] += v[k] * xn;
+                        for (int r = 0; r < 16; ++r) {
+                            const int i0 = (r & 3) + 8 * (r >> 2);
+                            const int row = 32 * m + (hi ? row_hw_packed(i0 + 4) : row_hw_packed(i0));
+                            dst[row * EPF + nf * 32 + col_l] = acc[mf][nf][r];
+                        }
                 }
             }
-            *(uint4*)((T*)p.out + (size_t)(vox * (uint32_t)p.ldo + (uint32_t)col0)) = pack16<T>(v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (ok[j]) {
+                const int lr = pr0 + j * RPT;                // row inside the group
+                float v[KP];
+#pragma unroll
+                for (int k = 0; k < KP; ++k) v[k] = 0.f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    const float4* sp = (const float4*)(sc2 + w4 * (GROWS * EPF) + lr * EPF + cg * KP);
+#pragma unroll
+                    for (int k4 = 0; k4 < KP / 4; ++k4) { const float4 t4 = sp[k4]; v[k4 * 4] += t4.x; v[k4 * 4 + 1] += t4.y; v[k4 * 4 + 2] += t4.z; v[k4 * 4 + 3] += t4.w; }
+                }
+                if (EPI == 0) {
+                    if (p.res) {
+                        float rr[KP];
+                        unpack16<T>(ev[j], rr);
+#pragma unroll
+                        for (int k = 0; k < KP; ++k) v[k] += rr[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) { v[k] = Elem<T>::rnd(v[k]); s1[k] += v[k]; s2[k] += v[k] * v[k]; }
+                } else {
+                    float xx[KP];
+                    unpack16<T>(ev[j], xx);
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const float xn = (xx[k] - emu[k]) * ers[k];
+                        v[k] = Elem<T>::rnd(xn > 0.f ? v[k] : 0.f);
+                        s1[k] += v[k]; s2[k] += v[k] * xn;
+                    }
+                }
+                *(uint4*)((T*)p.out + (size_t)(vox[j] * (uint32_t)p.ldo + (uint32_t)col0)) = pack16<T>(v);
+            }
         }
     }
+    BOX_STAMP(4);
     if (p.part) {
         __syncthreads();
         float* red = (float*)smem;                           // [RPT][BN][2]
@@ -368,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
             }
         }
     }
+    BOX_STAMP(5);
 }
 
 template <typename B, int NFR>
@@ -376,9 +399,9 @@ int launch_box(const IgemmParams& p, int epi, hipStream_t st) {
     if (p.ntiles % NFR) return RS_ERR_ARG;
     const int ngroups = p.ntiles / NFR;
     const size_t main_b = 2 * (size_t)B::HALO + (((size_t)(p.a.C + p.b.C) * 8 + 15) / 16) * 16;
-    const size_t epi_b = (size_t)B::MFR * 32 * (NFR * 32 + 4) * 4;
+    const size_t epi_b = (size_t)4 * (B::MFR >= 2 ? 64 : 32) * (NFR * 32 + 4) * 4;      // four partial copies of one row group
     const size_t red_b = (size_t)(256 / (NFR * 4)) * NFR * 32 * 2 * 4;
-    size_t smem = main_b > 48 * 1024 ? main_b : 48 * 1024;
+    size_t smem = main_b;
     if (epi_b > smem) smem = epi_b;
     if (red_b > smem) smem = red_b;
     if (smem > 160 * 1024) return RS_ERR_UNSUPPORTED;
@@ -392,6 +415,22 @@ int launch_box(const IgemmParams& p, int epi, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, block, smem, st, p, bd, bh, bw);
     }
+#ifdef RS_BOX_PROF
+    if (getenv("RSUPER_BOX_PROF")) {
+        static unsigned long long h[64 * 32];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_box_prof), sizeof(h));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < 64; ++b) if (h[b * 32] && h[b * 32] < t0) t0 = h[b * 32];
+        for (int b = 0; b < 64; b += 3) {
+            if (!h[b * 32]) continue;
+            fprintf(stderr, "box_prof blk %4d: prologue %6llu main %7llu epi %6llu stats %6llu | total %7llu\n", b * 16,
+                    h[b * 32 + 1] - h[b * 32], h[b * 32 + 2] - h[b * 32 + 1], h[b * 32 + 4] - h[b * 32 + 2], h[b * 32 + 5] - h[b * 32 + 4], h[b * 32 + 5] - h[b * 32]);
+        }
+        memset(h, 0, sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_box_prof), h, sizeof(h));
+    }
+#endif
     return rs_check_launch();
 }
 
