@@ -76,6 +76,14 @@ int rsuper_conv3_variant(int v);
  * (pack the weights with bn = 64 then), else 0. */
 int rsuper_conv3_box_bn(int dtype, int N, int D, int H, int W, int n_cols);
 
+/* Volumes of at most 6x6x6 voxels (the 6^3 bottleneck level: model/dim3/unet.py:53, four poolings of a 96^3 patch) run one box
+ * per sample with the REDUCTION (32-channel chunks) split over blocks: each block writes its raw f32 tile to a workspace and a
+ * second kernel adds the splits and applies the epilogue (deterministic: fixed split order).  The caller registers ONE device
+ * buffer of at least rsuper_conv3_workspace_bytes() for that; launches on one stream may share it.  Without a registered
+ * workspace those volumes take the 4x4x4-box shape.  rsuper_conv3_box_bn returns 32 for them. */
+int rsuper_conv3_set_workspace(void* ptr, size_t bytes);
+size_t rsuper_conv3_workspace_bytes(void);
+
 /* Rows per sample of the `part` buffer rsuper_conv3_igemm(dtype, epi, ..., n_cols, bn, N, D, H, W) writes under the
  * current variant (classic: one row per tile; producer/consumer: one row per (persistent block, consumer wave row)). */
 int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn);

@@ -124,22 +124,38 @@ static bool use_pc(int dtype, int epi, int bn, int tiles_total) {
     return g_variant == 1;
 }
 
-// Volume-fitted K-split kernel (conv3d_igemm_box.hip) for launches that cannot fill the chip with 4x4x16-voxel tiles: bf16, 64-column
-// blocks, more than 32 columns, and fewer than 512 classic work items (the 24^3 / 12^3 / 6^3 levels at batch 2).  Variants 6 / 7 force
-// it for every eligible dtype / column count (6: shape chosen per volume, 7: the 4x4x4 box) -- test paths.
-static int box_for(int dtype, int bn, int N, int D, int H, int W, int n_cols) {
-    if (dtype != RS_BF16 || bn != 64) return 0;
-    if (g_variant == 6) return rs_box_config(N, D, H, W, n_cols);
+// Volume-fitted K-split kernel (conv3d_igemm_box.hip) for launches that cannot fill the chip with 4x4x16-voxel tiles: bf16, more than
+// 32 columns, and fewer than 512 classic work items (the 24^3 / 12^3 / 6^3 levels at batch 2).  Shapes 1 / 2 (4x4x8 / 4x4x4 boxes) take
+// 64-column blocks; shape 3 (volumes of at most 6x6x6: one box per sample, the reduction split over blocks through the registered
+// workspace, second pass box_splitk_epilogue_kernel) takes 32-column blocks.  Variants 6 / 7 force the kernel for every bf16 launch
+// (6: shape chosen per volume, 7: the 4x4x4 box) -- test paths.
+static void* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+static const size_t BOXC_WS_BYTES = (size_t)256 * 216 * 32 * 4;    // upper bound of nsplit x N x 216 x n_cols floats (rs_box_nsplit)
+static int box_shape(int dtype, int N, int D, int H, int W, int n_cols) {
+    if (dtype != RS_BF16) return 0;
+    const bool forced = g_variant == 6 || g_variant == 7;
+    static const int off = getenv("RSUPER_NO_BOX") ? atoi(getenv("RSUPER_NO_BOX")) : 0;      // 1: no box kernel, 2: no split shape
+    if (!forced && (g_variant != 3 || off == 1 || n_cols <= 32)) return 0;
+    if (g_variant != 7 && off != 2 && D <= 6 && H <= 6 && W <= 6 && g_ws && g_ws_bytes >= BOXC_WS_BYTES) return 3;
     if (g_variant == 7) return 2;
-    if (g_variant != 3 || n_cols <= 32) return 0;
-    static const int off = getenv("RSUPER_NO_BOX") ? atoi(getenv("RSUPER_NO_BOX")) : 0;
-    if (off) return 0;
-    if ((long)N * rsuper_conv3_tiles(D, H, W) * ((n_cols + 127) / 128) >= 512) return 0;
+    if (!forced && (long)N * rsuper_conv3_tiles(D, H, W) * ((n_cols + 127) / 128) >= 512) return 0;
     return rs_box_config(N, D, H, W, n_cols);
 }
+static int box_for(int dtype, int bn, int N, int D, int H, int W, int n_cols) {
+    const int cfg = box_shape(dtype, N, D, H, W, n_cols);
+    return (cfg && bn == (cfg == 3 ? 32 : 64)) ? cfg : 0;
+}
+
+int rsuper_conv3_set_workspace(void* ptr, size_t bytes) {
+    g_ws = ptr; g_ws_bytes = ptr ? bytes : 0;
+    return RS_OK;
+}
+size_t rsuper_conv3_workspace_bytes(void) { return BOXC_WS_BYTES; }
 
 int rsuper_conv3_box_bn(int dtype, int N, int D, int H, int W, int n_cols) {
-    return box_for(dtype, 64, N, D, H, W, n_cols) ? 64 : 0;
+    const int cfg = box_shape(dtype, N, D, H, W, n_cols);
+    return cfg == 3 ? 32 : cfg ? 64 : 0;
 }
 
 int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn) {
@@ -175,6 +191,7 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     p.ea = {exa, elda, eCa, emra};
     p.eb = {exb, eldb, eCb, emrb};
     p.box = box_for(dtype, bn, N, D, H, W, n_cols);
+    if (p.box == 3) { p.ws = (float*)g_ws; p.nsplit = rs_box_nsplit(N, n_cols, (Ca + 31) / 32 + (Cb + 31) / 32); }
     p.pc = use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0;
     if (p.pc && g_variant == 5) p.pc = 3;
     if (p.pc && bn == 32 && (g_variant == 4 || (g_variant == 3 && (Ca + 31) / 32 + (Cb + 31) / 32 == 1))) p.pc = 2;

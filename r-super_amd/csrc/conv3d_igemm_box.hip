@@ -53,7 +53,9 @@ __device__ unsigned long long g_box_prof[64 * 32];        // [block slot][stamp]
 #endif
 
 // EPI: 0 forward (optional residual, statistics of the output), 1 data gradient (ReLU mask, InstanceNorm-backward sums)
-template <typename B, int NFR, int EPI>
+// SPLIT: the block handles the chunk range [cb, cb + nk) of split blockIdx-derived `sp` and writes the raw f32 tile to the workspace
+//        p.ws[sp][n][voxel][Cout] (cross-block split of the reduction for volumes of at most one box: box_splitk_epilogue_kernel finishes)
+template <typename B, int NFR, int EPI, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd, int bh, int bw) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,6 +79,8 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     const int boxes = bd * bh * bw;
     const int ngroups = p.ntiles / NFR;
     const int box = L % boxes; L /= boxes;
+    const int sp = SPLIT ? L % p.nsplit : 0;
+    if (SPLIT) L /= p.nsplit;
     const int ng = L % ngroups;
     const int n = L / ngroups;
     int t = box;
@@ -87,6 +91,9 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     BOX_STAMP(0);
     const int nchA = (p.a.C + KC - 1) / KC, nchB = (p.b.C + KC - 1) / KC;
     const int nch = nchA + nchB;
+    const int cper = SPLIT ? (nch + p.nsplit - 1) / p.nsplit : nch;      // chunks per split
+    const int cb = sp * cper;                                  // first chunk of this block; `ch` below counts from it
+    const int nk = SPLIT ? (nch - cb < cper ? nch - cb : cper) : nch;
     const bool normA = p.a.mr != nullptr, normB = p.b.mr != nullptr;
     if (normA) for (int i = tid; i < 2 * p.a.C; i += 256) mr_lds[i] = p.a.mr[(size_t)n * 2 * p.a.C + i];
     if (normB) for (int i = tid; i < 2 * p.b.C; i += 256) mr_lds[2 * p.a.C + i] = p.b.mr[(size_t)n * 2 * p.b.C + i];
@@ -117,9 +124,10 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     uint4 pre[NH];
     const uint32_t nvox_total = (uint32_t)(p.N * p.D * p.H * p.W);
     auto issue_to = [&](int ch, int i, uint4& dst) {         // out-of-volume voxels / channel slots past C: hardware zeros
-        const bool isB = ch >= nchA;
+        const int cc = cb + ch;
+        const bool isB = cc >= nchA;
         const ConvSrc& src = isB ? p.b : p.a;
-        const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
+        const int c = (isB ? cc - nchA : cc) * KC + slot * KP;
         const uint32_t rowb = (uint32_t)src.ld * 2u;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src.x, 0, nvox_total * rowb, 0x00020000);
         const bool ok = hw_ok && ((dmask >> i) & 1u) && c < src.C;
@@ -132,9 +140,10 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
         for (int i = g * NH; i < (g ? NVEC : NH); ++i) issue_one(ch, i);
     };
     auto commit_from = [&](int ch, int i0, int i1, const uint4* src_q) {   // planes [i0, i1) of chunk ch (src_q[i - i0]) -> halo buffer ch & 1
-        const bool isB = ch >= nchA;
+        const int cc = cb + ch;
+        const bool isB = cc >= nchA;
         const ConvSrc& src = isB ? p.b : p.a;
-        const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
+        const int c = (isB ? cc - nchA : cc) * KC + slot * KP;
         const bool norm = src.mr != nullptr && c < src.C && hw_ok;      // (a cached flag ends up in a spilled VGPR)
         float sc_[KP], nb_[KP];
         if (norm) {
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     constexpr int RB = 3;                                    // weight ring depth (k-steps); 14 + 13 steps per chunk pair = 0 (mod 3)
     uint4 bq[RB][NFR];
     auto load_b = [&](int ch, int tap, uint4* dst) {         // tap is a compile-time constant at every call site
-        const uint32_t so = wn_off + ((uint32_t)ch * 54u + (uint32_t)tap * 2u) * wstep16;
+        const uint32_t so = wn_off + ((uint32_t)(cb + ch) * 54u + (uint32_t)tap * 2u) * wstep16;
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf) {
             const auto q = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + nf * 1024, so, 0);
@@ -200,8 +209,8 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
             plane = __builtin_amdgcn_readfirstlane(pv);
             wstep16 = (uint32_t)__builtin_amdgcn_readfirstlane(wv);
         }
-        const int nx = ch + 1 < nch ? ch + 1 : 0;            // weight prefetch past the last chunk wraps (harmless re-load)
-        if (ch + 1 < nch) { commit(ch + 1, 0); issue_group(ch + 1, 1); }
+        const int nx = ch + 1 < nk ? ch + 1 : 0;            // weight prefetch past the last chunk wraps (harmless re-load)
+        if (ch + 1 < nk) { commit(ch + 1, 0); issue_group(ch + 1, 1); }
         // MFMA phase in units of AU activation fragments: the fragments of unit u + 1 are read from LDS while unit u's MFMAs issue
         constexpr int AU = (MFR % 2 == 0) ? 2 : 1, G = MFR / AU;
         uint4 aq[2][AU];
@@ -221,8 +230,8 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
 #pragma unroll
                 for (int nf = 0; nf < NFR; ++nf) mma32<T>(acc[g * AU + i][nf], aq[u & 1][i], bq[(Q0 + j) % RB][nf]);
             if (g == G - 1 && j == NJ / 2) {
-                if (ch + 1 < nch) commit(ch + 1, 1);
-                if (ch + 2 < nch) issue_group(ch + 2, 0);
+                if (ch + 1 < nk) commit(ch + 1, 1);
+                if (ch + 2 < nk) issue_group(ch + 2, 0);
             }
             if (g == G - 1) {
                 if (j + RB < NJ) load_b(ch, T0 + 2 * (j + RB), bq[(Q0 + j) % RB]);
@@ -238,9 +247,9 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     auto run = [&](auto Hc) {
         constexpr int H = decltype(Hc)::value;               // tap parity of this wave in even chunks
         constexpr int QB = (H ? 13 : 14) % RB;               // ring phase at the second chunk of a pair
-        for (int ch = 0; ch < nch; ch += 2) {
+        for (int ch = 0; ch < nk; ch += 2) {
             chunk(std::integral_constant<int, H>{}, std::integral_constant<int, 0>{}, ch);
-            if (ch + 1 < nch) chunk(std::integral_constant<int, 1 - H>{}, std::integral_constant<int, QB>{}, ch + 1);
+            if (ch + 1 < nk) chunk(std::integral_constant<int, 1 - H>{}, std::integral_constant<int, QB>{}, ch + 1);
         }
     };
 
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
         __syncthreads();                                     // mr_lds visible
         commit_from(0, 0, NVEC, p0);
     }
-    if (nch > 1) issue_group(1, 0);
+    if (nk > 1) issue_group(1, 0);
     __syncthreads();
 #pragma unroll
     for (int mf = 0; mf < MFR; ++mf)
@@ -289,14 +298,14 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     const ConvSrc& es = useb ? p.eb : p.ea;
     const int ecol0 = useb ? col0 - p.ea.C : (cok ? col0 : 0);
     float emu[KP], ers[KP];
-    if (EPI == 1 && cok) {
+    if (EPI == 1 && cok && !SPLIT) {
 #pragma unroll
         for (int j = 0; j < KP; ++j) { emu[j] = es.mr[((size_t)n * es.C + ecol0 + j) * 2]; ers[j] = es.mr[((size_t)n * es.C + ecol0 + j) * 2 + 1]; }
     }
     float s1[KP], s2[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    const bool need_ld = EPI == 1 || p.res != nullptr;
+    const bool need_ld = !SPLIT && (EPI == 1 || p.res != nullptr);
     const T* ld_base = EPI == 1 ? (const T*)es.x + ecol0 : (const T*)p.res + (cok ? col0 : 0);
     const uint32_t ld_ld = EPI == 1 ? (uint32_t)es.ld : (uint32_t)p.ldr;
 #pragma unroll
@@ -343,35 +352,41 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
                 for (int k = 0; k < KP; ++k) v[k] = 0.f;
 #pragma unroll
                 for (int w4 = 0; w4 < 4; ++w4) {
-                    const float4* sp = (const float4*)(sc2 + w4 * (GROWS * EPF) + lr * EPF + cg * KP);
+                    const float4* sp4 = (const float4*)(sc2 + w4 * (GROWS * EPF) + lr * EPF + cg * KP);
 #pragma unroll
-                    for (int k4 = 0; k4 < KP / 4; ++k4) { const float4 t4 = sp[k4]; v[k4 * 4] += t4.x; v[k4 * 4 + 1] += t4.y; v[k4 * 4 + 2] += t4.z; v[k4 * 4 + 3] += t4.w; }
+                    for (int k4 = 0; k4 < KP / 4; ++k4) { const float4 t4 = sp4[k4]; v[k4 * 4] += t4.x; v[k4 * 4 + 1] += t4.y; v[k4 * 4 + 2] += t4.z; v[k4 * 4 + 3] += t4.w; }
                 }
-                if (EPI == 0) {
-                    if (p.res) {
-                        float rr[KP];
-                        unpack16<T>(ev[j], rr);
-#pragma unroll
-                        for (int k = 0; k < KP; ++k) v[k] += rr[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < KP; ++k) { v[k] = Elem<T>::rnd(v[k]); s1[k] += v[k]; s2[k] += v[k] * v[k]; }
+                if constexpr (SPLIT) {                       // raw f32 tile of this split: the epilogue kernel adds the splits
+                    float4* wd = (float4*)(p.ws + ((size_t)sp * nvox_total + vox[j]) * (size_t)p.Cout + col0);
+                    wd[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    wd[1] = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
-                    float xx[KP];
-                    unpack16<T>(ev[j], xx);
+                    if (EPI == 0) {
+                        if (p.res) {
+                            float rr[KP];
+                            unpack16<T>(ev[j], rr);
 #pragma unroll
-                    for (int k = 0; k < KP; ++k) {
-                        const float xn = (xx[k] - emu[k]) * ers[k];
-                        v[k] = Elem<T>::rnd(xn > 0.f ? v[k] : 0.f);
-                        s1[k] += v[k]; s2[k] += v[k] * xn;
+                            for (int k = 0; k < KP; ++k) v[k] += rr[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < KP; ++k) { v[k] = Elem<T>::rnd(v[k]); s1[k] += v[k]; s2[k] += v[k] * v[k]; }
+                    } else {
+                        float xx[KP];
+                        unpack16<T>(ev[j], xx);
+#pragma unroll
+                        for (int k = 0; k < KP; ++k) {
+                            const float xn = (xx[k] - emu[k]) * ers[k];
+                            v[k] = Elem<T>::rnd(xn > 0.f ? v[k] : 0.f);
+                            s1[k] += v[k]; s2[k] += v[k] * xn;
+                        }
                     }
+                    *(uint4*)((T*)p.out + (size_t)(vox[j] * (uint32_t)p.ldo + (uint32_t)col0)) = pack16<T>(v);
                 }
-                *(uint4*)((T*)p.out + (size_t)(vox[j] * (uint32_t)p.ldo + (uint32_t)col0)) = pack16<T>(v);
             }
         }
     }
     BOX_STAMP(4);
-    if (p.part) {
+    if (p.part && !SPLIT) {
         __syncthreads();
         float* red = (float*)smem;                           // [RPT][BN][2]
 #pragma unroll
@@ -393,7 +408,73 @@ __global__ __launch_bounds__(256, 2) void igemm_box_kernel(IgemmParams p, int bd
     BOX_STAMP(5);
 }
 
-template <typename B, int NFR>
+// Second pass of the cross-block split: out = epilogue(sum over the splits of ws[s][voxel][Cout]).  Block = 32 voxels x 64 columns
+// (8 column groups of 8), thread = one 16-byte output vector; per-block partial statistics row = voxel block (part rows =
+// ceil(vox / 32) per sample), reduced over the 32 voxel threads through LDS in a fixed order.
+template <int EPI>
+__global__ __launch_bounds__(256) void box_splitk_epilogue_kernel(IgemmParams p) {
+    typedef bf16_t T;
+    constexpr int KP = 8;
+    __shared__ float red[32][64][2];
+    const int tid = threadIdx.x, cg = tid & 7, vr = tid >> 3;
+    const int n = blockIdx.z, vb = blockIdx.x;
+    const int vox_s = p.D * p.H * p.W;
+    const int vloc = vb * 32 + vr;
+    const int col0 = blockIdx.y * 64 + cg * KP;
+    const bool ok = vloc < vox_s && col0 < p.Cout;
+    const uint32_t vox = (uint32_t)(n * vox_s + (vloc < vox_s ? vloc : 0));
+    const size_t nvox_total = (size_t)p.N * vox_s;
+    float v[KP], s1[KP], s2[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { v[k] = 0.f; s1[k] = 0.f; s2[k] = 0.f; }
+    if (ok) {
+        for (int s = 0; s < p.nsplit; ++s) {
+            const float4* w = (const float4*)(p.ws + ((size_t)s * nvox_total + vox) * (size_t)p.Cout + col0);
+            const float4 a = w[0], b = w[1];
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        if (EPI == 0) {
+            if (p.res) {
+                float rr[KP];
+                unpack16<T>(*(const uint4*)((const T*)p.res + (size_t)(vox * (uint32_t)p.ldr + (uint32_t)col0)), rr);
+#pragma unroll
+                for (int k = 0; k < KP; ++k) v[k] += rr[k];
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k) { v[k] = Elem<T>::rnd(v[k]); s1[k] = v[k]; s2[k] = v[k] * v[k]; }
+        } else {
+            const bool useb = col0 >= p.ea.C;
+            const ConvSrc& es = useb ? p.eb : p.ea;
+            const int ecol0 = useb ? col0 - p.ea.C : col0;
+            float xx[KP];
+            unpack16<T>(*(const uint4*)((const T*)es.x + (size_t)(vox * (uint32_t)es.ld + (uint32_t)ecol0)), xx);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const float mu = es.mr[((size_t)n * es.C + ecol0 + k) * 2], rs = es.mr[((size_t)n * es.C + ecol0 + k) * 2 + 1];
+                const float xn = (xx[k] - mu) * rs;
+                v[k] = Elem<T>::rnd(xn > 0.f ? v[k] : 0.f);
+                s1[k] = v[k]; s2[k] = v[k] * xn;
+            }
+        }
+        *(uint4*)((T*)p.out + (size_t)(vox * (uint32_t)p.ldo + (uint32_t)col0)) = pack16<T>(v);
+    }
+    if (p.part) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { red[vr][cg * KP + k][0] = s1[k]; red[vr][cg * KP + k][1] = s2[k]; }
+        __syncthreads();
+        if (tid < 64) {
+            float a = 0.f, b = 0.f;
+            for (int m = 0; m < 32; ++m) { a += red[m][tid][0]; b += red[m][tid][1]; }
+            const int col = blockIdx.y * 64 + tid;
+            if (col < p.Cout) {
+                float* pp = p.part + (((size_t)n * gridDim.x + vb) * p.Cout + col) * 2;
+                pp[0] = a; pp[1] = b;
+            }
+        }
+    }
+}
+
+template <typename B, int NFR, bool SPLIT>
 int launch_box(const IgemmParams& p, int epi, hipStream_t st) {
     const int bd = (p.D + B::TD - 1) / B::TD, bh = (p.H + B::TH - 1) / B::TH, bw = (p.W + B::TW - 1) / B::TW;
     if (p.ntiles % NFR) return RS_ERR_ARG;
@@ -405,13 +486,14 @@ int launch_box(const IgemmParams& p, int epi, hipStream_t st) {
     if (epi_b > smem) smem = epi_b;
     if (red_b > smem) smem = red_b;
     if (smem > 160 * 1024) return RS_ERR_UNSUPPORTED;
-    dim3 grid((unsigned)(bd * bh * bw * ngroups * p.N)), block(256);
+    if (SPLIT && (!p.ws || p.nsplit < 1)) return RS_ERR_ARG;
+    dim3 grid((unsigned)(bd * bh * bw * ngroups * p.N * (SPLIT ? p.nsplit : 1))), block(256);
     if (epi == 0) {
-        auto k = igemm_box_kernel<B, NFR, 0>;
+        auto k = igemm_box_kernel<B, NFR, 0, SPLIT>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, block, smem, st, p, bd, bh, bw);
     } else {
-        auto k = igemm_box_kernel<B, NFR, 1>;
+        auto k = igemm_box_kernel<B, NFR, 1, SPLIT>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, block, smem, st, p, bd, bh, bw);
     }
@@ -420,8 +502,6 @@ int launch_box(const IgemmParams& p, int epi, hipStream_t st) {
         static unsigned long long h[64 * 32];
         (void)hipDeviceSynchronize();
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_box_prof), sizeof(h));
-        unsigned long long t0 = ~0ull;
-        for (int b = 0; b < 64; ++b) if (h[b * 32] && h[b * 32] < t0) t0 = h[b * 32];
         for (int b = 0; b < 64; b += 3) {
             if (!h[b * 32]) continue;
             fprintf(stderr, "box_prof blk %4d: prologue %6llu main %7llu epi %6llu stats %6llu | total %7llu\n", b * 16,
@@ -431,11 +511,18 @@ int launch_box(const IgemmParams& p, int epi, hipStream_t st) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_box_prof), h, sizeof(h));
     }
 #endif
+    if (SPLIT) {
+        const int vox_s = p.D * p.H * p.W;
+        dim3 g2((unsigned)((vox_s + 31) / 32), (unsigned)((p.Cout + 63) / 64), (unsigned)p.N);
+        if (epi == 0) hipLaunchKernelGGL(box_splitk_epilogue_kernel<0>, g2, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(box_splitk_epilogue_kernel<1>, g2, dim3(256), 0, st, p);
+    }
     return rs_check_launch();
 }
 
 typedef Box<4, 4, 8> BoxA;      // 128 voxels, 4 fragments: 24^3-class volumes (W, H multiples of 8 / 4)
 typedef Box<4, 4, 4> BoxB;      // 64 voxels, 2 fragments: 12^3-class volumes
+typedef Box<6, 6, 6> BoxC;      // 216 voxels, 7 fragments x 32 columns: a whole 6^3 sample per block, reduction split over blocks
 
 }  // namespace
 
@@ -451,14 +538,26 @@ int rs_box_config(int N, int D, int H, int W, int n_cols) {
     return 2;
 }
 
+// Split factor of config 3 (one 6x6x6 box per sample, 32-column blocks, chunks dealt to `nsplit` blocks): about one block per CU.
+int rs_box_nsplit(int N, int n_cols, int nch) {
+    const int groups = (n_cols + 31) / 32;
+    int s = 256 / (N * groups > 0 ? N * groups : 1);
+    if (s < 1) s = 1;
+    if (s > nch) s = nch;
+    const int cper = (nch + s - 1) / s;
+    return (nch + cper - 1) / cper;
+}
+
 int rs_box_part_rows(int cfg, int D, int H, int W) {
     if (cfg == 1) return ((D + 3) / 4) * ((H + 3) / 4) * ((W + 7) / 8);
+    if (cfg == 3) return (D * H * W + 31) / 32;
     return ((D + 3) / 4) * ((H + 3) / 4) * ((W + 3) / 4);
 }
 
 int rs_launch_igemm_box(const IgemmParams& p, int cfg, int epi, hipStream_t st) {
+    if (cfg == 3) return p.bn == 32 ? launch_box<BoxC, 1, true>(p, epi, st) : RS_ERR_ARG;
     if (p.bn != 64) return RS_ERR_ARG;
-    if (cfg == 1) return launch_box<BoxA, 2>(p, epi, st);
-    if (cfg == 2) return launch_box<BoxB, 2>(p, epi, st);
+    if (cfg == 1) return launch_box<BoxA, 2, false>(p, epi, st);
+    if (cfg == 2) return launch_box<BoxB, 2, false>(p, epi, st);
     return RS_ERR_ARG;
 }

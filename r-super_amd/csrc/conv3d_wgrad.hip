@@ -853,35 +853,41 @@ __global__ __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) void wgrad_pc_ker
 }
 
 // dW[m][cin][tap] = sum_s ws[s][tap][m][cin]; rows [0,Ya) -> dwa, [Ya, Ya+Yb) -> dwb.
-// Block = 32 consecutive slab elements x 8 split groups: the loads of one element are spread over 8 threads (a single
-// thread walking 256 slabs serialised ~64 dependent load rounds and dominated small layers), each row of 32 threads
-// reads 128 contiguous bytes per slab; the 8 partials meet in LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Mtot, int Ya, int Cin,
-                                                           float* dwa, float* dwb) {
-    __shared__ float part[8][32];
-    const size_t E = (size_t)27 * Mtot * Cin;
+// Block = 32 consecutive slab elements x SG split groups (SG = 32 for >= 128 splits, else 8): the loads of one element are spread
+// over SG threads and every thread issues ALL its loads before the first add (round 2 walked the slabs in four dependent rounds of
+// four loads: ~10 us per launch, pure latency -- the slabs were just written and sit in L2 / Infinity Cache); each row of 32
+// threads reads 128 contiguous bytes per slab; the SG partials meet in LDS in a fixed order (deterministic).
+template <int SG, int UN>
+__global__ __launch_bounds__(32 * SG) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Mtot, int Ya, int Cin,
+                                                               float* dwa, float* dwb) {
+    __shared__ float4 part[SG][32];
+    const size_t E = (size_t)27 * Mtot * Cin;                    // multiple of 8 (Cin is)
     const int el = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    const size_t e = (size_t)blockIdx.x * 32 + el;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const size_t e = ((size_t)blockIdx.x * 32 + el) * 4;         // four consecutive slab elements (same tap and row, cin .. cin + 3)
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < E) {
-        int s = sg;
-        for (; s + 24 < splits; s += 32) {
-            a0 += ws[(size_t)s * E + e]; a1 += ws[(size_t)(s + 8) * E + e];
-            a2 += ws[(size_t)(s + 16) * E + e]; a3 += ws[(size_t)(s + 24) * E + e];
+        for (int s0 = sg; s0 < splits; s0 += SG * UN) {
+            float4 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int s = s0 + u * SG;
+                v[u] = s < splits ? *(const float4*)(ws + (size_t)s * E + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
-        for (; s < splits; s += 8) a0 += ws[(size_t)s * E + e];
     }
-    part[sg][el] = (a0 + a1) + (a2 + a3);
+    part[sg][el] = acc;
     __syncthreads();
     if (sg == 0 && e < E) {
-        float v = part[0][el];
+        float4 v = part[0][el];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v += part[k][el];
+        for (int k = 1; k < SG; ++k) { const float4 t = part[k][el]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
         const int c = (int)(e % Cin);
         const size_t r = e / Cin;
         const int m = (int)(r % Mtot), tap = (int)(r / Mtot);
-        float* dst = m < Ya ? dwa + ((size_t)m * Cin + c) * 27 : dwb + ((size_t)(m - Ya) * Cin + c) * 27;
-        dst[tap] = v;
+        float* dst = (m < Ya ? dwa + ((size_t)m * Cin + c) * 27 : dwb + ((size_t)(m - Ya) * Cin + c) * 27) + tap;
+        dst[0] = v.x; dst[27] = v.y; dst[54] = v.z; dst[81] = v.w;
     }
 }
 
@@ -896,16 +902,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
     const int m = blockIdx.x / cchunks, c0 = (blockIdx.x % cchunks) * 64;
     const int nc = min(64, Cin - c0);
     const size_t E = (size_t)27 * Mtot * Cin;
-    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-        const int tap = i >> 6, c = i & 63;
-        float a0 = 0.f, a1 = 0.f;
-        if (c < nc) {
-            const size_t e = ((size_t)tap * Mtot + m) * Cin + c0 + c;
-            int s = 0;
-            for (; s + 2 <= splits; s += 2) { a0 += ws[(size_t)s * E + e]; a1 += ws[(size_t)(s + 1) * E + e]; }
-            if (s < splits) a0 += ws[(size_t)s * E + e];
+    // all loads of a thread's seven (tap, c) items for one group of up to four slabs are issued before the first add
+    constexpr int NI = (27 * 64 + 255) / 256;
+    float a[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) a[q] = 0.f;
+    for (int s0 = 0; s0 < splits; s0 += 4) {
+        float v[NI][4];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int i = threadIdx.x + q * 256;
+            const int tap = i >> 6, c = i & 63;
+            const bool ok = i < 27 * 64 && c < nc;
+            const size_t e = ((size_t)(ok ? tap : 0) * Mtot + m) * Cin + c0 + (ok ? c : 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[q][u] = (ok && s0 + u < splits) ? ws[(size_t)(s0 + u) * E + e] : 0.f;
         }
-        tile[c * 27 + tap] = a0 + a1;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) a[q] += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+    }
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        const int i = threadIdx.x + q * 256;
+        if (i < 27 * 64) tile[(i & 63) * 27 + (i >> 6)] = a[q];
     }
     __syncthreads();
     float* dst = m < Ya ? dwa + ((size_t)m * Cin + c0) * 27 : dwb + ((size_t)(m - Ya) * Cin + c0) * 27;
@@ -915,8 +934,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
 static void launch_reduce(const WgradParams& p, hipStream_t st) {
     const int Mtot = p.ya.C + p.yb.C, Cin = p.xa.C + p.xb.C;
     const size_t elems = (size_t)27 * Mtot * Cin;
-    if (p.splits >= 16)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C, Cin, p.dwa, p.dwb);
+    if (p.splits >= 128)
+        hipLaunchKernelGGL((wgrad_reduce_kernel<32, 8>), dim3((unsigned)((elems + 127) / 128)), dim3(1024), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C, Cin, p.dwa, p.dwb);
+    else if (p.splits >= 16)
+        hipLaunchKernelGGL((wgrad_reduce_kernel<8, 8>), dim3((unsigned)((elems + 127) / 128)), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C, Cin, p.dwa, p.dwb);
     else
         hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)(Mtot * ((Cin + 63) / 64))), dim3(256), 0, st, (const float*)p.ws, p.splits, Mtot, p.ya.C, Cin, p.dwa, p.dwb);
 }

@@ -24,7 +24,8 @@ struct IgemmParams {
     float* part;           // per-block partial sums [N][rows][Cout][2] or nullptr (rows = rs_igemm_part_rows)
     int pc;                // 1: producer/consumer persistent kernel (bf16); 2: weight-stationary kernel (bf16, bn 32); 3: producer/consumer v2 (bf16, bn <= 64)
     ConvSrc ea, eb;        // EPI 1: forward inputs (with mr) whose relu mask / x_n the data-gradient needs
-    int box;               // > 0: volume-fitted K-split kernel (conv3d_igemm_box.hip), value = rs_box_config
+    int box;               // > 0: volume-fitted K-split kernel (conv3d_igemm_box.hip), value = rs_box_config (3: one box per sample, reduction split over blocks)
+    float* ws; int nsplit; // box == 3: f32 workspace [nsplit][N * D * H * W][Cout] and the number of chunk ranges
 };
 
 struct PackParams {
@@ -62,6 +63,7 @@ int rs_launch_igemm_pc2(const IgemmParams& p, int epi, hipStream_t st);
 // volume-fitted in-block K-split kernel for under-filled (low-resolution) launches (conv3d_igemm_box.hip): bf16, bn 64
 int rs_box_config(int N, int D, int H, int W, int n_cols);
 int rs_box_part_rows(int cfg, int D, int H, int W);
+int rs_box_nsplit(int N, int n_cols, int nch);
 int rs_launch_igemm_box(const IgemmParams& p, int cfg, int epi, hipStream_t st);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);

@@ -39,8 +39,17 @@ def _ptr(t, off_elems=0):
     return t.data_ptr() + off_elems * t.element_size()
 
 
+_WS = None
+
+
 def _L():
-    return _l.lib()
+    """The C library, with the split-reduction workspace of the 6^3-level convolutions registered on first use on a GPU."""
+    global _WS
+    L = _l.lib()
+    if _WS is None and torch.cuda.is_available():
+        _WS = torch.empty((L.rsuper_conv3_workspace_bytes(),), device='cuda', dtype=torch.uint8)
+        _l.check(L.rsuper_conv3_set_workspace(_WS.data_ptr(), _WS.numel()), 'conv3_set_workspace')
+    return L
 
 
 def pick_bn(n_cols, dtype, tiles_total=None, dims=None):
@@ -50,7 +59,7 @@ def pick_bn(n_cols, dtype, tiles_total=None, dims=None):
     dims = (N, D, H, W): launches the library would hand to the volume-fitted K-split kernel (rsuper_conv3_box_bn: low-resolution
     levels that cannot fill the chip with 4x4x16 tiles) take its 64-column blocks."""
     cands = (32, 64) if dtype == torch.float32 else (32, 64, 128)
-    if dtype != torch.float32 and _L().rsuper_conv3_variant(-1) in (6, 7):
+    if dtype != torch.float32 and dims is None and _L().rsuper_conv3_variant(-1) in (6, 7):
         return 64         # forced volume-fitted kernel (tests): 64-column blocks whatever the column count
     if dims is not None and dtype != torch.float32:
         bn = _L().rsuper_conv3_box_bn(_DT[dtype], *dims, n_cols)

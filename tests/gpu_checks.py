@@ -106,7 +106,7 @@ def check_conv_fwd(mode, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, nor
     mra = stats_ref(xa).to(DEV) if norm else None
     mrb = stats_ref(xb).to(DEV) if (norm and xb is not None) else None
     nc = Cout * (2 if fused_sc else 1)
-    bn = ops.pick_bn(nc, dt)
+    bn = ops.pick_bn(nc, dt, dims=(N, D, H, W))
     wp = ops.pack_weights(dt, 0, w1.to(DEV), ws.to(DEV) if ws is not None else None, Ca, Cb, Cout, Cout if fused_sc else 0, bn)
     out = torch.empty((N, D, H, W, nc), device=DEV, dtype=dt)
     part = ops.part_buffer(dt, (N, D, H, W), nc, bn, DEV, fill=float('nan'))
@@ -161,7 +161,7 @@ def check_conv_bwd(mode, N, S, Ca, Cb, Cout, fused_sc, seed=0, tr=None):
     sb = ops.Src(to_cl(xb, dt), mr=mrb) if xb is not None else None
     y1 = ops.Src(to_cl(dy1, dt))
     y2 = ops.Src(to_cl(dys, dt)) if fused_sc else None
-    bn = ops.pick_bn(Cin, dt)
+    bn = ops.pick_bn(Cin, dt, dims=(N, D, H, W))
     wp = ops.pack_weights(dt, 1, w1.to(DEV), ws.to(DEV) if ws is not None else None, Cout, Cout if fused_sc else 0, Cin, 0, bn)
     g0 = torch.empty((N, D, H, W, Cin), device=DEV, dtype=dt)
     part = ops.part_buffer(dt, (N, D, H, W), Cin, bn, DEV, fill=float('nan'), epi=1)
