@@ -117,6 +117,14 @@ int rsuper_conv3_wgrad(int dtype, int use_tr,
                        const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
                        float* dwa, float* dwb, float* workspace, int N, int D, int H, int W, int splits, void* stream);
 
+/* The same in two steps, so that the slab reduction (a small bandwidth-bound kernel nothing on the data-gradient chain waits for)
+ * can run on another stream: _partial writes the per-split slabs only, _reduce sums them into dwa / dwb (Cin = Ca + Cb). */
+int rsuper_conv3_wgrad_partial(int dtype, int use_tr, const void* xa, int lda, int Ca, const float* mra,
+                               const void* xb, int ldb, int Cb, const float* mrb,
+                               const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
+                               float* workspace, int N, int D, int H, int W, int splits, void* stream);
+int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Ya, int Yb, float* dwa, float* dwb, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine=False) statistics and backward tail -- conv_layers.py:40-42
  * ------------------------------------------------------------------------------------------------ */

@@ -203,7 +203,7 @@ int rsuper_conv3_wgrad_splits(int dtype, int Ca, int Cb, int Mtot, int N, int D,
     return rs_wgrad_splits(dtype, Mtot, (Ca + 31) / 32 + (Cb + 31) / 32, N * rsuper_conv3_tiles(D, H, W));
 }
 
-int rsuper_conv3_wgrad(int dtype, int use_tr, const void* xa, int lda, int Ca, const float* mra,
+static int conv3_wgrad_impl(int reduce, int dtype, int use_tr, const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,
                        const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
                        float* dwa, float* dwb, float* workspace, int N, int D, int H, int W, int splits, void* stream) {
@@ -222,7 +222,29 @@ int rsuper_conv3_wgrad(int dtype, int use_tr, const void* xa, int lda, int Ca, c
     p.ya = {ya, ldya, Ya, nullptr};
     p.yb = {yb, ldyb, Yb > 0 ? Yb : 0, nullptr};
     p.dwa = dwa; p.dwb = dwb; p.ws = workspace; p.N = N; p.D = D; p.H = H; p.W = W; p.splits = splits;
-    return rs_launch_wgrad(p, dtype, use_tr, ST(stream));
+    return rs_launch_wgrad(p, dtype, use_tr, ST(stream), reduce != 0);
+}
+
+int rsuper_conv3_wgrad(int dtype, int use_tr, const void* xa, int lda, int Ca, const float* mra,
+                       const void* xb, int ldb, int Cb, const float* mrb,
+                       const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
+                       float* dwa, float* dwb, float* workspace, int N, int D, int H, int W, int splits, void* stream) {
+    return conv3_wgrad_impl(1, dtype, use_tr, xa, lda, Ca, mra, xb, ldb, Cb, mrb, ya, ldya, Ya, yb, ldyb, Yb, dwa, dwb, workspace, N, D, H, W, splits, stream);
+}
+int rsuper_conv3_wgrad_partial(int dtype, int use_tr, const void* xa, int lda, int Ca, const float* mra,
+                               const void* xb, int ldb, int Cb, const float* mrb,
+                               const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
+                               float* workspace, int N, int D, int H, int W, int splits, void* stream) {
+    float dummy;                                                   // the partial kernel never touches dW
+    return conv3_wgrad_impl(0, dtype, use_tr, xa, lda, Ca, mra, xb, ldb, Cb, mrb, ya, ldya, Ya, yb, ldyb, Yb, &dummy, Yb > 0 ? &dummy : nullptr,
+                            workspace, N, D, H, W, splits, stream);
+}
+int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Ya, int Yb, float* dwa, float* dwb, void* stream) {
+    if (!workspace || splits <= 0 || Cin <= 0 || (Cin % 8) || Ya <= 0 || Yb < 0 || !dwa || (Yb > 0 && !dwb)) return RS_ERR_ARG;
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.xa.C = Cin; p.ya.C = Ya; p.yb.C = Yb; p.dwa = dwa; p.dwb = dwb; p.ws = (float*)workspace; p.splits = splits;
+    return rs_launch_wgrad_reduce(p, ST(stream));
 }
 
 int rsuper_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, int split, float* out, void* stream) {

@@ -931,7 +931,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
     for (int i = threadIdx.x; i < nc * 27; i += 256) dst[i] = tile[i];
 }
 
-static void launch_reduce(const WgradParams& p, hipStream_t st) {
+static bool g_skip_reduce = false;                               // set by rs_launch_wgrad for the duration of one launch call
+static void launch_reduce_now(const WgradParams& p, hipStream_t st);
+static void launch_reduce(const WgradParams& p, hipStream_t st) { if (!g_skip_reduce) launch_reduce_now(p, st); }
+static void launch_reduce_now(const WgradParams& p, hipStream_t st) {
     const int Mtot = p.ya.C + p.yb.C, Cin = p.xa.C + p.xb.C;
     const size_t elems = (size_t)27 * Mtot * Cin;
     if (p.splits >= 128)
@@ -1022,7 +1025,21 @@ int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total) {
     return s < 1 ? 1 : s;
 }
 
-int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st) {
+int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st) {
+    launch_reduce_now(p, st);
+    return rs_check_launch();
+}
+
+static int launch_wgrad_impl(const WgradParams& p, int dtype, int use_tr, hipStream_t st);
+// reduce = false: only the partial-slab kernel (the caller launches rs_launch_wgrad_reduce itself, e.g. on another stream)
+int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st, bool reduce) {
+    g_skip_reduce = !reduce;
+    const int rc = launch_wgrad_impl(p, dtype, use_tr, st);
+    g_skip_reduce = false;
+    return rc;
+}
+
+static int launch_wgrad_impl(const WgradParams& p, int dtype, int use_tr, hipStream_t st) {
     const int Mtot = p.ya.C + p.yb.C;
     const int tiles_total = p.N * ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);

@@ -67,5 +67,6 @@ int rs_box_nsplit(int N, int n_cols, int nch);
 int rs_launch_igemm_box(const IgemmParams& p, int cfg, int epi, hipStream_t st);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
-int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st);
+int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st, bool reduce = true);
+int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);

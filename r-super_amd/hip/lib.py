@@ -31,6 +31,9 @@ _SIGS = {
                                    P, c_int, P, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, P]),
     'rsuper_conv3_wgrad': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int,
                                    P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'rsuper_conv3_wgrad_partial': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int,
+                                           P, c_int, c_int, c_int, c_int, c_int, P]),
+    'rsuper_conv3_wgrad_reduce': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     'rsuper_stats_finalize': (c_int, [P, c_int, c_int, c_int, c_double, c_float, c_int, c_int, P, P]),
     'rsuper_in_bwd_finalize': (c_int, [c_int, P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     'rsuper_maxpool2_fwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

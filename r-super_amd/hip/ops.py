@@ -255,6 +255,8 @@ def overlap_enabled(voxels=None):
     interleaves them.  voxels=None asks whether the side stream is in use at all (the gradient reducer orders its
     collectives after it)."""
     m = overlap_mode()
+    if voxels is None and reduce_side_enabled():
+        return True
     if m == '1':
         return True
     if m == 'auto':
@@ -340,7 +342,16 @@ def igemm(epi, a, b, packed, n_cols, bn, dims, out, out_ld=None, res=None, part=
         run()
 
 
-def wgrad(xa, xb, ya, yb, dwa, dwb, dims):
+def reduce_side_enabled():
+    """RSUPER_WGRAD_REDUCE_SIDE=1 (opt-in; same-box A/B 11.68 vs 11.24 ms per step: the cross-stream event waits cost more than the
+    overlap gains): the slab reduction of every weight gradient (a ~10 us bandwidth-bound kernel that only the
+    optimiser waits for) runs on the side stream, concurrently with the data-gradient chain, instead of between two of its kernels."""
+    return os.environ.get('RSUPER_WGRAD_REDUCE_SIDE', '0') == '1'
+
+
+def wgrad(xa, xb, ya, yb, dwa, dwb, dims, side_reduce=False):
+    """side_reduce (only from inside an autograd backward, where the join callback can be queued): partial slabs on the current
+    stream, their reduction into dwa / dwb on the side stream."""
     dt = _DT[xa.t.dtype]
     N, D, H, W = dims
     Mtot = ya.C + (yb.C if yb is not None else 0)
@@ -349,16 +360,36 @@ def wgrad(xa, xb, ya, yb, dwa, dwb, dims):
     yb_args = (None, 0, 0) if yb is None else (_ptr(yb.t, yb.off), yb.ld, yb.C)
     Cin_t = xa.C + (xb.C if xb is not None else 0)
     ws = torch.empty((splits * 27 * Mtot * Cin_t,), device=dwa.device, dtype=torch.float32)
+    flops = 2.0 * N * D * H * W * Mtot * Cin_t * 27
 
-    def run():
-        _l.check(_L().rsuper_conv3_wgrad(dt, use_tr(), *xa.args(), *(xb.args() if xb is not None else _NONE),
-                                         _ptr(ya.t, ya.off), ya.ld, ya.C, *yb_args, _ptr(dwa), _ptr(dwb), _ptr(ws), N, D, H, W, splits,
-                                         _stream()), 'conv3_wgrad')
+    if not side_reduce:
+        def run():
+            _l.check(_L().rsuper_conv3_wgrad(dt, use_tr(), *xa.args(), *(xb.args() if xb is not None else _NONE),
+                                             _ptr(ya.t, ya.off), ya.ld, ya.C, *yb_args, _ptr(dwa), _ptr(dwb), _ptr(ws), N, D, H, W, splits,
+                                             _stream()), 'conv3_wgrad')
+        if TIMER is not None:
+            TIMER.launch('conv3d_wgrad', flops, run)
+        else:
+            run()
+        return
+
+    def run_partial():
+        _l.check(_L().rsuper_conv3_wgrad_partial(dt, use_tr(), *xa.args(), *(xb.args() if xb is not None else _NONE),
+                                                 _ptr(ya.t, ya.off), ya.ld, ya.C, *yb_args, _ptr(ws), N, D, H, W, splits, _stream()),
+                 'conv3_wgrad_partial')
+
+    def run_reduce():
+        _l.check(_L().rsuper_conv3_wgrad_reduce(_ptr(ws), splits, Cin_t, ya.C, yb.C if yb is not None else 0, _ptr(dwa), _ptr(dwb),
+                                                _stream()), 'conv3_wgrad_reduce')
     if TIMER is not None:
-        Cin = xa.C + (xb.C if xb is not None else 0)
-        TIMER.launch('conv3d_wgrad', 2.0 * N * D * H * W * Mtot * Cin * 27, run)
+        TIMER.launch('conv3d_wgrad', flops, run_partial)
     else:
-        run()
+        run_partial()
+    with _Side(True, (ws, dwa, dwb)):
+        if TIMER is not None:
+            TIMER.launch('conv3d_wgrad_reduce', 0.0, run_reduce)      # events on the side stream: counted in the union of intervals
+        else:
+            run_reduce()
 
 
 def in_bwd_finalize(g, x, gm, out_C, add1=None):
@@ -527,10 +558,12 @@ class BasicBlockFn(torch.autograd.Function):
         gm1 = stats_finalize(part, cnt, mode=1)
         # the join with the side stream is deferred to the end of backward: only safe when AccumulateGrad merely stores
         # the new gradient (p.grad is None, zero_grad(set_to_none=True)); an in-place `p.grad += dw` would race
-        ov = overlap_enabled(D * H * W) and all(w.grad is None for w in (w1, w2, ws) if w is not None)
+        fresh = all(w.grad is None for w in (w1, w2, ws) if w is not None)
+        ov = overlap_enabled(D * H * W) and fresh
+        sr = reduce_side_enabled() and fresh and not ov
         dw2 = grad_dest(w2)
         with _Side(ov, (ys, mr_y1, dout, dw2)):
-            wgrad(y1, None, sdo, None, dw2, None, dims)
+            wgrad(y1, None, sdo, None, dw2, None, dims, side_reduce=sr)
         dy1 = in_bwd_finalize(Src(g1), y1, gm1, Cout)
         # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
         sa = Src(xa, mr=mra)
@@ -543,14 +576,14 @@ class BasicBlockFn(torch.autograd.Function):
         dw1 = grad_dest(w1)
         dws = grad_dest(ws) if has_sc else None
         with _Side(ov, (xa, mra, xb, mrb, dy1, dout, dw1, dws)):
-            wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims)
+            wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims, side_reduce=sr)
         if xb is None:
             dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca, add1=None if has_sc else dout)
             dxb = None
         else:
             dxa = in_bwd_finalize(Src(g0, C=Ca), sa, gm0[0], Ca)
             dxb = in_bwd_finalize(Src(g0, C=Cb, off=Ca), sb, gm0[1], Cb)
-        if ov and _join_per_block():
+        if (ov or sr) and _join_per_block():
             join_side()
         return dxa, None, dxb, None, dw1, dw2, dws, None, None
 
