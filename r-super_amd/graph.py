@@ -43,10 +43,17 @@ class GraphedTrainStep:
             raise ValueError('data-parallel modules take the eager step (the gradient exchange is not captured)')
         if float(getattr(args, 'report_volume_loss_basic', 0.0)) > 0:
             raise ValueError('report supervision has host-side control flow (ball search): use the eager train_step')
+        if int(warmup) < 1:
+            # a fresh optimiser creates exp_avg / exp_avg_sq (zeros_like) and its norm scratch lazily in the first step: inside the capture
+            # those zero-fills would be recorded and both moments reset on every replay
+            raise ValueError('GraphedTrainStep needs warmup >= 1: the optimiser state must exist before the capture')
         self.net, self.ema, self.opt, self.args, self.classes = net, ema_net, optimizer, args, list(classes)
         self.warmup, self.calls = int(warmup), 0
         self.graph, self.static, self.out = None, None, None
         self.dyn = None
+        self._replays = 0
+        on = os.environ.get('RSUPER_GRAPH_VERIFY', '1') != '0'
+        self.verify_at, self.verify_every = ((1, 12, 50) if on else ()), (1000 if on else 0)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _scalars(self, step):
@@ -98,10 +105,57 @@ class GraphedTrainStep:
         # once the copies recorded on it have completed.
         self.dyn.copy_(torch.tensor(self._scalars(step), dtype=torch.float32).pin_memory(), non_blocking=True)
         t = self._opt_step() + 1
+        self._replays += 1
+        check = self._replays in self.verify_at or (self.verify_every and self._replays % self.verify_every == 0)
+        before = [p.detach().clone() for p in self._params()] if check else None
         self.graph.replay()
         self._set_opt_step(t)
         ops.WEIGHTS_EPOCH += 1
+        if check:
+            self._verify(before)
         return self.out
+
+    def _params(self):
+        return [p for p in self.opt.param_groups[0]['params'] if p.requires_grad]
+
+    def _verify(self, before):
+        """The replayed step's gradients (still in the graph's gradient buffers) against an eager forward + loss + backward from the same
+        batch and the PRE-step parameters -- the check GraphedNetwork runs, for the whole-step graph: a captured ATen reduction returned
+        garbage from the 12th replay on in round 2, silently.  Replays 1, 12, 50 and every 1000th; costs one parameter
+        copy each way and one eager forward + backward; RSUPER_GRAPH_VERIFY=0 turns it off."""
+        params = self._params()
+        grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+        after = [p.detach().clone() for p in params]
+        sanity = lf.SANITY_CHECKS
+        lf.SANITY_CHECKS = False
+        try:
+            with torch.no_grad():
+                torch._foreach_copy_(params, before)
+            ops.WEIGHTS_EPOCH += 1
+            with torch.enable_grad():
+                b = self.static
+                result = self.net(b['image'])
+                loss_all = lf.calculate_loss(model_output=result, label=b['label'], unk_voxels=b.get('unk_channels'), args=self.args, matcher=None,
+                                             chosen_segment_mask=b.get('mask'), tumor_volumes_report=b.get('volumes'),
+                                             tumor_diameters=b.get('diameters'), classes=self.classes, input_tensor=b['image'],
+                                             class_weights=b.get('weights'))
+                ref = torch.autograd.grad(loss_all['overall'], params, allow_unused=True)
+        finally:
+            lf.SANITY_CHECKS = sanity
+            with torch.no_grad():
+                torch._foreach_copy_(params, after)
+            ops.WEIGHTS_EPOCH += 1
+        names = {id(p): k for k, p in self.net.named_parameters()}
+        for p, g, r in zip(params, grads, ref):
+            if g is None or r is None:
+                continue
+            scale = float(r.abs().max())
+            err = float((g - r).abs().max())
+            if not (err <= 1e-3 * max(scale, 1e-30) or err <= 1e-12):
+                raise RuntimeError(f'GraphedTrainStep: replay {self._replays} disagrees with the eager step on the gradient of '
+                                   f'{names.get(id(p), "?")} (max difference {err:.3e}, largest entry {scale:.3e}); the parameters have already '
+                                   'been updated with it -- reload the last checkpoint and run without --hip_graph '
+                                   '(tools/mode_consistency.py narrows the kernel down)')
 
     def _capture(self, batch, step):
         dev = next(self.net.parameters()).device

@@ -3,8 +3,9 @@
 `train_step` is the hot loop body of train_epoch (:308-357):
     zero_grad -> net(img) -> calculate_loss -> backward -> clip_grad_norm_(1.0) -> AdamW.step -> EMA
 with clip + AdamW + EMA fused into one HBM pass.  One process per GPU; gradients are averaged with RCCL
-(`torch.distributed` backend 'nccl') by torch's DistributedDataParallel, whose bucketed all-reduce overlaps the
-backward kernels because every block's weight gradients are separate autograd leaves.
+(`torch.distributed` backend 'nccl'): by `rsuper_amd.reducer.GradReducer` (default of `wrap_ddp`: flat buckets the weight-gradient
+kernels write into, one asynchronous all-reduce per bucket overlapping the data-gradient chain), by `GraphedNetwork.exchange_gradients`
+when the network is replayed from hipGraphs, or by torch's DistributedDataParallel (`RSUPER_REDUCER=0`, CPU modules).
 """
 import argparse
 import copy
@@ -224,7 +225,12 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
         for k, v in loss_all.items():
             val = v.item()
             if k == 'overall' and val != val:            # the NaN guard of calculate_loss (:1070-1071) also for replayed steps
-                raise ValueError('loss is nan, propagating this can destroy the network weights, STOP!')
+                # eager steps raise inside calculate_loss, before backward; a REPLAYED step has already run clip / AdamW / EMA with the
+                # NaN gradients when the host reads the loss here: net and ema_net are then invalid and must be reloaded from the last
+                # checkpoint (train_net keeps `latest`); in a multi-rank run stop all ranks (the others block in the next collective)
+                raise ValueError('loss is nan, propagating this can destroy the network weights, STOP!'
+                                 + (' (hipGraph replay: the weights of this step are already updated -- resume from the last checkpoint)'
+                                    if stepper is not None else ''))
             loss_meters[k].update(val, img.shape[0])
         loss_meters['Elapsed Time'].update(time.time() - start, n=1)
         if progress is None:

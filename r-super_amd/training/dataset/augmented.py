@@ -198,9 +198,11 @@ class AugmentedCropDataset(data.Dataset):
 
     @classmethod
     def from_directory(cls, save_destination, classes, **kw):
-        """Dataset over every crop found in `save_destination`: `<name>.npy` + `<name>_gt.npy` pairs in sorted order; a crop
-        with a `<name>.json` beside it is report-supervised (the reference derives the same split from its data lists,
-        :244-286, which are offline artefacts and not read here)."""
+        """Dataset over every crop found in `save_destination`: `<name>.npy` + `<name>_gt.npy` pairs in sorted order.  A crop with a
+        `<name>.json` beside it is LOADED through the report path (the reference derives that split from its data lists, :244-286,
+        offline artefacts that are not read here).  The reference's save() writes the .json for every crop, so in a directory it
+        produced all crops take that path -- equivalent for per-voxel crops: their `tumor_in_crop` is null and their side masks are
+        zero, which is what the mask path yields."""
         files = set(os.listdir(save_destination))
         names = sorted(f[:-len('_gt.npy')] for f in files if f.endswith('_gt.npy') and f[:-len('_gt.npy')] + '.npy' in files)
         img_list = [os.path.join(save_destination, n + '.npy') for n in names]

@@ -736,14 +736,14 @@ def test_graphed_step_matches_eager(model):
         net, ema, opt = build()
         stepper = GraphedTrainStep(net, ema, opt, largs, classes, warmup=2) if graphed else None
         hist = []
-        for i in range(7):
-            if i == 4:
+        for i in range(16):                                           # 14 replays: past the 12th, where a captured ATen reduction once went
+            if i == 4:                                                # wrong (the step verifies itself against an eager step at replays 1 and 12)
                 opt.param_groups[0]['lr'] = 2e-4                      # epoch boundary of the LR schedule
             b = batches[i % 2]
             loss, gn = stepper(b, i) if graphed else train_step(net, ema, opt, b, largs, classes, i)
             hist.append((float(loss['overall'].detach()), float(gn)))
         if graphed:
-            assert stepper.graph is not None and stepper.calls == 7
+            assert stepper.graph is not None and stepper.calls == 16 and stepper._replays == 14
         return hist, [p.detach().clone() for p in net.parameters()], [p.detach().clone() for p in ema.parameters()], opt
 
     h_e, p_e, e_e, opt_e = run(False)
@@ -751,9 +751,24 @@ def test_graphed_step_matches_eager(model):
     assert h_e == h_g, (h_e, h_g)
     assert all(torch.equal(a, b) for a, b in zip(p_e, p_g)) and all(torch.equal(a, b) for a, b in zip(e_e, e_g))
     st_e, st_g = next(iter(opt_e.state.values())), next(iter(opt_g.state.values()))
-    assert int(st_e['step']) == int(st_g['step']) == 7
+    assert int(st_e['step']) == int(st_g['step']) == 16
     with pytest.raises(ValueError):
         GraphedTrainStep(*build(), argparse.Namespace(**{**vars(largs), 'report_volume_loss_basic': 0.1}), classes)
+    with pytest.raises(ValueError):                                   # the optimiser state must exist before the capture
+        GraphedTrainStep(*build(), largs, classes, warmup=0)
+    if model == 'unet':
+        # self-verification: a replay whose gradient buffers disagree with the eager step is reported (here: scribbled on before the check)
+        net, ema, opt = build()
+        stepper = GraphedTrainStep(net, ema, opt, largs, classes, warmup=1)
+        stepper(batches[0], 0)
+        stepper(batches[0], 1)                                        # capture + replay 1 (verified, healthy)
+        real = stepper._verify
+        def broken(before):
+            next(p for p in net.parameters() if p.grad is not None).grad.add_(1.0)
+            return real(before)
+        stepper._verify, stepper.verify_at = broken, (2,)
+        with pytest.raises(RuntimeError, match='disagrees with the eager step'):
+            stepper(batches[1], 2)
 
 
 @pytest.mark.gpu
