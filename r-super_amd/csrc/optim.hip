@@ -30,7 +30,14 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(MTChunk c, double* partial)
 #pragma unroll
         for (int k = 0; k < MT_ELEMS / 1024; ++k) { const float4 v = g4[threadIdx.x + 256 * k]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
     } else {
-        for (size_t i = base + threadIdx.x; i < base + MT_ELEMS && i < n; i += 256) { const float v = g[i]; s += v * v; }
+        // unaligned tensors (views into the gradient buckets of rsuper_amd.reducer) and tails: the SAME element-to-thread map and the same
+        // association as the vector path, so the norm -- and with it the clip coefficient -- does not depend on where a gradient lives
+#pragma unroll
+        for (int k = 0; k < MT_ELEMS / 1024; ++k) {
+            const size_t i = base + (size_t)(threadIdx.x + 256 * k) * 4;
+            const float x = i < n ? g[i] : 0.f, y = i + 1 < n ? g[i + 1] : 0.f, z = i + 2 < n ? g[i + 2] : 0.f, w = i + 3 < n ? g[i + 3] : 0.f;
+            s += x * x + y * y + z * z + w * w;
+        }
     }
     s = wave_sum(s);
     __shared__ float red[4];

@@ -415,7 +415,7 @@ class BasicBlockFn(torch.autograd.Function):
         and sampled at the even voxels (8x the minimal FLOPs of these two convolutions; the shipped configs use MaxPool and
         never take this path), conv2 runs at the half resolution."""
         if stride == 2:
-            return BasicBlockFn._forward_s2(ctx, xa, mra, w1, w2, ws)
+            return _BB._forward_s2(ctx, xa, mra, w1, w2, ws)
         assert stride == 1
         ctx.stride = 1
         _chk_act(xa)
@@ -532,7 +532,7 @@ class BasicBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _unused):
         if ctx.stride == 2:
-            return BasicBlockFn._backward_s2(ctx, dout)
+            return _BB._backward_s2(ctx, dout)
         xa, mra, xb, mrb, ys, mr_y1, w1, w2, ws = ctx.saved_tensors
         dout = dout.contiguous()
         N, D, H, W, Ca = xa.shape
@@ -586,6 +586,9 @@ class BasicBlockFn(torch.autograd.Function):
         if (ov or sr) and _join_per_block():
             join_side()
         return dxa, None, dxb, None, dw1, dw2, dws, None, None
+
+
+_BB = BasicBlockFn        # the class itself: `BasicBlockFn` is rebound to the registered dispatcher op below
 
 
 # ------------------------------------------------------------------------------------------------ pool / upsample
@@ -1004,3 +1007,11 @@ def dilate_volume(vol_u8, kernel_size):
     _l.check(_L().rsuper_dilate_volume_sparse(_ptr(v), _ptr(out), _ptr(tmp), _ptr(flags), nvol, D, H, W, kernel_size, _stream()),
              'dilate_volume')
     return out
+
+
+# ------------------------------------------------------------------------------------------------ dispatcher registration
+# every *Fn above becomes the torch.library op rsuper::<name> (schema + CUDA kernel + autograd formula); `XFn.apply` keeps working
+from . import library as _library   # noqa: E402
+
+if os.environ.get('RSUPER_NO_TORCH_LIBRARY', '0') != '1':     # =1: the plain autograd.Function classes (A/B of the dispatcher's host cost)
+    _library.install()

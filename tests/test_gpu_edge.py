@@ -1021,3 +1021,27 @@ def test_train_epoch_with_hip_graph_matches_eager(tmp_path, report):
     sd_e = sd_e.state_dict() if hasattr(sd_e, 'state_dict') else sd_e
     sd_g = sd_g.state_dict() if hasattr(sd_g, 'state_dict') else sd_g
     assert all(torch.equal(sd_e[k], sd_g[k]) for k in sd_e)
+
+
+@pytest.mark.gpu
+def test_dispatcher_ops_forward_only_and_autograd_paths_agree():
+    """rsuper::maxpool2 / rsuper::head_conv through the dispatcher: the AutogradCUDA kernel (forward + autograd node) and the CUDA kernel
+    alone (inference_mode skips the autograd key) give identical results, and gradients flow through the registered op."""
+    from rsuper_amd.hip import ops
+    torch.manual_seed(0)
+    x = torch.randn(2, 8, 8, 8, 16, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    y, mr = torch.ops.rsuper.maxpool2(x)
+    assert y.grad_fn is not None and not mr.requires_grad
+    with torch.inference_mode():
+        y2, mr2 = torch.ops.rsuper.maxpool2(x.detach())
+    assert torch.equal(y.detach(), y2) and torch.equal(mr, mr2)
+    y.float().sum().backward()
+    assert x.grad is not None and float(x.grad.float().abs().sum()) > 0
+    w = torch.randn(5, 16, 1, 1, 1, device=DEV).requires_grad_(True)
+    b = torch.randn(5, device=DEV).requires_grad_(True)
+    lo = ops.HeadFn.apply(y.detach(), w, b)                                     # the modules' spelling of torch.ops.rsuper.head_conv
+    with torch.inference_mode():
+        lo2 = torch.ops.rsuper.head_conv(y.detach(), w.detach(), b.detach())
+    assert torch.equal(lo.detach(), lo2)
+    lo.sum().backward()
+    assert w.grad is not None and b.grad is not None

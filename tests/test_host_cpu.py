@@ -232,3 +232,23 @@ def test_graph_gradient_exchange_world2_gloo_cpu():
                         '--master-port', '29541', script], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'EXCHANGE_OK' in r.stdout
+
+
+def test_ops_are_registered_with_the_dispatcher():
+    """north_star: "the conv / norm / loss ops are registered as custom HIP ops": every operator of hip/ops.py is a torch.library op
+    rsuper::<name> with a schema and kernels at the CUDA / AutogradCUDA keys only -- a CPU tensor finds no kernel (no CPU fallback)."""
+    import torch
+    from rsuper_amd.hip import ops, library   # noqa: F401  (import registers)
+    names = ['basic_block', 'maxpool2', 'upsample_trilinear', 'stem_conv', 'head_conv', 'conv3', 'cl_planar', 'squeeze_excite',
+             'bidir_attention', 'channel_norm', 'depthwise_conv3']
+    for n in names:
+        op = getattr(torch.ops.rsuper, n)
+        schema = op.default._schema
+        assert schema.name == f'rsuper::{n}' and len(schema.arguments) >= 1 and len(schema.returns) >= 1
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f'rsuper::{n}', 'CUDA')
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f'rsuper::{n}', 'AutogradCUDA')
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f'rsuper::{n}', 'CPU')
+    assert str(torch.ops.rsuper.basic_block.default._schema).startswith('rsuper::basic_block(Tensor xa, Tensor mra, Tensor? xb')
+    with pytest.raises(NotImplementedError):
+        torch.ops.rsuper.maxpool2(torch.zeros(1, 2, 2, 2, 8))
+    assert ops.MaxPoolFn.apply.__self__.op is torch.ops.rsuper.maxpool2          # the modules' call sites go through the dispatcher
