@@ -355,7 +355,7 @@ def check_unet_tiny_nopool(mode):
     # the fp32 reference fixture (measured 1.1e-2, i.e. the reference's own rounding noise)
     # bf16: relative L2 per tensor; the stem gradient of this ill-conditioned net is mostly rounding noise in bf16 (measured 0.55 at
     # inc.conv1, 0.04 on the logits), so bf16 only guards against gross errors here -- per-layer bf16 parity is checked block by block
-    tol_y, tol_g = (1e-3, 2e-2) if mode == 'f32' else (0.25, 0.8)
+    tol_y, tol_g = (1e-4, 2e-2) if mode == 'f32' else (0.25, 0.8)          # f32 logits: measured 6.5e-6
     return result(f'unet_tiny_nopool[{mode}]', max(e_y / tol_y, worst / tol_g, worst64 / 1.2e-2), 1.0,
                   f'logits {e_y:.2e} (tol {tol_y}); worst grad vs reference {worst:.2e} @ {wk} (tol {tol_g}); vs float64 {worst64:.2e} (tol 1.2e-2)')
 
