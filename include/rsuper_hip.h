@@ -128,6 +128,16 @@ int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Y
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine=False) statistics and backward tail -- conv_layers.py:40-42
  * ------------------------------------------------------------------------------------------------ */
+/* 1x1x1 convolution / linear layer over the channel axis of f32 channels-last rows, as an MFMA GEMM (bf16 or exact-f32 compute, f32
+ * storage): the pointwise members of MedFormer's attention stages -- DepthwiseSeparableConv.pointwise (conv_layers.py:126-157), MBConv
+ * expand / project (:197-239), BidirectionAttention's feat_qv / map_qv / out projections (medformer_utils.py:13-99).
+ *   mode 0: y[r][n] = sum_k x[r][k] w[n][k] (+ bias[n]),  w = (N, K) as in the state_dict   (F.conv3d(k=1) / F.linear forward)
+ *   mode 1: y[r][n] = sum_k x[r][k] w[k][n],              w = (K, N)                        (their data gradient, x := dy)
+ * N, ldx, ldy multiples of 4; R * ldx * 4 < 2^32; packed: device workspace of rsuper_pointwise_packed_bytes(dtype, K, N) bytes. */
+size_t rsuper_pointwise_packed_bytes(int dtype, int K, int N);
+int rsuper_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, long R, int K, int N,
+                     void* packed, void* stream);
+
 /* part [N][nblk][C][2] -> out [N][C][2]: mode 0 (mean, rstd = 1/sqrt(var+eps)), mode 1 (sum0/cnt, sum1/cnt).
  * split > 0 writes two contiguous tables instead, [N][split][2] followed by [N][C-split][2] (the column groups of a fused
  * conv1 + shortcut GEMM, or the two sources of a concatenated input), so each can be handed to a kernel as-is. */

@@ -70,3 +70,8 @@ int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st, bool reduce = true);
 int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
+
+// 1x1x1 convolution / linear layer as an MFMA GEMM on f32 channels-last rows (pointwise.hip); packed = workspace of rs_pw_packed_bytes
+size_t rs_pw_packed_bytes(int N, int K, int dtype);
+int rs_launch_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int R, int K, int N,
+                        void* packed, hipStream_t st);

@@ -1,0 +1,170 @@
+// 1x1x1 convolution / linear layer on channels-last activations as an MFMA GEMM (gfx950): the pointwise members of MedFormer's
+// attention stages -- DepthwiseSeparableConv.pointwise (rsuper_train/model/dim3/conv_layers.py:126-157), MBConv expand / project
+// (:197-239), the feat_qv / map_qv / out projections of BidirectionAttention (medformer_utils.py:13-99), SemanticMapGeneration's
+// 1x1x1 members (:206-232) -- forward and data gradient.  Round 2 issued them as fp32 library GEMMs (rocBLAS / hipBLASLt: 45-70 TF/s,
+// 480 launches, 6.2 ms of the 29 ms step).
+//
+//   forward        y[r][n] = sum_k x[r][k] * W[n][k] (+ b[n])        x: [R][ldx] f32, W: (Cout, Cin) f32 (state_dict layout)
+//   data gradient  dx[r][k] = sum_n dy[r][n] * W[n][k]                the same kernel on the transposed weights (pack mode 1)
+//
+// These products are HBM-bound (K, N <= 1024 against 10^4..10^5 rows), so the kernel moves every byte once and keeps the matrix pipe
+// out of the way:
+//   * operand roles are swapped -- the WEIGHTS are the MFMA A operand (rows = output channels), the ACTIVATIONS the B operand (columns =
+//     voxels): a lane's B fragment is 8 (bf16 compute) / 4 (f32 compute) consecutive channels of ONE voxel row, i.e. a plain 16 / 32-byte
+//     global load of the row-major source, converted in registers -- no LDS staging, no transpose, no barrier in the whole kernel;
+//   * the accumulator comes out with the voxel in the lane and four consecutive output channels per register quad: 16-byte stores
+//     straight from the accumulators (+ bias), no LDS transpose either;
+//   * weights are packed once per call into A-fragment order (pw_pack_kernel: [k-step][32-row tile][lane] x 16 B, converted to the
+//     compute type) and stream through L2 as coalesced 1 KB wave loads.
+// Compute type: bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate) in the bf16 mode, exact-f32 MFMA (4 x v_mfma_f32_32x32x2_f32)
+// in the f32 parity mode; storage stays fp32 either way (the attention stages' activation dtype).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+struct PwParams {
+    const float* x; int ldx;       // [R][ldx] f32 (row = voxel)
+    const void* wp;                // packed A fragments: [ksteps][ntiles][64 lanes] x 16 B
+    const float* bias;             // [N] or nullptr
+    float* y; int ldy;             // [R][ldy] f32
+    int R, K, N, ntiles, ksteps;
+};
+
+// W (rows x cols f32, row-major, leading dimension ldw) -> fragments of op(W): mode 0: A[n][k] = W[n][k] (forward, N = rows, K = cols),
+// mode 1: A[n][k] = W[k][n] (data gradient, N = cols, K = rows).  Lane l of (kstep, ntile) holds A[ntile*32 + (l & 31)][kstep*2*KP + (l >> 5)*KP .. + KP).
+template <typename CT>
+__global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ w, int rows, int cols, int mode, int ntiles, int ksteps, CT* out) {
+    constexpr int KP = Elem<CT>::KP;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ksteps * ntiles * 64) return;
+    const int lane = idx & 63, nt = (idx >> 6) % ntiles, ks = (idx >> 6) / ntiles;
+    const int n = nt * 32 + (lane & 31), k0 = ks * 2 * KP + (lane >> 5) * KP;
+    const int N = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
+    float f[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int k = k0 + j;
+        f[j] = (n < N && k < K) ? (mode == 0 ? w[(size_t)n * cols + k] : w[(size_t)k * cols + n]) : 0.f;
+    }
+    *(uint4*)(out + (size_t)idx * KP) = pack16<CT>(f);
+}
+
+// block = 4 waves, wave = 32 voxel rows x NF*32 output channels; grid (row blocks of 128, column blocks of NF*32)
+template <typename CT, int NF>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(PwParams p) {
+    constexpr int KP = Elem<CT>::KP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = lane & 31, half = lane >> 5;
+    const int row = (blockIdx.x * 4 + wave) * 32 + v;
+    const int nt0 = blockIdx.y * NF;
+    // activations through a buffer descriptor: rows past R and channels past K read zeros (no branches around the loads)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)((size_t)p.R * p.ldx * 4), 0x00020000);
+    const uint32_t xrow = row < p.R ? (uint32_t)row * (uint32_t)p.ldx * 4u : 0xFFFFFFFFu;
+    const uint4* wp = (const uint4*)p.wp + (size_t)nt0 * 64 + lane;
+    const size_t wstep = (size_t)p.ntiles * 64;
+
+    f32x16_t acc[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
+
+    auto load_x = [&](int ks, uint4* raw) {                  // KP consecutive f32 channels of this lane's voxel: 1 (f32) / 2 (bf16) vectors
+#pragma unroll
+        for (int q = 0; q < KP / 4; ++q) {
+            const int k = ks * 2 * KP + half * KP + q * 4;
+            const uint32_t off = (xrow != 0xFFFFFFFFu && k < p.K) ? xrow + (uint32_t)k * 4u : 0xFFFFFFFFu;
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+            raw[q] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+    };
+    auto to_frag = [&](const uint4* raw) {
+        float f[KP];
+#pragma unroll
+        for (int q = 0; q < KP / 4; ++q) {
+            f[q * 4] = __uint_as_float(raw[q].x); f[q * 4 + 1] = __uint_as_float(raw[q].y);
+            f[q * 4 + 2] = __uint_as_float(raw[q].z); f[q * 4 + 3] = __uint_as_float(raw[q].w);
+        }
+        return pack16<CT>(f);
+    };
+    // software pipeline: the operands of k-step s + 2 are requested while step s multiplies (memory-bound: keep loads in flight)
+    constexpr int D = 2;
+    uint4 xraw[D + 1][KP / 4], wq[D + 1][NF];
+    auto issue = [&](int ks, int slot) {
+        load_x(ks, xraw[slot]);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) wq[slot][nf] = (nt0 + nf < p.ntiles) ? wp[(size_t)ks * wstep + nf * 64] : make_uint4(0, 0, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) if (d < p.ksteps) issue(d, d);
+    int ks = 0;
+    for (; ks + 3 <= p.ksteps; ks += 3) {                    // ring of three slots, unrolled so that the slot indices are static
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (ks + u + D < p.ksteps) issue(ks + u + D, (u + D) % 3);
+            const uint4 xf = to_frag(xraw[u]);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) mma32<CT>(acc[nf], wq[u][nf], xf);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                            // tail (< 3 steps): step ks + u sits in slot u (static indices)
+        if (ks + u < p.ksteps) {
+            const uint4 xf = to_frag(xraw[u]);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) mma32<CT>(acc[nf], wq[u][nf], xf);
+        }
+    }
+
+    // epilogue: lane = voxel `row`, registers 4q .. 4q+3 of fragment nf = output channels (nt0 + nf)*32 + 8q + 4*half .. + 3
+    if (row < p.R) {
+        float* yrow = p.y + (size_t)row * p.ldy;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = (nt0 + nf) * 32 + 8 * q + 4 * half;
+                if (n < p.N) {                               // N is a multiple of 4 (checked by the launcher)
+                    float4 o = make_float4(acc[nf][4 * q], acc[nf][4 * q + 1], acc[nf][4 * q + 2], acc[nf][4 * q + 3]);
+                    if (p.bias) { const float4 b = *(const float4*)(p.bias + n); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
+                    *(float4*)(yrow + n) = o;
+                }
+            }
+        }
+    }
+}
+
+template <typename CT>
+int launch_pw(const PwParams& p, hipStream_t st) {
+    const int nf = p.ntiles >= 4 ? 4 : p.ntiles >= 2 ? 2 : 1;
+    dim3 grid((unsigned)((p.R + 127) / 128), (unsigned)((p.ntiles + nf - 1) / nf)), block(256);
+    if (nf == 4) hipLaunchKernelGGL((pw_gemm_kernel<CT, 4>), grid, block, 0, st, p);
+    else if (nf == 2) hipLaunchKernelGGL((pw_gemm_kernel<CT, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((pw_gemm_kernel<CT, 1>), grid, block, 0, st, p);
+    return rs_check_launch();
+}
+
+}  // namespace
+
+size_t rs_pw_packed_bytes(int N, int K, int dtype) {
+    const int KS = dtype == RS_F32 ? 8 : 16;
+    return (size_t)((K + KS - 1) / KS) * ((N + 31) / 32) * 64 * 16;
+}
+
+// mode 0: y = x W^T (+ bias), W (N, K);  mode 1: y = x W, W (K, N) (the data gradient of mode 0 with x := dy)
+int rs_launch_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int R, int K, int N,
+                        void* packed, hipStream_t st) {
+    const int KS = dtype == RS_F32 ? 8 : 16;
+    PwParams p;
+    p.x = x; p.ldx = ldx; p.wp = packed; p.bias = bias; p.y = y; p.ldy = ldy; p.R = R; p.K = K; p.N = N;
+    p.ntiles = (N + 31) / 32; p.ksteps = (K + KS - 1) / KS;
+    const int items = p.ksteps * p.ntiles * 64;
+    const int rows = mode == 0 ? N : K, cols = mode == 0 ? K : N;
+    if (dtype == RS_F32) {
+        hipLaunchKernelGGL(pw_pack_kernel<float>, dim3((items + 255) / 256), dim3(256), 0, st, w, rows, cols, mode, p.ntiles, p.ksteps, (float*)packed);
+        return launch_pw<float>(p, st);
+    }
+    hipLaunchKernelGGL(pw_pack_kernel<bf16_t>, dim3((items + 255) / 256), dim3(256), 0, st, w, rows, cols, mode, p.ntiles, p.ksteps, (bf16_t*)packed);
+    return launch_pw<bf16_t>(p, st);
+}

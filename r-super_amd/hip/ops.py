@@ -1009,6 +1009,28 @@ def dilate_volume(vol_u8, kernel_size):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ pointwise GEMM
+def pointwise_gemm(x2, w, bias, mode, compute):
+    """csrc/pointwise.hip on f32 rows.  mode 0: y = x2 @ w.T (+ bias), w (N, K); mode 1: y = x2 @ w, w (K, N) (the data gradient of mode 0).
+    compute: torch.bfloat16 (bf16 MFMA, fp32 accumulate) or torch.float32 (exact-f32 MFMA); storage stays fp32."""
+    assert x2.dim() == 2 and x2.dtype == torch.float32 and x2.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+    R, K = x2.shape
+    N = w.shape[0] if mode == 0 else w.shape[1]
+    assert (w.shape[1] if mode == 0 else w.shape[0]) == K
+    dt = _DT[compute]
+    y = torch.empty((R, N), device=x2.device, dtype=torch.float32)
+    ws = torch.empty((_L().rsuper_pointwise_packed_bytes(dt, K, N),), device=x2.device, dtype=torch.uint8)
+    _l.check(_L().rsuper_pointwise(dt, mode, _ptr(x2), K, _ptr(w), _ptr(bias) if bias is not None else None, _ptr(y), N, R, K, N, _ptr(ws),
+                                   _stream()), 'pointwise')
+    return y
+
+
+def pointwise_supported(x, w):
+    """Shapes the HIP pointwise GEMM takes (f32 rows on the GPU, channel counts multiples of 4, below 4 GiB)."""
+    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0
+            and x.numel() * 4 < (1 << 32) and x.numel() // x.shape[-1] * w.shape[0] * 4 < (1 << 32))
+
+
 # ------------------------------------------------------------------------------------------------ dispatcher registration
 # every *Fn above becomes the torch.library op rsuper::<name> (schema + CUDA kernel + autograd formula); `XFn.apply` keeps working
 from . import library as _library   # noqa: E402

@@ -89,6 +89,9 @@ def upsample_trilinear(x, size, planar=False):
 
 # RSUPER_MF_ATEN_ATTENTION=1: the ATen composition of the attention core instead of csrc/battn.hip (A/B switch; same results to fp32 rounding)
 FUSED_ATTENTION = os.environ.get('RSUPER_MF_ATEN_ATTENTION') != '1'
+HIP_POINTWISE = os.environ.get('RSUPER_MF_LIBRARY_GEMM') != '1'      # 1x1x1 convolutions / linear layers on csrc/pointwise.hip (=1: library GEMMs, A/B)
+HIP_POINTWISE_MIN_ROWS = int(os.environ.get('RSUPER_MF_PW_MIN_ROWS', '8192'))   # below: library GEMM (few row blocks: the K loop of a block is latency-bound)
+GEMM_COMPUTE = torch.float32    # MFMA operand type of the HIP pointwise GEMMs: set per forward by MedFormer from its compute_dtype
 GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 operands for the 1x1x1 GEMMs, see medformer.py)
 
 
@@ -132,6 +135,11 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.hip = HIP_POINTWISE and x.numel() // x.shape[-1] >= HIP_POINTWISE_MIN_ROWS and ops.pointwise_supported(x, w)
+        ctx.compute = GEMM_COMPUTE
+        if ctx.hip:          # csrc/pointwise.hip: MFMA GEMM straight from the row-major rows (no library call, no staging copies)
+            wc = w.contiguous()
+            return ops.pointwise_gemm(x.reshape(-1, x.shape[-1]).contiguous(), wc, b, 0, ctx.compute).reshape(*x.shape[:-1], w.shape[0])
         with gemm_library(w.shape[1]):
             return F.linear(x, w, b)
 
@@ -141,8 +149,11 @@ class _LinearFn(torch.autograd.Function):
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            with gemm_library(w.shape[0]):
-                dx = torch.mm(dy2, w).reshape(x.shape)
+            if ctx.hip:
+                dx = ops.pointwise_gemm(dy2.contiguous(), w.contiguous(), None, 1, ctx.compute).reshape(x.shape)
+            else:
+                with gemm_library(w.shape[0]):
+                    dx = torch.mm(dy2, w).reshape(x.shape)
         if ctx.needs_input_grad[1]:
             rows = x2.shape[0]
             slabs = next((s for s in (32, 16, 8, 4) if rows % s == 0 and rows // s >= SPLITK_MIN_SLAB), 0) if rows >= SPLITK_MIN_ROWS else 0
@@ -178,6 +189,8 @@ def _ones_row(n, device):
 
 def linear(x, w, b=None):
     rows = x.numel() // x.shape[-1]
+    if HIP_POINTWISE and rows >= HIP_POINTWISE_MIN_ROWS and ops.pointwise_supported(x, w):
+        return _LinearFn.apply(x, w, b)
     if x.dtype == torch.float32 and (rows >= SPLITK_MIN_ROWS or (gemm_library.active and max(rows, w.shape[0], w.shape[1]) >= LT_MIN_K)):
         return _LinearFn.apply(x, w, b)
     return F.linear(x, w, b)

@@ -491,6 +491,25 @@ def check_linear_splitk(rows, cin, cout, bias, seed=99):
     return result(f'linear_splitk rows{rows} {cin}->{cout} bias{int(bias)}', max(errs), 2e-5)
 
 
+def check_pointwise(mode, R, K, N, bias, seed=103):
+    """csrc/pointwise.hip (1x1x1 convolution / linear layer as an MFMA GEMM, forward and data gradient) against float64 matmul:
+    exact-f32 MFMA at 2e-6 of the output scale, bf16 operands at 1.5e-2 (fp32 accumulate; measured 2e-3)."""
+    from rsuper_amd.hip import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(R, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) if bias else None
+    ref = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    dy = torch.randn(R, N, generator=g)
+    refd = dy.double() @ w.double()
+    comp = DT[mode]
+    y = ops.pointwise_gemm(x.to(DEV), w.to(DEV), b.to(DEV) if bias else None, 0, comp)
+    dx = ops.pointwise_gemm(dy.to(DEV), w.to(DEV), None, 1, comp)
+    torch.cuda.synchronize()
+    e = max(relerr(y.cpu(), ref), relerr(dx.cpu(), refd))
+    return result(f'pointwise[{mode} R{R} K{K} N{N} bias{int(bias)}]', e, 2e-6 if mode == 'f32' else 1.5e-2, 'forward + data gradient')
+
+
 def check_cl_planar(N, dims, C, K, seed=101):
     """Channels-last -> planar re-layout (csrc/instnorm.hip cl_planar_kernel) and its gradient: pure data movement, bit-exact against
     x[..., :K].permute(0, 4, 1, 2, 3) and the zero-padded inverse."""
@@ -832,7 +851,8 @@ def check_train_steps(mode='f32'):
 # ================================================================================================ registry
 def with_variant(variant, fn, *a):
     """Run a conv check under a forced igemm kernel variant (0 classic, 1 producer/consumer, 2 = round-1 auto choice,
-    4 = weight-stationary kernel on every 32-column launch); restores the default (3)."""
+    4 = weight-stationary kernel on every 32-column launch, 5 = producer/consumer v2, 6 / 7 = volume-fitted K-split kernel with the box
+    chosen per volume / the 4x4x4 box); restores the default (3)."""
     from rsuper_amd.hip import ops
     L = ops._L()
     L.rsuper_conv3_variant(variant)
@@ -868,7 +888,10 @@ def all_checks(quick=False):
             (check_unet_tiny_nopool, (mode,)),
             (check_unet_tiny, (mode,)),
         ]
-    for variant in (0, 1, 4, 5):        # every bf16 igemm kernel on every conv case (the default picks per launch)
+    for m in ('f32', 'bf16'):           # 1x1x1 convolutions of MedFormer's attention stages on MFMA: shipped shapes, ragged rows / channels
+        cs += [(check_pointwise, (m, 27648, 128, 512, False)), (check_pointwise, (m, 13824, 512, 128, True)), (check_pointwise, (m, 3456, 256, 1024, False)),
+               (check_pointwise, (m, 100, 36, 20, True)), (check_pointwise, (m, 33, 4, 4, False)), (check_pointwise, (m, 1000, 72, 260, True))]
+    for variant in (0, 1, 4, 5, 6, 7):  # every bf16 igemm kernel on every conv case (6 / 7: the volume-fitted K-split kernel, incl. its split-reduction shape) (the default picks per launch)
         cs += [(with_variant, (variant, fn) + a) for fn, a in list(cs) if fn in (check_conv_fwd, check_conv_bwd) and a[0] == 'bf16']
     cs += [(with_variant, (1, check_conv_fwd, 'bf16', 2, (8, 24, 32), 32, 0, 32, False, True)),       # persistent: several tiles per block
            (with_variant, (1, check_conv_fwd, 'bf16', 1, (12, 20, 48), 64, 64, 128, True, False)),    # 128 columns, 4 chunks, 2 sources
