@@ -240,7 +240,9 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         lmg = leg_of(args.dtype, False, medformer=True)
         lmg.use_graph()
         nm = min(n2, 10)
-        sec['medformer_graph_ms_per_step'] = lmg.timed(nm, 7) / nm * 1e3
+        # 3 eager warm-up steps + 13 replays: the step's self-verification against an eager step (replays 1 and 12, rsuper_amd/graph.py) falls
+        # into the warm-up; the timed replays are 14 .. 23
+        sec['medformer_graph_ms_per_step'] = lmg.timed(nm, 16) / nm * 1e3
         lmg.close()
 
     def medformer():
@@ -250,7 +252,7 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         sec['medformer_final_loss'] = lm.loss()
         sec['medformer_workload'] = ('MedFormer of config/abdomenatlas_ufo/medformer_3d.yaml (37.9 M parameters, deep supervision), same batch and '
                                      'segmentation loss: conv stem / BasicBlock stages / up-sampling / head / depthwise / InstanceNorm on the HIP kernels, '
-                                     '1x1x1 convolutions and attention products as library GEMMs (SURVEY 8f-1)')
+                                     '1x1x1 convolutions of the 24^3 / 48^3 stages on the HIP pointwise MFMA GEMM, the low-resolution ones, weight gradients and attention products as library GEMMs (SURVEY 8f-1)')
         lm.close()
 
     def medformer_report():
