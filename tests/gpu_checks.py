@@ -597,9 +597,22 @@ def check_medformer_tiny(mode):
     tol_y, tol_g = (1e-4, 6e-2) if mode == 'f32' else (0.15, 0.8)
     allg = (num / max(den, 1e-300)) ** 0.5
     eg = worst if mode == 'f32' else allg
-    return result(f'medformer_tiny[{mode}]', max(e_y / tol_y, e_a / tol_y, eg / tol_g), 1.0,
+    # f32 also against the FLOAT64 evaluation of the restatement (oracle/medformer_oracle.py, bit-exact against the reference class in fp32):
+    # separates kernel error from the rounding noise of the fp32 fixture.  Measured: HIP 4.2e-2 of max from float64, the fp32 reference
+    # itself 3.2e-2 (tools/medformer_diag.py) -> bound 5e-2, i.e. within 1.5x of the reference's own distance.
+    w64 = 0.0
+    if mode == 'f32':
+        from oracle import medformer_oracle as mo
+        sd = {k: T(v).double().requires_grad_(True) for k, v in synth.fill_state_dict(shapes, cfg['seed']).items()}
+        y64, a64 = mo.medformer_forward(sd, T(synth.image(1, cfg['size'], seed=1234)).double(), cfg)
+        ((y64 * T(go).double()).sum() + (a64 * T(ga).double()).sum()).backward()
+        g64max = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+        for k, p in net.named_parameters():
+            f64 = synth.subsample(sd[k].grad.numpy(), 1024)[0]
+            w64 = max(w64, float(np.abs(synth.subsample(p.grad.cpu().numpy(), 1024)[0] - f64).max() / max(np.abs(f64).max(), 1e-3 * g64max)))
+    return result(f'medformer_tiny[{mode}]', max(e_y / tol_y, e_a / tol_y, eg / tol_g, w64 / 5e-2), 1.0,
                   f'logits {e_y:.2e} aux {e_a:.2e} (tol {tol_y}); worst grad {worst:.2e} @ {wk}; all gradients rel-L2 {allg:.2e} (tol {tol_g} on '
-                  f'{"the worst tensor" if mode == "f32" else "all gradients"})')
+                  f'{"the worst tensor" if mode == "f32" else "all gradients"}); worst grad vs float64 restatement {w64:.2e} (tol 5e-2)')
 
 
 def check_plane_partials():
