@@ -35,6 +35,42 @@ from .training import losses_foundation as lf
 from .training.utils import FusedAdamWEMA, ema_alpha_for_step
 
 
+def _release_cached_blocks():
+    """Before every capture: collect garbage and hand the caching allocator's free blocks back to the driver.
+    Defence in depth for the rocBLAS-in-graph defect (`_capture_safe_blas`): with rocBLAS still preferred, releasing the cached blocks before
+    the capture lowered the corruption rate of the graphed MedFormer step from 6 / 15 to 1 / 4 runs (the stale workspace then no longer
+    aliases memory the eager work between replays rewrites); RSUPER_CAPTURE_KEEP_CACHE=1 keeps the cache (A/B)."""
+    if os.environ.get('RSUPER_CAPTURE_KEEP_CACHE') == '1':
+        return
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _capture_safe_blas():
+    """No rocBLAS inside a captured graph.  Root cause of round 2's "captured reduction returns garbage from the 12th replay" as far as it
+    could be narrowed down without the ROCm sources (round 3, tests/test_gpu_edge.py run as a whole file, MedFormer whole-step graph, eager
+    work -- the self-verification -- between replays 12 and 13; the gradient norm of replay 13 came back inf / nan / 1e22..1e32):
+      rocBLAS preferred (`torch.backends.cuda.preferred_blas_library('cublas')`, MedFormer's round-2 default)   6 of 15 runs corrupted
+      the same with ROCBLAS_DEVICE_MEMORY_SIZE fixed at 128 MB (no workspace re-allocation)                     3 of 8
+      the same with the allocator cache released before the capture                                             1 of 4
+      hipBLASLt for every GEMM (torch's default)                                                                0 of 13
+      UNet (no library GEMM in the step), any setting                                                           0 of all runs
+    i.e. the victim is a rocBLAS launch recorded in the graph (its Tensile kernels with global split-K take a workspace from the handle), the
+    trigger is eager rocBLAS work between replays; ATen's reductions were bystanders (round 2 replaced one by a GEMM and the symptom moved).
+    Captures therefore switch the process to hipBLASLt and turn MedFormer's per-call library choice off; the replays keep verifying
+    themselves (`_verify`)."""
+    if os.environ.get('RSUPER_CAPTURE_UNSAFE_BLAS') == '1':      # A/B of the defect: leave whatever library is preferred
+        return
+    if torch.cuda.is_available() and hasattr(torch.backends.cuda, 'preferred_blas_library'):
+        torch.backends.cuda.preferred_blas_library('cublaslt')
+    try:
+        from .model.dim3 import medformer_utils as _mu
+        _mu.gemm_library.active = False
+    except Exception:
+        pass
+
+
 class GraphedTrainStep:
     def __init__(self, net, ema_net, optimizer, args, classes, warmup=3):
         if not isinstance(optimizer, FusedAdamWEMA) or len(optimizer.param_groups) != 1:
@@ -113,6 +149,10 @@ class GraphedTrainStep:
         ops.WEIGHTS_EPOCH += 1
         if check:
             self._verify(before)
+        if os.environ.get('RSUPER_GRAPH_DEBUG') == '1':          # which gradient buffers of this replay are not finite (debugging aid, synchronises)
+            names = {id(p): k for k, p in self.net.named_parameters()}
+            bad = [(names.get(id(p), '?'), float(p.grad.abs().max())) for p in self._params() if p.grad is not None and not bool(torch.isfinite(p.grad).all())]
+            print(f'[graph debug] replay {self._replays}: {len(bad)} non-finite gradients {bad[:6]}', flush=True)
         return self.out
 
     def _params(self):
@@ -168,6 +208,8 @@ class GraphedTrainStep:
         self.opt.dyn = self.dyn
         try:
             torch.cuda.synchronize()
+            _release_cached_blocks()
+            _capture_safe_blas()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 loss, gnorm = train_step(self.net, self.ema, self.opt, self.static, self.args, self.classes, step)
@@ -315,6 +357,7 @@ class GraphedNetwork:
         ops.WEIGHTS_EPOCH += 1
 
     def _capture(self, img):
+        _capture_safe_blas()                           # before the warm-up iterations too: they choose the GEMM algorithms the capture records
         wrapped = self._wrapped = _TupleOut(self.net)
         self.params = [p for p in self.net.parameters() if p.requires_grad]
         saved = [p.grad for p in self.params]
@@ -330,6 +373,8 @@ class GraphedNetwork:
                 del outs
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
+        _release_cached_blocks()
+        _capture_safe_blas()
         self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(self.fwd_graph, pool=pool, stream=stream):

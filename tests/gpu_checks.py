@@ -480,11 +480,16 @@ def check_linear_splitk(rows, cin, cout, bias, seed=99):
     xd, wd = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
     bd = b.detach().to(DEV).requires_grad_(True) if bias else None
     assert rows >= mu.SPLITK_MIN_ROWS
-    mu.gemm_library.active = True                       # the per-call library switch of the MedFormer default
+    prev, was = torch.backends.cuda.preferred_blas_library(), mu.gemm_library.active
+    mu.gemm_library.active = True                       # the per-call library switch of the opt-in rocBLAS mode (RSUPER_MF_BLAS=cublas)
     torch.backends.cuda.preferred_blas_library('cublas')
-    y = mu.linear(xd, wd, bd)
-    (y * go.to(DEV)).sum().backward()
-    torch.cuda.synchronize()
+    try:
+        y = mu.linear(xd, wd, bd)
+        (y * go.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+    finally:                                            # process-wide setting: leave it as it was for the checks that follow
+        mu.gemm_library.active = was
+        torch.backends.cuda.preferred_blas_library(prev)
     errs = [relerr(y.detach().cpu(), y_ref.detach().float()), relerr(xd.grad.cpu(), x.grad), relerr(wd.grad.cpu(), w.grad)]
     if bias:
         errs.append(relerr(bd.grad.cpu(), b.grad))
