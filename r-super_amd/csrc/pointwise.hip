@@ -50,14 +50,20 @@ __global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ 
     *(uint4*)(out + (size_t)idx * KP) = pack16<CT>(f);
 }
 
-// block = 4 waves, wave = 32 voxel rows x NF*32 output channels; grid (row blocks of 128, column blocks of NF*32)
-template <typename CT, int NF>
+// block = 4 waves.  KSPLIT = false: wave = 32 voxel rows x NF*32 output channels, the block covers 128 rows (grid: row blocks of 128 x column
+// blocks of NF*32).  KSPLIT = true (few rows, long reductions: the 12^3 / 6^3 stages -- 27 row blocks of 128 would leave the chip empty and every
+// wave with a 64-step dependent chain): the four waves take a quarter of the k-steps each for the SAME 32 rows (grid: row blocks of 32) and
+// waves 1-3 hand their partial tiles to wave 0 through LDS, which adds them in wave order (deterministic) and stores.
+template <typename CT, int NF, bool KSPLIT>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwParams p) {
     constexpr int KP = Elem<CT>::KP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int v = lane & 31, half = lane >> 5;
-    const int row = (blockIdx.x * 4 + wave) * 32 + v;
+    const int row = (KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave) * 32 + v;
     const int nt0 = blockIdx.y * NF;
+    const int kper = KSPLIT ? (p.ksteps + 3) / 4 : p.ksteps;                   // k-steps of this wave: [kbeg, kend)
+    const int kbeg = KSPLIT ? wave * kper : 0;
+    const int kend = KSPLIT ? (kbeg + kper < p.ksteps ? kbeg + kper : p.ksteps) : p.ksteps;
     // activations through a buffer descriptor: rows past R and channels past K read zeros (no branches around the loads)
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)((size_t)p.R * p.ldx * 4), 0x00020000);
     const uint32_t xrow = row < p.R ? (uint32_t)row * (uint32_t)p.ldx * 4u : 0xFFFFFFFFu;
@@ -97,12 +103,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwParams p) {
         for (int nf = 0; nf < NF; ++nf) wq[slot][nf] = (nt0 + nf < p.ntiles) ? wp[(size_t)ks * wstep + nf * 64] : make_uint4(0, 0, 0, 0);
     };
 #pragma unroll
-    for (int d = 0; d < D; ++d) if (d < p.ksteps) issue(d, d);
-    int ks = 0;
-    for (; ks + 3 <= p.ksteps; ks += 3) {                    // ring of three slots, unrolled so that the slot indices are static
+    for (int d = 0; d < D; ++d) if (kbeg + d < kend) issue(kbeg + d, d);
+    int ks = kbeg;
+    for (; ks + 3 <= kend; ks += 3) {                        // ring of three slots, unrolled so that the slot indices are static
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            if (ks + u + D < p.ksteps) issue(ks + u + D, (u + D) % 3);
+            if (ks + u + D < kend) issue(ks + u + D, (u + D) % 3);
             const uint4 xf = to_frag(xraw[u]);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) mma32<CT>(acc[nf], wq[u][nf], xf);
@@ -110,13 +116,33 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwParams p) {
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                            // tail (< 3 steps): step ks + u sits in slot u (static indices)
-        if (ks + u < p.ksteps) {
+        if (ks + u < kend) {
             const uint4 xf = to_frag(xraw[u]);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) mma32<CT>(acc[nf], wq[u][nf], xf);
         }
     }
 
+    if constexpr (KSPLIT) {                                  // partial tiles of waves 1-3 -> wave 0 (16-byte lane-contiguous rows: conflict-free)
+        __shared__ float4 xch[3][NF][4][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xch[wave - 1][nf][q][lane] = make_float4(acc[nf][4 * q], acc[nf][4 * q + 1], acc[nf][4 * q + 2], acc[nf][4 * q + 3]);
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t = xch[w][nf][q][lane];
+                    acc[nf][4 * q] += t.x; acc[nf][4 * q + 1] += t.y; acc[nf][4 * q + 2] += t.z; acc[nf][4 * q + 3] += t.w;
+                }
+    }
     // epilogue: lane = voxel `row`, registers 4q .. 4q+3 of fragment nf = output channels (nt0 + nf)*32 + 8q + 4*half .. + 3
     if (row < p.R) {
         float* yrow = p.y + (size_t)row * p.ldy;
@@ -138,10 +164,19 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwParams p) {
 template <typename CT>
 int launch_pw(const PwParams& p, hipStream_t st) {
     const int nf = p.ntiles >= 4 ? 4 : p.ntiles >= 2 ? 2 : 1;
-    dim3 grid((unsigned)((p.R + 127) / 128), (unsigned)((p.ntiles + nf - 1) / nf)), block(256);
-    if (nf == 4) hipLaunchKernelGGL((pw_gemm_kernel<CT, 4>), grid, block, 0, st, p);
-    else if (nf == 2) hipLaunchKernelGGL((pw_gemm_kernel<CT, 2>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((pw_gemm_kernel<CT, 1>), grid, block, 0, st, p);
+    const unsigned gy = (unsigned)((p.ntiles + nf - 1) / nf);
+    // split the reduction over the waves when whole-K blocks of 128 rows would cover less than half of the CUs
+    const bool ksplit = p.ksteps >= 8 && (long)((p.R + 127) / 128) * gy < 128;   // measured: 216 whole-K blocks beat 864 split ones (26 vs 37 us), 54 lose (37 vs 17 us)
+    dim3 grid((unsigned)((p.R + (ksplit ? 31 : 127)) / (ksplit ? 32 : 128)), gy), block(256);
+    if (ksplit) {
+        if (nf == 4) hipLaunchKernelGGL((pw_gemm_kernel<CT, 4, true>), grid, block, 0, st, p);
+        else if (nf == 2) hipLaunchKernelGGL((pw_gemm_kernel<CT, 2, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((pw_gemm_kernel<CT, 1, true>), grid, block, 0, st, p);
+    } else {
+        if (nf == 4) hipLaunchKernelGGL((pw_gemm_kernel<CT, 4, false>), grid, block, 0, st, p);
+        else if (nf == 2) hipLaunchKernelGGL((pw_gemm_kernel<CT, 2, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((pw_gemm_kernel<CT, 1, false>), grid, block, 0, st, p);
+    }
     return rs_check_launch();
 }
 

@@ -90,7 +90,7 @@ def upsample_trilinear(x, size, planar=False):
 # RSUPER_MF_ATEN_ATTENTION=1: the ATen composition of the attention core instead of csrc/battn.hip (A/B switch; same results to fp32 rounding)
 FUSED_ATTENTION = os.environ.get('RSUPER_MF_ATEN_ATTENTION') != '1'
 HIP_POINTWISE = os.environ.get('RSUPER_MF_LIBRARY_GEMM') != '1'      # 1x1x1 convolutions / linear layers on csrc/pointwise.hip (=1: library GEMMs, A/B)
-HIP_POINTWISE_MIN_ROWS = int(os.environ.get('RSUPER_MF_PW_MIN_ROWS', '8192'))   # below: library GEMM (few row blocks: the K loop of a block is latency-bound)
+HIP_POINTWISE_MIN_ROWS = int(os.environ.get('RSUPER_MF_PW_MIN_ROWS', '256'))    # below (the 27-token maps): library GEMM
 GEMM_COMPUTE = torch.float32    # MFMA operand type of the HIP pointwise GEMMs: set per forward by MedFormer from its compute_dtype
 GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 operands for the 1x1x1 GEMMs, see medformer.py)
 

@@ -908,6 +908,7 @@ def all_checks(quick=False):
         ]
     for m in ('f32', 'bf16'):           # 1x1x1 convolutions of MedFormer's attention stages on MFMA: shipped shapes, ragged rows / channels
         cs += [(check_pointwise, (m, 27648, 128, 512, False)), (check_pointwise, (m, 13824, 512, 128, True)), (check_pointwise, (m, 3456, 256, 1024, False)),
+               (check_pointwise, (m, 3456, 1024, 256, True)), (check_pointwise, (m, 432, 320, 1280, False)),       # reduction split over the waves
                (check_pointwise, (m, 100, 36, 20, True)), (check_pointwise, (m, 33, 4, 4, False)), (check_pointwise, (m, 1000, 72, 260, True))]
     for variant in (0, 1, 4, 5, 6, 7):  # every bf16 igemm kernel on every conv case (6 / 7: the volume-fitted K-split kernel, incl. its split-reduction shape) (the default picks per launch)
         cs += [(with_variant, (variant, fn) + a) for fn, a in list(cs) if fn in (check_conv_fwd, check_conv_bwd) and a[0] == 'bf16']
