@@ -106,7 +106,15 @@ int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, cons
 int rsuper_conv3_tiles(int D, int H, int W) { return ((D + 3) / 4) * ((H + 3) / 4) * ((W + 15) / 16); }
 
 static int g_variant = 3;
+int rsuper_has_experimental(void) {
+#ifdef RS_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
 int rsuper_conv3_variant(int v) {
+    if (v == 5 && !rsuper_has_experimental()) return g_variant;      // variant 5 only exists in `make EXPERIMENTAL=1` builds
     if (v >= 0 && v <= 7) g_variant = v;
     return g_variant;
 }

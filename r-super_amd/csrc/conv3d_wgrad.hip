@@ -361,6 +361,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
 // two 64-byte halves swapped on rows with bit 1 set, which keeps the four rows of a ds_read_b64_tr_b16 group on disjoint
 // bank ranges (the padded 192-byte pitch would not fit twice).
 // =====================================================================================================================
+#ifdef RS_EXPERIMENTAL                                          // measured slower than the single-buffer kernel: `make EXPERIMENTAL=1` only
 template <int MT>
 __global__ __launch_bounds__(512, 2) void wgrad_db_kernel(WgradParams p) {
     typedef bf16_t T;
@@ -605,6 +606,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_db_kernel(WgradParams p) {
         }
     }
 }
+
+#endif
 
 // =====================================================================================================================
 // Producer / consumer (wave-specialised) variant, bf16.  NCW consumer waves run the VALU-free MFMA loop (two
@@ -975,6 +978,7 @@ int launch(const WgradParams& p, hipStream_t st) {
     return rs_check_launch();
 }
 
+#ifdef RS_EXPERIMENTAL
 template <int MT>
 int launch_db(const WgradParams& p, hipStream_t st) {
     const size_t smem = 2 * ((size_t)(TD + 2) * HH * HW * 64 + 256 * MT * 64);
@@ -988,6 +992,7 @@ int launch_db(const WgradParams& p, hipStream_t st) {
     launch_reduce(p, st);
     return rs_check_launch();
 }
+#endif
 
 template <int MT, int NTAPS, int TR, int NCW, bool PF2>
 int launch_pc(const WgradParams& p, hipStream_t st) {
@@ -1047,9 +1052,11 @@ static int launch_wgrad_impl(const WgradParams& p, int dtype, int use_tr, hipStr
     if (dtype == RS_BF16) {
         // config 0 runs the producer/consumer kernel (177 -> 131 us on 32->32 @96^3); on configs 1/2 it measured equal or
         // slower (12 waves hit the 168-VGPR cap) and the classic kernel stays
+#ifdef RS_EXPERIMENTAL
         static const int db = getenv("RSUPER_WGRAD_DB") ? atoi(getenv("RSUPER_WGRAD_DB")) : 0;   // double-buffered kernel (opt-in: measured slower than the single-buffer kernel)
         if (use_tr && db && cfg == 0) return launch_db<1>(p, st);
         if (use_tr && db && cfg == 2) return launch_db<2>(p, st);
+#endif
         static const int c0 = getenv("RSUPER_WGRAD_CFG0") ? atoi(getenv("RSUPER_WGRAD_CFG0")) : 2;   // 0: producer/consumer kernel, 1 / 2: classic kernel with 4 / 8 waves (155 vs 161 us on 32 -> 32 @96^3)
         if (use_tr && cfg == 0 && c0 == 1) return launch<bf16_t, 1, 27, 1, 4>(p, st);
         if (use_tr && cfg == 0 && c0 == 2) return launch<bf16_t, 1, 27, 1, 8>(p, st);

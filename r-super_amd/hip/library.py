@@ -1,5 +1,5 @@
 """torch.library registration of the HIP ops: every operator of the hot path is a dispatcher op `rsuper::<name>` with a schema, a CUDA
-(= HIP on ROCm) kernel registration and an autograd formula (`torch.library.register_autograd`) -- "the conv / norm / loss ops are
+(= HIP on ROCm) kernel registration and an autograd formula (an AutogradCUDA registration, see below) -- "the conv / norm / loss ops are
 registered as custom HIP ops behind the repo's existing model/ and training/ interfaces" (BASELINE.json north_star).  The modules call
 `torch.ops.rsuper.*` through the `*Fn.apply` names they always used (hip/ops.py rebinds them to the registered ops at import).
 
