@@ -139,6 +139,18 @@ int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Y
 size_t rsuper_pointwise_packed_bytes(int dtype, int K, int N);
 int rsuper_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, long R, int K, int N,
                      void* packed, void* stream);
+/* The fragments of MANY weights in one launch.  table (device): n + 1 rows of 8 x int64 {weight pointer (f32, row-major rows x cols), byte offset
+ * of its fragments in `arena`, rows, cols, mode, ceil(N / 32), k-steps = ceil(K / (dtype == f32 ? 8 : 16)), first item}; an item is one 16-byte
+ * fragment slot (64 per (k-step, 32-row tile)), numbered through all entries; row n holds {.., first item = total_items}.  rsuper_pointwise with
+ * w == nullptr then takes `packed` = arena + offset as is. */
+int rsuper_pointwise_pack_batch(int dtype, const long long* table, int n, long total_items, void* arena, void* stream);
+/* Weight and bias gradient of the same layer (autograd of F.linear / Conv3d(k=1) under loss.backward(), train_ddp.py:349):
+ *   dw[n][k] = sum_r dy[r][n] x[r][k]  (N, K) f32, overwritten;   db[n] = sum_r dy[r][n] (nullptr: not wanted)
+ * The rows are cut into `splits` = rsuper_pointwise_wgrad_splits(R, N, K) slabs whose partial results go through `workspace`
+ * (splits * (N*K + N) floats) and are added in slab order (deterministic).  N, K multiples of 4; (R + 1) * ld * 4 < 2^32. */
+int rsuper_pointwise_wgrad_splits(long R, int N, int K);
+int rsuper_pointwise_wgrad(int dtype, const float* dy, int ldy, const float* x, int ldx, long R, int N, int K, float* workspace, int splits,
+                           float* dw, float* db, void* stream);
 
 /* part [N][nblk][C][2] -> out [N][C][2]: mode 0 (mean, rstd = 1/sqrt(var+eps)), mode 1 (sum0/cnt, sum1/cnt).
  * split > 0 writes two contiguous tables instead, [N][split][2] followed by [N][C-split][2] (the column groups of a fused

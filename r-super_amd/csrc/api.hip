@@ -258,10 +258,23 @@ int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Y
 size_t rsuper_pointwise_packed_bytes(int dtype, int K, int N) { return dt_ok(dtype) && K > 0 && N > 0 ? rs_pw_packed_bytes(N, K, dtype) : 0; }
 int rsuper_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, long R, int K, int N,
                      void* packed, void* stream) {
-    if (!dt_ok(dtype) || (mode != 0 && mode != 1) || !x || !w || !y || !packed || R <= 0 || K <= 0 || N <= 0) return RS_ERR_ARG;
+    if (!dt_ok(dtype) || (mode != 0 && mode != 1) || !x || !y || !packed || R <= 0 || K <= 0 || N <= 0) return RS_ERR_ARG;   // w == nullptr: `packed` already holds the fragments
     if ((N % 4) || (ldx % 4) || (ldy % 4) || ldx < K || ldy < N || (mode == 1 && bias)) return RS_ERR_ARG;
     if ((unsigned long long)R * ldx * 4ull >= (1ull << 32) || R > 0x7FFFFFFFl) return RS_ERR_UNSUPPORTED;   // buffer-addressed operand loads
     return rs_launch_pointwise(dtype, mode, x, ldx, w, bias, y, ldy, (int)R, K, N, packed, ST(stream));
+}
+
+int rsuper_pointwise_pack_batch(int dtype, const long long* table, int n, long total_items, void* arena, void* stream) {
+    if (!dt_ok(dtype) || !table || n <= 0 || total_items <= 0 || !arena) return RS_ERR_ARG;
+    return rs_launch_pointwise_pack_batch(dtype, table, n, total_items, arena, ST(stream));
+}
+int rsuper_pointwise_wgrad_splits(long R, int N, int K) { return (R > 0 && R <= 0x7FFFFFFFl && N > 0 && K > 0) ? rs_pw_wgrad_splits((int)R, N, K) : 0; }
+int rsuper_pointwise_wgrad(int dtype, const float* dy, int ldy, const float* x, int ldx, long R, int N, int K, float* workspace, int splits,
+                           float* dw, float* db, void* stream) {
+    if (!dt_ok(dtype) || !dy || !x || !workspace || !dw || R <= 0 || N <= 0 || K <= 0 || splits <= 0) return RS_ERR_ARG;
+    if ((N % 4) || (K % 4) || ldy < N || ldx < K) return RS_ERR_ARG;
+    if ((unsigned long long)(R + 1) * ldx * 4ull >= (1ull << 32) || (unsigned long long)(R + 1) * ldy * 4ull >= (1ull << 32)) return RS_ERR_UNSUPPORTED;
+    return rs_launch_pointwise_wgrad(dtype, dy, ldy, x, ldx, (int)R, N, K, workspace, splits, dw, db, ST(stream));
 }
 
 int rsuper_stats_finalize(const float* part, int N, int nblk, int C, double cnt, float eps, int mode, int split, float* out, void* stream) {

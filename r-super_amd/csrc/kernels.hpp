@@ -75,3 +75,8 @@ int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
 size_t rs_pw_packed_bytes(int N, int K, int dtype);
 int rs_launch_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int R, int K, int N,
                         void* packed, hipStream_t st);
+// weight (+ bias) gradient of the same layer: dW = dy^T x, db = column sums of dy; part = workspace of S * (N*K + N) floats, S = rs_pw_wgrad_splits
+int rs_pw_wgrad_splits(int R, int N, int K);
+int rs_launch_pointwise_pack_batch(int dtype, const long long* table, int n, long total_items, void* arena, hipStream_t st);
+int rs_launch_pointwise_wgrad(int dtype, const float* dy, int ldy, const float* x, int ldx, int R, int N, int K, float* part, int S,
+                              float* dw, float* db, hipStream_t st);

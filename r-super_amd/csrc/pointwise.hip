@@ -50,6 +50,35 @@ __global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ 
     *(uint4*)(out + (size_t)idx * KP) = pack16<CT>(f);
 }
 
+// The same packing for MANY weights in one launch (one MedFormer step packs 156 fragments sets: 0.8 ms of 5-us launches one by one).
+// table: n rows of 8 x int64 {w pointer, byte offset of the fragments in `arena`, rows, cols, mode, ntiles, ksteps, first item}, items = 16-byte
+// fragment slots numbered through all entries (row n holds the total); a thread finds its entry by bisection (the table stays in L2).
+template <typename CT>
+__global__ __launch_bounds__(256) void pw_pack_batch_kernel(const long long* __restrict__ table, int n, long total, char* arena) {
+    constexpr int KP = Elem<CT>::KP;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int lo = 0, hi = n;                                       // largest e with first_item[e] <= idx
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (table[(size_t)mid * 8 + 7] <= idx) lo = mid; else hi = mid;
+    }
+    const long long* d = table + (size_t)lo * 8;
+    const float* w = (const float*)d[0];
+    const int rows = (int)d[2], cols = (int)d[3], mode = (int)d[4], ntiles = (int)d[5];
+    const int li = (int)(idx - d[7]);
+    const int lane = li & 63, nt = (li >> 6) % ntiles, ks = (li >> 6) / ntiles;
+    const int nn = nt * 32 + (lane & 31), k0 = ks * 2 * KP + (lane >> 5) * KP;
+    const int N = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
+    float f[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int k = k0 + j;
+        f[j] = (nn < N && k < K) ? (mode == 0 ? w[(size_t)nn * cols + k] : w[(size_t)k * cols + nn]) : 0.f;
+    }
+    *(uint4*)(arena + d[1] + (size_t)li * 16) = pack16<CT>(f);
+}
+
 // block = 4 waves.  KSPLIT = false: wave = 32 voxel rows x NF*32 output channels, the block covers 128 rows (grid: row blocks of 128 x column
 // blocks of NF*32).  KSPLIT = true (few rows, long reductions: the 12^3 / 6^3 stages -- 27 row blocks of 128 would leave the chip empty and every
 // wave with a 64-step dependent chain): the four waves take a quarter of the k-steps each for the SAME 32 rows (grid: row blocks of 32) and
@@ -180,6 +209,148 @@ int launch_pw(const PwParams& p, hipStream_t st) {
     return rs_check_launch();
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight (+ bias) gradient
+//   dW[n][k] = sum_r dy[r][n] * x[r][k],   db[n] = sum_r dy[r][n]            (dy: [R][ldy] f32, x: [R][ldx] f32, dW: (N, K) as the state_dict)
+// The reduction runs over the SLOW memory axis of both operands, so a lane's fragment (KP consecutive reduction steps of one channel) is KP
+// dword loads, each a coalesced 128-byte row segment across the 32 lanes of a half-wave -- no LDS transpose, no barrier.  Wave = 64 x 64
+// output tile (2 x 2 fragments: 4 MFMAs per 4 fragments), block = 4 waves as WNW x (4 / WNW) tiles, blockIdx.z = slab of the rows; every
+// slab writes its partial dW (and the column sums of dy, accumulated from the A fragments already in registers) with plain stores and
+// pw_wgrad_reduce_kernel adds the slabs in slab order (deterministic; round 2: torch.bmm over slabs + .sum(0), and a ones-row GEMM for db).
+struct PwWgParams {
+    const float* dy; int ldy;
+    const float* x; int ldx;
+    float* part;                   // [S][N*K + N]
+    int R, N, K, rows_per, bias;
+};
+
+template <typename CT, int WNW>
+__global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgParams p) {
+    constexpr int KP = Elem<CT>::KP, RS = 2 * KP;                              // rows per MFMA step: 16 (bf16) / 8 (f32)
+    constexpr int WKW = 4 / WNW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, half = lane >> 5;
+    const int wn = wave / WKW, wk = wave % WKW;
+    const int n0 = (blockIdx.x * WNW + wn) * 64, k0 = (blockIdx.y * WKW + wk) * 64;
+    const int rbeg = blockIdx.z * p.rows_per;
+    const int rend = rbeg + p.rows_per < p.R ? rbeg + p.rows_per : p.R;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (uint32_t)((size_t)p.R * p.ldy * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)((size_t)p.R * p.ldx * 4), 0x00020000);
+    // channels past N / K are clamped to a valid column: they only reach accumulator rows / columns that are never stored
+    uint32_t an[2], bk[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int n = n0 + m * 32 + c, k = k0 + m * 32 + c;
+        an[m] = (uint32_t)(n < p.N ? n : p.N - 1) * 4u;
+        bk[m] = (uint32_t)(k < p.K ? k : p.K - 1) * 4u;
+    }
+    // rows past the slab read zeros: an offset past num_records that cannot wrap when the column is added (the launcher checks (R + 1) * ld * 4 < 2^32)
+    const uint32_t oob_y = 0xFFFFFFFFu - (uint32_t)p.ldy * 4u, oob_x = 0xFFFFFFFFu - (uint32_t)p.ldx * 4u;
+    const uint32_t sy = (uint32_t)p.ldy * 4u, sx = (uint32_t)p.ldx * 4u;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+    float bs[2] = {0.f, 0.f};
+    const bool do_bias = p.bias && blockIdx.y == 0 && wk == 0;
+
+    float ya[2][2][KP], xb[2][2][KP];                                         // [slot][fragment][reduction step]
+    auto issue = [&](int r0, int slot) {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const int r = r0 + half * KP + j;
+            const uint32_t oy = r < rend ? (uint32_t)r * sy : oob_y, ox = r < rend ? (uint32_t)r * sx : oob_x;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ya[slot][m][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, oy + an[m], 0, 0));
+                xb[slot][m][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ox + bk[m], 0, 0));
+            }
+        }
+    };
+    auto compute = [&](int slot) {
+        uint4 a[2], b[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < KP; ++j) bs[m] += ya[slot][m][j];
+            }
+            a[m] = pack16<CT>(ya[slot][m]);
+            b[m] = pack16<CT>(xb[slot][m]);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) mma32<CT>(acc[m][q], a[m], b[q]);
+    };
+    if (n0 < p.N && k0 < p.K) {                                                // wave-uniform: tiles wholly outside the matrix do nothing
+        int r = rbeg;
+        if (r < rend) issue(r, 0);
+        for (; r + RS < rend; r += 2 * RS) {                                   // two steps per trip: static slot indices
+            issue(r + RS, 1);
+            compute(0);
+            if (r + 2 * RS < rend) issue(r + 2 * RS, 0);
+            compute(1);
+        }
+        if (r < rend) compute(0);
+    }
+    // C layout: column (x channel) = lane & 31, row (dy channel) of register reg = (reg & 3) + 8 * (reg >> 2) + 4 * half
+    float* part = p.part + (size_t)blockIdx.z * ((size_t)p.N * p.K + p.N);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = k0 + q * 32 + c;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int n = n0 + m * 32 + cd_row32(reg, lane);
+                if (n < p.N && k < p.K) part[(size_t)n * p.K + k] = acc[m][q][reg];
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float t = bs[m] + __shfl_xor(bs[m], 32);
+            const int n = n0 + m * 32 + c;
+            if (half == 0 && n < p.N) part[(size_t)p.N * p.K + n] = t;
+        }
+    }
+}
+
+// dW / db = sum over the slabs, in slab order.  One float4 of the (N*K + N)-element slab per thread, four slab loads in flight.
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __restrict__ part, int S, long E, long NK, float* dw, float* db) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= E) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = 0;
+    for (; i + 4 <= S; i += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(part + (size_t)(i + u) * E + e);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; i < S; ++i) { const float4 v = *(const float4*)(part + (size_t)i * E + e); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    if (e < NK) *(float4*)(dw + e) = s;
+    else if (db) *(float4*)(db + (e - NK)) = s;
+}
+
+template <typename CT>
+int launch_pw_wgrad(const PwWgParams& p, int S, float* dw, float* db, hipStream_t st) {
+    const int wnw = p.N <= 64 ? 1 : p.K <= 64 ? 4 : 2;
+    dim3 grid((unsigned)((p.N + wnw * 64 - 1) / (wnw * 64)), (unsigned)((p.K + (4 / wnw) * 64 - 1) / ((4 / wnw) * 64)), (unsigned)S), block(256);
+    if (wnw == 1) hipLaunchKernelGGL((pw_wgrad_kernel<CT, 1>), grid, block, 0, st, p);
+    else if (wnw == 4) hipLaunchKernelGGL((pw_wgrad_kernel<CT, 4>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((pw_wgrad_kernel<CT, 2>), grid, block, 0, st, p);
+    const long NK = (long)p.N * p.K, E = NK + p.N;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((E / 4 + 255) / 256)), dim3(256), 0, st, (const float*)p.part, S, E, NK, dw, db);
+    return rs_check_launch();
+}
+
 }  // namespace
 
 size_t rs_pw_packed_bytes(int N, int K, int dtype) {
@@ -197,9 +368,37 @@ int rs_launch_pointwise(int dtype, int mode, const float* x, int ldx, const floa
     const int items = p.ksteps * p.ntiles * 64;
     const int rows = mode == 0 ? N : K, cols = mode == 0 ? K : N;
     if (dtype == RS_F32) {
-        hipLaunchKernelGGL(pw_pack_kernel<float>, dim3((items + 255) / 256), dim3(256), 0, st, w, rows, cols, mode, p.ntiles, p.ksteps, (float*)packed);
+        if (w) hipLaunchKernelGGL(pw_pack_kernel<float>, dim3((items + 255) / 256), dim3(256), 0, st, w, rows, cols, mode, p.ntiles, p.ksteps, (float*)packed);
         return launch_pw<float>(p, st);
     }
-    hipLaunchKernelGGL(pw_pack_kernel<bf16_t>, dim3((items + 255) / 256), dim3(256), 0, st, w, rows, cols, mode, p.ntiles, p.ksteps, (bf16_t*)packed);
+    if (w) hipLaunchKernelGGL(pw_pack_kernel<bf16_t>, dim3((items + 255) / 256), dim3(256), 0, st, w, rows, cols, mode, p.ntiles, p.ksteps, (bf16_t*)packed);
     return launch_pw<bf16_t>(p, st);
+}
+
+int rs_launch_pointwise_pack_batch(int dtype, const long long* table, int n, long total_items, void* arena, hipStream_t st) {
+    const dim3 grid((unsigned)((total_items + 255) / 256)), block(256);
+    if (dtype == RS_F32) hipLaunchKernelGGL(pw_pack_batch_kernel<float>, grid, block, 0, st, table, n, total_items, (char*)arena);
+    else hipLaunchKernelGGL(pw_pack_batch_kernel<bf16_t>, grid, block, 0, st, table, n, total_items, (char*)arena);
+    return rs_check_launch();
+}
+
+// slabs of the row axis for the weight gradient: about one resident block per CU (more slabs = more partial traffic for the reduce), at least 64 rows per slab, whole MFMA steps per slab
+int rs_pw_wgrad_splits(int R, int N, int K) {
+    const int wnw = N <= 64 ? 1 : K <= 64 ? 4 : 2;
+    const int tiles = ((N + wnw * 64 - 1) / (wnw * 64)) * ((K + (4 / wnw) * 64 - 1) / ((4 / wnw) * 64));
+    static const int target = getenv("RSUPER_PW_WG_TARGET") ? atoi(getenv("RSUPER_PW_WG_TARGET")) : 256;   // blocks per launch (measured: 128 / 256 / 512 / 1024 -> MedFormer step 28.6 / 28.5 / 28.9 / 29.4 ms)
+    int s = target / tiles;
+    if (s > (R + 63) / 64) s = (R + 63) / 64;
+    if (s < 1) s = 1;
+    const int rows_per = (((R + s - 1) / s) + 15) / 16 * 16;                      // as the launcher cuts them: no slab without rows
+    return (R + rows_per - 1) / rows_per;
+}
+
+int rs_launch_pointwise_wgrad(int dtype, const float* dy, int ldy, const float* x, int ldx, int R, int N, int K, float* part, int S,
+                              float* dw, float* db, hipStream_t st) {
+    PwWgParams p;
+    p.dy = dy; p.ldy = ldy; p.x = x; p.ldx = ldx; p.part = part; p.R = R; p.N = N; p.K = K; p.bias = db != nullptr;
+    p.rows_per = (((R + S - 1) / S) + 15) / 16 * 16;
+    // (a slab past the last row still writes its -- zero -- partial: any S is valid, rs_pw_wgrad_splits just avoids empty ones)
+    return dtype == RS_F32 ? launch_pw_wgrad<float>(p, S, dw, db, st) : launch_pw_wgrad<bf16_t>(p, S, dw, db, st);
 }

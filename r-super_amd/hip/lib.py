@@ -37,6 +37,9 @@ _SIGS = {
     'rsuper_conv3_wgrad_reduce': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     'rsuper_pointwise_packed_bytes': (c_size_t, [c_int, c_int, c_int]),
     'rsuper_pointwise': (c_int, [c_int, c_int, P, c_int, P, P, P, c_int, c_long, c_int, c_int, P, P]),
+    'rsuper_pointwise_pack_batch': (c_int, [c_int, P, c_int, c_long, P, P]),
+    'rsuper_pointwise_wgrad_splits': (c_int, [c_long, c_int, c_int]),
+    'rsuper_pointwise_wgrad': (c_int, [c_int, P, c_int, P, c_int, c_long, c_int, c_int, P, c_int, P, P, P]),
     'rsuper_stats_finalize': (c_int, [P, c_int, c_int, c_int, c_double, c_float, c_int, c_int, P, P]),
     'rsuper_in_bwd_finalize': (c_int, [c_int, P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     'rsuper_maxpool2_fwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -1010,25 +1010,112 @@ def dilate_volume(vol_u8, kernel_size):
 
 
 # ------------------------------------------------------------------------------------------------ pointwise GEMM
+_PW_SEEN = {}      # (data_ptr, mode) -> weakref of a weight pointwise_gemm had to pack by itself: candidates of the next pointwise_prepack
+_PW_PACKED = {}    # (data_ptr, mode, dtype code) -> (validity key, arena, byte offset)
+_PW_TABLES = {}    # dtype code -> (device table, total items, arena, entries)
+_PW_SEEN_DIRTY = False
+
+
+def _pw_key(w):
+    return (WEIGHTS_EPOCH, w._version)              # a view shares its base's version counter
+
+
+def pointwise_prepack(compute):
+    """The MFMA fragments of every weight the pointwise GEMMs packed on their own so far (forward and data-gradient layouts), in ONE launch
+    -- a module calls it at the top of its forward; later pointwise_gemm calls of this step find their fragments ready and launch only the GEMM
+    (MedFormer: 156 pack launches per step -> 1).  Entries are valid for one (WEIGHTS_EPOCH, parameter version): the fused optimiser's update
+    invalidates them.  A changed set of weights rebuilds the device table -- never inside a hipGraph capture (a host copy), where the calls
+    then pack individually as before."""
+    global _PW_SEEN_DIRTY
+    dt = _DT[compute]
+    tab = _PW_TABLES.get(dt)
+    if tab is None or _PW_SEEN_DIRTY:
+        if not _PW_SEEN or torch.cuda.is_current_stream_capturing():
+            return
+        live = []
+        for (ptr, mode), (ref, shape) in list(_PW_SEEN.items()):
+            base = ref()                                        # the parameter (the GEMM may have seen a 2-D view of a Conv3d weight)
+            if base is None or base.data_ptr() != ptr or base.numel() != shape[0] * shape[1]:
+                del _PW_SEEN[(ptr, mode)]
+            else:
+                live.append((ptr, mode, shape, ref))
+        if not live:
+            return
+        KS = 8 if compute == torch.float32 else 16
+        rows, off, item, entries = [], 0, 0, []
+        for ptr, mode, (R_, C_), ref in live:
+            N, K = (R_, C_) if mode == 0 else (C_, R_)
+            ntiles, ksteps = (N + 31) // 32, (K + KS - 1) // KS
+            rows.append([ptr, off, R_, C_, mode, ntiles, ksteps, item])
+            entries.append(((ptr, mode, dt), off, ref))
+            off += ntiles * ksteps * 64 * 16
+            item += ntiles * ksteps * 64
+        rows.append([0, 0, 0, 0, 0, 1, 1, item])
+        dev = live[0][3]().device
+        tab = (torch.tensor(rows, dtype=torch.int64).to(dev), item, torch.empty((off,), device=dev, dtype=torch.uint8), entries)
+        for d in list(_PW_TABLES):                               # one table per compute type, all from the same set of weights
+            del _PW_TABLES[d]
+        _PW_TABLES[dt] = tab
+        _PW_SEEN_DIRTY = False
+    table, total, arena, entries = tab
+    for key, off, ref in entries:                                # a parameter that is gone invalidates the table (its memory may be anybody's by now)
+        if ref() is None:
+            del _PW_TABLES[dt]
+            _PW_SEEN_DIRTY = True
+            return
+    _l.check(_L().rsuper_pointwise_pack_batch(dt, _ptr(table), len(entries), total, _ptr(arena), _stream()), 'pointwise_pack_batch')
+    ep = WEIGHTS_EPOCH
+    for key, off, ref in entries:
+        _PW_PACKED[key] = ((ep, ref()._version), arena, off)
+
+
 def pointwise_gemm(x2, w, bias, mode, compute):
     """csrc/pointwise.hip on f32 rows.  mode 0: y = x2 @ w.T (+ bias), w (N, K); mode 1: y = x2 @ w, w (K, N) (the data gradient of mode 0).
     compute: torch.bfloat16 (bf16 MFMA, fp32 accumulate) or torch.float32 (exact-f32 MFMA); storage stays fp32."""
+    import weakref
     assert x2.dim() == 2 and x2.dtype == torch.float32 and x2.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
     R, K = x2.shape
     N = w.shape[0] if mode == 0 else w.shape[1]
     assert (w.shape[1] if mode == 0 else w.shape[0]) == K
     dt = _DT[compute]
     y = torch.empty((R, N), device=x2.device, dtype=torch.float32)
-    ws = torch.empty((_L().rsuper_pointwise_packed_bytes(dt, K, N),), device=x2.device, dtype=torch.uint8)
-    _l.check(_L().rsuper_pointwise(dt, mode, _ptr(x2), K, _ptr(w), _ptr(bias) if bias is not None else None, _ptr(y), N, R, K, N, _ptr(ws),
+    hit = _PW_PACKED.get((w.data_ptr(), mode, dt))
+    if hit is not None and hit[0] == _pw_key(w):           # fragments from this step's pointwise_prepack
+        wptr, packed = None, hit[1].data_ptr() + hit[2]
+    else:
+        base = w._base if w._base is not None else w
+        if isinstance(base, torch.nn.Parameter) and base.data_ptr() == w.data_ptr() and base.numel() == w.numel():
+            k = (w.data_ptr(), mode)
+            if k not in _PW_SEEN or _PW_SEEN[k][0]() is not base:
+                global _PW_SEEN_DIRTY
+                _PW_SEEN[k] = (weakref.ref(base), tuple(w.shape))
+                _PW_SEEN_DIRTY = True
+        ws = torch.empty((_L().rsuper_pointwise_packed_bytes(dt, K, N),), device=x2.device, dtype=torch.uint8)
+        wptr, packed = _ptr(w), _ptr(ws)
+    _l.check(_L().rsuper_pointwise(dt, mode, _ptr(x2), K, wptr, _ptr(bias) if bias is not None else None, _ptr(y), N, R, K, N, packed,
                                    _stream()), 'pointwise')
     return y
+
+
+def pointwise_wgrad(dy2, x2, want_bias, compute):
+    """dW = dy2^T x2 (N, K) and, if wanted, db = dy2.sum(0): csrc/pointwise.hip, slabs of the rows added in slab order (deterministic)."""
+    assert dy2.dim() == 2 and x2.dim() == 2 and dy2.shape[0] == x2.shape[0] and dy2.dtype == x2.dtype == torch.float32
+    assert dy2.is_contiguous() and x2.is_contiguous()
+    R, N = dy2.shape
+    K = x2.shape[1]
+    S = _L().rsuper_pointwise_wgrad_splits(R, N, K)
+    ws = torch.empty((S * (N * K + N),), device=dy2.device, dtype=torch.float32)
+    dw = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+    db = torch.empty((N,), device=dy2.device, dtype=torch.float32) if want_bias else None
+    _l.check(_L().rsuper_pointwise_wgrad(_DT[compute], _ptr(dy2), N, _ptr(x2), K, R, N, K, _ptr(ws), S, _ptr(dw), _ptr(db) if want_bias else None,
+                                         _stream()), 'pointwise_wgrad')
+    return dw, db
 
 
 def pointwise_supported(x, w):
     """Shapes the HIP pointwise GEMM takes (f32 rows on the GPU, channel counts multiples of 4, below 4 GiB)."""
     return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0
-            and x.numel() * 4 < (1 << 32) and x.numel() // x.shape[-1] * w.shape[0] * 4 < (1 << 32))
+            and (x.numel() // x.shape[-1] + 1) * max(w.shape[0], w.shape[1]) * 4 < (1 << 32))
 
 
 # ------------------------------------------------------------------------------------------------ dispatcher registration

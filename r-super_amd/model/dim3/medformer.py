@@ -83,6 +83,8 @@ class MedFormer(nn.Module):
         # measured SLOWER, 47-53 vs 44 ms/step: the casts around every GEMM cost more than the faster MFMA rate saves at these sizes)
         _mu.GEMM_DTYPE = dt if os.environ.get('RSUPER_MF_GEMM_BF16') == '1' else torch.float32
         _mu.GEMM_COMPUTE = dt                      # HIP pointwise GEMMs: bf16 MFMA operands in the bf16 mode, exact-f32 MFMA in the parity mode
+        if _mu.HIP_POINTWISE and os.environ.get('RSUPER_MF_PREPACK', '1') == '1':
+            ops.pointwise_prepack(dt)              # MFMA fragments of every 1x1x1 / linear weight of the attention stages: one launch per step
         x0 = self.inc(x, dt)
         x1, _ = self.down1(x0, dt)
         x2, m2 = self.down2(x1, dt)

@@ -90,6 +90,7 @@ def upsample_trilinear(x, size, planar=False):
 # RSUPER_MF_ATEN_ATTENTION=1: the ATen composition of the attention core instead of csrc/battn.hip (A/B switch; same results to fp32 rounding)
 FUSED_ATTENTION = os.environ.get('RSUPER_MF_ATEN_ATTENTION') != '1'
 HIP_POINTWISE = os.environ.get('RSUPER_MF_LIBRARY_GEMM') != '1'      # 1x1x1 convolutions / linear layers on csrc/pointwise.hip (=1: library GEMMs, A/B)
+HIP_POINTWISE_WGRAD = os.environ.get('RSUPER_MF_LIBRARY_WGRAD') != '1'   # their weight / bias gradients too (=1: library GEMMs, A/B)
 HIP_POINTWISE_MIN_ROWS = int(os.environ.get('RSUPER_MF_PW_MIN_ROWS', '256'))    # below (the 27-token maps): library GEMM
 GEMM_COMPUTE = torch.float32    # MFMA operand type of the HIP pointwise GEMMs: set per forward by MedFormer from its compute_dtype
 GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 operands for the 1x1x1 GEMMs, see medformer.py)
@@ -154,6 +155,11 @@ class _LinearFn(torch.autograd.Function):
             else:
                 with gemm_library(w.shape[0]):
                     dx = torch.mm(dy2, w).reshape(x.shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.hip and HIP_POINTWISE_WGRAD and ctx.needs_input_grad[1]:
+            # csrc/pointwise.hip: dW and db from one pass over dy and x (slabs of the rows, added in slab order)
+            dw, db = ops.pointwise_wgrad(dy2.contiguous(), x2.contiguous(), want_db, ctx.compute)
+            return dx, dw, db
         if ctx.needs_input_grad[1]:
             rows = x2.shape[0]
             slabs = next((s for s in (32, 16, 8, 4) if rows % s == 0 and rows // s >= SPLITK_MIN_SLAB), 0) if rows >= SPLITK_MIN_ROWS else 0

@@ -508,11 +508,31 @@ def check_pointwise(mode, R, K, N, bias, seed=103):
     dy = torch.randn(R, N, generator=g)
     refd = dy.double() @ w.double()
     comp = DT[mode]
+    refw, refb = dy.double().t() @ x.double(), dy.double().sum(0)
     y = ops.pointwise_gemm(x.to(DEV), w.to(DEV), b.to(DEV) if bias else None, 0, comp)
     dx = ops.pointwise_gemm(dy.to(DEV), w.to(DEV), None, 1, comp)
+    dw, db = ops.pointwise_wgrad(dy.to(DEV), x.to(DEV), bias, comp)
+    dw2, db2 = ops.pointwise_wgrad(dy.to(DEV), x.to(DEV), bias, comp)
     torch.cuda.synchronize()
-    e = max(relerr(y.cpu(), ref), relerr(dx.cpu(), refd))
-    return result(f'pointwise[{mode} R{R} K{K} N{N} bias{int(bias)}]', e, 2e-6 if mode == 'f32' else 1.5e-2, 'forward + data gradient')
+    e = max(relerr(y.cpu(), ref), relerr(dx.cpu(), refd), relerr(dw.cpu(), refw))
+    if bias:                                   # column sums: fp32 adds of the UNROUNDED dy in both modes
+        e = max(e, relerr(db.cpu(), refb) * (1.0 if mode == 'f32' else 1e3))
+    det = bool(torch.equal(dw, dw2)) and (not bias or bool(torch.equal(db, db2)))
+    # batched fragment packing (ops.pointwise_prepack): a parameter the GEMM has seen once is packed by the batch launch from then on -- same bits;
+    # and a raw-pointer update of the parameter (WEIGHTS_EPOCH) must not be served stale fragments
+    wp = torch.nn.Parameter(w.to(DEV))
+    y1 = ops.pointwise_gemm(x.to(DEV), wp, None, 0, comp)
+    ops.pointwise_prepack(comp)
+    hit = (wp.data_ptr(), 0, ops._DT[comp]) in ops._PW_PACKED
+    y2 = ops.pointwise_gemm(x.to(DEV), wp, None, 0, comp)
+    with torch.no_grad():
+        wp.mul_(2.0)
+    y3 = ops.pointwise_gemm(x.to(DEV), wp, None, 0, comp)
+    ops.WEIGHTS_EPOCH += 1
+    y4 = ops.pointwise_gemm(x.to(DEV), wp, None, 0, comp)
+    det = det and hit and bool(torch.equal(y1, y2)) and bool(torch.equal(y3, 2.0 * y1)) and bool(torch.equal(y4, y3))
+    return result(f'pointwise[{mode} R{R} K{K} N{N} bias{int(bias)}]', e if det else float('inf'), 2e-6 if mode == 'f32' else 1.5e-2,
+                  'forward + data gradient + weight / bias gradient (run twice: bit-identical)')
 
 
 def check_cl_planar(N, dims, C, K, seed=101):

@@ -38,7 +38,7 @@ if len(sys.argv) > 3 and sys.argv[3].startswith('netgraph'):   # forward / backw
     gnet = GraphedNetwork(net, warmup=2)
     step_fn = lambda b, i: train_step(gnet, ema, opt, b, largs, classes, i)
     dtype += ' netgraph'
-warm = 14 if (len(sys.argv) > 3 and sys.argv[3].startswith('netgraph')) else 4      # GraphedNetwork verifies itself at replays 1 and 12: keep them out of the timing
+warm = 16 if len(sys.argv) > 3 and (sys.argv[3].startswith('netgraph') or sys.argv[3] == 'graph') else 4      # GraphedNetwork verifies itself at replays 1 and 12: keep them out of the timing
 for i in range(warm):
     step_fn(batch, i)
 torch.cuda.synchronize()

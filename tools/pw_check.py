@@ -32,3 +32,18 @@ for R, K, N in [(27648, 128, 512), (27648, 512, 128), (27648, 128, 256), (3456, 
             line += f' | hip {th:7.1f} us ({gb / th * 1e3:5.2f} TB/s) library {tl:7.1f} us'
         print(line, flush=True)
 print('FAILURES', bad)
+# weight / bias gradient: HIP slab kernel vs the library formulation of round 2 (bmm over slabs + sum, ones-row GEMM)
+for R, K, N in [(27648, 128, 512), (27648, 512, 128), (27648, 128, 256), (3456, 256, 1024), (3456, 1024, 256), (432, 320, 1280), (432, 1280, 320), (221184, 64, 128)]:
+    x = torch.randn(R, K, device='cuda'); dy = torch.randn(R, N, device='cuda')
+    refw, refb = dy.double().t() @ x.double(), dy.double().sum(0)
+    for comp, tol in ((torch.float32, 2e-6), (torch.bfloat16, 1.5e-2)):
+        dw, db = ops.pointwise_wgrad(dy, x, True, comp)
+        e1 = float((dw.double() - refw).abs().max() / refw.abs().max()); e2 = float((db.double() - refb).abs().max() / refb.abs().max())
+        ok = e1 < tol and e2 < 2e-6
+        bad += not ok
+        th = t(lambda: ops.pointwise_wgrad(dy, x, True, comp))
+        slabs = next((s for s in (32, 16, 8, 4) if R % s == 0 and R // s >= 512), 1)
+        tl = t(lambda: (torch.bmm(dy.reshape(slabs, R // slabs, -1).transpose(1, 2), x.reshape(slabs, R // slabs, -1)).sum(0), dy.sum(0)))
+        gb = (R * K + R * N) * 4 / 1e9
+        print(f'wgrad R{R} K{K} N{N} {str(comp)[6:]:8s} dw {e1:.1e} db {e2:.1e} {"ok" if ok else "FAIL"} | hip {th:7.1f} us ({gb / th * 1e3:5.2f} TB/s) library {tl:7.1f} us', flush=True)
+print('FAILURES', bad)
