@@ -91,7 +91,7 @@ def upsample_trilinear(x, size, planar=False):
 FUSED_ATTENTION = os.environ.get('RSUPER_MF_ATEN_ATTENTION') != '1'
 HIP_POINTWISE = os.environ.get('RSUPER_MF_LIBRARY_GEMM') != '1'      # 1x1x1 convolutions / linear layers on csrc/pointwise.hip (=1: library GEMMs, A/B)
 HIP_POINTWISE_WGRAD = os.environ.get('RSUPER_MF_LIBRARY_WGRAD') != '1'   # their weight / bias gradients too (=1: library GEMMs, A/B)
-HIP_POINTWISE_MIN_ROWS = int(os.environ.get('RSUPER_MF_PW_MIN_ROWS', '256'))    # below (the 27-token maps): library GEMM
+HIP_POINTWISE_MIN_ROWS = int(os.environ.get('RSUPER_MF_PW_MIN_ROWS', '32'))    # below (the 27-token maps): library GEMM
 GEMM_COMPUTE = torch.float32    # MFMA operand type of the HIP pointwise GEMMs: set per forward by MedFormer from its compute_dtype
 GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 operands for the 1x1x1 GEMMs, see medformer.py)
 
