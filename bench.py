@@ -252,8 +252,35 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         sec['medformer_final_loss'] = lm.loss()
         sec['medformer_workload'] = ('MedFormer of config/abdomenatlas_ufo/medformer_3d.yaml (37.9 M parameters, deep supervision), same batch and '
                                      'segmentation loss: conv stem / BasicBlock stages / up-sampling / head / depthwise / InstanceNorm on the HIP kernels, '
-                                     '1x1x1 convolutions of the 24^3 / 48^3 stages on the HIP pointwise MFMA GEMM, the low-resolution ones, weight gradients and attention products as library GEMMs (SURVEY 8f-1)')
+                                     'every 1x1x1 convolution / linear layer of the attention stages (forward, data and weight gradient) on the HIP pointwise MFMA GEMMs; '
+                                     'only the 81-token SemanticMapFusion transformer and the 26-class aux head remain library GEMMs (SURVEY 8f-1)')
         lm.close()
+
+    def medformer_roofline():
+        # the attention stages' dominant product class is HBM-bound (K, N <= 1280 against 10^3..10^5 fp32 rows): the MBConv expand projection of the
+        # 24^3 stage (27648 rows, 128 -> 512) forward / data gradient / weight gradient, HIP-event timed on the launch stream, against 8 TB/s
+        from rsuper_amd.hip import ops as _ops
+        R, K, N = 2 * 24 ** 3, 128, 512
+        dev = torch.device('cuda', local)
+        x = torch.randn(R, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5; dy = torch.randn(R, N, device=dev)
+        comp = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+
+        def t(fn, it=20):
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(it):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / it * 1e-3
+        gb = (R * K + R * N + N * K) * 4 / 1e9                         # every operand once, fp32 storage
+        legs = {'forward': t(lambda: _ops.pointwise_gemm(x, w, None, 0, comp)), 'dgrad': t(lambda: _ops.pointwise_gemm(dy, w, None, 1, comp)),
+                'wgrad': t(lambda: _ops.pointwise_wgrad(dy, x, False, comp))}
+        tot = sum(legs.values())
+        sec['medformer_roofline'] = {'kernel': 'pw_gemm / pw_wgrad (csrc/pointwise.hip), MBConv expand 128 -> 512 at 24^3 x 2 = 27648 rows', 'bound': 'hbm',
+                                     'achieved': 3 * gb / tot, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 3 * gb / tot / 8000.0,
+                                     'per_pass_us': {k: v * 1e6 for k, v in legs.items()}, 'algorithmic_bytes_per_pass': gb * 1e9,
+                                     'note': 'launch-inclusive (weight packing, slab reduce); each pass reads / writes x, y and W once'}
 
     def medformer_report():
         # the R-Super use proper: MedFormer with report supervision (one mask + one report sample); eager, then with the network's forward
@@ -303,6 +330,7 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         if args.base == 32:
             guarded('medformer_graph', medformer_graph)
             guarded('medformer', medformer)
+            guarded('medformer_roofline', medformer_roofline)
             guarded('medformer_report', medformer_report)
     if args.dtype == 'bf16':
         guarded('f32', f32)

@@ -116,7 +116,8 @@ def wrap_ddp(net, local_rank, bucket_cap_mb=25):
     from torch.nn.parallel import DistributedDataParallel as DDP
     if next(net.parameters()).is_cuda and os.environ.get('RSUPER_REDUCER', '1') == '1':
         from .reducer import GradReducer
-        net._rsuper_reducer = GradReducer(net, bucket_mb=int(os.environ.get('RSUPER_DDP_BUCKET_MB', 48)))
+        net._rsuper_reducer = GradReducer(net, bucket_mb=int(os.environ.get('RSUPER_DDP_BUCKET_MB', 48)),
+                                          wire_dtype=torch.bfloat16 if os.environ.get('RSUPER_DDP_BF16', '0') == '1' else None)
         return net
     if next(net.parameters()).is_cuda:
         bucket_cap_mb = int(os.environ.get('RSUPER_DDP_BUCKET_MB', bucket_cap_mb))

@@ -47,6 +47,26 @@ def main():
             assert torch.allclose(p.grad, a, atol=1e-6), (p.grad - a).abs().max()
             b, off = red._slot[p]
             assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * off, 'gradient does not live in its bucket'
+    # bf16 on the wire (RSUPER_DDP_BF16): same flow, the mean of bf16-rounded gradients -- within 2^-8 of the largest entry of the f32 mean
+    red.remove()
+    redw = GradReducer(net, bucket_mb=0.0005, wire_dtype=torch.bfloat16)
+    for p in net.parameters():
+        p.grad = None
+    x = torch.randn(2, 1, 6, 6, 6, generator=torch.Generator().manual_seed(500 + rank))
+    net(x).square().mean().backward()
+    redw.finish()
+    acc = [torch.zeros_like(p) for p in ref.parameters()]
+    for r in range(world):
+        ref.zero_grad()
+        xr = torch.randn(2, 1, 6, 6, 6, generator=torch.Generator().manual_seed(500 + r))
+        ref(xr).square().mean().backward()
+        for a, p in zip(acc, ref.parameters()):
+            a += p.grad / world
+    for p, a in zip(net.parameters(), acc):
+        assert p.grad.dtype == torch.float32 and (p.grad - a).abs().max() <= 2.0 ** -8 * a.abs().max() + 1e-12, (p.grad - a).abs().max()
+        assert not torch.equal(p.grad, a) or a.abs().max() == 0, 'the bf16 wire format was not used'
+    redw.remove()
+    red = GradReducer(net, bucket_mb=0.0005)
     # a second backward pass before finish() (gradient accumulation) is refused instead of corrupting the buckets
     for p in net.parameters():
         p.grad = None

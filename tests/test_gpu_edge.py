@@ -254,12 +254,19 @@ def test_grad_reducer_single_rank_nccl_matches_plain():
     dist.init_process_group(backend='nccl', rank=0, world_size=1)
     try:
         a = run(True)
+        os.environ['RSUPER_DDP_BF16'] = '1'                 # bf16 buckets on the wire: the same run with gradients rounded to bf16 on the way
+        try:
+            w = run(True)
+        finally:
+            del os.environ['RSUPER_DDP_BF16']
     finally:
         dist.destroy_process_group()
         ops.GRAD_DEST = None
     b = run(False)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+    # two AdamW steps at lr 1e-3 from bf16-rounded gradients: parameters within a few 1e-4 of the exact run, and not identical to it
+    assert max(float((x - y).abs().max()) for x, y in zip(w, b)) < 2e-3 and any(not torch.equal(x, y) for x, y in zip(w, b))
 
 
 @pytest.mark.gpu
