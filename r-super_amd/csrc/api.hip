@@ -171,6 +171,36 @@ int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n
     return rs_igemm_part_rows(bn, use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0, rsuper_conv3_tiles(D, H, W), n_cols, N);
 }
 
+int rsuper_conv3_s2_part_rows(int mode, int FD, int FH, int FW) {
+    const int OD = (FD + 1) / 2, OH = (FH + 1) / 2, OW = (FW + 1) / 2, td = mode == 2 ? 2 : 4;
+    return (mode == 1 || mode == 2) && FD > 0 && FH > 0 && FW > 0 ? ((OD + td - 1) / td) * ((OH + 3) / 4) * ((OW + 15) / 16) : 0;
+}
+// Stride-2 forward (mode 1) / its data gradient (mode 2) on the parity-class kernel (conv3d_igemm_s2.hip); 64-column blocks
+int rsuper_conv3_igemm_s2(int dtype, int mode, const void* xa, int lda, int Ca, const float* mra,
+                          const void* xb, int ldb, int Cb, const void* packed, int n_cols, int N, int FD, int FH, int FW,
+                          void* out, int ldo, float* part, const void* exa, int elda, const float* emra, void* stream) {
+    if (!dt_ok(dtype) || (mode != 1 && mode != 2) || !xa || !packed || !out) return RS_ERR_ARG;
+    if (!ch_ok(Ca, lda) || Ca == 0 || (Cb > 0 && (!xb || !ch_ok(Cb, ldb))) || n_cols <= 0 || (n_cols % 8) || (ldo % 8) || ldo < n_cols) return RS_ERR_ARG;
+    if (N <= 0 || FD <= 0 || FH <= 0 || FW <= 0) return RS_ERR_ARG;
+    if (mode == 1 && (Cb > 0 || !mra)) return RS_ERR_ARG;                      // forward: one normalised source
+    if (mode == 2 && (mra || !exa || !emra || (elda % 8) || elda < n_cols)) return RS_ERR_ARG;
+    {
+        const unsigned long long vox = (unsigned long long)N * FD * FH * FW, es = dtype == RS_F32 ? 4 : 2;
+        const int lds[4] = {lda, Cb > 0 ? ldb : 0, ldo, mode == 2 ? elda : 0};
+        for (int i = 0; i < 4; ++i)
+            if (vox * (unsigned long long)lds[i] * es >= (1ull << 32)) return RS_ERR_UNSUPPORTED;
+    }
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.a = {xa, lda, Ca, mode == 1 ? mra : nullptr};
+    p.b = {xb, ldb, Cb > 0 ? Cb : 0, nullptr};
+    p.wp = packed; p.ntiles = ntiles_for(n_cols, 64); p.bn = 64;
+    p.N = N; p.D = (FD + 1) / 2; p.H = (FH + 1) / 2; p.W = (FW + 1) / 2; p.Cout = n_cols;
+    p.out = out; p.ldo = ldo; p.part = part;
+    p.ea = {exa, elda, n_cols, emra};
+    return rs_launch_igemm_s2(p, dtype, mode, FD, FH, FW, ST(stream));
+}
+
 int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,
                        const void* packed, int n_cols, int bn, int N, int D, int H, int W,

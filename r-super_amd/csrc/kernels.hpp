@@ -65,6 +65,8 @@ int rs_box_config(int N, int D, int H, int W, int n_cols);
 int rs_box_part_rows(int cfg, int D, int H, int W);
 int rs_box_nsplit(int N, int n_cols, int nch);
 int rs_launch_igemm_box(const IgemmParams& p, int cfg, int epi, hipStream_t st);
+// stride-2 forward (mode 1) / data gradient (mode 2) by parity classes (conv3d_igemm_s2.hip): p.D/H/W = half-resolution grid, bn 64
+int rs_launch_igemm_s2(const IgemmParams& p, int dtype, int mode, int FD, int FH, int FW, hipStream_t st);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st, bool reduce = true);

@@ -342,6 +342,40 @@ def igemm(epi, a, b, packed, n_cols, bn, dims, out, out_ld=None, res=None, part=
         run()
 
 
+def igemm_s2(mode, a, b, packed, n_cols, full_dims, out, part, ea=None):
+    """Stride-2 forward (mode 1: a = Src with statistics on the full grid, out on the half grid) / its data gradient (mode 2: a, b = dy sources
+    on the half grid, out and the forward input `ea` on the full grid) -- csrc/conv3d_igemm_s2.hip, 64-column blocks."""
+    dt = _DT[a.t.dtype]
+    N, FD, FH, FW = full_dims
+    bx = (None, 0, 0) if b is None else (_ptr(b.t, b.off), b.ld, b.C)
+    ex = (None, 0, None) if ea is None else (_ptr(ea.t, ea.off), ea.ld, _ptr(ea.mr))
+
+    def run():
+        _l.check(_L().rsuper_conv3_igemm_s2(dt, mode, _ptr(a.t, a.off), a.ld, a.C, _ptr(a.mr) if mode == 1 else None, *bx, _ptr(packed), n_cols,
+                                            N, FD, FH, FW, _ptr(out), out.shape[-1], _ptr(part), *ex, _stream()), 'conv3_igemm_s2')
+    if TIMER is not None:
+        K = a.C + (b.C if b is not None else 0)
+        OD, OH, OW = (FD + 1) // 2, (FH + 1) // 2, (FW + 1) // 2
+        TIMER.launch('conv3d_igemm_fwd' if mode == 1 else 'conv3d_igemm_dgrad', 2.0 * N * OD * OH * OW * n_cols * K * 27, run)
+    else:
+        run()
+
+
+def strided_kernel(dtype, dims, direction):
+    """Whether a strided [conv1 | shortcut] GEMM takes the parity-class kernel (csrc/conv3d_igemm_s2.hip: the minimal MFMA work, no
+    full-resolution temporary) or the rounds-1/2 evaluation (the tuned stride-1 kernels at full resolution + subsample / zero-stuffed dy: 8x
+    the work).  Measured on MI355X (tools/bench_conv.py, B = 2): f32 -- parity-class kernel 2.1-3.5x faster in both directions at every level;
+    bf16 forward 1.6x faster at 96^3 -> 48^3, equal below; bf16 data gradient 1.0x / 0.7x / 0.4x (one 4-wave block per CU holding 8 accumulator
+    sets: latency-bound) -- so bf16 takes it for the forward of large volumes only.  RSUPER_S2_KERNEL=1 / 0 forces either one (tests, A/B)."""
+    force = os.environ.get('RSUPER_S2_KERNEL', 'auto')
+    if force in ('0', '1'):
+        return force == '1'
+    if dtype == torch.float32:
+        return True
+    N, D, H, W = dims
+    return direction == 'fwd' and D * H * W >= 80 ** 3
+
+
 def reduce_side_enabled():
     """RSUPER_WGRAD_REDUCE_SIDE=1 (opt-in; same-box A/B 11.68 vs 11.24 ms per step: the cross-stream event waits cost more than the
     overlap gains): the slab reduction of every weight gradient (a ~10 us bandwidth-bound kernel that only the
@@ -411,9 +445,9 @@ class BasicBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xa, mra, xb, mrb, w1, w2, ws, packs=None, stride=1):
         """packs: optional (tensors, bns) from pack_weights_batch / block_pack_specs (whole-network batched packing).
-        stride 2 (down_block(pool=False), unet_utils.py:38-39): conv1 and the shortcut conv are evaluated at full resolution
-        and sampled at the even voxels (8x the minimal FLOPs of these two convolutions; the shipped configs use MaxPool and
-        never take this path), conv2 runs at the half resolution."""
+        stride 2 (down_block(pool=False), unet_utils.py:38-39): conv1 and the shortcut conv run as one strided GEMM on the parity-class
+        kernel (csrc/conv3d_igemm_s2.hip: the minimal MFMA work, forward and data gradient; their weight gradient still reads a
+        zero-stuffed dy at full resolution), conv2 at the half resolution."""
         if stride == 2:
             return _BB._forward_s2(ctx, xa, mra, w1, w2, ws)
         assert stride == 1
@@ -467,15 +501,24 @@ class BasicBlockFn(torch.autograd.Function):
         tiles = _L().rsuper_conv3_tiles(D, H, W)
         sa = Src(xa, mr=mra)
         nc1 = 2 * Cout
-        specs, bns = block_pack_specs(w1, w2, ws, Ca, 0, dt, tiles * N, False, dims)
-        wp = pack_weights_batch(dt, specs)
-        full = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
-        igemm(0, sa, None, wp[0], nc1, bns[0], dims, full)                       # [conv1 | shortcut] at stride 1, no statistics
-        ys, mr_ys = subsample2(full)
-        del full
-        OD, OH, OW = ys.shape[1:4]
+        if not strided_kernel(dt, dims, 'fwd'):
+            specs, bns = block_pack_specs(w1, w2, ws, Ca, 0, dt, tiles * N, False, dims)
+            wp = pack_weights_batch(dt, specs)
+            full = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
+            igemm(0, sa, None, wp[0], nc1, bns[0], dims, full)                   # [conv1 | shortcut] at stride 1, no statistics
+            ys, mr_ys = subsample2(full)
+            del full
+            OD, OH, OW = ys.shape[1:4]
+            mr_y1 = mr_ys[:, :Cout].contiguous()
+        else:
+            # [conv1 | shortcut] as ONE strided GEMM on the parity-class kernel: 1/8 of the MFMA work of the full-resolution evaluation
+            OD, OH, OW = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+            wp1 = pack_weights(dt, 0, w1, ws, Ca, 0, Cout, Cout, 64)
+            ys = torch.empty((N, OD, OH, OW, nc1), device=dev, dtype=dt)
+            part1 = torch.empty((N, _L().rsuper_conv3_s2_part_rows(1, D, H, W), nc1, 2), device=dev, dtype=torch.float32)
+            igemm_s2(1, sa, None, wp1, nc1, dims, ys, part1)
+            mr_y1 = stats_finalize(part1, OD * OH * OW, split=Cout)[0]
         dims2 = (N, OD, OH, OW)
-        mr_y1 = mr_ys[:, :Cout].contiguous()
         tiles2 = _L().rsuper_conv3_tiles(OD, OH, OW)
         bn2 = pick_bn(Cout, dt, tiles2 * N, dims2)
         wp2 = pack_weights(dt, 0, w2, None, Cout, 0, Cout, 0, bn2)
@@ -518,11 +561,17 @@ class BasicBlockFn(torch.autograd.Function):
         subsample2_scatter(dout, dfull, Cout, dims)
         sa = Src(xa, mr=mra)
         tiles = _L().rsuper_conv3_tiles(D, H, W)
-        bnd = pick_bn(Ca, dt, tiles * N, dims)
-        wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, bnd)
         g0 = torch.empty((N, D, H, W, Ca), device=dev, dtype=dt)
-        part0 = part_buffer(dt, dims, Ca, bnd, dev, epi=1)
-        igemm(1, Src(dfull, C=Cout), Src(dfull, C=Cout, off=Cout), wpd1, Ca, bnd, dims, g0, part=part0, ea=sa)
+        if not strided_kernel(dt, dims, 'dgrad'):
+            bnd = pick_bn(Ca, dt, tiles * N, dims)
+            wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, bnd)
+            part0 = part_buffer(dt, dims, Ca, bnd, dev, epi=1)
+            igemm(1, Src(dfull, C=Cout), Src(dfull, C=Cout, off=Cout), wpd1, Ca, bnd, dims, g0, part=part0, ea=sa)
+        else:
+            # the transposed convolution by output parity classes, straight from [dy1 | dOut] on the half grid (no zero-stuffed operand)
+            wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, 64)
+            part0 = torch.empty((N, _L().rsuper_conv3_s2_part_rows(2, D, H, W), Ca, 2), device=dev, dtype=torch.float32)
+            igemm_s2(2, Src(dy1), sdo, wpd1, Ca, dims, g0, part0, ea=sa)
         gm0 = stats_finalize(part0, D * H * W, mode=1)
         dw1, dws = grad_dest(w1), grad_dest(ws)
         wgrad(sa, None, Src(dfull, C=Cout), Src(dfull, C=Cout, off=Cout), dw1, dws, dims)

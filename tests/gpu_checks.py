@@ -887,6 +887,22 @@ def check_train_steps(mode='f32'):
 
 
 # ================================================================================================ registry
+def with_strided(force, fn, *a):
+    """Run a check with the strided convolutions forced onto the parity-class kernel (force '1', csrc/conv3d_igemm_s2.hip) or onto the
+    stride-1 evaluation at full resolution (force '0'); the default picks per dtype / volume (ops.strided_kernel)."""
+    old = os.environ.get('RSUPER_S2_KERNEL')
+    os.environ['RSUPER_S2_KERNEL'] = force
+    try:
+        r = fn(*a)
+    finally:
+        if old is None:
+            del os.environ['RSUPER_S2_KERNEL']
+        else:
+            os.environ['RSUPER_S2_KERNEL'] = old
+    r['name'] = f"s2kernel={force}:{r['name']}"
+    return r
+
+
 def with_variant(variant, fn, *a):
     """Run a conv check under a forced igemm kernel variant (0 classic, 1 producer/consumer, 2 = round-1 auto choice,
     4 = weight-stationary kernel on every 32-column launch, 5 = producer/consumer v2, 6 / 7 = volume-fitted K-split kernel with the box
@@ -929,6 +945,9 @@ def all_checks(quick=False):
             (check_unet_tiny_nopool, (mode,)),
             (check_unet_tiny, (mode,)),
         ]
+        for force in ('0', '1'):         # both evaluations of the strided convolutions, whatever the default picks for this dtype / size
+            cs += [(with_strided, (force, check_basic_block, mode, 'b8_16_s2', 8, 16, 12, 4)), (with_strided, (force, check_basic_block, mode, 'b16_16_s2', 16, 16, 9, 5)),
+                   (with_strided, (force, check_unet_tiny_nopool, mode))]
     for m in ('f32', 'bf16'):           # 1x1x1 convolutions of MedFormer's attention stages on MFMA: shipped shapes, ragged rows / channels
         cs += [(check_pointwise, (m, 27648, 128, 512, False)), (check_pointwise, (m, 13824, 512, 128, True)), (check_pointwise, (m, 3456, 256, 1024, False)),
                (check_pointwise, (m, 3456, 1024, 256, True)), (check_pointwise, (m, 432, 320, 1280, False)),       # reduction split over the waves

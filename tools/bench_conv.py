@@ -61,3 +61,37 @@ for name, S, Ca, Cb, Cout, sc in LAYERS:
     t_w = timeit(lambda: ops.wgrad(sa, sb, ops.Src(dy1), ops.Src(dy2) if sc else None, dw1, dws, dims))
     print(f'{name:20s} S{S:3d} {fl / 1e9:7.1f} GF | fwd bn{bn:3d} {t_f * 1e3:8.1f} us {fl / t_f / 1e9:7.1f} TF | dgrad bn{bnd:3d} {t_d * 1e3:8.1f} us {fl / t_d / 1e9:7.1f} TF | '
           f'wgrad {t_w * 1e3:8.1f} us {fl / t_w / 1e9:7.1f} TF', flush=True)
+
+# ---- the strided member (down_block(pool=False)): [conv1 | shortcut] of BasicBlock(Cin, Cout, stride=2) on the parity-class kernel against the
+#      rounds-1/2 evaluation (the stride-1 GEMM at full resolution + rsuper_subsample2 / zero-stuffed dy).  FLOPs = the strided convolution's own.
+print('# stride-2 [conv1 | shortcut]: parity-class kernel (conv3d_igemm_s2.hip) vs stride-1 evaluation at full resolution', flush=True)
+for name, S, Ca, Cout in [('down1.0 s2 32->64+sc', 96, 32, 64), ('down2.0 s2 64->128+sc', 48, 64, 128), ('down3.0 s2 128->256+sc', 24, 128, 256)]:
+    dims = (N, S, S, S); O = (S + 1) // 2
+    xa = torch.randn((N, S, S, S, Ca), device=dev).to(dt)
+    mra = torch.stack([torch.zeros(N, Ca, device=dev), torch.ones(N, Ca, device=dev)], -1).contiguous()
+    w1 = torch.randn((Cout, Ca, 3, 3, 3), device=dev) / math.sqrt(27 * Ca); ws = torch.randn((Cout, Ca, 3, 3, 3), device=dev) / math.sqrt(27 * Ca)
+    nc = 2 * Cout
+    sa = ops.Src(xa, mr=mra)
+    wp = ops.pack_weights(dt, 0, w1, ws, Ca, 0, Cout, Cout, 64)
+    ys = torch.empty((N, O, O, O, nc), device=dev, dtype=dt)
+    part = torch.empty((N, ops._L().rsuper_conv3_s2_part_rows(1, S, S, S), nc, 2), device=dev, dtype=torch.float32)
+    t_f = timeit(lambda: ops.igemm_s2(1, sa, None, wp, nc, dims, ys, part))
+    tiles = ops._L().rsuper_conv3_tiles(S, S, S)
+    bn = ops.pick_bn(nc, dt, tiles * N, dims)
+    wpl = ops.pack_weights(dt, 0, w1, ws, Ca, 0, Cout, Cout, bn)
+    full = torch.empty((N, S, S, S, nc), device=dev, dtype=dt)
+    t_fl = timeit(lambda: (ops.igemm(0, sa, None, wpl, nc, bn, dims, full), ops.subsample2(full)))
+    dy1 = torch.randn((N, O, O, O, Cout), device=dev).to(dt); dy2 = torch.randn((N, O, O, O, Cout), device=dev).to(dt)
+    wpd = ops.pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, 64)
+    g0 = torch.empty((N, S, S, S, Ca), device=dev, dtype=dt)
+    partd = torch.empty((N, ops._L().rsuper_conv3_s2_part_rows(2, S, S, S), Ca, 2), device=dev, dtype=torch.float32)
+    t_d = timeit(lambda: ops.igemm_s2(2, ops.Src(dy1), ops.Src(dy2), wpd, Ca, dims, g0, partd, ea=sa))
+    bnd = ops.pick_bn(Ca, dt, tiles * N, dims)
+    wpdl = ops.pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, bnd)
+    dfull = torch.empty((N, S, S, S, nc), device=dev, dtype=dt)
+    partl = ops.part_buffer(dt, dims, Ca, bnd, dev, epi=1)
+    t_dl = timeit(lambda: (ops.subsample2_scatter(dy1, dfull, 0, dims), ops.subsample2_scatter(dy2, dfull, Cout, dims),
+                           ops.igemm(1, ops.Src(dfull, C=Cout), ops.Src(dfull, C=Cout, off=Cout), wpdl, Ca, bnd, dims, g0, part=partl, ea=sa)))
+    fl = 2.0 * N * O ** 3 * nc * Ca * 27
+    print(f'{name:22s} S{S:3d}->{O:2d} {fl / 1e9:6.1f} GF | fwd {t_f * 1e3:7.1f} us {fl / t_f / 1e9:6.1f} TF (full-res + subsample {t_fl * 1e3:7.1f} us: x{t_fl / t_f:4.1f}) | '
+          f'dgrad {t_d * 1e3:7.1f} us {fl / t_d / 1e9:6.1f} TF (zero-stuffed full-res {t_dl * 1e3:7.1f} us: x{t_dl / t_d:4.1f})', flush=True)
