@@ -26,6 +26,9 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+#ifndef S2_SKIP
+#define S2_SKIP 0
+#endif
 namespace {
 
 constexpr int TH = 4, TW = 16;
@@ -111,13 +114,14 @@ __global__ __launch_bounds__(256, 1) void igemm_s2_kernel(IgemmParams p, int FD,
     const uint32_t nvox_src = (uint32_t)(p.N * SD * SH * SW);
     uint4 pre[NVEC];
     uint32_t okmask = 0;
-    auto stage = [&](int ch, int cls) {
-        const bool isB = ch >= nchA;
-        const ConvSrc& src = isB ? p.b : p.a;
+    auto stage = [&](int ch, int cls) __attribute__((always_inline)) {
+        const bool isB = MODE == 2 && ch >= nchA;                               // field selects, not a reference select: `isB ? p.b : p.a` made the
+        const void* sx = isB ? p.b.x : p.a.x;                                   // compiler keep a copy of the kernel arguments in scratch memory
+        const int sld = isB ? p.b.ld : p.a.ld, sC = isB ? p.b.C : p.a.C;
         const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
-        const uint32_t rowb = (uint32_t)src.ld * (uint32_t)sizeof(T);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src.x, 0, nvox_src * rowb, 0x00020000);
-        const bool cok = c < src.C;
+        const uint32_t rowb = (uint32_t)sld * (uint32_t)sizeof(T);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sx, 0, nvox_src * rowb, 0x00020000);
+        const bool cok = c < sC;
         const int cd = (cls >> 2) & 1, chh = (cls >> 1) & 1, cw = cls & 1;
         okmask = 0;
 #pragma unroll
@@ -137,11 +141,11 @@ __global__ __launch_bounds__(256, 1) void igemm_s2_kernel(IgemmParams p, int FD,
             okmask |= ok ? (1u << i) : 0u;
         }
     };
-    auto commit = [&](int ch) {
-        const bool isB = ch >= nchA;
-        const ConvSrc& src = isB ? p.b : p.a;
+    auto commit = [&](int ch) __attribute__((always_inline)) {
+        const bool isB = MODE == 2 && ch >= nchA;
+        const int sC = isB ? p.b.C : p.a.C;
         const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
-        const bool norm = (isB ? normB : normA) && c < src.C;
+        const bool norm = (isB ? normB : normA) && c < sC;
         float sc_[KP], nb_[KP];
         if (norm) {
             const float* mr = mr_lds + 2 * ((isB ? p.a.C : 0) + c);
@@ -155,8 +159,11 @@ __global__ __launch_bounds__(256, 1) void igemm_s2_kernel(IgemmParams p, int FD,
             if (hq[i] >= 0) *(uint4*)(lds_st + i * (64 * PITCH)) = q;
         }
     };
-    // the taps of class CLS, fully unrolled: per-axis pair lists from ax_a / ax_b
-    auto mfma_class = [&](auto clsc, const uint4* wch) {
+    // Forward: one (chunk, class) item = the class's rows staged, then its taps, fully unrolled (per-axis pair lists from ax_a / ax_b).  The
+    // 8 items of a chunk are a static sequence: while item c multiplies, the rows AND the weight fragments (<= 16) of item c + 1 are in flight
+    // (register staging `pre`, two fragment sets) -- fetched at their use, every fragment was an L2 round trip the matrix pipe waited for, and
+    // every item a full memory latency with one 4-wave block per CU.
+    auto load_b = [&](auto clsc, const uint4* wch, uint4 (&bq)[16][NF]) __attribute__((always_inline)) {
         constexpr int CLS = decltype(clsc)::value;
         constexpr int bd = (CLS >> 2) & 1, bh = (CLS >> 1) & 1, bw = CLS & 1;
 #pragma unroll
@@ -165,87 +172,126 @@ __global__ __launch_bounds__(256, 1) void igemm_s2_kernel(IgemmParams p, int FD,
             for (int ih = 0; ih <= bh; ++ih)
 #pragma unroll
                 for (int iw = 0; iw <= bw; ++iw) {
-                    const int aoff = ((ax_a<MODE>(bd, id) * HH + ax_a<MODE>(bh, ih)) * HW + ax_a<MODE>(bw, iw)) * PITCH;
+                    const int ti = (id * (bh + 1) + ih) * (bw + 1) + iw;
                     const int tapb = (ax_b<MODE>(bd, id) * 3 + ax_b<MODE>(bh, ih)) * 3 + ax_b<MODE>(bw, iw);
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        uint4 bq[NF], aq[MF];
+                    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int nf = 0; nf < NF; ++nf) bq[nf] = wch[(size_t)(tapb * 2 + ks) * wstep + nf * 64];
-#pragma unroll
-                        for (int mf = 0; mf < MF; ++mf) aq[mf] = *(const uint4*)(halo + a_base + a_const(mf) + aoff + ks * 32);
-#pragma unroll
-                        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                            for (int nf = 0; nf < NF; ++nf) mma32<T>(acc[0][mf][nf], aq[mf], bq[nf]);
-                    }
+                        for (int nf = 0; nf < NF; ++nf) bq[ti * 2 + ks][nf] = wch[(size_t)(tapb * 2 + ks) * wstep + nf * 64];
                 }
     };
-    auto mfma_dispatch = [&](int cls, const uint4* wch) {
-        switch (cls) {                                                          // wave-uniform
-            case 0: mfma_class(std::integral_constant<int, 0>{}, wch); break;
-            case 1: mfma_class(std::integral_constant<int, 1>{}, wch); break;
-            case 2: mfma_class(std::integral_constant<int, 2>{}, wch); break;
-            case 3: mfma_class(std::integral_constant<int, 3>{}, wch); break;
-            case 4: mfma_class(std::integral_constant<int, 4>{}, wch); break;
-            case 5: mfma_class(std::integral_constant<int, 5>{}, wch); break;
-            case 6: mfma_class(std::integral_constant<int, 6>{}, wch); break;
-            default: mfma_class(std::integral_constant<int, 7>{}, wch); break;
-        }
-    };
-
-    // dgrad: all 27 (class, tap) pairs of a chunk from one staged brick; A fragments by halo position (1 or 2 per axis), each serving the
-    // pairs that read it: per axis position 1 <- (class bit 0, fragment 1) and (class bit 1, fragment 0), position 2 <- (class bit 1, fragment 2)
-    auto mfma_all = [&](const uint4* wch) {
+    auto mfma_class = [&](auto clsc, uint4 (&bq)[16][NF]) __attribute__((always_inline)) {
+        constexpr int CLS = decltype(clsc)::value;
+        constexpr int bd = (CLS >> 2) & 1, bh = (CLS >> 1) & 1, bw = CLS & 1;
 #pragma unroll
-        for (int pd = 1; pd <= 2; ++pd)
+        for (int id = 0; id <= bd; ++id)
 #pragma unroll
-            for (int ph = 1; ph <= 2; ++ph)
+            for (int ih = 0; ih <= bh; ++ih)
 #pragma unroll
-                for (int pw = 1; pw <= 2; ++pw) {
-                    const int aoff = ((pd * HH + ph) * HW + pw) * PITCH;
+                for (int iw = 0; iw <= bw; ++iw) {
+                    const int ti = (id * (bh + 1) + ih) * (bw + 1) + iw;
+                    const int aoff = ((ax_a<MODE>(bd, id) * HH + ax_a<MODE>(bh, ih)) * HW + ax_a<MODE>(bw, iw)) * PITCH;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         uint4 aq[MF];
 #pragma unroll
                         for (int mf = 0; mf < MF; ++mf) aq[mf] = *(const uint4*)(halo + a_base + a_const(mf) + aoff + ks * 32);
 #pragma unroll
-                        for (int od_ = 0; od_ < (pd == 1 ? 2 : 1); ++od_)
+                        for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                            for (int oh_ = 0; oh_ < (ph == 1 ? 2 : 1); ++oh_)
-#pragma unroll
-                                for (int ow_ = 0; ow_ < (pw == 1 ? 2 : 1); ++ow_) {
-                                    const int cd = pd == 1 ? od_ : 1, chh = ph == 1 ? oh_ : 1, cw = pw == 1 ? ow_ : 1;        // class bits
-                                    const int fd = pd == 1 ? (cd ? 0 : 1) : 2, fh = ph == 1 ? (chh ? 0 : 1) : 2, fw = pw == 1 ? (cw ? 0 : 1) : 2;
-                                    const int cls = cd * 4 + chh * 2 + cw, tapb = (fd * 3 + fh) * 3 + fw;
-#pragma unroll
-                                    for (int nf = 0; nf < NF; ++nf) {
-                                        const uint4 bq = wch[(size_t)(tapb * 2 + ks) * wstep + nf * 64];
-#pragma unroll
-                                        for (int mf = 0; mf < MF; ++mf) mma32<T>(acc[cls % NACC][mf][nf], aq[mf], bq);
-                                    }
-                                }
+                            for (int nf = 0; nf < NF; ++nf) mma32<T>(acc[0][mf][nf], aq[mf], bq[ti * 2 + ks][nf]);
                     }
                 }
+    };
+    uint4 fbqA[16][NF], fbqB[16][NF];                                          // fragments of the even / odd classes
+    // item CLS of chunk ch: its rows are in `pre`, its fragments in fbq[CLS & 1]; requests item CLS + 1 (or class 0 of the next chunk)
+    auto item = [&](auto clsc, int ch, const uint4* wch) __attribute__((always_inline)) {
+        constexpr int CLS = decltype(clsc)::value;
+        __syncthreads();                                                        // previous item consumed (and mr_lds visible)
+        if (!(S2_SKIP & 4)) commit(ch);
+        __syncthreads();
+        if constexpr (CLS < 7) {
+            if (!(S2_SKIP & 4)) stage(ch, CLS + 1);
+            if constexpr (CLS & 1) load_b(std::integral_constant<int, (CLS + 1) & 7>{}, wch, fbqA);
+            else load_b(std::integral_constant<int, (CLS + 1) & 7>{}, wch, fbqB);
+        } else if (ch + 1 < nch) {
+            if (!(S2_SKIP & 4)) stage(ch + 1, 0);
+            load_b(std::integral_constant<int, 0>{}, wch + (size_t)27 * 2 * wstep, fbqA);
+        }
+        __builtin_amdgcn_sched_barrier(0);                                      // the requests stay ahead of this item's MFMAs
+        if (!(S2_SKIP & 2)) {
+            if constexpr (CLS & 1) mfma_class(clsc, fbqB);
+            else mfma_class(clsc, fbqA);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // dgrad: all 27 (class, tap) pairs of a chunk from one staged brick, in 16 groups = (halo position (1 or 2 per axis), k-step): the group's A
+    // fragments are read once and serve every pair that uses the position -- per axis position 1 <- (class bit 0, fragment 1) and (class bit 1,
+    // fragment 0), position 2 <- (class bit 1, fragment 2) -- and the weight fragments of group g + 1 (<= 8) are in flight while group g multiplies.
+    auto group_pairs = [&](int g, auto&& fn) {                                  // fn(pair index, class, weight fragment) for every pair of group g
+        const int pd = 1 + (g >> 3), ph = 1 + ((g >> 2) & 1), pw = 1 + ((g >> 1) & 1), ks = g & 1;
+        int j = 0;
+#pragma unroll
+        for (int od_ = 0; od_ < (pd == 1 ? 2 : 1); ++od_)
+#pragma unroll
+            for (int oh_ = 0; oh_ < (ph == 1 ? 2 : 1); ++oh_)
+#pragma unroll
+                for (int ow_ = 0; ow_ < (pw == 1 ? 2 : 1); ++ow_) {
+                    const int cd = pd == 1 ? od_ : 1, chh = ph == 1 ? oh_ : 1, cw = pw == 1 ? ow_ : 1;        // class bits
+                    const int fd = pd == 1 ? (cd ? 0 : 1) : 2, fh = ph == 1 ? (chh ? 0 : 1) : 2, fw = pw == 1 ? (cw ? 0 : 1) : 2;
+                    fn(j, cd * 4 + chh * 2 + cw, ((fd * 3 + fh) * 3 + fw) * 2 + ks);
+                    ++j;
+                }
+    };
+    auto mfma_all = [&](const uint4* wch) __attribute__((always_inline)) {
+        uint4 bq[2][8][NF];
+        group_pairs(0, [&](int j, int, int frag) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) bq[0][j][nf] = wch[(size_t)frag * wstep + nf * 64];
+        });
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            if (g + 1 < 16)
+                group_pairs(g + 1, [&](int j, int, int frag) {
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) bq[(g + 1) & 1][j][nf] = wch[(size_t)frag * wstep + nf * 64];
+                });
+            __builtin_amdgcn_sched_barrier(0);                                  // keep the requests ahead of this group's MFMAs (the scheduler
+                                                                                // otherwise sinks every load to its use: one L2 round trip per pair)
+            const int pd = 1 + (g >> 3), ph = 1 + ((g >> 2) & 1), pw = 1 + ((g >> 1) & 1), ks = g & 1;
+            const int aoff = ((pd * HH + ph) * HW + pw) * PITCH;
+            uint4 aq[MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) aq[mf] = *(const uint4*)(halo + a_base + a_const(mf) + aoff + ks * 32);
+            group_pairs(g, [&](int j, int cls, int) {
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) mma32<T>(acc[cls % NACC][mf][nf], aq[mf], bq[g & 1][j][nf]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     for (int ch = 0; ch < nch; ++ch) {
         const uint4* wch = wp + (size_t)ch * 27 * 2 * wstep + (size_t)ntile0 * 64 + lane;
         if constexpr (MODE == 1) {
-            for (int cls = 0; cls < 8; ++cls) {
-                stage(ch, cls);
-                __syncthreads();                                                // previous item consumed (and mr_lds visible)
-                commit(ch);
-                __syncthreads();
-                mfma_dispatch(cls, wch);
+            if (ch == 0) {
+                if (!(S2_SKIP & 4)) stage(0, 0);
+                load_b(std::integral_constant<int, 0>{}, wch, fbqA);
             }
+            item(std::integral_constant<int, 0>{}, ch, wch); item(std::integral_constant<int, 1>{}, ch, wch);
+            item(std::integral_constant<int, 2>{}, ch, wch); item(std::integral_constant<int, 3>{}, ch, wch);
+            item(std::integral_constant<int, 4>{}, ch, wch); item(std::integral_constant<int, 5>{}, ch, wch);
+            item(std::integral_constant<int, 6>{}, ch, wch); item(std::integral_constant<int, 7>{}, ch, wch);
         } else {
-            if (ch == 0) stage(0, 0);
+            if (!(S2_SKIP & 4)) { if (ch == 0) stage(0, 0); }
             __syncthreads();
-            commit(ch);
+            if (!(S2_SKIP & 4)) commit(ch);
             __syncthreads();
-            if (ch + 1 < nch) stage(ch + 1, 0);                                 // the next chunk's loads fly during this chunk's MFMAs
-            mfma_all(wch);
+            if (!(S2_SKIP & 4)) { if (ch + 1 < nch) stage(ch + 1, 0); }         // the next chunk's loads fly during this chunk's MFMAs
+            if (!(S2_SKIP & 2)) mfma_all(wch);
         }
     }
 
@@ -274,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void igemm_s2_kernel(IgemmParams p, int FD,
     for (int j = 0; j < KP; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     const int LD = MODE == 2 ? FD : p.D, LH = MODE == 2 ? FH : p.H, LW = MODE == 2 ? FW : p.W;      // grid of the stores
 #pragma unroll
-    for (int c = 0; c < NACC; ++c) {
+    for (int c = 0; c < ((S2_SKIP & 1) ? 1 : NACC); ++c) {
         const int od = (c >> 2) & 1, oh = (c >> 1) & 1, ow = c & 1;
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {

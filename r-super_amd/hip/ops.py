@@ -364,16 +364,10 @@ def igemm_s2(mode, a, b, packed, n_cols, full_dims, out, part, ea=None):
 def strided_kernel(dtype, dims, direction):
     """Whether a strided [conv1 | shortcut] GEMM takes the parity-class kernel (csrc/conv3d_igemm_s2.hip: the minimal MFMA work, no
     full-resolution temporary) or the rounds-1/2 evaluation (the tuned stride-1 kernels at full resolution + subsample / zero-stuffed dy: 8x
-    the work).  Measured on MI355X (tools/bench_conv.py, B = 2): f32 -- parity-class kernel 2.1-3.5x faster in both directions at every level;
-    bf16 forward 1.6x faster at 96^3 -> 48^3, equal below; bf16 data gradient 1.0x / 0.7x / 0.4x (one 4-wave block per CU holding 8 accumulator
-    sets: latency-bound) -- so bf16 takes it for the forward of large volumes only.  RSUPER_S2_KERNEL=1 / 0 forces either one (tests, A/B)."""
-    force = os.environ.get('RSUPER_S2_KERNEL', 'auto')
-    if force in ('0', '1'):
-        return force == '1'
-    if dtype == torch.float32:
-        return True
-    N, D, H, W = dims
-    return direction == 'fwd' and D * H * W >= 80 ** 3
+    the work).  Measured on MI355X (tools/bench_conv.py, B = 2, 96^3 / 48^3 / 24^3 inputs): f32 forward 4.5x / 3.0x / 3.3x and data gradient
+    3.6x / 3.5x / 4.1x faster; bf16 forward 1.8x / 1.0x / 1.4x, data gradient 2.0x / 1.7x / 1.2x -- so it is the default everywhere;
+    RSUPER_S2_KERNEL=0 selects the old evaluation (tests run both, A/B)."""
+    return os.environ.get('RSUPER_S2_KERNEL', '1') != '0'
 
 
 def reduce_side_enabled():

@@ -889,7 +889,7 @@ def check_train_steps(mode='f32'):
 # ================================================================================================ registry
 def with_strided(force, fn, *a):
     """Run a check with the strided convolutions forced onto the parity-class kernel (force '1', csrc/conv3d_igemm_s2.hip) or onto the
-    stride-1 evaluation at full resolution (force '0'); the default picks per dtype / volume (ops.strided_kernel)."""
+    stride-1 evaluation at full resolution (force '0'); the parity-class kernel is the default (ops.strided_kernel)."""
     old = os.environ.get('RSUPER_S2_KERNEL')
     os.environ['RSUPER_S2_KERNEL'] = force
     try:
@@ -945,7 +945,7 @@ def all_checks(quick=False):
             (check_unet_tiny_nopool, (mode,)),
             (check_unet_tiny, (mode,)),
         ]
-        for force in ('0', '1'):         # both evaluations of the strided convolutions, whatever the default picks for this dtype / size
+        for force in ('0',):             # the rounds-1/2 evaluation of the strided convolutions stays selectable (RSUPER_S2_KERNEL=0): keep it pinned too
             cs += [(with_strided, (force, check_basic_block, mode, 'b8_16_s2', 8, 16, 12, 4)), (with_strided, (force, check_basic_block, mode, 'b16_16_s2', 16, 16, 9, 5)),
                    (with_strided, (force, check_unet_tiny_nopool, mode))]
     for m in ('f32', 'bf16'):           # 1x1x1 convolutions of MedFormer's attention stages on MFMA: shipped shapes, ragged rows / channels
