@@ -22,8 +22,9 @@ namespace {
 constexpr int TD = 4, TH = 4, TW = 16;
 constexpr int WG_BD = 3;                                         // B-fragment prefetch distance (MFMA units), classic kernel (>= 2 waves / SIMD)
 #ifndef WG_LS
-#define WG_LS 5
-#endif
+#define WG_LS 2                                                  // MFMA units between two staging loads of the next tile: 2 (round 3) -- with 5 the last loads
+#endif                                                           // were issued late in the phase and their latency was exposed behind it (same box: up3.0 301 -> 271-288 us,
+                                                                 // 128 -> 128 @24^3 56 -> 52-53, 64 -> 64 @48^3 76 -> 73; 1 measures the same as 2)
 constexpr int WG_PC_BD = 7;                                      // producer/consumer kernel: one MFMA wave per SIMD, latency covered by distance
 constexpr int HH = TH + 2, HW = TW + 2;
 
