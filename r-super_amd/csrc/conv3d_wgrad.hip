@@ -20,7 +20,10 @@
 namespace {
 
 constexpr int TD = 4, TH = 4, TW = 16;
-constexpr int WG_BD = 3;                                         // B-fragment prefetch distance (MFMA units), classic kernel (>= 2 waves / SIMD)
+#ifndef WG_BD_
+#define WG_BD_ 3
+#endif
+constexpr int WG_BD = WG_BD_;                                         // B-fragment prefetch distance (MFMA units), classic kernel (>= 2 waves / SIMD)
 #ifndef WG_LS
 #define WG_LS 2                                                  // MFMA units between two staging loads of the next tile: 2 (round 3) -- with 5 the last loads
 #endif                                                           // were issued late in the phase and their latency was exposed behind it (same box: up3.0 301 -> 271-288 us,
