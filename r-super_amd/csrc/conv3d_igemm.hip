@@ -171,7 +171,10 @@ __global__ __launch_bounds__(256, (MF * NF <= 4 && sizeof(T) == 2) ? 3 : 2) void
         constexpr int AU = 2;                                     // A fragments per pipeline unit (register budget)
         constexpr int G = MF / AU;                                // units per step
         constexpr int NSTEP = KSPLIT == 1 ? 54 : 28;              // (tap, k-step) pairs handled by this wave
-        constexpr int RB = 2;                                     // B ring depth (steps)
+#ifndef RS_CL_RB
+#define RS_CL_RB 2
+#endif
+        constexpr int RB = RS_CL_RB;                              // B ring depth (steps); swept 2 / 3 / 4 (round 3)
         const int wv = KSPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(kt);
         auto step_tap = [&](int st) { return KSPLIT == 1 ? st >> 1 : wv + KSPLIT * (st >> 1); };
         auto tap_off = [&](int tap) {

@@ -237,7 +237,10 @@ __global__ __launch_bounds__(NT_THREADS, 1) void igemm_ws_kernel(IgemmParams p) 
         const int kw = f / 12, r2 = f % 12, dr = r2 / 4, s = s_order(r2 % 4);
         return ((dr * HH + s) * HW + kw) * PITCH;
     };
-    constexpr int ADIST = 2, AR = 3;
+#ifndef RS_WS_ADIST
+#define RS_WS_ADIST 2
+#endif
+    constexpr int ADIST = RS_WS_ADIST, AR = ADIST + 1;
     uint4 aq[AR];
 
     f32x16_t acc[2];
