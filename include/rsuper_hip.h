@@ -147,10 +147,12 @@ int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Y
  * expand / project (:197-239), BidirectionAttention's feat_qv / map_qv / out projections (medformer_utils.py:13-99).
  *   mode 0: y[r][n] = sum_k x[r][k] w[n][k] (+ bias[n]),  w = (N, K) as in the state_dict   (F.conv3d(k=1) / F.linear forward)
  *   mode 1: y[r][n] = sum_k x[r][k] w[k][n],              w = (K, N)                        (their data gradient, x := dy)
+ * res (nullable, [R][ldr] f32): added after the bias -- the identity shortcut of MBConv (`... + x`, conv_layers.py:239) and of the attention
+ * blocks, in the GEMM's epilogue instead of a separate element-wise launch (same fp32 additions in the same order: bit-identical).
  * N, ldx, ldy multiples of 4; R * ldx * 4 < 2^32; packed: device workspace of rsuper_pointwise_packed_bytes(dtype, K, N) bytes. */
 size_t rsuper_pointwise_packed_bytes(int dtype, int K, int N);
-int rsuper_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, long R, int K, int N,
-                     void* packed, void* stream);
+int rsuper_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, const float* res, int ldr,
+                     float* y, int ldy, long R, int K, int N, void* packed, void* stream);
 /* The fragments of MANY weights in one launch.  table (device): n + 1 rows of 8 x int64 {weight pointer (f32, row-major rows x cols), byte offset
  * of its fragments in `arena`, rows, cols, mode, ceil(N / 32), k-steps = ceil(K / (dtype == f32 ? 8 : 16)), first item}; an item is one 16-byte
  * fragment slot (64 per (k-step, 32-row tile)), numbered through all entries; row n holds {.., first item = total_items}.  rsuper_pointwise with

@@ -286,12 +286,13 @@ int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Y
 }
 
 size_t rsuper_pointwise_packed_bytes(int dtype, int K, int N) { return dt_ok(dtype) && K > 0 && N > 0 ? rs_pw_packed_bytes(N, K, dtype) : 0; }
-int rsuper_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, long R, int K, int N,
-                     void* packed, void* stream) {
+int rsuper_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, const float* res, int ldr,
+                     float* y, int ldy, long R, int K, int N, void* packed, void* stream) {
     if (!dt_ok(dtype) || (mode != 0 && mode != 1) || !x || !y || !packed || R <= 0 || K <= 0 || N <= 0) return RS_ERR_ARG;   // w == nullptr: `packed` already holds the fragments
     if ((N % 4) || (ldx % 4) || (ldy % 4) || ldx < K || ldy < N || (mode == 1 && bias)) return RS_ERR_ARG;
+    if (res && ((ldr % 4) || ldr < N)) return RS_ERR_ARG;
     if ((unsigned long long)R * ldx * 4ull >= (1ull << 32) || R > 0x7FFFFFFFl) return RS_ERR_UNSUPPORTED;   // buffer-addressed operand loads
-    return rs_launch_pointwise(dtype, mode, x, ldx, w, bias, y, ldy, (int)R, K, N, packed, ST(stream));
+    return rs_launch_pointwise(dtype, mode, x, ldx, w, bias, res, ldr, y, ldy, (int)R, K, N, packed, ST(stream));
 }
 
 int rsuper_pointwise_pack_batch(int dtype, const long long* table, int n, long total_items, void* arena, void* stream) {

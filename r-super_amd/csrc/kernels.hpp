@@ -75,8 +75,8 @@ int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
 
 // 1x1x1 convolution / linear layer as an MFMA GEMM on f32 channels-last rows (pointwise.hip); packed = workspace of rs_pw_packed_bytes
 size_t rs_pw_packed_bytes(int N, int K, int dtype);
-int rs_launch_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int R, int K, int N,
-                        void* packed, hipStream_t st);
+int rs_launch_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, const float* res, int ldr,
+                        float* y, int ldy, int R, int K, int N, void* packed, hipStream_t st);
 // weight (+ bias) gradient of the same layer: dW = dy^T x, db = column sums of dy; part = workspace of S * (N*K + N) floats, S = rs_pw_wgrad_splits
 int rs_pw_wgrad_splits(int R, int N, int K);
 int rs_launch_pointwise_pack_batch(int dtype, const long long* table, int n, long total_items, void* arena, hipStream_t st);

@@ -27,6 +27,7 @@ struct PwParams {
     const float* x; int ldx;       // [R][ldx] f32 (row = voxel)
     const void* wp;                // packed A fragments: [ksteps][ntiles][64 lanes] x 16 B
     const float* bias;             // [N] or nullptr
+    const float* res; int ldr;     // [R][ldr] residual added after the bias (MBConv / attention shortcuts), or nullptr
     float* y; int ldy;             // [R][ldy] f32
     int R, K, N, ntiles, ksteps;
 };
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwParams p) {
                 if (n < p.N) {                               // N is a multiple of 4 (checked by the launcher)
                     float4 o = make_float4(acc[nf][4 * q], acc[nf][4 * q + 1], acc[nf][4 * q + 2], acc[nf][4 * q + 3]);
                     if (p.bias) { const float4 b = *(const float4*)(p.bias + n); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
+                    if (p.res) { const float4 r = *(const float4*)(p.res + (size_t)row * p.ldr + n); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
                     *(float4*)(yrow + n) = o;
                 }
             }
@@ -359,11 +361,11 @@ size_t rs_pw_packed_bytes(int N, int K, int dtype) {
 }
 
 // mode 0: y = x W^T (+ bias), W (N, K);  mode 1: y = x W, W (K, N) (the data gradient of mode 0 with x := dy)
-int rs_launch_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int R, int K, int N,
-                        void* packed, hipStream_t st) {
+int rs_launch_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, const float* res, int ldr,
+                        float* y, int ldy, int R, int K, int N, void* packed, hipStream_t st) {
     const int KS = dtype == RS_F32 ? 8 : 16;
     PwParams p;
-    p.x = x; p.ldx = ldx; p.wp = packed; p.bias = bias; p.y = y; p.ldy = ldy; p.R = R; p.K = K; p.N = N;
+    p.x = x; p.ldx = ldx; p.wp = packed; p.bias = bias; p.res = res; p.ldr = ldr; p.y = y; p.ldy = ldy; p.R = R; p.K = K; p.N = N;
     p.ntiles = (N + 31) / 32; p.ksteps = (K + KS - 1) / KS;
     const int items = p.ksteps * p.ntiles * 64;
     const int rows = mode == 0 ? N : K, cols = mode == 0 ? K : N;

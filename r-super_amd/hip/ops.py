@@ -1112,9 +1112,10 @@ def pointwise_prepack(compute):
         _PW_PACKED[key] = ((ep, ref()._version), arena, off)
 
 
-def pointwise_gemm(x2, w, bias, mode, compute):
+def pointwise_gemm(x2, w, bias, mode, compute, res=None):
     """csrc/pointwise.hip on f32 rows.  mode 0: y = x2 @ w.T (+ bias), w (N, K); mode 1: y = x2 @ w, w (K, N) (the data gradient of mode 0).
-    compute: torch.bfloat16 (bf16 MFMA, fp32 accumulate) or torch.float32 (exact-f32 MFMA); storage stays fp32."""
+    compute: torch.bfloat16 (bf16 MFMA, fp32 accumulate) or torch.float32 (exact-f32 MFMA); storage stays fp32.
+    res (R, N) f32 contiguous: added after the bias in the epilogue (identity shortcuts)."""
     import weakref
     assert x2.dim() == 2 and x2.dtype == torch.float32 and x2.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
     R, K = x2.shape
@@ -1135,7 +1136,8 @@ def pointwise_gemm(x2, w, bias, mode, compute):
                 _PW_SEEN_DIRTY = True
         ws = torch.empty((_L().rsuper_pointwise_packed_bytes(dt, K, N),), device=x2.device, dtype=torch.uint8)
         wptr, packed = _ptr(w), _ptr(ws)
-    _l.check(_L().rsuper_pointwise(dt, mode, _ptr(x2), K, wptr, _ptr(bias) if bias is not None else None, _ptr(y), N, R, K, N, packed,
+    assert res is None or (res.shape == (R, N) and res.dtype == torch.float32 and res.is_contiguous())
+    _l.check(_L().rsuper_pointwise(dt, mode, _ptr(x2), K, wptr, _ptr(bias) if bias is not None else None, _ptr(res), N, _ptr(y), N, R, K, N, packed,
                                    _stream()), 'pointwise')
     return y
 

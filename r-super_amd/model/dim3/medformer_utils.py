@@ -90,6 +90,7 @@ def upsample_trilinear(x, size, planar=False):
 # RSUPER_MF_ATEN_ATTENTION=1: the ATen composition of the attention core instead of csrc/battn.hip (A/B switch; same results to fp32 rounding)
 FUSED_ATTENTION = os.environ.get('RSUPER_MF_ATEN_ATTENTION') != '1'
 HIP_POINTWISE = os.environ.get('RSUPER_MF_LIBRARY_GEMM') != '1'      # 1x1x1 convolutions / linear layers on csrc/pointwise.hip (=1: library GEMMs, A/B)
+FUSE_RESIDUAL = os.environ.get('RSUPER_MF_FUSE_RES', '1') == '1'          # identity shortcuts added in the pointwise GEMM's epilogue
 HIP_POINTWISE_WGRAD = os.environ.get('RSUPER_MF_LIBRARY_WGRAD') != '1'   # their weight / bias gradients too (=1: library GEMMs, A/B)
 HIP_POINTWISE_MIN_ROWS = int(os.environ.get('RSUPER_MF_PW_MIN_ROWS', '32'))    # below (the 27-token maps): library GEMM
 GEMM_COMPUTE = torch.float32    # MFMA operand type of the HIP pointwise GEMMs: set per forward by MedFormer from its compute_dtype
@@ -133,16 +134,20 @@ class _LinearFn(torch.autograd.Function):
     on 256 CUs, 186 us for a 128 x 27648 x 512 product (3.4 ms per MedFormer step over all such layers); split 16-way it takes ~35 us."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, res=None):
+        """res: a tensor of the output's shape added to it (identity shortcut) -- in the GEMM's epilogue on the HIP path; its gradient is dy."""
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.has_res = res is not None
         ctx.hip = HIP_POINTWISE and x.numel() // x.shape[-1] >= HIP_POINTWISE_MIN_ROWS and ops.pointwise_supported(x, w)
         ctx.compute = GEMM_COMPUTE
         if ctx.hip:          # csrc/pointwise.hip: MFMA GEMM straight from the row-major rows (no library call, no staging copies)
             wc = w.contiguous()
-            return ops.pointwise_gemm(x.reshape(-1, x.shape[-1]).contiguous(), wc, b, 0, ctx.compute).reshape(*x.shape[:-1], w.shape[0])
+            r2 = None if res is None else res.reshape(-1, w.shape[0]).contiguous()
+            return ops.pointwise_gemm(x.reshape(-1, x.shape[-1]).contiguous(), wc, b, 0, ctx.compute, r2).reshape(*x.shape[:-1], w.shape[0])
         with gemm_library(w.shape[1]):
-            return F.linear(x, w, b)
+            y = F.linear(x, w, b)
+        return y if res is None else y + res
 
     @staticmethod
     def backward(ctx, dy):
@@ -159,7 +164,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.hip and HIP_POINTWISE_WGRAD and ctx.needs_input_grad[1]:
             # csrc/pointwise.hip: dW and db from one pass over dy and x (slabs of the rows, added in slab order)
             dw, db = ops.pointwise_wgrad(dy2.contiguous(), x2.contiguous(), want_db, ctx.compute)
-            return dx, dw, db
+            return dx, dw, db, (dy if ctx.has_res else None)
         if ctx.needs_input_grad[1]:
             rows = x2.shape[0]
             slabs = next((s for s in (32, 16, 8, 4) if rows % s == 0 and rows // s >= SPLITK_MIN_SLAB), 0) if rows >= SPLITK_MIN_ROWS else 0
@@ -179,7 +184,7 @@ class _LinearFn(torch.autograd.Function):
                     db = torch.mm(_ones_row(dy2.shape[0], dy2.device), dy2).reshape(-1)
             else:
                 db = dy2.sum(0)
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.has_res else None)
 
 
 _ONES = {}
@@ -193,23 +198,28 @@ def _ones_row(n, device):
     return _ONES[k]
 
 
-def linear(x, w, b=None):
+def linear(x, w, b=None, res=None):
+    """F.linear(x, w, b) [+ res]: the shortcut addition rides in the HIP GEMM's epilogue (RSUPER_MF_FUSE_RES=0: a separate add, A/B)."""
     rows = x.numel() // x.shape[-1]
+    if res is not None and not FUSE_RESIDUAL:
+        return linear(x, w, b) + res
     if HIP_POINTWISE and rows >= HIP_POINTWISE_MIN_ROWS and ops.pointwise_supported(x, w):
-        return _LinearFn.apply(x, w, b)
+        return _LinearFn.apply(x, w, b, res)
     if x.dtype == torch.float32 and (rows >= SPLITK_MIN_ROWS or (gemm_library.active and max(rows, w.shape[0], w.shape[1]) >= LT_MIN_K)):
-        return _LinearFn.apply(x, w, b)
-    return F.linear(x, w, b)
+        return _LinearFn.apply(x, w, b, res)
+    y = F.linear(x, w, b)
+    return y if res is None else y + res
 
 
-def pointwise(x, conv):
-    """Conv3d(k=1) as a GEMM over the channel axis (rocBLAS / hipBLASLt, forward and both gradients; the weight gradient of the
-    high-resolution stages split along the voxel axis); fp32 unless GEMM_DTYPE says bf16 (opt-in experiment)."""
+def pointwise(x, conv, res=None):
+    """Conv3d(k=1) as a GEMM over the channel axis (csrc/pointwise.hip, forward and both gradients; library GEMMs below 32 rows / for channel
+    counts that are not multiples of 4); fp32 storage unless GEMM_DTYPE says bf16 (opt-in experiment).  res: shortcut added to the output."""
     w = conv.weight.reshape(conv.weight.shape[0], conv.weight.shape[1])
     if GEMM_DTYPE != torch.float32 and x.numel() // x.shape[-1] >= 64:
         y = F.linear(x.to(GEMM_DTYPE), w.to(GEMM_DTYPE)).float()
-        return y if conv.bias is None else y + conv.bias
-    return linear(x, w, conv.bias)
+        y = y if conv.bias is None else y + conv.bias
+        return y if res is None else y + res
+    return linear(x, w, conv.bias, res)
 
 
 def depthwise(x, conv):
@@ -227,9 +237,12 @@ class GlueConvNormAct(nn.Module):
         self.conv = nn.Conv3d(in_ch, out_ch, kernel_size, padding=kernel_size // 2, groups=groups, bias=False)
         self.act = act
 
-    def forward(self, x):
+    def forward(self, x, res=None):
         h = instance_norm(x, IN_EPS_CNA, relu=self.act)
-        return pointwise(h, self.conv) if self.conv.kernel_size[0] == 1 else depthwise(h, self.conv)
+        if self.conv.kernel_size[0] == 1:
+            return pointwise(h, self.conv, res)
+        y = depthwise(h, self.conv)
+        return y if res is None else y + res
 
 
 class DepthwiseSeparableConv(nn.Module):
@@ -241,8 +254,8 @@ class DepthwiseSeparableConv(nn.Module):
         self.depthwise = nn.Conv3d(in_ch, in_ch, 3, padding=1, groups=in_ch, bias=False)
         self.pointwise = nn.Conv3d(in_ch, out_ch, 1, bias=False)
 
-    def forward(self, x):
-        return pointwise(depthwise(x, self.depthwise), self.pointwise)
+    def forward(self, x, res=None):
+        return pointwise(depthwise(x, self.depthwise), self.pointwise, res)
 
 
 class SEBlock(nn.Module):
@@ -270,7 +283,7 @@ class MBConv(nn.Module):
         self.pointwise = GlueConvNormAct(e, ch, 1, act=False)
 
     def forward(self, x):
-        return self.pointwise(self.se(self.depthwise(self.expand_proj(x)))) + x
+        return self.pointwise(self.se(self.depthwise(self.expand_proj(x))), res=x)          # `... + x` (conv_layers.py:239) in the GEMM's epilogue
 
 
 def _split_heads(t, heads):
@@ -298,7 +311,9 @@ class BidirectionAttention(nn.Module):
         self.map_qv = nn.Conv3d(map_dim, 2 * inner, 1, bias=False)
         self.map_out = nn.Identity() if no_map_out else nn.Conv3d(inner, map_dim, 1, bias=False)
 
-    def forward(self, feat, smap):
+    def forward(self, feat, smap, feat_res=None, map_res=None):
+        """feat_res / map_res: the block's shortcuts (BidirectionAttentionBlock: `out + shortcut(x)`, `m + smap`), added in the epilogues of the
+        output projections."""
         dim_head = self.map_qv.weight.shape[0] // (2 * self.heads)
         tokens = smap.shape[1] * smap.shape[2] * smap.shape[3]
         if FUSED_ATTENTION and ops.battn_supported(tokens, dim_head, self.heads):
@@ -306,8 +321,8 @@ class BidirectionAttention(nn.Module):
             f_out, m_out = ops.BidirAttnFn.apply(self.feat_qv(feat).flatten(1, 3), pointwise(smap, self.map_qv).flatten(1, 3), self.heads,
                                                  self.scale)
             f_out, m_out = f_out.reshape(*feat.shape[:4], -1), m_out.reshape(*smap.shape[:4], -1)
-            m_out = m_out if isinstance(self.map_out, nn.Identity) else pointwise(m_out, self.map_out)
-            return self.feat_out(f_out), m_out
+            m_out = self._map_out(m_out, map_res)
+            return self.feat_out(f_out, feat_res), m_out
         fq, fv = self.feat_qv(feat).chunk(2, -1)
         mq, mv = pointwise(smap, self.map_qv).chunk(2, -1)
         fq, fv, mq, mv = (_split_heads(t, self.heads) for t in (fq, fv, mq, mv))
@@ -315,8 +330,13 @@ class BidirectionAttention(nn.Module):
         # softmax over the map tokens for the feature update, over the voxels (the contiguous axis here) for the map update
         f_out = _merge_heads(torch.matmul(F.softmax(score, -2).transpose(-1, -2), mv), feat.shape[1:4])
         m_out = _merge_heads(torch.matmul(F.softmax(score, -1), fv), smap.shape[1:4])
-        m_out = m_out if isinstance(self.map_out, nn.Identity) else pointwise(m_out, self.map_out)
-        return self.feat_out(f_out), m_out
+        m_out = self._map_out(m_out, map_res)
+        return self.feat_out(f_out, feat_res), m_out
+
+    def _map_out(self, m_out, map_res):
+        if isinstance(self.map_out, nn.Identity):
+            return m_out if map_res is None else m_out + map_res
+        return pointwise(m_out, self.map_out, map_res)
 
 
 class BidirectionAttentionBlock(nn.Module):
@@ -327,8 +347,9 @@ class BidirectionAttentionBlock(nn.Module):
         self.feedforward = MBConv(out_dim, expansion)
 
     def forward(self, x, smap):
-        out, m = self.attn(instance_norm(x, IN_EPS), instance_norm(smap, IN_EPS))
-        return self.feedforward(out + self.shortcut(x)), m + smap
+        # `out + shortcut(x)` and `m + smap` ride in the epilogues of the attention's output projections
+        out, m = self.attn(instance_norm(x, IN_EPS), instance_norm(smap, IN_EPS), feat_res=self.shortcut(x), map_res=smap)
+        return self.feedforward(out), m
 
 
 class BasicLayer(nn.Module):

@@ -518,6 +518,10 @@ def check_pointwise(mode, R, K, N, bias, seed=103):
     if bias:                                   # column sums: fp32 adds of the UNROUNDED dy in both modes
         e = max(e, relerr(db.cpu(), refb) * (1.0 if mode == 'f32' else 1e3))
     det = bool(torch.equal(dw, dw2)) and (not bias or bool(torch.equal(db, db2)))
+    # shortcut in the epilogue: the same fp32 additions in the same order as a separate add
+    res = torch.randn(R, N, generator=g).to(DEV)
+    yr = ops.pointwise_gemm(x.to(DEV), w.to(DEV), b.to(DEV) if bias else None, 0, comp, res)
+    det = det and bool(torch.equal(yr, y + res))
     # batched fragment packing (ops.pointwise_prepack): a parameter the GEMM has seen once is packed by the batch launch from then on -- same bits;
     # and a raw-pointer update of the parameter (WEIGHTS_EPOCH) must not be served stale fragments
     wp = torch.nn.Parameter(w.to(DEV))
