@@ -12,11 +12,11 @@ def read_pass(d):
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if 'igemm' not in k and 'wgrad' not in k:
+            if 'igemm' not in k and 'wgrad' not in k and 'pw_gemm' not in k:
                 continue
             if 'reduce' in k or 'pack' in k:
                 continue
-            m = re.search(r'(igemm_box_kernel|igemm_pc_kernel|igemm_kernel|wgrad_pc_kernel|wgrad_kernel|igemm_ws_kernel|wgrad\w*_kernel)<([^>]*)>', k)
+            m = re.search(r'(igemm_box_kernel|igemm_s2_kernel|pw_gemm_kernel|pw_wgrad_kernel|igemm_pc_kernel|igemm_kernel|wgrad_pc_kernel|wgrad_kernel|igemm_ws_kernel|wgrad\w*_kernel)<([^>]*)>', k)
             name = (m.group(1) + '<' + m.group(2) + '>') if m else k[:60]
             e = out.setdefault(name, {})
             e.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
@@ -38,7 +38,10 @@ def main():
         print(f'### {k}')
         vg, ag, sg, lds, grid, wg = e['_regs']
         print(f'- grid {grid} threads / wg {wg}, VGPR {vg} + AGPR {ag}, SGPR {sg}, LDS {lds} B; duration {e["_dur"]:.1f} us (profiled clock)')
-        g = lambda c: e.get(c, float('nan'))
+        class _Z(float):                                     # a counter that read 0 (LDS-free kernels): ratios print as nan instead of raising
+            def __rtruediv__(self, o):
+                return float('nan') if self == 0 else float(o) / float(self)
+        g = lambda c: _Z(e.get(c, float('nan')))
         wc = g('SQ_WAVE_CYCLES')
         mf = g('SQ_VALU_MFMA_BUSY_CYCLES')
         busy = g('SQ_BUSY_CYCLES')
