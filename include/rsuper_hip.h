@@ -325,6 +325,9 @@ int rsuper_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, floa
                             void* stream);
 /* insert_ball :1336-1385; count (device u32, pre-zeroed) += voxels set. */
 int rsuper_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, void* stream);
+/* The same with the centre decoded on the device from `best` (the argmax key rsuper_ball_conv_argmax wrote): isolate_tumor's argmax -> insert_ball
+ * hand-over (losses_foundation.py:1445-1448) without a device->host read.  count: device u32, pre-zeroed, receives the ball's voxel count. */
+int rsuper_insert_ball_at(uint8_t* out, int D, int H, int W, const unsigned long long* best, int d_odd, int half, unsigned int* count, void* stream);
 /* exact top-k as radix select over non-negative f32 (torch.topk use at :1483-1492); ties -> lower index first. */
 int rsuper_radix_hist(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist256, void* stream);
 /* need_eq = 0xFFFFFFFF: every element equal to the threshold is selected (parallel); otherwise the first need_eq in index order. */

@@ -535,6 +535,10 @@ int rsuper_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx
     if (!out || !count) return RS_ERR_ARG;
     return rs_launch_insert_ball(out, D, H, W, cz, cy, cx, d_odd, half, count, ST(stream));
 }
+int rsuper_insert_ball_at(uint8_t* out, int D, int H, int W, const unsigned long long* best, int d_odd, int half, unsigned int* count, void* stream) {
+    if (!out || !count || !best) return RS_ERR_ARG;
+    return rs_launch_insert_ball_at(out, D, H, W, best, d_odd, half, count, ST(stream));
+}
 int rsuper_radix_hist(const float* x, const uint8_t* m, long V, uint32_t prefix, int shift, unsigned int* hist256, void* stream) {
     if (!x || !hist256 || (shift != 24 && shift != 16 && shift != 8 && shift != 0)) return RS_ERR_ARG;
     return rs_launch_radix_hist(x, m, V, prefix, shift, hist256, ST(stream));

@@ -287,6 +287,22 @@ __global__ void insert_ball_kernel(uint8_t* out, int D, int H, int W, int cz, in
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
 }
 
+// the same ball, its centre decoded on the device from the argmax key of ball_conv_argmax (no host round trip between the two)
+__global__ void insert_ball_at_kernel(uint8_t* out, int D, int H, int W, const unsigned long long* best, int d_odd, int half, unsigned int* count) {
+    const long V = (long)D * H * W;
+    const unsigned int idx = 0xFFFFFFFFu - (unsigned int)(*best & 0xFFFFFFFFull);
+    const int cx = (int)(idx % (unsigned)W), cy = (int)((idx / (unsigned)W) % (unsigned)H), cz = (int)(idx / ((unsigned)W * (unsigned)H));
+    unsigned int c = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W) - cx, y = (int)((i / W) % H) - cy, z = (int)(i / ((long)W * H)) - cz;
+        const bool in = abs(x) <= half && abs(y) <= half && abs(z) <= half && 4 * (x * x + y * y + z * z) <= d_odd * d_odd;
+        out[i] = in ? 1 : 0;
+        c += in;
+    }
+    c = (unsigned int)wave_sum((float)c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
 // ------------------------------------------------------------------------------------------------ exact top-k (radix select)
 // values are non-negative floats (bit pattern order == value order), optionally masked by m.
 // pass `shift` in {24,16,8,0}: histogram of byte (bits >> shift) & 255 over elements whose higher bits == prefix.
@@ -537,6 +553,11 @@ int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, f
 
 int rs_launch_insert_ball(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count, hipStream_t st) {
     hipLaunchKernelGGL(insert_ball_kernel, dim3(rs_elem_blocks((size_t)D * H * W)), dim3(256), 0, st, out, D, H, W, cz, cy, cx, d_odd, half, count);
+    return rs_check_launch();
+}
+
+int rs_launch_insert_ball_at(uint8_t* out, int D, int H, int W, const unsigned long long* best, int d_odd, int half, unsigned int* count, hipStream_t st) {
+    hipLaunchKernelGGL(insert_ball_at_kernel, dim3(rs_elem_blocks((size_t)D * H * W)), dim3(256), 0, st, out, D, H, W, best, d_odd, half, count);
     return rs_check_launch();
 }
 

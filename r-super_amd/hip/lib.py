@@ -82,6 +82,7 @@ _SIGS = {
     'rsuper_ball_workspace_floats': (c_long, [c_int, c_int, c_int, c_int]),
     'rsuper_ball_conv_argmax': (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, P, P, P]),
     'rsuper_insert_ball': (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    'rsuper_insert_ball_at': (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P]),
     'rsuper_radix_hist': (c_int, [P, P, c_long, c_uint32, c_int, P, P]),
     'rsuper_topk_mark': (c_int, [P, P, c_long, c_uint32, c_uint, P, P]),
     'rsuper_compact': (c_int, [P, P, c_long, P, P, P, P]),

@@ -315,6 +315,64 @@ def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_ma
     return masks[0], masks[1], masks[2]
 
 
+def isolate_tumor_spec(x, diameter, gaussian_std, tumor_volume, checks, diameter_margin=0.5, volume_margin=0.5):
+    """isolate_tumor without device->host reads, valid under two assumptions that hold for almost every tumour: the first ball already holds
+    `vol` voxels (no growth loop, :1450-1461) and the top-k mask keeps >= 70 % of `vol` inside the ball (no dilation rounds, :1513-1522).  The
+    two counts that decide this stay on the device; `checks` collects (ball count, mask count, vol) and the caller reads them all in ONE copy
+    after the last tumour of the sample -- if any assumption fails it repeats the sample with isolate_tumor proper.  Returns the masks or None
+    when the preconditions of the device-resident selection do not hold (then the caller falls back at once)."""
+    D, H, W = x.shape
+    V = x.numel()
+    diameter = int(np.round(diameter).astype(int))
+    vol = int(np.round(tumor_volume).astype(int))
+    if diameter % 2 == 0:
+        diameter += 1
+    nnz = ball_nnz(diameter)
+    f32 = False
+    if nnz > vol:
+        vol, f32 = nnz - 1, True
+    t = min(V - 1, vol)
+    ms = min(0.5, volume_margin)
+    t_small = int(np.float32(t) * np.float32(1 - ms)) if f32 else int(t * (1 - ms))
+    t_small = max(t_small, min(100, vol))
+    t_big = min(V - 1, int(np.float32(vol) * np.float32(1 + volume_margin)) if f32 else int(vol * (1 + volume_margin)))
+    ks = (t, t_small, t_big)
+    if min(ks) <= 0 or os.environ.get('RSUPER_TOPK_HOST', '0') == '1':
+        return None
+    import ctypes
+    best = torch.zeros(1, device=x.device, dtype=torch.int64)
+    ws = (torch.empty((_L().rsuper_ball_workspace_floats(D, H, W, diameter),), device=x.device, dtype=torch.float32)
+          if (diameter >= 5 and os.environ.get('RSUPER_BALL_DIRECT', '0') != '1') else None)
+    _l.check(_L().rsuper_ball_conv_argmax(_ptr(x), D, H, W, diameter, float(gaussian_std * (diameter / 2.0)), _ptr(best), None, _ptr(ws), _stream()),
+              'ball_conv_argmax')
+    d_odd, kedge = ball_kernel_geometry(diameter * (1 + diameter_margin))
+    ball = torch.empty((D, H, W), device=x.device, dtype=torch.uint8)
+    cnts = torch.zeros(2, device=x.device, dtype=torch.int32)          # [ball voxels, voxels of the top-k mask inside the ball]
+    _l.check(_L().rsuper_insert_ball_at(_ptr(ball), D, H, W, _ptr(best), d_odd, kedge // 2, _ptr(cnts), _stream()), 'insert_ball_at')
+    out3 = torch.empty((3, D, H, W), device=x.device, dtype=torch.uint8)
+    ws3 = torch.empty(3 * 260, device=x.device, dtype=torch.int32)
+    _l.check(_L().rsuper_topk_select_multi(_ptr(x), _ptr(ball), V, (ctypes.c_uint * 3)(*ks), 3, _ptr(out3), _ptr(ws3), 1, _stream()), 'topk_select_multi')
+    _l.check(_L().rsuper_count(_ptr(out3), V, _ptr(cnts, 1), _stream()), 'count')
+    checks.append((cnts, vol))
+    return out3[0], out3[1], out3[2]
+
+
+def _spec_ok(checks, extra=None):
+    """ONE device->host copy for all tumours of a sample (+ `extra`, a device int32 tensor the caller wants along): True when no tumour needed the
+    growth loop or the dilation rounds.  Returns (ok, extra values)."""
+    parts = [c for c, _ in checks] + ([extra] if extra is not None else [])
+    h = torch.cat(parts).cpu().numpy()
+    ok = True
+    for i, (_, vol) in enumerate(checks):
+        bsum, c0 = int(h[2 * i]), int(h[2 * i + 1])
+        if bsum < vol or (vol < 50 ** 3 and c0 < vol * 0.7):
+            ok = False
+    return ok, (h[2 * len(checks):] if extra is not None else None)
+
+
+SPECULATIVE_BALL_SEARCH = os.environ.get('RSUPER_BALL_SPEC', '1') == '1'
+
+
 def _plane_any(t, lead_dims):
     """any() over the trailing volume of a contiguous uint8 tensor, one flag per leading index: (B, ...) -> bool tensor of
     shape t.shape[:lead_dims] on the device (HIP kernel at HBM rate instead of an ATen byte reduction)."""
@@ -335,11 +393,12 @@ def _count(m):
     return int(c.item())
 
 
-def gwrp_foreground_weights(x_plane, pm, c=0.5):
+def gwrp_foreground_weights(x_plane, pm, c=0.5, N=None):
     """GlobalWeightedRankPooling(sig(x)*pm + pm, N=|pm|, c, return_weights=True, hard_cutoff=True) * |pm| * pm
     (:1780-1791): rank the pseudo-mask voxels by sig(x) (desc, ties by index), weight d^rank, renormalise."""
     V = x_plane.numel()
-    N = _count(pm)
+    if N is None:
+        N = _count(pm)
     w = torch.zeros(x_plane.shape, device=x_plane.device, dtype=torch.float32)
     if N == 0:
         return w, 0
@@ -391,28 +450,51 @@ def _ball_plans(out, label_u8, unk_u8, mask_u8, volumes, diameters, groups, marg
         penal = pen[b, li].contiguous()
         tumor_seg = mseg[b].sum(0).clamp(max=1).to(torch.uint8).contiguous()       # one channel active -> 0/1
         order = [int(i) for i in np.argsort(-vols_h[b], kind='stable') if vols_h[b][int(i)] > 0]
-        x_it = torch.empty((D, H, W), device=out.device, dtype=torch.float32)
-        _l.check(_L().rsuper_sigmoid_mask(_ptr(out, (b * C + c) * V), _ptr(tumor_seg), _ptr(x_it), V, _stream()), 'sigmoid_mask')
-        pm_small, pm_big = None, None
-        for ti in order:                                                # :1695-1719
-            vol, dmax = float(vols_h[b][ti]), float(dias_h[b][ti].max())
-            if dmax <= 1:
-                dmax = 3
-            if vol <= 1:
-                vol = 9
-            pm, pms, pmb = isolate_tumor(x_it, dmax, True, 1.5, vol, margin, margin)
-            _l.check(_L().rsuper_zero_where(_ptr(x_it), _ptr(pm), V, _stream()), 'zero_where')    # x_iter *= (1 - pseudo_mask)
-            if pm_small is None:
-                pm_small, pm_big = pms, pmb
+        def tumour_loop(spec):
+            x_it = torch.empty((D, H, W), device=out.device, dtype=torch.float32)
+            _l.check(_L().rsuper_sigmoid_mask(_ptr(out, (b * C + c) * V), _ptr(tumor_seg), _ptr(x_it), V, _stream()), 'sigmoid_mask')
+            pm_small, pm_big, checks = None, None, []
+            for ti in order:                                            # :1695-1719
+                vol, dmax = float(vols_h[b][ti]), float(dias_h[b][ti].max())
+                if dmax <= 1:
+                    dmax = 3
+                if vol <= 1:
+                    vol = 9
+                if spec:
+                    r3 = isolate_tumor_spec(x_it, dmax, 1.5, vol, checks, margin, margin)
+                    if r3 is None:
+                        return None
+                    pm, pms, pmb = r3
+                else:
+                    pm, pms, pmb = isolate_tumor(x_it, dmax, True, 1.5, vol, margin, margin)
+                _l.check(_L().rsuper_zero_where(_ptr(x_it), _ptr(pm), V, _stream()), 'zero_where')    # x_iter *= (1 - pseudo_mask)
+                if pm_small is None:
+                    pm_small, pm_big = pms, pmb
+                else:
+                    _l.check(_L().rsuper_mask_op(_ptr(pm_small), _ptr(pms), V, 1, _stream()), 'mask_or')
+                    _l.check(_L().rsuper_mask_op(_ptr(pm_big), _ptr(pmb), V, 1, _stream()), 'mask_or')
+            return pm_small, pm_big, checks
+
+        npm_known = None
+        res3 = tumour_loop(True) if SPECULATIVE_BALL_SEARCH else None
+        if res3 is not None:
+            # the counts that validate the speculation and |pseudo mask| (needed on the host by the rank weights) come over in one copy
+            npm_dev = torch.zeros(1, device=out.device, dtype=torch.int32)
+            _l.check(_L().rsuper_count(_ptr(res3[0]), V, _ptr(npm_dev), _stream()), 'count')
+            ok, extra = _spec_ok(res3[2], npm_dev)
+            if ok:
+                npm_known = int(extra[0])
             else:
-                _l.check(_L().rsuper_mask_op(_ptr(pm_small), _ptr(pms), V, 1, _stream()), 'mask_or')
-                _l.check(_L().rsuper_mask_op(_ptr(pm_big), _ptr(pmb), V, 1, _stream()), 'mask_or')
+                res3 = None
+        if res3 is None:
+            res3 = tumour_loop(False)
+        pm_small, pm_big = res3[0], res3[1]
         big = ops.dilate_volume(pm_big, 7)                              # :1727-1731
         # border = (BIG - PM) > 0 ; penalize *= (1 - border)  ==  penal &= ~(BIG & ~PM)
         border = big.clone()
         _l.check(_L().rsuper_mask_op(_ptr(border), _ptr(pm_small), V, 2, _stream()), 'mask_andnot')
         _l.check(_L().rsuper_mask_op(_ptr(penal), _ptr(border), V, 2, _stream()), 'mask_andnot')
-        fw, npm = gwrp_foreground_weights(out[b, c], pm_small)
+        fw, npm = gwrp_foreground_weights(out[b, c], pm_small, N=npm_known)
         if SANITY_CHECKS:
             assert npm > 0, 'Pseudo mask should have at least one voxel'
         p.kind, p.c, p.pm, p.penal, p.fw, p.big = 'tumor', c, pm_small, penal, fw, big

@@ -750,7 +750,25 @@ def check_isolate_tumor():
         d = int((got.cpu().numpy() != ref).sum())
         bad += d
         notes.append(f'border{key}:{d}')
-    return result('isolate_tumor masks (bit-exact vs reference golden)', bad, 0, ' '.join(notes))
+    # the speculative, device-resident search (no host reads between argmax, ball, top-k): where its two assumptions hold it must give the same
+    # bits, where they do not (the border case needs the growth loop / dilation rounds) its check must say so -- the caller then repeats exactly
+    spec_valid = 0
+    for name, xx, dia, vol in [('a', x, 7.0, 150.0), ('b', x, 4.6, 40.0), ('c', x, 9.0, 300.0), ('border', xb, 9.0, 380.0)]:
+        checks = []
+        r3 = lf.isolate_tumor_spec(xx.to(DEV), dia, 1.5, vol, checks, 0.2, 0.2)
+        ok, _ = lf._spec_ok(checks)
+        ref3 = lf.isolate_tumor(xx.to(DEV), dia, True, 1.5, vol, 0.2, 0.2)
+        if ok:
+            spec_valid += 1
+            d = sum(int((a != b).sum()) for a, b in zip(r3, ref3))
+            bad += d
+            notes.append(f'spec_{name}:{d}')
+        else:
+            notes.append(f'spec_{name}:fallback')
+    if spec_valid == 0:
+        bad += 1
+        notes.append('speculation never valid')
+    return result('isolate_tumor masks (bit-exact vs reference golden; speculative search == exact search)', bad, 0, ' '.join(notes))
 
 
 def check_gwrp():
