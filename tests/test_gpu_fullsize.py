@@ -265,3 +265,46 @@ def test_medformer_shipped_config_128_42_classes():
     assert runs[0][-1] < runs[0][0], runs[0]
     assert runs[1] == runs[0][:2], (runs[0][:2], runs[1])
     assert torch.cuda.max_memory_allocated() < 30 * 2 ** 30
+
+
+@pytest.mark.parametrize('mode,s,ci,co', [('f32', 48, 32, 64), ('f32', 23, 16, 32), ('bf16', 96, 32, 64), ('bf16', 47, 64, 128)])
+def test_strided_block_parity_class_kernel_matches_full_resolution_evaluation(mode, s, ci, co):
+    """BasicBlock(stride=2) of down_block(pool=False) at full size (and an odd size: 47 -> 24): the parity-class kernels (conv3d_igemm_s2.hip,
+    forward + data gradient with the minimal MFMA work) against the rounds-1/2 evaluation (stride-1 kernels at full resolution + subsample /
+    zero-stuffed dy) of the SAME operator on the same inputs -- output, output statistics, input gradient and the three weight gradients.
+    f32: different summation orders only (1e-5 of the largest entry); bf16: the two evaluations round conv1's output to bf16 from different fp32
+    sums, a few ReLU masks of the second convolution flip: relative L2 2e-2 (measured 3e-3 .. 8e-3; 2.2e-2 of the largest entry at worst)."""
+    import os
+    from rsuper_amd.hip import ops
+    dt = {'f32': torch.float32, 'bf16': torch.bfloat16}[mode]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((1, s, s, s, ci), generator=g).to(DEV).to(dt)
+    w1 = (torch.randn((co, ci, 3, 3, 3), generator=g) / math.sqrt(27 * ci)).to(DEV)
+    w2 = (torch.randn((co, co, 3, 3, 3), generator=g) / math.sqrt(27 * co)).to(DEV)
+    ws = (torch.randn((co, ci, 3, 3, 3), generator=g) / math.sqrt(27 * ci)).to(DEV)
+    o = (s + 1) // 2
+    go = torch.randn((1, o, o, o, co), generator=g).to(DEV).to(dt)
+
+    def run(force):
+        os.environ['RSUPER_S2_KERNEL'] = force
+        try:
+            xa = x.clone().requires_grad_(True)
+            ps = [w.clone().requires_grad_(True) for w in (w1, w2, ws)]
+            mra = ops.stats_of(xa.detach()) if hasattr(ops, 'stats_of') else None
+            if mra is None:
+                xf = xa.detach().float()
+                m = xf.mean(dim=(1, 2, 3)); v = xf.var(dim=(1, 2, 3), unbiased=False)
+                mra = torch.stack([m, 1.0 / torch.sqrt(v + 1e-4)], -1).contiguous()
+            y, mr = ops._BB.apply(xa, mra, None, None, ps[0], ps[1], ps[2], None, 2)
+            y.backward(go)
+            torch.cuda.synchronize()
+            return [y.detach().float(), mr.detach(), xa.grad.float()] + [p.grad for p in ps]
+        finally:
+            del os.environ['RSUPER_S2_KERNEL']
+    a, b = run('1'), run('0')
+    for name, u, v in zip(('out', 'stats', 'dx', 'dw1', 'dw2', 'dws'), a, b):
+        if mode == 'f32':
+            err, tol = float((u - v).abs().max() / v.abs().max().clamp_min(1e-20)), 1e-5
+        else:
+            err, tol = float((u - v).double().norm() / v.double().norm().clamp_min(1e-20)), 2e-2
+        assert err <= tol, (name, err)
