@@ -333,7 +333,7 @@ int rsuper_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int l
     if ((D & 1) || (H & 1) || (W & 1)) {
         // MaxPool3d(2) floors odd sizes: the trailing plane/row/column is never pooled and receives zero gradient
         if (lddx != C) return RS_ERR_UNSUPPORTED;
-        if (hipMemsetAsync(dx, 0, (size_t)N * D * H * W * C * (dtype == RS_F32 ? 4 : 2), ST(stream)) != hipSuccess) return RS_ERR_LAUNCH;
+        if (const int rc = rs_launch_zero_bytes(dx, (size_t)N * D * H * W * C * (dtype == RS_F32 ? 4 : 2), ST(stream))) return rc;   // a kernel, not a memset node
     }
     PoolParams p = {x, ldx, (void*)dy, lddy, dx, lddx, nullptr, N, D, H, W, C};
     return rs_launch_pool(p, dtype, 1, 1, ST(stream));
@@ -589,8 +589,15 @@ int rsuper_count(const uint8_t* m, long V, unsigned int* count, void* stream) {
 
 int rsuper_grad_sqnorm(int n, void* const* host_g, const size_t* host_numel, double* total_sq, void* stream) {
     if (n <= 0 || !host_g || !host_numel || !total_sq) return RS_ERR_ARG;
-    if (hipMemsetAsync(total_sq, 0, sizeof(double), ST(stream)) != hipSuccess) return RS_ERR_LAUNCH;
-    return for_chunks(n, nullptr, host_g, nullptr, nullptr, nullptr, host_numel, [&](const MTChunk& c) { return rs_launch_sqnorm(c, total_sq, ST(stream)); });
+    // no hipMemsetAsync of the accumulator: the first chunk's reduce assigns it (a captured memset node wrote 0xC0 bytes after eager launches, optim.hip)
+    int first = 1;
+    const int rc = for_chunks(n, nullptr, host_g, nullptr, nullptr, nullptr, host_numel, [&](const MTChunk& c) {
+        const int r = rs_launch_sqnorm(c, total_sq, first, ST(stream));
+        first = 0;
+        return r;
+    });
+    if (rc == RS_OK && first) return rs_launch_zero_bytes(total_sq, sizeof(double), ST(stream));   // no element at all: the norm is 0
+    return rc;
 }
 int rsuper_clip_scale(int n, void* const* host_g, const size_t* host_numel, float max_norm, const double* total_sq, void* stream) {
     if (n <= 0 || !host_g || !host_numel || !total_sq) return RS_ERR_ARG;

@@ -654,8 +654,13 @@ __global__ __launch_bounds__(256) void plane_any_kernel(const uint8_t* __restric
     if (__any(any != 0) && (threadIdx.x & 63) == 0) flags[blockIdx.y] = 1;
 }
 
+__global__ void plane_flags_zero_kernel(uint8_t* flags, long planes) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < planes) flags[i] = 0;
+}
+
 int rs_launch_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, hipStream_t st) {
-    if (hipMemsetAsync(flags, 0, (size_t)planes, st) != hipSuccess) return RS_ERR_LAUNCH;
+    hipLaunchKernelGGL(plane_flags_zero_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, st, flags, planes);   // a kernel, not a memset node (optim.hip)
     long nb = (V / 16 + 255) / 256;
     if (nb > 32) nb = 32;
     if (nb < 1) nb = 1;

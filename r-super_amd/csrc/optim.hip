@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(MTChunk c, double* partial)
     if (threadIdx.x == 0) partial[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
 }
 
-__global__ __launch_bounds__(256) void sqnorm_reduce_kernel(const double* partial, int n, double* total) {
+// first: this chunk starts the sum (assigns) -- there is NO hipMemsetAsync of the accumulator any more: captured in a hipGraph, the memset node
+// wrote the byte 0xC0 instead of 0 from the first replay that followed eager launches on, so the norm came out as sqrt(-8577.5 + sum) = NaN
+// (found with tools/mode_consistency.py: total_sq = 0xC0C0C0C0C0C0C0C0 + the correct sum at every later replay)
+__global__ __launch_bounds__(256) void sqnorm_reduce_kernel(const double* partial, int n, double* total, int first) {
     __shared__ double red[256];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void sqnorm_reduce_kernel(const double* partia
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total += red[0];
+    if (threadIdx.x == 0) *total = first ? red[0] : *total + red[0];
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(MTChunk c, AdamParams a, const double* total_sq) {
@@ -90,11 +93,29 @@ __global__ __launch_bounds__(256) void scale_kernel(MTChunk c, float max_norm, c
     for (size_t i = base + threadIdx.x; i < base + MT_ELEMS && i < n; i += 256) g[i] *= coef;
 }
 
+// zero-fill as a KERNEL (never a memset node: see sqnorm_reduce_kernel)
+__global__ __launch_bounds__(256) void zero_bytes_kernel(unsigned char* p, size_t bytes) {
+    const size_t nv = bytes / 16, stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) ((uint4*)p)[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0) for (size_t i = nv * 16 + threadIdx.x; i < bytes; i += 256) p[i] = 0;
+}
+
 }  // namespace
 
+int rs_launch_zero_bytes(void* p, size_t bytes, hipStream_t st) {
+    if (!bytes) return RS_OK;
+    const size_t nv = bytes / 16;
+    size_t blocks = (nv + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    const bool aligned = (((uintptr_t)p) & 15) == 0;
+    if (!aligned) return RS_ERR_ARG;
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char*)p, bytes);
+    return rs_check_launch();
+}
 int rs_mt_blocks(size_t numel) { return (int)((numel + MT_ELEMS - 1) / MT_ELEMS); }
 
-int rs_launch_sqnorm(const MTChunk& c, double* total, hipStream_t st) {
+int rs_launch_sqnorm(const MTChunk& c, double* total, int first, hipStream_t st) {
     static double* ws[16] = {};                                  // per-device partial sums (stream-ordered reuse)
     constexpr int WS_BLOCKS = 1 << 16;
     int dev = 0;
@@ -103,7 +124,7 @@ int rs_launch_sqnorm(const MTChunk& c, double* total, hipStream_t st) {
     const int blocks = c.blk_start[c.n];
     if (blocks > WS_BLOCKS) return RS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, st, c, ws[dev]);
-    hipLaunchKernelGGL(sqnorm_reduce_kernel, dim3(1), dim3(256), 0, st, (const double*)ws[dev], blocks, total);
+    hipLaunchKernelGGL(sqnorm_reduce_kernel, dim3(1), dim3(256), 0, st, (const double*)ws[dev], blocks, total, first);
     return rs_check_launch();
 }
 int rs_launch_adamw_ema(const MTChunk& c, const AdamParams& a, const double* total_sq, hipStream_t st) {

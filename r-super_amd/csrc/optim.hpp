@@ -20,6 +20,7 @@ struct AdamParams {
     const float* dyn;    // optional device array [lr, step_size, sqrt_bc2, ema_alpha] overriding the fields above (hipGraph replay)
 };
 int rs_mt_blocks(size_t numel);
-int rs_launch_sqnorm(const MTChunk& c, double* total, hipStream_t st);
+int rs_launch_sqnorm(const MTChunk& c, double* total, int first, hipStream_t st);   // first: assigns *total (no memset of the accumulator)
+int rs_launch_zero_bytes(void* p, size_t bytes, hipStream_t st);                   // zero-fill kernel (16-byte aligned pointer)
 int rs_launch_adamw_ema(const MTChunk& c, const AdamParams& a, const double* total_sq, hipStream_t st);
 int rs_launch_scale(const MTChunk& c, float max_norm, const double* total_sq, hipStream_t st);

@@ -36,10 +36,10 @@ from .training.utils import FusedAdamWEMA, ema_alpha_for_step
 
 
 def _release_cached_blocks():
-    """Before every capture: collect garbage and hand the caching allocator's free blocks back to the driver.
-    Defence in depth for the rocBLAS-in-graph defect (`_capture_safe_blas`): with rocBLAS still preferred, releasing the cached blocks before
-    the capture lowered the corruption rate of the graphed MedFormer step from 6 / 15 to 1 / 4 runs (the stale workspace then no longer
-    aliases memory the eager work between replays rewrites); RSUPER_CAPTURE_KEEP_CACHE=1 keeps the cache (A/B)."""
+    """Before every capture: collect garbage and hand the caching allocator's free blocks back to the driver (a collection that frees device
+    tensors INSIDE a capture aborts the process; and the capture's private pool then starts from a clean allocator).  Introduced while the replay
+    corruption was still attributed to rocBLAS; the real cause were captured memset nodes.  RSUPER_CAPTURE_KEEP_CACHE=1 keeps
+    the cache (A/B)."""
     if os.environ.get('RSUPER_CAPTURE_KEEP_CACHE') == '1':
         return
     import gc
@@ -48,18 +48,12 @@ def _release_cached_blocks():
 
 
 def _capture_safe_blas():
-    """No rocBLAS inside a captured graph.  Root cause of round 2's "captured reduction returns garbage from the 12th replay" as far as it
-    could be narrowed down without the ROCm sources (round 3, tests/test_gpu_edge.py run as a whole file, MedFormer whole-step graph, eager
-    work -- the self-verification -- between replays 12 and 13; the gradient norm of replay 13 came back inf / nan / 1e22..1e32):
-      rocBLAS preferred (`torch.backends.cuda.preferred_blas_library('cublas')`, MedFormer's round-2 default)   6 of 15 runs corrupted
-      the same with ROCBLAS_DEVICE_MEMORY_SIZE fixed at 128 MB (no workspace re-allocation)                     3 of 8
-      the same with the allocator cache released before the capture                                             1 of 4
-      hipBLASLt for every GEMM (torch's default)                                                                0 of 13
-      UNet (no library GEMM in the step), any setting                                                           0 of all runs
-    i.e. the victim is a rocBLAS launch recorded in the graph (its Tensile kernels with global split-K take a workspace from the handle), the
-    trigger is eager rocBLAS work between replays; ATen's reductions were bystanders (round 2 replaced one by a GEMM and the symptom moved).
-    Captures therefore switch the process to hipBLASLt and turn MedFormer's per-call library choice off; the replays keep verifying
-    themselves (`_verify`)."""
+    """hipBLASLt (torch's default on ROCm) for the library GEMMs a capture records; MedFormer's per-call library choice off.
+    History: while the "garbage after a few replays" defect was being bisected, runs with rocBLAS preferred were corrupted in 6 of 15 cases and
+    runs with hipBLASLt in 0 of 13, and this switch was taken for the fix.  It was not: the victim was a captured `hipMemsetAsync` node of this
+    repo's own gradient-norm accumulator, which writes 0xC0 bytes after eager interludes (removed in csrc/optim.hip) -- with that
+    fixed, rocBLAS inside the capture is correct too (5 of 5 runs, RSUPER_CAPTURE_UNSAFE_BLAS=1).  The switch stays because it costs nothing
+    (the pointwise products run on csrc/pointwise.hip) and keeps ADVICE r02's point: no process-wide BLAS preference survives a capture."""
     if os.environ.get('RSUPER_CAPTURE_UNSAFE_BLAS') == '1':      # A/B of the defect: leave whatever library is preferred
         return
     if torch.cuda.is_available() and hasattr(torch.backends.cuda, 'preferred_blas_library'):

@@ -59,13 +59,10 @@ class MedFormer(nn.Module):
             self.aux_out = nn.Conv3d(c[5], num_classes, kernel_size=1)
         self.outc = nn.Conv3d(c[7], num_classes, kernel_size=1)
         self.compute_dtype = compute_dtype or os.environ.get('RSUPER_DTYPE', 'bf16')
-        # RSUPER_MF_BLAS=cublas (opt-in, eager runs only): the fp32 library GEMMs of the attention stages through rocBLAS instead of torch's
-        # default hipBLASLt -- 7.5 vs 18.5 us of host time per call and < 8 us instead of 21 us kernels for the 54-row map-token products
-        # (MedFormer step 41.0 -> 36.6 ms eager when host-bound, 30.55 -> 30.15 ms replayed).  It was the default in round 2 and is NOT any
-        # more: (i) it is a process-wide torch setting; (ii) rocBLAS GEMMs captured in a hipGraph are what produced the
-        # "garbage after a few replays" defect -- with eager rocBLAS calls between replays, non-finite gradients in 6 of 15 runs of the
-        # graphed-step test, 0 of 13 through hipBLASLt (rsuper_amd/graph.py:_capture_safe_blas, which switches back before
-        # every capture).
+        # RSUPER_MF_BLAS=cublas (opt-in): the fp32 library GEMMs that are left (81-token fusion transformer, aux head) through rocBLAS instead of
+        # torch's default hipBLASLt -- 7.5 vs 18.5 us of host time per call.  It was the default in round 2 and is NOT any more: it is a
+        # process-wide torch setting, and with the pointwise products on csrc/pointwise.hip it no longer pays.  (The replay corruption
+        # once attributed to captured rocBLAS launches was a captured memset node: DESIGN.md 3.4c.)
         blas = os.environ.get('RSUPER_MF_BLAS', 'default')
         if blas != 'default' and torch.cuda.is_available() and hasattr(torch.backends.cuda, 'preferred_blas_library'):
             torch.backends.cuda.preferred_blas_library(blas)

@@ -1064,3 +1064,40 @@ def test_dispatcher_ops_forward_only_and_autograd_paths_agree():
     assert torch.equal(lo.detach(), lo2)
     lo.sum().backward()
     assert w.grad is not None and b.grad is not None
+
+
+@pytest.mark.gpu
+def test_accumulators_need_no_memset():
+    """The three entry points that used to zero their destination with hipMemsetAsync -- a node that, captured in a hipGraph, wrote 0xC0 bytes
+    after eager interludes and turned the gradient norm into NaN -- now initialise it with kernels of their own: pre-filled with
+    garbage (0xC0, as the defect did), the destinations must come out exactly as from a clean buffer."""
+    import ctypes
+    from rsuper_amd.hip import ops, lib as _l
+    from rsuper_amd.training import losses_foundation as lf
+    L = ops._L()
+    st = torch.cuda.current_stream().cuda_stream
+    # gradient norm accumulator (rsuper_grad_sqnorm): several chunks of tensors, accumulator holding 0xC0C0C0C0C0C0C0C0
+    gs = [torch.randn(n, device=DEV) for n in (5, 4096 * 3 + 7, 1, 70000)] * 40            # 160 tensors: more than one launch chunk
+    total = torch.empty(1, device=DEV, dtype=torch.float64)
+    total.view(torch.uint8).fill_(0xC0)
+    numel = (ctypes.c_size_t * len(gs))(*[g.numel() for g in gs])
+    arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+    _l.check(L.rsuper_grad_sqnorm(len(gs), arr, numel, total.data_ptr(), st), 'grad_sqnorm')
+    ref = sum(float((g.double() ** 2).sum()) for g in gs)
+    assert abs(float(total) - ref) <= 1e-6 * ref, (float(total), ref)
+    # plane_any flags
+    m = torch.zeros((6, 4096), device=DEV, dtype=torch.uint8)
+    m[1, 17] = 1; m[4, 4095] = 3
+    flags = torch.full((6,), 0xC0, device=DEV, dtype=torch.uint8)
+    _l.check(L.rsuper_plane_any(m.data_ptr(), 6, 4096, flags.data_ptr(), st), 'plane_any')
+    assert flags.cpu().tolist() == [0, 1, 0, 0, 1, 0]
+    # MaxPool3d(2) backward of an odd volume: the never-pooled trailing planes receive exactly zero
+    x = torch.randn((1, 5, 7, 9, 8), device=DEV).to(torch.bfloat16)
+    y, _ = ops._MaxPoolFn.apply(x.clone().requires_grad_(True)) if hasattr(ops, '_MaxPoolFn') else ops.MaxPoolFn.apply(x.clone().requires_grad_(True))
+    dy = torch.ones_like(y)
+    dx = torch.empty_like(x)
+    dx.view(torch.uint8).fill_(0xC0)
+    _l.check(L.rsuper_maxpool2_bwd(ops._DT[x.dtype], x.data_ptr(), 8, dy.data_ptr(), 8, dx.data_ptr(), 8, 1, 5, 7, 9, 8, st), 'maxpool2_bwd')
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dx.float()).all()) and float(dx.float().sum()) == float(dy.float().sum())
+    assert float(dx[:, 4].float().abs().sum()) == 0.0 and float(dx[:, :, 6].float().abs().sum()) == 0.0 and float(dx[:, :, :, 8].float().abs().sum()) == 0.0

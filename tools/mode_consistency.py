@@ -51,6 +51,10 @@ for graphed in (False, True):
     for i in range(steps):
         loss, gn = st(batch, i) if st is not None else train_step(f, ema, opt, batch, largs, classes, i)
         ls.append({k: float(v.detach()) for k, v in loss.items()} | {'gn': float(gn)})
+        if os.environ.get('MC_DEBUG') == '1' and graphed and 48 <= i <= 55:
+            tot = float(opt._total_sq) if getattr(opt, '_total_sq', None) is not None else float('nan')
+            ref = float(sum((p.grad.double() ** 2).sum() for p in net.parameters() if p.grad is not None))
+            print(f'[mc] step {i}: gn {float(gn)!r} total_sq {tot!r} sqrt {tot ** 0.5 if tot >= 0 else float("nan")!r}; torch sum g^2 {ref!r} sqrt {ref ** 0.5!r}', flush=True)
         gs.append({k: p.grad.detach().clone() for k, p in net.named_parameters()} if i < 24 else None)
     hist.append(ls); grads.append(gs)
     del net, ema, opt, st, f
@@ -59,6 +63,8 @@ for i in range(steps):
     a, b = hist[0][i], hist[1][i]
     if a != b:
         print('first difference at step', i, {k: (a[k], b[k]) for k in a if a[k] != b[k]})
+        for j in range(i + 1, min(i + 4, steps)):
+            print('   step', j, {k: (hist[0][j][k], hist[1][j][k]) for k in hist[0][j] if hist[0][j][k] != hist[1][j][k]})
         if grads[0][i] is not None:
             ga, gb = grads[0][i], grads[1][i]
             bad = [(k, float((ga[k] - gb[k]).abs().max()), float(ga[k].abs().max())) for k in ga if not torch.equal(ga[k], gb[k])]
