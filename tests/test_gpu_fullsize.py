@@ -308,3 +308,15 @@ def test_strided_block_parity_class_kernel_matches_full_resolution_evaluation(mo
         else:
             err, tol = float((u - v).double().norm() / v.double().norm().clamp_min(1e-20)), 2e-2
         assert err <= tol, (name, err)
+
+
+def test_graphed_step_full_size_56_steps_identical_to_eager():
+    """Regression test of the hipGraph defect of DESIGN.md 3.4c at the size where it showed in ~60 % of the runs: the whole-step graph of the
+    full UNet (B = 2, 96^3, 26 classes) over 56 steps -- self-verifications (eager interludes) at replays 1, 12 and 50 -- must give the losses and
+    the gradient norm of the eager run at every step.  Before the fix the captured memset of the norm accumulator wrote 0xC0 bytes from replay
+    51 on: gradient norm NaN, parameters poisoned one step later."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'mode_consistency.py'), 'unet', '96', '26', '56', 'seg', 'step'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'identical over 56 steps' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
