@@ -320,3 +320,21 @@ def test_graphed_step_full_size_56_steps_identical_to_eager():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'mode_consistency.py'), 'unet', '96', '26', '56', 'seg', 'step'],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'identical over 56 steps' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize('which,cos_min,l2_max', [('unet', 0.95, 0.20), ('medformer', 0.82, 0.25)])
+def test_bf16_gradients_of_the_real_loss_align_with_f32(which, cos_min, l2_max):
+    """The benchmarked arithmetic (bf16 conv stages) against the parity arithmetic (exact-f32 MFMA) on the REAL objective at full size (B = 2,
+    96^3, 26 classes, segmentation loss, identical initial weights and batch): the loss agrees to 1e-3, the logits to `l2_max` relative L2 and
+    the parameter gradients point the same way -- cosine of all gradients together (measured: UNet 0.973, MedFormer 0.884; per-tensor medians
+    0.948 / 0.881).  A statement about the whole bf16 network that random-output-gradient probes on tiny, ill-conditioned nets cannot make
+    (there both modes are 0.6-1.0 apart in relative L2: tools/medformer_bf16_vs_f32.py)."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'grad_bf16_vs_f32.py'), which], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith(which + ':')][-1]
+    m = re.search(r'loss f32 ([\d.]+) bf16 ([\d.]+); logits relL2 ([\d.]+); all gradients: relL2 ([\d.]+), cosine ([\d.]+)', line)
+    lf32, lbf, l2, gl2, cos = (float(v) for v in m.groups())
+    assert abs(lf32 - lbf) <= 1e-3 * abs(lf32), line
+    assert l2 <= l2_max and cos >= cos_min, line
