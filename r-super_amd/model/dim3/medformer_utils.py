@@ -415,8 +415,8 @@ class _PreNorm(nn.Module):
         self.norm = nn.LayerNorm(dim)
         self.fn = fn
 
-    def forward(self, x):
-        return self.fn(self.norm(x))
+    def forward(self, x, res=None):
+        return self.fn(self.norm(x), res)
 
 
 class _TokenAttention(nn.Module):
@@ -426,11 +426,12 @@ class _TokenAttention(nn.Module):
         self.to_qkv = nn.Linear(dim, 3 * heads * dim_head, bias=False)
         self.to_out = nn.Linear(heads * dim_head, dim)
 
-    def forward(self, x):
+    def forward(self, x, res=None):
         B, L, _ = x.shape
-        q, k, v = (t.reshape(B, L, self.heads, -1).transpose(1, 2) for t in self.to_qkv(x).chunk(3, -1))
+        # projections through linear(): csrc/pointwise.hip (162 token rows: reduction split over the waves), shortcut in the epilogue
+        q, k, v = (t.reshape(B, L, self.heads, -1).transpose(1, 2) for t in linear(x, self.to_qkv.weight).chunk(3, -1))
         att = F.softmax(torch.matmul(q, k.transpose(-1, -2)) * self.scale, -1)
-        return self.to_out(torch.matmul(att, v).transpose(1, 2).reshape(B, L, -1))
+        return linear(torch.matmul(att, v).transpose(1, 2).reshape(B, L, -1), self.to_out.weight, self.to_out.bias, res)
 
 
 class _Mlp(nn.Module):
@@ -438,8 +439,8 @@ class _Mlp(nn.Module):
         super().__init__()
         self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
 
-    def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+    def forward(self, x, res=None):
+        return linear(F.gelu(linear(x, self.fc1.weight, self.fc1.bias)), self.fc2.weight, self.fc2.bias, res)
 
 
 class TransformerBlock(nn.Module):
@@ -452,8 +453,8 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x):
         for attn, ffn in self.layers:
-            x = attn(x) + x
-            x = ffn(x) + x
+            x = attn(x, x)                        # `attn(x) + x`, `ffn(x) + x`: the residual rides in the output projection's epilogue
+            x = ffn(x, x)
         return x
 
 
