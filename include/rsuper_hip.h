@@ -359,6 +359,9 @@ int rsuper_count(const uint8_t* m, long V, unsigned int* count, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Optimiser -- train_ddp.py:352-357, training/utils.py:46-51,154-161.  host_* are HOST arrays of device pointers.
  * ------------------------------------------------------------------------------------------------ */
+/* *total_sq = sum of squared elements of the n gradient tensors (f64, deterministic order).  The accumulator need not be zeroed: the first launch
+ * assigns it -- and no hipMemsetAsync is issued, so the call is safe to capture in a hipGraph (a captured memset node writes 0xC0 bytes after eager
+ * interludes on ROCm 7.2: DESIGN.md 3.4c).  The same holds for rsuper_plane_any's flags and rsuper_maxpool2_bwd's zero fill. */
 int rsuper_grad_sqnorm(int n, void* const* host_g, const size_t* host_numel, double* total_sq, void* stream);
 int rsuper_clip_scale(int n, void* const* host_g, const size_t* host_numel, float max_norm, const double* total_sq, void* stream);
 /* One fused pass: clip (coef from *total_sq, NULL = no clipping) + AdamW + EMA (host_ema NULL = no EMA). */
