@@ -100,17 +100,31 @@ __global__ __launch_bounds__(256, 1) void igemm_s2_kernel(IgemmParams p, int FD,
 
     // staging: vector i of this thread = halo row (tid >> 2) + 64 i, 16-byte slot tid & 3; (hd, hh, hw) per vector are fixed
     const int slot = tid & 3;
-    int hq[NVEC];                                                               // packed (hd, hh, hw) or -1 past the halo
+    // Per-thread constants of the staging (vector i = halo row (tid >> 2) + 64 i): the voxel index of the row for class 0 and, per axis and class
+    // bit, one bit per vector saying whether that row is inside the source volume AND needed by the class (a class whose bit is 0 on an axis only
+    // uses the centre tap there: its halo rows on that axis are never read) -- an item then costs three ANDs plus an add / select / multiply per
+    // vector instead of re-deriving coordinates and bounds (26.7 VALU per MFMA in the first version, profiles/r03_pmc_new_kernels.md).
+    const int SD = MODE == 1 ? FD : p.D, SH = MODE == 1 ? FH : p.H, SW = MODE == 1 ? FW : p.W;      // source grid: full resolution (forward) / half (dgrad)
+    constexpr int SS = MODE == 1 ? 2 : 1;                                        // source stride of a halo step
+    int vbase[NVEC];
+    uint32_t okd[2] = {0, 0}, okh[2] = {0, 0}, okw[2] = {0, 0}, vrow = 0;
 #pragma unroll
     for (int i = 0; i < NVEC; ++i) {
         const int r = (tid >> 2) + 64 * i;
         const int hd = r / (HH * HW), rem = r - hd * (HH * HW);
         const int hh = rem / HW, hw = rem - hh * HW;
-        hq[i] = r < HROWS ? (hd << 16) | (hh << 8) | hw : -1;
+        const int d = SS * (d0 - 1 + hd), h = SS * (h0 - 1 + hh), w = SS * (w0 - 1 + hw);
+        vbase[i] = ((n * SD + d) * SH + h) * SW + w;
+        vrow |= r < HROWS ? (1u << i) : 0u;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {                                            // b = class bit of the axis (dgrad: always 0)
+            const bool nd = MODE != 1 || b || (hd >= 1 && hd <= TD), nh = MODE != 1 || b || (hh >= 1 && hh <= TH), nw = MODE != 1 || b || (hw >= 1 && hw <= TW);
+            okd[b] |= (nd && d + b >= 0 && d + b < SD) ? (1u << i) : 0u;
+            okh[b] |= (nh && h + b >= 0 && h + b < SH) ? (1u << i) : 0u;
+            okw[b] |= (nw && w + b >= 0 && w + b < SW) ? (1u << i) : 0u;
+        }
     }
     char* lds_st = halo + (tid >> 2) * PITCH + slot * 16;
-    // source grid of the staging: forward reads the FULL-resolution input at 2q + class, dgrad the half-resolution dy at q
-    const int SD = MODE == 1 ? FD : p.D, SH = MODE == 1 ? FH : p.H, SW = MODE == 1 ? FW : p.W;
     const uint32_t nvox_src = (uint32_t)(p.N * SD * SH * SW);
     uint4 pre[NVEC];
     uint32_t okmask = 0;
@@ -121,24 +135,15 @@ __global__ __launch_bounds__(256, 1) void igemm_s2_kernel(IgemmParams p, int FD,
         const int c = (isB ? ch - nchA : ch) * KC + slot * KP;
         const uint32_t rowb = (uint32_t)sld * (uint32_t)sizeof(T);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sx, 0, nvox_src * rowb, 0x00020000);
-        const bool cok = c < sC;
-        const int cd = (cls >> 2) & 1, chh = (cls >> 1) & 1, cw = cls & 1;
-        okmask = 0;
+        const int cd = MODE == 1 ? (cls >> 2) & 1 : 0, chh = MODE == 1 ? (cls >> 1) & 1 : 0, cw = MODE == 1 ? cls & 1 : 0;
+        const int coff = (cd * SH + chh) * SW + cw;                              // voxel offset of the class inside its 2x2x2 cell
+        okmask = (c < sC) ? (vrow & okd[cd] & okh[chh] & okw[cw]) : 0u;
+        const uint32_t cb = (uint32_t)c * (uint32_t)sizeof(T);
 #pragma unroll
         for (int i = 0; i < NVEC; ++i) {
-            bool ok = hq[i] >= 0 && cok;
-            const int hd = hq[i] >> 16, hh = (hq[i] >> 8) & 255, hw = hq[i] & 255;
-            int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;              // half-resolution coordinates of the halo row
-            if (MODE == 1) {
-                // a class whose bit is 0 on an axis only uses the centre tap there: its halo rows on that axis are never read
-                ok = ok && (cd || (hd >= 1 && hd <= TD)) && (chh || (hh >= 1 && hh <= TH)) && (cw || (hw >= 1 && hw <= TW));
-                d = 2 * d + cd; h = 2 * h + chh; w = 2 * w + cw;
-            }
-            ok = ok && d >= 0 && d < SD && h >= 0 && h < SH && w >= 0 && w < SW;
-            const uint32_t off = ok ? (uint32_t)(((n * SD + d) * SH + h) * SW + w) * rowb + (uint32_t)c * (uint32_t)sizeof(T) : 0xFFFFFFFFu;
+            const uint32_t off = ((okmask >> i) & 1u) ? (uint32_t)(vbase[i] + coff) * rowb + cb : 0xFFFFFFFFu;
             const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
             pre[i] = make_uint4(q[0], q[1], q[2], q[3]);
-            okmask |= ok ? (1u << i) : 0u;
         }
     };
     auto commit = [&](int ch) __attribute__((always_inline)) {
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void igemm_s2_kernel(IgemmParams p, int FD,
         for (int i = 0; i < NVEC; ++i) {
             uint4 q = pre[i];
             if (norm && ((okmask >> i) & 1u)) q = norm_relu16<T>(q, sc_, nb_);     // zero padding is applied AFTER the activation
-            if (hq[i] >= 0) *(uint4*)(lds_st + i * (64 * PITCH)) = q;
+            if ((vrow >> i) & 1u) *(uint4*)(lds_st + i * (64 * PITCH)) = q;
         }
     };
     // Forward: one (chunk, class) item = the class's rows staged, then its taps, fully unrolled (per-axis pair lists from ax_a / ax_b).  The

@@ -364,8 +364,8 @@ def igemm_s2(mode, a, b, packed, n_cols, full_dims, out, part, ea=None):
 def strided_kernel(dtype, dims, direction):
     """Whether a strided [conv1 | shortcut] GEMM takes the parity-class kernel (csrc/conv3d_igemm_s2.hip: the minimal MFMA work, no
     full-resolution temporary) or the rounds-1/2 evaluation (the tuned stride-1 kernels at full resolution + subsample / zero-stuffed dy: 8x
-    the work).  Measured on MI355X (tools/bench_conv.py, B = 2, 96^3 / 48^3 / 24^3 inputs): f32 forward 4.5x / 3.0x / 3.3x and data gradient
-    3.6x / 3.5x / 4.1x faster; bf16 forward 1.8x / 1.0x / 1.4x, data gradient 2.0x / 1.7x / 1.2x -- so it is the default everywhere;
+    the work).  Measured on MI355X (tools/bench_conv.py, B = 2, 96^3 / 48^3 / 24^3 inputs): f32 forward 5.3x / 3.4x / 3.8x and data gradient
+    3.7x / 3.6x / 4.2x faster; bf16 forward 2.3x / 1.3x / 1.7x, data gradient 2.2x / 1.8x / 1.3x -- so it is the default everywhere;
     RSUPER_S2_KERNEL=0 selects the old evaluation (tests run both, A/B)."""
     return os.environ.get('RSUPER_S2_KERNEL', '1') != '0'
 
