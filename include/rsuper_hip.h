@@ -344,6 +344,9 @@ int rsuper_topk_select_multi(const float* x, const uint8_t* m, long V, const uns
 /* GlobalWeightedRankPooling(return_weights, hard_cutoff) :442-535 restricted to the pseudo mask. */
 int rsuper_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, void* stream);
 int rsuper_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float log2_d, float scale, float* w, void* stream);
+/* The same weights from a rank order: w[ids[r]] = 2^(r * log2_d) * scale for r < n (ids = voxel indices sorted by value descending, ties by index
+ * ascending -- what rsuper_rank_weights derives by pairwise counting in O(n^2)); identical arithmetic, O(n): the large-tumour path of GWRP. */
+int rsuper_rank_assign(const long long* ids, unsigned int n, float log2_d, float scale, float* w, void* stream);
 /* flags[p] = any(m[p][:]) for `planes` contiguous byte volumes of V voxels (V % 16 == 0 when planes > 1): the
  * `.sum() > 0` / `.any()` tests of calculate_loss / ball_loss (:1625, :313, :335) at HBM rate. */
 int rsuper_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, void* stream);

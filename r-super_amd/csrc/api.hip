@@ -566,6 +566,10 @@ int rsuper_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, 
     if (!vals || !idx || !w) return RS_ERR_ARG;
     return rs_launch_rank_weights(vals, idx, n, log2_d, scale, w, ST(stream));
 }
+int rsuper_rank_assign(const long long* ids, unsigned int n, float log2_d, float scale, float* w, void* stream) {
+    if (!ids || !w) return RS_ERR_ARG;
+    return rs_launch_rank_assign(ids, n, log2_d, scale, w, ST(stream));
+}
 int rsuper_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, void* stream) {
     if (!packed || !out || B <= 0 || P <= 0 || C <= 0 || C > 8 * P || V <= 0) return RS_ERR_ARG;
     return rs_launch_unpack_bits(packed, out, B, P, C, V, ST(stream));

@@ -18,3 +18,4 @@ int rs_launch_mask_op(uint8_t* a, const uint8_t* b, long V, int op, hipStream_t 
 int rs_launch_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, hipStream_t st);
 int rs_launch_zero_where(float* x, const uint8_t* m, long V, hipStream_t st);
 int rs_launch_count(const uint8_t* m, long V, unsigned int* count, hipStream_t st);
+int rs_launch_rank_assign(const long long* ids, unsigned int n, float dlog2, float scale, float* w, hipStream_t st);

@@ -87,6 +87,7 @@ _SIGS = {
     'rsuper_topk_mark': (c_int, [P, P, c_long, c_uint32, c_uint, P, P]),
     'rsuper_compact': (c_int, [P, P, c_long, P, P, P, P]),
     'rsuper_rank_weights': (c_int, [P, P, c_uint, c_float, c_float, P, P]),
+    'rsuper_rank_assign': (c_int, [P, c_uint, c_float, c_float, P, P]),
     'rsuper_topk_select': (c_int, [P, P, c_long, c_uint, P, P, P]),
     'rsuper_topk_select_multi': (c_int, [P, P, c_long, P, c_int, P, P, c_int, P]),
     'rsuper_plane_any': (c_int, [P, c_long, c_long, P, P]),

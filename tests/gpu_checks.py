@@ -779,7 +779,22 @@ def check_gwrp():
     logit = torch.log(xsig / (1 - xsig))
     w, n = lf.gwrp_foreground_weights(logit.to(DEV), pm.to(torch.uint8).to(DEV))
     ref = T(p['gwrp_w']) * pm.sum() * pm
-    return result('gwrp_weights', relerr(w.cpu(), ref), 1e-4, f'N {n}')
+    e = relerr(w.cpu(), ref)
+    # the sort-based path of large pseudo masks: bit-identical to the pairwise-count kernel, on the fixture and on a 40 k-voxel mask with many ties
+    old = lf.GWRP_SORT_ABOVE
+    try:
+        lf.GWRP_SORT_ABOVE = 0
+        w2, _ = lf.gwrp_foreground_weights(logit.to(DEV), pm.to(torch.uint8).to(DEV))
+        g = torch.Generator().manual_seed(5)
+        big_x = (torch.randint(0, 50, (40, 40, 40), generator=g).float() / 7.0).to(DEV)        # few distinct values: thousands of ties
+        big_pm = (torch.rand((40, 40, 40), generator=g) < 0.65).to(torch.uint8).to(DEV)
+        wb_sort, nb = lf.gwrp_foreground_weights(big_x, big_pm)
+        lf.GWRP_SORT_ABOVE = 1 << 30
+        wb_pair, _ = lf.gwrp_foreground_weights(big_x, big_pm)
+    finally:
+        lf.GWRP_SORT_ABOVE = old
+    same = bool(torch.equal(w2, w)) and bool(torch.equal(wb_sort, wb_pair))
+    return result('gwrp_weights', e if same else float('inf'), 1e-4, f'N {n}; sort path == pairwise path on the fixture and on {nb} voxels with ties')
 
 
 def make_args(**kw):
