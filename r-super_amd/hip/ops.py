@@ -1098,6 +1098,7 @@ def pointwise_prepack(compute):
         tab = (torch.tensor(rows, dtype=torch.int64).to(dev), item, torch.empty((off,), device=dev, dtype=torch.uint8), entries)
         for d in list(_PW_TABLES):                               # one table per compute type, all from the same set of weights
             del _PW_TABLES[d]
+        _PW_PACKED.clear()                                       # entries of the old arena (they would keep it alive)
         _PW_TABLES[dt] = tab
         _PW_SEEN_DIRTY = False
     table, total, arena, entries = tab

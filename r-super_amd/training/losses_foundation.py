@@ -249,11 +249,9 @@ def _topk_mask(x, ball, k):
     return out
 
 
-def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_margin=0.5, volume_margin=0.5):
-    """(:1387-1532) x: (D,H,W) f32 >= 0 on device.  Returns three uint8 masks (tumor, small, big)."""
-    assert gaussian, 'the reference always calls isolate_tumor with gaussian=True (:1713)'
-    D, H, W = x.shape
-    V = x.numel()
+def _isolate_params(diameter, tumor_volume, V, volume_margin):
+    """The data-independent part of isolate_tumor (:1400-1433, :1466-1481): odd diameter, target volume (raised to the ball's own voxel count - 1
+    when the report's volume is smaller; the products then run in float32 as in the reference) and the three top-k sizes (tumour, small, big)."""
     diameter = int(np.round(diameter).astype(int))
     vol = int(np.round(tumor_volume).astype(int))
     if diameter % 2 == 0:
@@ -262,6 +260,20 @@ def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_ma
     f32 = False
     if nnz > vol:                         # :1431-1433 (vol becomes a 0-dim tensor there -> float32 products below)
         vol, f32 = nnz - 1, True
+    t = min(V - 1, vol)
+    ms = min(0.5, volume_margin)
+    t_small = int(np.float32(t) * np.float32(1 - ms)) if f32 else int(t * (1 - ms))
+    t_small = max(t_small, min(100, vol))
+    t_big = min(V - 1, int(np.float32(vol) * np.float32(1 + volume_margin)) if f32 else int(vol * (1 + volume_margin)))
+    return diameter, vol, (t, t_small, t_big)
+
+
+def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_margin=0.5, volume_margin=0.5):
+    """(:1387-1532) x: (D,H,W) f32 >= 0 on device.  Returns three uint8 masks (tumor, small, big)."""
+    assert gaussian, 'the reference always calls isolate_tumor with gaussian=True (:1713)'
+    D, H, W = x.shape
+    V = x.numel()
+    diameter, vol, ks = _isolate_params(diameter, tumor_volume, V, volume_margin)
     best = torch.zeros(1, device=x.device, dtype=torch.int64)
     # separable two-stage correlation (k^2 gathers per voxel instead of k^3 taps); direct form for tiny balls
     ws = (torch.empty((_L().rsuper_ball_workspace_floats(D, H, W, diameter),), device=x.device, dtype=torch.float32)
@@ -283,12 +295,6 @@ def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_ma
         if new_dim >= max(D, H, W):
             break
         ball, bsum = _insert_ball((D, H, W), center, new_dim, diameter_margin, x.device)
-    t = min(V - 1, vol)
-    ms = min(0.5, volume_margin)
-    t_small = int(np.float32(t) * np.float32(1 - ms)) if f32 else int(t * (1 - ms))
-    t_small = max(t_small, min(100, vol))
-    t_big = min(V - 1, int(np.float32(vol) * np.float32(1 + volume_margin)) if f32 else int(vol * (1 + volume_margin)))
-    ks = (t, t_small, t_big)
     if min(ks) > 0 and os.environ.get('RSUPER_TOPK_HOST', '0') != '1':
         # the three selections share x and the ball: one batched radix select, AND with the ball folded into the marking (:1504-1507)
         import ctypes
@@ -323,20 +329,7 @@ def isolate_tumor_spec(x, diameter, gaussian_std, tumor_volume, checks, diameter
     when the preconditions of the device-resident selection do not hold (then the caller falls back at once)."""
     D, H, W = x.shape
     V = x.numel()
-    diameter = int(np.round(diameter).astype(int))
-    vol = int(np.round(tumor_volume).astype(int))
-    if diameter % 2 == 0:
-        diameter += 1
-    nnz = ball_nnz(diameter)
-    f32 = False
-    if nnz > vol:
-        vol, f32 = nnz - 1, True
-    t = min(V - 1, vol)
-    ms = min(0.5, volume_margin)
-    t_small = int(np.float32(t) * np.float32(1 - ms)) if f32 else int(t * (1 - ms))
-    t_small = max(t_small, min(100, vol))
-    t_big = min(V - 1, int(np.float32(vol) * np.float32(1 + volume_margin)) if f32 else int(vol * (1 + volume_margin)))
-    ks = (t, t_small, t_big)
+    diameter, vol, ks = _isolate_params(diameter, tumor_volume, V, volume_margin)
     if min(ks) <= 0 or os.environ.get('RSUPER_TOPK_HOST', '0') == '1':
         return None
     import ctypes
