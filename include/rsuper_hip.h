@@ -139,6 +139,16 @@ int rsuper_conv3_wgrad_partial(int dtype, int use_tr, const void* xa, int lda, i
                                float* workspace, int N, int D, int H, int W, int splits, void* stream);
 int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Ya, int Yb, float* dwa, float* dwb, void* stream);
 
+/* Weight gradient of the STRIDED member (Conv3d(k=3, stride=2, pad=1): BasicBlock(stride=2) conv1 + shortcut of down_block(pool=False),
+ * unet_utils.py:18-33, conv_layers.py:60-94):  dW[co][ci][t] = sum_o dy[o][co] * x_hat[2o + t - 1][ci].
+ * x (with its mean/rstd) lives on the full-resolution grid (N, FD, FH, FW); dy rows [0,Ya) -> dwa, [Ya,Ya+Yb) -> dwb live on the
+ * ((FD+1)/2, (FH+1)/2, (FW+1)/2) grid -- no zero-stuffed operand.  workspace: splits * 27 * (Ya+Yb) * Ca floats, splits from
+ * rsuper_conv3_wgrad_s2_splits.  dwa / dwb are overwritten (deterministic slab reduction). */
+int rsuper_conv3_wgrad_s2_splits(int dtype, int Ca, int Mtot, int N, int FD, int FH, int FW);
+int rsuper_conv3_wgrad_s2(int dtype, const void* xa, int lda, int Ca, const float* mra,
+                          const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
+                          float* dwa, float* dwb, float* workspace, int N, int FD, int FH, int FW, int splits, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine=False) statistics and backward tail -- conv_layers.py:40-42
  * ------------------------------------------------------------------------------------------------ */

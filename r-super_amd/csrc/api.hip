@@ -285,6 +285,26 @@ int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Y
     return rs_launch_wgrad_reduce(p, ST(stream));
 }
 
+int rsuper_conv3_wgrad_s2_splits(int dtype, int Ca, int Mtot, int N, int FD, int FH, int FW) {
+    if (!dt_ok(dtype) || Ca <= 0 || Mtot <= 0 || N <= 0 || FD <= 0 || FH <= 0 || FW <= 0) return -1;
+    return rs_wgrad_s2_splits(dtype, Ca, Mtot, N, FD, FH, FW);
+}
+int rsuper_conv3_wgrad_s2(int dtype, const void* xa, int lda, int Ca, const float* mra,
+                          const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
+                          float* dwa, float* dwb, float* workspace, int N, int FD, int FH, int FW, int splits, void* stream) {
+    if (!dt_ok(dtype) || !xa || !ya || !dwa || !workspace || !ch_ok(Ca, lda) || Ca == 0 || !ch_ok(Ya, ldya) || Ya == 0) return RS_ERR_ARG;
+    if (Yb > 0 && (!yb || !dwb || !ch_ok(Yb, ldyb))) return RS_ERR_ARG;
+    if (N <= 0 || FD <= 0 || FH <= 0 || FW <= 0 || splits <= 0) return RS_ERR_ARG;
+    if ((unsigned long long)N * FD * FH * FW * (unsigned long long)lda * (dtype == RS_F32 ? 4 : 2) >= (1ull << 32)) return RS_ERR_UNSUPPORTED;
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.xa = {xa, lda, Ca, mra};
+    p.ya = {ya, ldya, Ya, nullptr};
+    p.yb = {yb, ldyb, Yb > 0 ? Yb : 0, nullptr};
+    p.dwa = dwa; p.dwb = dwb; p.ws = workspace; p.N = N; p.D = FD; p.H = FH; p.W = FW; p.splits = splits;
+    return rs_launch_wgrad_s2(p, dtype, ST(stream));
+}
+
 size_t rsuper_pointwise_packed_bytes(int dtype, int K, int N) { return dt_ok(dtype) && K > 0 && N > 0 ? rs_pw_packed_bytes(N, K, dtype) : 0; }
 int rsuper_pointwise(int dtype, int mode, const float* x, int ldx, const float* w, const float* bias, const float* res, int ldr,
                      float* y, int ldy, long R, int K, int N, void* packed, void* stream) {

@@ -72,6 +72,9 @@ int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st, bool reduce = true);
 int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
+// stride-2 convolution (conv3d_wgrad_s2.hip): p.N/D/H/W = the FULL-resolution grid of x, dY lives on the ((D+1)/2, (H+1)/2, (W+1)/2) grid; xb unused
+int rs_wgrad_s2_splits(int dtype, int Ca, int Mtot, int N, int D, int H, int W);
+int rs_launch_wgrad_s2(const WgradParams& p, int dtype, hipStream_t st);
 
 // 1x1x1 convolution / linear layer as an MFMA GEMM on f32 channels-last rows (pointwise.hip); packed = workspace of rs_pw_packed_bytes
 size_t rs_pw_packed_bytes(int N, int K, int dtype);

@@ -367,7 +367,11 @@ def strided_kernel(dtype, dims, direction):
     the work).  Measured on MI355X (tools/bench_conv.py, B = 2, 96^3 / 48^3 / 24^3 inputs): f32 forward 5.3x / 3.4x / 3.8x and data gradient
     3.7x / 3.6x / 4.2x faster; bf16 forward 2.3x / 1.3x / 1.7x, data gradient 2.2x / 1.8x / 1.3x -- so it is the default everywhere;
     RSUPER_S2_KERNEL=0 selects the old evaluation (tests run both, A/B)."""
-    return os.environ.get('RSUPER_S2_KERNEL', '1') != '0'
+    if os.environ.get('RSUPER_S2_KERNEL', '1') == '0':
+        return False
+    if direction == 'wgrad':          # csrc/conv3d_wgrad_s2.hip (round 3); RSUPER_S2_WGRAD=0: stride-1 kernel on the zero-stuffed dy
+        return os.environ.get('RSUPER_S2_WGRAD', '1') != '0'
+    return True
 
 
 def reduce_side_enabled():
@@ -418,6 +422,27 @@ def wgrad(xa, xb, ya, yb, dwa, dwb, dims, side_reduce=False):
             TIMER.launch('conv3d_wgrad_reduce', 0.0, run_reduce)      # events on the side stream: counted in the union of intervals
         else:
             run_reduce()
+
+
+def wgrad_s2(xa, ya, yb, dwa, dwb, full_dims):
+    """Weight gradient of the stride-2 [conv1 | shortcut] pair: xa (with statistics) on the full grid, ya / yb = dy sources on the half grid
+    (csrc/conv3d_wgrad_s2.hip -- every x voxel staged once, 27 dense taps on the half grid, no zero-stuffed dy)."""
+    dt = _DT[xa.t.dtype]
+    N, FD, FH, FW = full_dims
+    Mtot = ya.C + (yb.C if yb is not None else 0)
+    splits = _L().rsuper_conv3_wgrad_s2_splits(dt, xa.C, Mtot, N, FD, FH, FW)
+    assert splits >= 1
+    yb_args = (None, 0, 0) if yb is None else (_ptr(yb.t, yb.off), yb.ld, yb.C)
+    ws = torch.empty((splits * 27 * Mtot * xa.C,), device=dwa.device, dtype=torch.float32)
+
+    def run():
+        _l.check(_L().rsuper_conv3_wgrad_s2(dt, _ptr(xa.t, xa.off), xa.ld, xa.C, _ptr(xa.mr), _ptr(ya.t, ya.off), ya.ld, ya.C, *yb_args,
+                                            _ptr(dwa), _ptr(dwb), _ptr(ws), N, FD, FH, FW, splits, _stream()), 'conv3_wgrad_s2')
+    if TIMER is not None:
+        OD, OH, OW = (FD + 1) // 2, (FH + 1) // 2, (FW + 1) // 2
+        TIMER.launch('conv3d_wgrad', 2.0 * N * OD * OH * OW * Mtot * xa.C * 27, run)
+    else:
+        run()
 
 
 def in_bwd_finalize(g, x, gm, out_C, add1=None):
@@ -549,14 +574,18 @@ class BasicBlockFn(torch.autograd.Function):
         dw2 = grad_dest(w2)
         wgrad(y1, None, sdo, None, dw2, None, dims2)
         dy1 = in_bwd_finalize(Src(g1), y1, gm1, Cout)
-        # conv1 + shortcut: the output gradient lives at the even voxels of the full-resolution grid
-        dfull = torch.empty((N, D, H, W, 2 * Cout), device=dev, dtype=dt)
-        subsample2_scatter(dy1, dfull, 0, dims)
-        subsample2_scatter(dout, dfull, Cout, dims)
+        # conv1 + shortcut.  Parity-class / strided kernels read [dy1 | dOut] on the half grid; the rounds-1/2 evaluation needs the output
+        # gradient zero-stuffed to the even voxels of the full-resolution grid
         sa = Src(xa, mr=mra)
         tiles = _L().rsuper_conv3_tiles(D, H, W)
         g0 = torch.empty((N, D, H, W, Ca), device=dev, dtype=dt)
-        if not strided_kernel(dt, dims, 'dgrad'):
+        k_dgrad, k_wgrad = strided_kernel(dt, dims, 'dgrad'), strided_kernel(dt, dims, 'wgrad')
+        dfull = None
+        if not (k_dgrad and k_wgrad):
+            dfull = torch.empty((N, D, H, W, 2 * Cout), device=dev, dtype=dt)
+            subsample2_scatter(dy1, dfull, 0, dims)
+            subsample2_scatter(dout, dfull, Cout, dims)
+        if not k_dgrad:
             bnd = pick_bn(Ca, dt, tiles * N, dims)
             wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, bnd)
             part0 = part_buffer(dt, dims, Ca, bnd, dev, epi=1)
@@ -568,7 +597,10 @@ class BasicBlockFn(torch.autograd.Function):
             igemm_s2(2, Src(dy1), sdo, wpd1, Ca, dims, g0, part0, ea=sa)
         gm0 = stats_finalize(part0, D * H * W, mode=1)
         dw1, dws = grad_dest(w1), grad_dest(ws)
-        wgrad(sa, None, Src(dfull, C=Cout), Src(dfull, C=Cout, off=Cout), dw1, dws, dims)
+        if k_wgrad:
+            wgrad_s2(sa, Src(dy1), sdo, dw1, dws, dims)
+        else:
+            wgrad(sa, None, Src(dfull, C=Cout), Src(dfull, C=Cout, off=Cout), dw1, dws, dims)
         dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca)
         return dxa, None, None, None, dw1, dw2, dws, None, None
 

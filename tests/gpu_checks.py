@@ -198,6 +198,39 @@ def check_conv_bwd(mode, N, S, Ca, Cb, Cout, fused_sc, seed=0, tr=None):
                   f'g {e_g:.2e} dx {e_dx:.2e} dw {e_w:.2e}')
 
 
+def check_wgrad_s2(mode, N, S, Ca, Ya, Yb, seed=0):
+    """Strided weight gradient (csrc/conv3d_wgrad_s2.hip) of [conv1 | shortcut] against autograd of F.conv3d(stride=2, padding=1) on the
+    normalised + rectified input (float64 reference of the operands the kernel sees)."""
+    from rsuper_amd.hip import ops
+    import torch.nn.functional as F
+    dt = DT[mode]
+    D, H, W = S
+    OD, OH, OW = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    xa = rnd(_rng_t(seed + 1, (N, Ca, D, H, W)) + 0.3, mode)
+    dy1 = rnd(_rng_t(seed + 6, (N, Ya, OD, OH, OW)), mode)
+    dy2 = rnd(_rng_t(seed + 7, (N, Yb, OD, OH, OW)), mode) if Yb else None
+    mr = stats_ref(xa)
+    xh = torch.relu((xa.double() - mr[:, :, 0].double()[:, :, None, None, None]) * mr[:, :, 1].double()[:, :, None, None, None])
+    if mode == 'bf16':
+        xh = xh.float().bfloat16().double()
+    refs = []
+    for dy, Y in ((dy1, Ya), (dy2, Yb)):
+        if dy is None:
+            continue
+        w = torch.zeros((Y, Ca, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+        F.conv3d(xh, w, stride=2, padding=1).backward(dy.double())
+        refs.append(w.grad.float())
+    sa = ops.Src(to_cl(xa, dt), mr=mr.to(DEV))
+    dw1 = torch.full((Ya, Ca, 3, 3, 3), float('nan'), device=DEV)
+    dw2 = torch.full((Yb, Ca, 3, 3, 3), float('nan'), device=DEV) if Yb else None
+    ops.wgrad_s2(sa, ops.Src(to_cl(dy1, dt)), ops.Src(to_cl(dy2, dt)) if Yb else None, dw1, dw2, (N, D, H, W))
+    torch.cuda.synchronize()
+    e = relerr(dw1.cpu(), refs[0])
+    if Yb:
+        e = max(e, relerr(dw2.cpu(), refs[1]))
+    return result(f'wgrad_s2[{mode} N{N} S{S} {Ca}->{Ya}+{Yb}]', e, TOL[mode], f'dw {e:.2e}')
+
+
 def check_tr16_probe():
     """Raw ds_read_b64_tr_b16 behaviour is exercised through wgrad with tr=1 vs tr=0 (bit-identical operands ->
     identical MFMA results up to atomic order)."""
@@ -985,6 +1018,9 @@ def all_checks(quick=False):
         for force in ('0',):             # the rounds-1/2 evaluation of the strided convolutions stays selectable (RSUPER_S2_KERNEL=0): keep it pinned too
             cs += [(with_strided, (force, check_basic_block, mode, 'b8_16_s2', 8, 16, 12, 4)), (with_strided, (force, check_basic_block, mode, 'b16_16_s2', 16, 16, 9, 5)),
                    (with_strided, (force, check_unet_tiny_nopool, mode))]
+    for m in ('f32', 'bf16'):           # strided weight gradient: even / odd / ragged sizes, one and two dy sources, channel tails, several tiles per split
+        cs += [(check_wgrad_s2, (m, 1, (8, 8, 32), 32, 32, 0)), (check_wgrad_s2, (m, 2, (12, 10, 20), 16, 32, 32)), (check_wgrad_s2, (m, 1, (7, 9, 35), 8, 16, 16)),
+               (check_wgrad_s2, (m, 2, (5, 17, 66), 40, 24, 24)), (check_wgrad_s2, (m, 1, (2, 3, 5), 8, 8, 8)), (check_wgrad_s2, (m, 3, (24, 24, 24), 64, 128, 128))]
     for m in ('f32', 'bf16'):           # 1x1x1 convolutions of MedFormer's attention stages on MFMA: shipped shapes, ragged rows / channels
         cs += [(check_pointwise, (m, 27648, 128, 512, False)), (check_pointwise, (m, 13824, 512, 128, True)), (check_pointwise, (m, 3456, 256, 1024, False)),
                (check_pointwise, (m, 3456, 1024, 256, True)), (check_pointwise, (m, 432, 320, 1280, False)),       # reduction split over the waves

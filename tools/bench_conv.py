@@ -18,6 +18,9 @@ LAYERS = [('inc 32->32', 96, 32, 0, 32, False), ('up4.0 96->32+sc', 96, 32, 64, 
           ('64->64', 48, 64, 0, 64, False), ('up3.0 192->64+sc', 48, 64, 128, 64, True), ('128->128', 24, 128, 0, 128, False),
           ('up2.0 384->128+sc', 24, 128, 256, 128, True), ('256->256', 12, 256, 0, 256, False), ('320->320', 6, 320, 0, 320, False)]
 
+if os.environ.get('BC_ONLY_S2'):                       # only the strided rows below
+    LAYERS = []
+
 
 def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize()
@@ -92,6 +95,10 @@ for name, S, Ca, Cout in [('down1.0 s2 32->64+sc', 96, 32, 64), ('down2.0 s2 64-
     partl = ops.part_buffer(dt, dims, Ca, bnd, dev, epi=1)
     t_dl = timeit(lambda: (ops.subsample2_scatter(dy1, dfull, 0, dims), ops.subsample2_scatter(dy2, dfull, Cout, dims),
                            ops.igemm(1, ops.Src(dfull, C=Cout), ops.Src(dfull, C=Cout, off=Cout), wpdl, Ca, bnd, dims, g0, part=partl, ea=sa)))
+    dw1 = torch.zeros_like(w1); dws = torch.zeros_like(ws)
+    t_w = timeit(lambda: ops.wgrad_s2(sa, ops.Src(dy1), ops.Src(dy2), dw1, dws, dims))
+    t_wl = timeit(lambda: ops.wgrad(sa, None, ops.Src(dfull, C=Cout), ops.Src(dfull, C=Cout, off=Cout), dw1, dws, dims))   # + the stuffing pass timed with the dgrad
     fl = 2.0 * N * O ** 3 * nc * Ca * 27
     print(f'{name:22s} S{S:3d}->{O:2d} {fl / 1e9:6.1f} GF | fwd {t_f * 1e3:7.1f} us {fl / t_f / 1e9:6.1f} TF (full-res + subsample {t_fl * 1e3:7.1f} us: x{t_fl / t_f:4.1f}) | '
-          f'dgrad {t_d * 1e3:7.1f} us {fl / t_d / 1e9:6.1f} TF (zero-stuffed full-res {t_dl * 1e3:7.1f} us: x{t_dl / t_d:4.1f})', flush=True)
+          f'dgrad {t_d * 1e3:7.1f} us {fl / t_d / 1e9:6.1f} TF (zero-stuffed full-res {t_dl * 1e3:7.1f} us: x{t_dl / t_d:4.1f}) | '
+          f'wgrad {t_w * 1e3:7.1f} us {fl / t_w / 1e9:6.1f} TF (stride-1 kernel on the zero-stuffed dy {t_wl * 1e3:7.1f} us: x{t_wl / t_w:4.1f})', flush=True)
