@@ -136,7 +136,8 @@ class Leg:
                                  trans_num=[0, 2, 4, 6, 4, 2, 0, 0], num_heads=[1, 4, 8, 10, 8, 4, 1, 1], fusion_depth=2, fusion_dim=320,
                                  fusion_heads=10, expansion=4, aux_loss=True, compute_dtype=dtype).to(dev)
         else:
-            self.net = UNet(1, args.base, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype=dtype).to(dev)
+            self.net = UNet(1, args.base, num_classes=len(classes), block='BasicBlock', norm='in', compute_dtype=dtype,
+                            pool=not getattr(args, 'no_pool', False)).to(dev)
         self.ema = make_ema(self.net)
         self.model = wrap_ddp(self.net, local) if (world > 1 or force_ddp) else self.net
         self.opt = FusedAdamWEMA(self.net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
@@ -347,6 +348,7 @@ def main():
     ap.add_argument('--base', type=int, default=32)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--report', action='store_true', help='config 3: report supervision on (ball_dice_both, 50/50 mask/report batch)')
+    ap.add_argument('--no-pool', action='store_true', help="variant (not the headline): down_block(pool=False) -- the strided BasicBlock members (SURVEY 8 row g)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the config-3 / f32 / bf16-vs-f32 legs')
     ap.add_argument('--roofline-steps', type=int, default=10, help='steps of the separate HIP-event pass after the timed region')
@@ -405,7 +407,7 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        default_wl = args.dtype == 'bf16' and args.base == 32 and B == 2 and S == 96 and not args.report
+        default_wl = args.dtype == 'bf16' and args.base == 32 and B == 2 and S == 96 and not args.report and not args.no_pool
         if default_wl and os.path.exists(TRAFFIC_PROFILE):
             tp = json.load(open(TRAFFIC_PROFILE))
             traffic, traffic_src = tp.get('conv_bytes_per_step'), tp.get('source')
@@ -415,7 +417,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'R-Super 3D UNet(base {args.base}, {len(classes)} classes, BasicBlock/IN) full training step '
                                    f'(fwd + {"seg+Volume+Ball" if args.report else "masked BCE + Dice"} loss + bwd + clip + AdamW + EMA), '
-                                   f'{S}^3 patches, batch {B}/GPU (BASELINE.json configs[{2 if args.report else 1}])',
+                                   f'{S}^3 patches, batch {B}/GPU (BASELINE.json configs[{2 if args.report else 1}])' + (' -- VARIANT pool=False (strided down blocks)' if args.no_pool else ''),
                        'global_batch': world * B, 'patch': S, 'parallelism': f'dp{world}', 'final_loss': loss_val,
                        'sanity_checks_in_timed_region': False},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
