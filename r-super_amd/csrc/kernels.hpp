@@ -69,6 +69,9 @@ int rs_launch_igemm_box(const IgemmParams& p, int cfg, int epi, hipStream_t st);
 int rs_launch_igemm_s2(const IgemmParams& p, int dtype, int mode, int FD, int FH, int FW, hipStream_t st);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
+// softmax(q k^T * scale) v of a short token sequence (token_attn.hip); d_qkv == nullptr: forward (o, p written), else backward (p, d_o read)
+int rs_token_attn_supported(int L, int Dh);
+int rs_launch_token_attn(const float* qkv, float* o, float* p, const float* d_o, float* d_qkv, int B, int L, int H, int Dh, float scale, hipStream_t st);
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st, bool reduce = true);
 int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);

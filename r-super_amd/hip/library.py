@@ -94,6 +94,7 @@ def install():
         ('PlanarFn', 'cl_planar', '(Tensor x, int K) -> Tensor', None, None),
         ('SqueezeExciteFn', 'squeeze_excite', '(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2) -> Tensor', None, None),
         ('BidirAttnFn', 'bidir_attention', '(Tensor fqv, Tensor mqv, int heads, float scale) -> (Tensor, Tensor)', None, None),
+        ('TokenAttnFn', 'token_attention', '(Tensor qkv, int heads, float scale) -> Tensor', None, None),
         ('ChannelNormFn', 'channel_norm', '(Tensor x, float eps, bool relu) -> Tensor', None, None),
         ('DepthwiseConvFn', 'depthwise_conv3', '(Tensor x, Tensor w) -> Tensor', None, None),
     ]

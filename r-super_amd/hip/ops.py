@@ -969,6 +969,40 @@ class BidirAttnFn(torch.autograd.Function):
         return d_fqv, d_mqv, None, None
 
 
+def token_attn_supported(L, dim_head):
+    return bool(_L().rsuper_token_attn_supported(int(L), int(dim_head)))
+
+
+class TokenAttnFn(torch.autograd.Function):
+    """softmax(q k^T * scale) v of the SemanticMapFusion transformer's Attention (model/dim3/trans_layers.py:52-84) in one launch per direction
+    (csrc/token_attn.hip).  qkv (B, L, 3 * heads * dim_head) f32 as `to_qkv(x)` produces it; returns (B, L, heads * dim_head)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        if not qkv.is_cuda:
+            raise _l.RSuperHipError('TokenAttnFn needs a device tensor (no CPU fallback)')
+        qkv = qkv.contiguous()
+        assert qkv.dim() == 3 and qkv.dtype == torch.float32 and qkv.shape[-1] % (3 * heads) == 0, (tuple(qkv.shape), qkv.dtype)
+        B, L, c3 = qkv.shape
+        dh = c3 // (3 * heads)
+        o = torch.empty((B, L, heads * dh), device=qkv.device, dtype=torch.float32)
+        p = torch.empty((B, heads, L, L), device=qkv.device, dtype=torch.float32)
+        _l.check(_L().rsuper_token_attn_fwd(_ptr(qkv), _ptr(o), _ptr(p), B, L, heads, dh, float(scale), _stream()), 'token_attn_fwd')
+        ctx.save_for_backward(qkv, p)
+        ctx.heads, ctx.scale = heads, float(scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, p = ctx.saved_tensors
+        B, L, c3 = qkv.shape
+        do = do.contiguous()
+        d_qkv = torch.empty_like(qkv)
+        _l.check(_L().rsuper_token_attn_bwd(_ptr(qkv), _ptr(p), _ptr(do), _ptr(d_qkv), B, L, ctx.heads, c3 // (3 * ctx.heads), ctx.scale, _stream()),
+                 'token_attn_bwd')
+        return d_qkv, None, None
+
+
 def channel_stats(x, eps):
     """(mean, rstd) per (sample, channel) of a channels-last fp32 tensor -> (N, C, 2) f32 (csrc/instnorm.hip + stats_finalize)."""
     N, C = x.shape[0], x.shape[-1]

@@ -91,6 +91,7 @@ def upsample_trilinear(x, size, planar=False):
 FUSED_ATTENTION = os.environ.get('RSUPER_MF_ATEN_ATTENTION') != '1'
 HIP_POINTWISE = os.environ.get('RSUPER_MF_LIBRARY_GEMM') != '1'      # 1x1x1 convolutions / linear layers on csrc/pointwise.hip (=1: library GEMMs, A/B)
 FUSE_RESIDUAL = os.environ.get('RSUPER_MF_FUSE_RES', '1') == '1'          # identity shortcuts added in the pointwise GEMM's epilogue
+HIP_TOKEN_ATTN = os.environ.get('RSUPER_MF_TOKEN_ATTN', '1') == '1'       # fusion transformer's attention core on csrc/token_attn.hip (=0: the ATen chain, A/B)
 HIP_POINTWISE_WGRAD = os.environ.get('RSUPER_MF_LIBRARY_WGRAD') != '1'   # their weight / bias gradients too (=1: library GEMMs, A/B)
 HIP_POINTWISE_MIN_ROWS = int(os.environ.get('RSUPER_MF_PW_MIN_ROWS', '32'))    # below (the 27-token maps): library GEMM
 GEMM_COMPUTE = torch.float32    # MFMA operand type of the HIP pointwise GEMMs: set per forward by MedFormer from its compute_dtype
@@ -429,9 +430,15 @@ class _TokenAttention(nn.Module):
     def forward(self, x, res=None):
         B, L, _ = x.shape
         # projections through linear(): csrc/pointwise.hip (162 token rows: reduction split over the waves), shortcut in the epilogue
-        q, k, v = (t.reshape(B, L, self.heads, -1).transpose(1, 2) for t in linear(x, self.to_qkv.weight).chunk(3, -1))
-        att = F.softmax(torch.matmul(q, k.transpose(-1, -2)) * self.scale, -1)
-        return linear(torch.matmul(att, v).transpose(1, 2).reshape(B, L, -1), self.to_out.weight, self.to_out.bias, res)
+        qkv = linear(x, self.to_qkv.weight)
+        if HIP_TOKEN_ATTN and qkv.is_cuda and ops.token_attn_supported(L, qkv.shape[-1] // (3 * self.heads)):
+            # score / soft-max / mixing in one launch per direction, no transposing copies (csrc/token_attn.hip)
+            o = ops.TokenAttnFn.apply(qkv, self.heads, self.scale)
+        else:
+            q, k, v = (t.reshape(B, L, self.heads, -1).transpose(1, 2) for t in qkv.chunk(3, -1))
+            att = F.softmax(torch.matmul(q, k.transpose(-1, -2)) * self.scale, -1)
+            o = torch.matmul(att, v).transpose(1, 2).reshape(B, L, -1)
+        return linear(o, self.to_out.weight, self.to_out.bias, res)
 
 
 class _Mlp(nn.Module):

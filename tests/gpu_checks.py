@@ -231,6 +231,25 @@ def check_wgrad_s2(mode, N, S, Ca, Ya, Yb, seed=0):
     return result(f'wgrad_s2[{mode} N{N} S{S} {Ca}->{Ya}+{Yb}]', e, TOL[mode], f'dw {e:.2e}')
 
 
+def check_token_attn(B, L, heads, dh, seed=0):
+    """csrc/token_attn.hip against the ATen chain of Attention.forward (trans_layers.py:52-84) in float64, forward and backward."""
+    from rsuper_amd.hip import ops
+    import torch.nn.functional as F
+    qkv = _rng_t(seed + 1, (B, L, 3 * heads * dh))
+    go = _rng_t(seed + 2, (B, L, heads * dh))
+    scale = dh ** -0.5
+    r = qkv.double().requires_grad_(True)
+    q, k, v = (t.reshape(B, L, heads, -1).transpose(1, 2) for t in r.chunk(3, -1))
+    o_ref = torch.matmul(F.softmax(torch.matmul(q, k.transpose(-1, -2)) * scale, -1), v).transpose(1, 2).reshape(B, L, -1)
+    o_ref.backward(go.double())
+    x = qkv.to(DEV).requires_grad_(True)
+    o = ops.TokenAttnFn.apply(x, heads, scale)
+    o.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    e_o, e_g = relerr(o.detach().cpu(), o_ref.detach()), relerr(x.grad.cpu(), r.grad)
+    return result(f'token_attn[B{B} L{L} h{heads} d{dh}]', max(e_o, e_g), 2e-5, f'o {e_o:.2e} dqkv {e_g:.2e}')
+
+
 def check_tr16_probe():
     """Raw ds_read_b64_tr_b16 behaviour is exercised through wgrad with tr=1 vs tr=0 (bit-identical operands ->
     identical MFMA results up to atomic order)."""
@@ -1018,6 +1037,8 @@ def all_checks(quick=False):
         for force in ('0',):             # the rounds-1/2 evaluation of the strided convolutions stays selectable (RSUPER_S2_KERNEL=0): keep it pinned too
             cs += [(with_strided, (force, check_basic_block, mode, 'b8_16_s2', 8, 16, 12, 4)), (with_strided, (force, check_basic_block, mode, 'b16_16_s2', 16, 16, 9, 5)),
                    (with_strided, (force, check_unet_tiny_nopool, mode))]
+    cs += [(check_token_attn, (2, 81, 10, 32)), (check_token_attn, (1, 112, 2, 16)), (check_token_attn, (3, 7, 3, 16)), (check_token_attn, (2, 65, 4, 24)),
+           (check_token_attn, (1, 1, 1, 4)), (check_token_attn, (2, 80, 2, 64))]      # fusion transformer's attention core: shipped shape, limits, ragged
     for m in ('f32', 'bf16'):           # strided weight gradient: even / odd / ragged sizes, one and two dy sources, channel tails, several tiles per split
         cs += [(check_wgrad_s2, (m, 1, (8, 8, 32), 32, 32, 0)), (check_wgrad_s2, (m, 2, (12, 10, 20), 16, 32, 32)), (check_wgrad_s2, (m, 1, (7, 9, 35), 8, 16, 16)),
                (check_wgrad_s2, (m, 2, (5, 17, 66), 40, 24, 24)), (check_wgrad_s2, (m, 1, (2, 3, 5), 8, 8, 8)), (check_wgrad_s2, (m, 3, (24, 24, 24), 64, 128, 128))]
