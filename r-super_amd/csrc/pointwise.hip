@@ -224,6 +224,7 @@ struct PwWgParams {
     const float* x; int ldx;
     float* part;                   // [S][N*K + N]
     int R, N, K, rows_per, bias;
+    float* out_w; float* out_b;    // one slab only: the block tiles write dW / db themselves (no reduce launch)
 };
 
 template <typename CT, int WNW>
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgParams p) {
         if (r < rend) compute(0);
     }
     // C layout: column (x channel) = lane & 31, row (dy channel) of register reg = (reg & 3) + 8 * (reg >> 2) + 4 * half
-    float* part = p.part + (size_t)blockIdx.z * ((size_t)p.N * p.K + p.N);
+    float* part = p.out_w ? p.out_w : p.part + (size_t)blockIdx.z * ((size_t)p.N * p.K + p.N);
+    float* bpart = p.out_w ? p.out_b : part + (size_t)p.N * p.K;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgParams p) {
         for (int m = 0; m < 2; ++m) {
             const float t = bs[m] + __shfl_xor(bs[m], 32);
             const int n = n0 + m * 32 + c;
-            if (half == 0 && n < p.N) part[(size_t)p.N * p.K + n] = t;
+            if (half == 0 && n < p.N) bpart[n] = t;
         }
     }
 }
@@ -342,14 +344,15 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __res
 }
 
 template <typename CT>
-int launch_pw_wgrad(const PwWgParams& p, int S, float* dw, float* db, hipStream_t st) {
+int launch_pw_wgrad(PwWgParams p, int S, float* dw, float* db, hipStream_t st) {
+    p.out_w = S == 1 ? dw : nullptr; p.out_b = S == 1 ? db : nullptr;
     const int wnw = p.N <= 64 ? 1 : p.K <= 64 ? 4 : 2;
     dim3 grid((unsigned)((p.N + wnw * 64 - 1) / (wnw * 64)), (unsigned)((p.K + (4 / wnw) * 64 - 1) / ((4 / wnw) * 64)), (unsigned)S), block(256);
     if (wnw == 1) hipLaunchKernelGGL((pw_wgrad_kernel<CT, 1>), grid, block, 0, st, p);
     else if (wnw == 4) hipLaunchKernelGGL((pw_wgrad_kernel<CT, 4>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((pw_wgrad_kernel<CT, 2>), grid, block, 0, st, p);
     const long NK = (long)p.N * p.K, E = NK + p.N;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((E / 4 + 255) / 256)), dim3(256), 0, st, (const float*)p.part, S, E, NK, dw, db);
+    if (S > 1) hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((E / 4 + 255) / 256)), dim3(256), 0, st, (const float*)p.part, S, E, NK, dw, db);
     return rs_check_launch();
 }
 
@@ -389,6 +392,9 @@ int rs_pw_wgrad_splits(int R, int N, int K) {
     const int wnw = N <= 64 ? 1 : K <= 64 ? 4 : 2;
     const int tiles = ((N + wnw * 64 - 1) / (wnw * 64)) * ((K + (4 / wnw) * 64 - 1) / ((4 / wnw) * 64));
     static const int target = getenv("RSUPER_PW_WG_TARGET") ? atoi(getenv("RSUPER_PW_WG_TARGET")) : 256;   // blocks per launch (measured: 128 / 256 / 512 / 1024 -> MedFormer step 28.6 / 28.5 / 28.9 / 29.4 ms)
+    static const int direct = getenv("RSUPER_PW_WG_DIRECT") ? atoi(getenv("RSUPER_PW_WG_DIRECT")) : 0;   // rows up to which ONE slab is forced (a single slab writes dW itself, no reduce launch): 768 measured no faster
+                                                                                                      // than 7 slabs + reduce at 432 rows (MedFormer 27.2 vs 27.0 ms); a naturally single slab (<= 64 rows) always writes directly
+    if (R <= direct) return 1;
     int s = target / tiles;
     if (s > (R + 63) / 64) s = (R + 63) / 64;
     if (s < 1) s = 1;
