@@ -108,15 +108,17 @@ __global__ __launch_bounds__(256) void cnorm_apply_kernel(CnParams p) {
 }
 
 // Small volumes (the 12^3 / 6^3 stages and the 27-token semantic maps: most of MedFormer's norm calls): one block per
-// (sample, 64-channel group) does statistics, finalize and apply in ONE launch -- the three-launch path is pure launch latency there.
+// (sample, 16-channel group: 4 channel vectors x 64 voxel lanes -- round 3; 64-channel groups left 10 blocks on the chip for 320 channels and 14
+// dependent trips per thread) does statistics, finalize and apply in ONE launch -- the three-launch path is pure launch latency there.
 // Same arithmetic: f32 partial sums per thread, fixed-order f64 combination, mean / rstd (or m1 / m2) in f32.
+constexpr int CS_CG = 16, CS_VPB = 64;
 template <int MODE>
 __global__ __launch_bounds__(256) void cnorm_small_kernel(CnParams p, float eps, float* mr_out) {
-    __shared__ double red[4][2][CN_CG];
-    __shared__ float fin[2][CN_CG];
+    __shared__ double red[4][2][CS_CG];
+    __shared__ float fin[2][CS_CG];
     const int n = blockIdx.y;
-    const int cv = threadIdx.x & 15, vl = threadIdx.x >> 4;
-    const int c = blockIdx.x * CN_CG + cv * 4;
+    const int cv = threadIdx.x & 3, vl = threadIdx.x >> 2;
+    const int c = blockIdx.x * CS_CG + cv * 4;
     const bool cok = c < p.C;
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu;
     if (MODE == 1 && cok) {
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void cnorm_small_kernel(CnParams p, float eps,
     const float* gb = MODE == 1 ? p.dy + (size_t)n * p.vox * p.C + c : nullptr;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     if (cok)
-        for (long v = vl; v < p.vox; v += CN_VPB) {
+        for (long v = vl; v < p.vox; v += CS_VPB) {
             const float4 q = *(const float4*)(xb + (size_t)v * p.C);
             if (MODE == 0) {
                 s1.x += q.x; s1.y += q.y; s1.z += q.z; s1.w += q.w;
@@ -142,14 +144,14 @@ __global__ __launch_bounds__(256) void cnorm_small_kernel(CnParams p, float eps,
         }
     double d1[4] = {s1.x, s1.y, s1.z, s1.w}, d2[4] = {s2.x, s2.y, s2.z, s2.w};
 #pragma unroll
-    for (int o = 16; o <= 32; o <<= 1)
+    for (int o = 4; o <= 32; o <<= 1)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { d1[j] += __shfl_xor(d1[j], o, 64); d2[j] += __shfl_xor(d2[j], o, 64); }
-    if ((threadIdx.x & 63) < 16)
+    if ((threadIdx.x & 63) < 4)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { red[threadIdx.x >> 6][0][cv * 4 + j] = d1[j]; red[threadIdx.x >> 6][1][cv * 4 + j] = d2[j]; }
     __syncthreads();
-    if (threadIdx.x < CN_CG) {
+    if (threadIdx.x < CS_CG) {
         const int cc = threadIdx.x;
         const double a = (red[0][0][cc] + red[1][0][cc]) + (red[2][0][cc] + red[3][0][cc]);
         const double b = (red[0][1][cc] + red[1][1][cc]) + (red[2][1][cc] + red[3][1][cc]);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void cnorm_small_kernel(CnParams p, float eps,
             double var = b / cnt - mean * mean;
             if (var < 0.0) var = 0.0;
             f0 = (float)mean; f1 = (float)(1.0 / sqrt(var + (double)eps));
-            if (blockIdx.x * CN_CG + cc < p.C) { float* o = mr_out + ((size_t)n * p.C + blockIdx.x * CN_CG + cc) * 2; o[0] = f0; o[1] = f1; }
+            if (blockIdx.x * CS_CG + cc < p.C) { float* o = mr_out + ((size_t)n * p.C + blockIdx.x * CS_CG + cc) * 2; o[0] = f0; o[1] = f1; }
         } else {
             f0 = (float)(a / cnt); f1 = (float)(b / cnt);
         }
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void cnorm_small_kernel(CnParams p, float eps,
     const float4 a0 = *(const float4*)&fin[0][cv * 4], a1 = *(const float4*)&fin[1][cv * 4];
     if (MODE == 0) { mu = a0; rs = a1; }
     float* ob = p.out + (size_t)n * p.vox * p.C + c;
-    for (long v = vl; v < p.vox; v += CN_VPB) {
+    for (long v = vl; v < p.vox; v += CS_VPB) {
         const float4 q = *(const float4*)(xb + (size_t)v * p.C);
         const float4 xh = make_float4((q.x - mu.x) * rs.x, (q.y - mu.y) * rs.y, (q.z - mu.z) * rs.z, (q.w - mu.w) * rs.w);
         float4 o;
@@ -433,7 +435,7 @@ int rs_launch_cl_planar(const float* src, float* dst, int N, long vox, int C, in
 int rs_launch_cnorm_small(const float* x, const float* dy, const float* mr, float* out, float* mr_out, int N, long vox, int C, int relu, float eps,
                           int mode, hipStream_t st) {
     CnParams p = {x, dy, mr, nullptr, out, nullptr, vox, C, relu, 0};
-    dim3 grid((C + CN_CG - 1) / CN_CG, N);
+    dim3 grid((C + 15) / 16, N);
     if (mode == 0) hipLaunchKernelGGL(cnorm_small_kernel<0>, grid, dim3(256), 0, st, p, eps, mr_out);
     else hipLaunchKernelGGL(cnorm_small_kernel<1>, grid, dim3(256), 0, st, p, eps, mr_out);
     return rs_check_launch();

@@ -1171,12 +1171,13 @@ def pointwise_prepack(compute):
     for key, off, ref in entries:                                # a parameter that is gone invalidates the table (its memory may be anybody's by now)
         if ref() is None:
             del _PW_TABLES[dt]
-            _PW_SEEN_DIRTY = True
+            _PW_PACKED.clear()                                   # ... and every fragment set packed from it: a new parameter at a recycled address with
+            _PW_SEEN_DIRTY = True                                # the same (epoch, version) would otherwise multiply with the dead one's fragments
             return
     _l.check(_L().rsuper_pointwise_pack_batch(dt, _ptr(table), len(entries), total, _ptr(arena), _stream()), 'pointwise_pack_batch')
     ep = WEIGHTS_EPOCH
     for key, off, ref in entries:
-        _PW_PACKED[key] = ((ep, ref()._version), arena, off)
+        _PW_PACKED[key] = ((ep, ref()._version), arena, off, ref)
 
 
 def pointwise_gemm(x2, w, bias, mode, compute, res=None):
@@ -1191,10 +1192,10 @@ def pointwise_gemm(x2, w, bias, mode, compute, res=None):
     dt = _DT[compute]
     y = torch.empty((R, N), device=x2.device, dtype=torch.float32)
     hit = _PW_PACKED.get((w.data_ptr(), mode, dt))
-    if hit is not None and hit[0] == _pw_key(w):           # fragments from this step's pointwise_prepack
-        wptr, packed = None, hit[1].data_ptr() + hit[2]
+    base = w._base if w._base is not None else w
+    if hit is not None and hit[0] == _pw_key(w) and hit[3]() is base:     # fragments from this step's pointwise_prepack, of THIS parameter (not of a
+        wptr, packed = None, hit[1].data_ptr() + hit[2]                   # dead one whose address and version counter it inherited)
     else:
-        base = w._base if w._base is not None else w
         if isinstance(base, torch.nn.Parameter) and base.data_ptr() == w.data_ptr() and base.numel() == w.numel():
             k = (w.data_ptr(), mode)
             if k not in _PW_SEEN or _PW_SEEN[k][0]() is not base:

@@ -1067,6 +1067,47 @@ def test_dispatcher_ops_forward_only_and_autograd_paths_agree():
 
 
 @pytest.mark.gpu
+def test_pointwise_prepack_never_serves_a_dead_parameters_fragments():
+    """A parameter that dies leaves its address (and a version counter of 0) to the next one: the prepacked fragments of the dead parameter
+    must not be served to its heir.  (Round 3: `test_medformer_shipped_config_128_42_classes` failed once in a while after other MedFormer
+    tests in the same process -- the first forward of a fresh model multiplied some activations with the previous test's weights.)"""
+    import gc
+    from rsuper_amd.hip import ops
+    ops._PW_SEEN.clear(); ops._PW_PACKED.clear(); ops._PW_TABLES.clear()
+    x = torch.randn(64, 32, device=DEV)
+
+    def make(seed):
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        return torch.nn.Parameter(torch.randn(48, 32, device=DEV, generator=g))
+    wa = make(1)
+    ops.pointwise_gemm(x, wa, None, 0, torch.float32)          # packs by itself, becomes a candidate
+    ops.pointwise_prepack(torch.float32)                       # table + arena
+    assert (wa.data_ptr(), 0, ops._DT[torch.float32]) in ops._PW_PACKED
+    ya = ops.pointwise_gemm(x, wa, None, 0, torch.float32)     # served from the arena
+    assert torch.allclose(ya, x @ wa.t(), atol=1e-4, rtol=1e-4)
+    ptr = wa.data_ptr()
+    del wa, ya
+    gc.collect()
+    wb = make(2)
+    if wb.data_ptr() != ptr:
+        pytest.skip('the allocator did not recycle the address')
+    ops.pointwise_prepack(torch.float32)                       # what a module does at the top of its forward
+    yb = ops.pointwise_gemm(x, wb, None, 0, torch.float32)
+    assert torch.allclose(yb, x @ wb.t(), atol=1e-4, rtol=1e-4), 'fragments of the dead parameter were used'
+    # and without the prepack call in between (a bare op call): the lookup itself must notice the heir
+    ops.pointwise_prepack(torch.float32)
+    ops.pointwise_prepack(torch.float32)
+    assert torch.allclose(ops.pointwise_gemm(x, wb, None, 0, torch.float32), x @ wb.t(), atol=1e-4, rtol=1e-4)
+    ptr = wb.data_ptr()
+    del wb, yb
+    gc.collect()
+    wc = make(3)
+    if wc.data_ptr() == ptr:
+        assert torch.allclose(ops.pointwise_gemm(x, wc, None, 0, torch.float32), x @ wc.t(), atol=1e-4, rtol=1e-4), 'stale fragments at lookup'
+    ops._PW_SEEN.clear(); ops._PW_PACKED.clear(); ops._PW_TABLES.clear()
+
+
+@pytest.mark.gpu
 def test_accumulators_need_no_memset():
     """The three entry points that used to zero their destination with hipMemsetAsync -- a node that, captured in a hipGraph, wrote 0xC0 bytes
     after eager interludes and turned the gradient norm into NaN -- now initialise it with kernels of their own: pre-filled with

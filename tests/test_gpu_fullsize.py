@@ -244,7 +244,7 @@ def test_medformer_shipped_config_128_42_classes():
     bt = synth.batch(2, S5, classes, ['mask', 'report'], seed=11, diam_range=(5.0, 40.0), max_tumors=3)
     batch = dict(image=torch.from_numpy(synth.image(2, S5, seed=99)).to(DEV), **{k: torch.from_numpy(v).to(DEV) for k, v in bt.items()})
     args = _args(loss='ball_dice_last', report_volume_loss_basic=0.1)
-    runs = []
+    runs, detail = [], []
     torch.cuda.reset_peak_memory_stats()
     for rep in range(2):
         torch.manual_seed(0)
@@ -259,11 +259,12 @@ def test_medformer_shipped_config_128_42_classes():
             assert all(math.isfinite(v) for v in vals.values()) and math.isfinite(float(gn)), vals
             assert {'segmentation', 'ball_loss_bce', 'ball_loss_dice', 'overall'} <= set(vals), vals
             losses.append(vals['overall'])
+            detail.append((rep, step, vals))
         runs.append(losses)
         del net, ema, opt
         torch.cuda.empty_cache()
     assert runs[0][-1] < runs[0][0], runs[0]
-    assert runs[1] == runs[0][:2], (runs[0][:2], runs[1])
+    assert runs[1] == runs[0][:2], [d for d in detail if d[1] < 2]
     assert torch.cuda.max_memory_allocated() < 30 * 2 ** 30
 
 

@@ -1,9 +1,8 @@
 #!/bin/bash
-# MedFormer step: pointwise / depthwise checks, then eager step time with the single-slab pointwise weight gradient on / off
+# MedFormer step: norm / pointwise / depthwise checks, then the replayed step time over RSUPER_CNORM_SMALL_VOX
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests -x -q -m gpu -k "pointwise or depthwise or medformer" 2>&1 | tail -3
-for e in "" "RSUPER_PW_WG_DIRECT=0"; do
-  echo "== $e"; env $e timeout 600 python tools/medformer_step.py 20 bf16 2>&1 | tail -1
-  env $e timeout 600 python tools/medformer_step.py 20 bf16 graph 2>&1 | tail -1
+timeout 600 python -m pytest tests -x -q -m gpu -k "norm or pointwise or depthwise or medformer" 2>&1 | tail -3
+for e in "RSUPER_CNORM_SMALL_VOX=512" "RSUPER_CNORM_SMALL_VOX=2048" "RSUPER_CNORM_SMALL_VOX=16384" "RSUPER_CNORM_SMALL_VOX=512"; do
+  echo "== $e"; env $e timeout 600 python tools/medformer_step.py 20 bf16 graph 2>&1 | tail -1
 done
