@@ -1,6 +1,8 @@
 """Modules mirroring rsuper_train/model/dim3/conv_layers.py (ConvNormAct :16-53, BasicBlock :71-94) so that
 parameter names/shapes match the reference state_dict; the math runs in fused gfx950 kernels
 (rsuper_amd.hip.ops.BasicBlockFn) instead of module-by-module ATen calls."""
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -58,9 +60,10 @@ class BasicBlock(nn.Module):
         tiles_total = ops._L().rsuper_conv3_tiles(D, H, W) * N
         key = (ops.WEIGHTS_EPOCH, w1._version, w2._version, None if ws is None else ws._version, w1.data_ptr(), xa.dtype, Ca, Cb, tiles_total)
         hit = getattr(self, '_pack_cache', None)
-        if hit is not None and hit[0] == key:
+        # ... and on the identity of the parameters: a replaced parameter can inherit address and version counter of the one it replaced
+        if hit is not None and hit[0] == key and all(r() is w for r, w in zip(hit[2], (w1, w2, ws)) if w is not None):
             return hit[1]
         specs, bns = ops.block_pack_specs(w1, w2, ws, Ca, Cb, xa.dtype, tiles_total, False, (N, D, H, W))
         packs = (ops.pack_weights_batch(xa.dtype, specs), bns)
-        self._pack_cache = (key, packs)
+        self._pack_cache = (key, packs, tuple(weakref.ref(w) if w is not None else None for w in (w1, w2, ws)))
         return packs
