@@ -287,12 +287,13 @@ int rsuper_cl_planar(const float* src, float* dst, int N, long vox, int C, int K
 /* Self-attention core of the SemanticMapFusion transformer (Attention.forward, trans_layers.py:52-84 under medformer_utils.py:239-273):
  *   o = softmax(q k^T * scale) v per (sample, head).  qkv (B, L, 3*heads*dim_head) f32 = q | k | v thirds with head h at columns
  *   [h*dim_head, (h+1)*dim_head) of its third (to_qkv(x).chunk(3, -1) + 'b l (h d) -> b h l d'); o (B, L, heads*dim_head) in the
- *   'b h l d -> b l (h d)' layout; p (B, heads, L, L) = the soft-max rows, written forward and read backward.  _bwd overwrites
- *   d_qkv (same layout as qkv).  One launch per direction, deterministic.  L <= 128 with the backward's LDS footprint <= 160 KB
+ *   'b h l d -> b l (h d)' layout; p (B, heads, L, L) = the soft-max rows, written forward and read backward (with o, the forward's
+ *   output).  _bwd overwrites d_qkv (same layout as qkv).  One launch per direction, deterministic.  L <= 128, dim_head <= 64
  *   (rsuper_token_attn_supported); other shapes -> RS_ERR_UNSUPPORTED. */
 int rsuper_token_attn_supported(int L, int dim_head);
 int rsuper_token_attn_fwd(const float* qkv, float* o, float* p, int B, int L, int heads, int dim_head, float scale, void* stream);
-int rsuper_token_attn_bwd(const float* qkv, const float* p, const float* d_o, float* d_qkv, int B, int L, int heads, int dim_head, float scale, void* stream);
+int rsuper_token_attn_bwd(const float* qkv, const float* o, const float* p, const float* d_o, float* d_qkv, int B, int L, int heads, int dim_head, float scale,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bidirectional attention between the L voxels of a stage and its T semantic-map tokens, f32 channels-last -- the score / soft-max /

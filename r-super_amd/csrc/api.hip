@@ -466,9 +466,10 @@ int rsuper_token_attn_fwd(const float* qkv, float* o, float* p, int B, int L, in
     if (!qkv || !o || !p || B <= 0 || L <= 0 || heads <= 0 || dim_head <= 0) return RS_ERR_ARG;
     return rs_launch_token_attn(qkv, o, p, nullptr, nullptr, B, L, heads, dim_head, scale, ST(stream));
 }
-int rsuper_token_attn_bwd(const float* qkv, const float* p, const float* d_o, float* d_qkv, int B, int L, int heads, int dim_head, float scale, void* stream) {
-    if (!qkv || !p || !d_o || !d_qkv || B <= 0 || L <= 0 || heads <= 0 || dim_head <= 0) return RS_ERR_ARG;
-    return rs_launch_token_attn(qkv, nullptr, (float*)p, d_o, d_qkv, B, L, heads, dim_head, scale, ST(stream));
+int rsuper_token_attn_bwd(const float* qkv, const float* o, const float* p, const float* d_o, float* d_qkv, int B, int L, int heads, int dim_head, float scale,
+                          void* stream) {
+    if (!qkv || !o || !p || !d_o || !d_qkv || B <= 0 || L <= 0 || heads <= 0 || dim_head <= 0) return RS_ERR_ARG;
+    return rs_launch_token_attn(qkv, (float*)o, (float*)p, d_o, d_qkv, B, L, heads, dim_head, scale, ST(stream));
 }
 int rsuper_battn_supported(int T, int dim_head, int heads) { return rs_battn_supported(T, dim_head, heads); }
 int rsuper_battn_chunks(int L, int heads) { return rs_battn_chunks(L, heads); }

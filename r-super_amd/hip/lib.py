@@ -66,7 +66,7 @@ _SIGS = {
     'rsuper_cnorm_apply': (c_int, [P, P, P, P, P, c_int, c_long, c_int, c_int, c_int, P]),
     'rsuper_token_attn_supported': (c_int, [c_int, c_int]),
     'rsuper_token_attn_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
-    'rsuper_token_attn_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    'rsuper_token_attn_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'rsuper_battn_supported': (c_int, [c_int, c_int, c_int]),
     'rsuper_battn_chunks': (c_int, [c_int, c_int]),
     'rsuper_battn_fwd': (c_int, [P] * 7 + [c_int] * 5 + [c_float, P]),

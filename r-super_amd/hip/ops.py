@@ -988,17 +988,17 @@ class TokenAttnFn(torch.autograd.Function):
         o = torch.empty((B, L, heads * dh), device=qkv.device, dtype=torch.float32)
         p = torch.empty((B, heads, L, L), device=qkv.device, dtype=torch.float32)
         _l.check(_L().rsuper_token_attn_fwd(_ptr(qkv), _ptr(o), _ptr(p), B, L, heads, dh, float(scale), _stream()), 'token_attn_fwd')
-        ctx.save_for_backward(qkv, p)
+        ctx.save_for_backward(qkv, p, o)
         ctx.heads, ctx.scale = heads, float(scale)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, p = ctx.saved_tensors
+        qkv, p, o = ctx.saved_tensors
         B, L, c3 = qkv.shape
         do = do.contiguous()
         d_qkv = torch.empty_like(qkv)
-        _l.check(_L().rsuper_token_attn_bwd(_ptr(qkv), _ptr(p), _ptr(do), _ptr(d_qkv), B, L, ctx.heads, c3 // (3 * ctx.heads), ctx.scale, _stream()),
+        _l.check(_L().rsuper_token_attn_bwd(_ptr(qkv), _ptr(o), _ptr(p), _ptr(do), _ptr(d_qkv), B, L, ctx.heads, c3 // (3 * ctx.heads), ctx.scale, _stream()),
                  'token_attn_bwd')
         return d_qkv, None, None
 

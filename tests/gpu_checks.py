@@ -1037,8 +1037,8 @@ def all_checks(quick=False):
         for force in ('0',):             # the rounds-1/2 evaluation of the strided convolutions stays selectable (RSUPER_S2_KERNEL=0): keep it pinned too
             cs += [(with_strided, (force, check_basic_block, mode, 'b8_16_s2', 8, 16, 12, 4)), (with_strided, (force, check_basic_block, mode, 'b16_16_s2', 16, 16, 9, 5)),
                    (with_strided, (force, check_unet_tiny_nopool, mode))]
-    cs += [(check_token_attn, (2, 81, 10, 32)), (check_token_attn, (1, 112, 2, 16)), (check_token_attn, (3, 7, 3, 16)), (check_token_attn, (2, 65, 4, 24)),
-           (check_token_attn, (1, 1, 1, 4)), (check_token_attn, (2, 80, 2, 64))]      # fusion transformer's attention core: shipped shape, limits, ragged
+    cs += [(check_token_attn, (2, 81, 10, 32)), (check_token_attn, (1, 128, 2, 32)), (check_token_attn, (3, 7, 3, 16)), (check_token_attn, (2, 65, 4, 24)),
+           (check_token_attn, (1, 1, 1, 4)), (check_token_attn, (2, 96, 2, 64))]      # fusion transformer's attention core: shipped shape, limits, ragged
     for m in ('f32', 'bf16'):           # strided weight gradient: even / odd / ragged sizes, one and two dy sources, channel tails, several tiles per split
         cs += [(check_wgrad_s2, (m, 1, (8, 8, 32), 32, 32, 0)), (check_wgrad_s2, (m, 2, (12, 10, 20), 16, 32, 32)), (check_wgrad_s2, (m, 1, (7, 9, 35), 8, 16, 16)),
                (check_wgrad_s2, (m, 2, (5, 17, 66), 40, 24, 24)), (check_wgrad_s2, (m, 1, (2, 3, 5), 8, 8, 8)), (check_wgrad_s2, (m, 3, (24, 24, 24), 64, 128, 128))]

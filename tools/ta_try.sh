@@ -5,7 +5,7 @@ timeout 300 python - > gpurun_out/ta_checks.txt 2>&1 <<'PY'
 import sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import gpu_checks as g
-for a in [(2, 81, 10, 32), (1, 112, 2, 16), (3, 7, 3, 16), (2, 65, 4, 24), (1, 1, 1, 4), (2, 80, 2, 64)]:
+for a in [(2, 81, 10, 32), (1, 128, 2, 32), (3, 7, 3, 16), (2, 65, 4, 24), (1, 1, 1, 4), (2, 96, 2, 64)]:
     r = g.check_token_attn(*a)
     print(r['name'], 'OK' if r['ok'] else 'FAIL', r['note'], flush=True)
 PY
