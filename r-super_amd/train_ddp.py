@@ -33,17 +33,23 @@ def make_ema(net):
     return ema
 
 
+PREFETCH_SUPERVISION = os.environ.get('RSUPER_PREFETCH_SUPERVISION', '1') == '1'      # =0: the report losses read their host inputs inside calculate_loss (A/B)
+
+
 def train_step(net, ema_net, optimizer, batch, args, classes, step, matcher=None):
     """One iteration of train_epoch (:308-357).  batch: dict with the reference keys image, label, unk_channels,
     volumes, mask, diameters[, weights] already on the device.  Returns the loss dict (device tensors) and the
     pre-clip gradient norm."""
     img = batch['image']
     optimizer.zero_grad(set_to_none=True)
+    # the batch-only inputs of the report losses (dilated segment masks, three small host reads) go into the queue AHEAD of the forward pass
+    pre = lf.prepare_report_supervision(batch['label'], batch.get('unk_channels'), batch.get('mask'), batch.get('volumes'), batch.get('diameters'),
+                                        classes, args) if PREFETCH_SUPERVISION else None
     result = net(img)
     loss_all = lf.calculate_loss(model_output=result, label=batch['label'], unk_voxels=batch.get('unk_channels'), args=args,
                                  matcher=matcher, chosen_segment_mask=batch.get('mask'),
                                  tumor_volumes_report=batch.get('volumes'), tumor_diameters=batch.get('diameters'),
-                                 classes=classes, input_tensor=img, class_weights=batch.get('weights'))
+                                 classes=classes, input_tensor=img, class_weights=batch.get('weights'), pre=pre)
     loss_all['overall'].backward()
     reducer = getattr(net, '_rsuper_reducer', None)
     if reducer is not None:

@@ -421,21 +421,72 @@ class _BallPlan:
     __slots__ = ('kind', 'b', 'c', 'pm', 'penal', 'fw', 'big', 'pens', 'chs')
 
 
-def _ball_plans(out, label_u8, unk_u8, mask_u8, volumes, diameters, groups, margin):
-    """The data-dependent, non-differentiable part of ball_loss (:1587-1737): returns one plan per sample."""
-    B, C, D, H, W = out.shape
-    chs = list(groups.values())
-    L = len(chs)
-    V = D * H * W
+def _pre_key(label_u8, unk_u8, mask_u8, volumes, diameters, chs):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (label_u8, unk_u8, mask_u8, volumes, diameters)) + (tuple(chs),)
+
+
+def _ball_inputs(label_u8, unk_u8, mask_u8, volumes, diameters, chs, prefetch):
+    """The part of _ball_plans that reads only the batch: dilated segment masks, the penalised region, and the host copies of the report
+    volumes / diameters / per-channel segment flags.  prefetch: the three host copies are asynchronous (pinned memory + an event)."""
     m_l = mask_u8[:, chs].contiguous()
     u_l = unk_u8[:, chs].contiguous()
     t_l = label_u8[:, chs].contiguous()
     mseg = ops.dilate_volume(m_l, 31)                                   # :1593
     # to_penalize = ((1 - unk)*(1 - labels) + segment) > 0   (:1597-1605); unk dilation 1 is the identity
     pen = (((1 - u_l) * (1 - t_l)) + mseg > 0).to(torch.uint8)
-    vols_h = volumes.detach().float().cpu().numpy()
-    dias_h = diameters.detach().float().cpu().numpy()
-    seg_any = _plane_any(mseg, 2).cpu().numpy()                         # (B, L)
+    srcs = (volumes.detach().float(), diameters.detach().float(), _plane_any(mseg, 2))
+    if prefetch:
+        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in srcs]
+        for h, t in zip(host, srcs):
+            h.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    else:
+        host, ev = [t.cpu() for t in srcs], None
+    return dict(key=_pre_key(label_u8, unk_u8, mask_u8, volumes, diameters, chs), mseg=mseg, pen=pen, vols=host[0], dias=host[1], seg_any=host[2],
+                event=ev, keep=srcs)
+
+
+def prepare_report_supervision(label, unk_voxels, chosen_segment_mask, tumor_volumes_report, tumor_diameters, classes, args):
+    """Call BEFORE the forward pass of a training step (train_ddp.train_step does): the batch-only inputs of the ball loss -- two dilations and
+    three small host reads -- are queued ahead of the network, so that calculate_loss(pre=...) does not start with a blocking copy.  Without
+    it the first host read drains the launch queue right after the forward, and the ~100 launches of the ball search that follow run at the
+    host's launch rate with the GPU idle in between (config 3: the report losses cost 3.0 ms per step, 1.1 ms of it kernel time).
+    Returns None when the step has no ball loss to prepare (or for lesion groups spanning several channels, which merge their tensors first)."""
+    rw = float(getattr(args, 'report_volume_loss_basic', 0.0))
+    if rw <= 0 or not ('ball' in args.loss or 'dynamic' in args.loss or 'dll' in args.loss) or chosen_segment_mask is None:
+        return None
+    if tumor_volumes_report is None or tumor_diameters is None or not label.is_cuda:
+        return None
+    if any(len(v) > 1 for v in lesion_channel_lists(classes).values()):
+        return None
+    chs = list(lesion_groups(classes).values())
+    if not chs:
+        return None
+    label_u8 = _u8(label)
+    unk_u8 = _u8(unk_voxels) if unk_voxels is not None else torch.zeros_like(label_u8)
+    mask_u8 = _u8(chosen_segment_mask)
+    with torch.no_grad():
+        pre = _ball_inputs(label_u8, unk_u8, mask_u8, tumor_volumes_report, tumor_diameters, chs, True)
+    pre['u8'] = (label, unk_voxels, chosen_segment_mask, label_u8, unk_u8, mask_u8)     # calculate_loss reuses the uint8 views (same key)
+    return pre
+
+
+def _ball_plans(out, label_u8, unk_u8, mask_u8, volumes, diameters, groups, margin, pre=None):
+    """The data-dependent, non-differentiable part of ball_loss (:1587-1737): returns one plan per sample.
+    pre: what prepare_report_supervision computed from the same batch before the forward pass (else it is computed here)."""
+    B, C, D, H, W = out.shape
+    chs = list(groups.values())
+    L = len(chs)
+    V = D * H * W
+    if pre is not None and ('pen' not in pre or pre['key'] != _pre_key(label_u8, unk_u8, mask_u8, volumes, diameters, chs)):
+        pre = None                                                      # other tensors, or already consumed by another head (pen is edited in place below)
+    if pre is None:
+        pre = _ball_inputs(label_u8, unk_u8, mask_u8, volumes, diameters, chs, False)
+    mseg, pen = pre['mseg'], pre.pop('pen')
+    if pre['event'] is not None:
+        pre['event'].synchronize()                                      # recorded before the forward was queued: long done, no pipeline drain
+    vols_h, dias_h, seg_any = pre['vols'].numpy(), pre['dias'].numpy(), pre['seg_any'].numpy()
     plans = []
     for b in range(B):
         p = _BallPlan()
@@ -561,7 +612,7 @@ def _delesioned(classes):
 
 def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segment_mask,
                    tumor_volumes_report, tumor_diameters, classes, input_tensor=None, class_weights=None,
-                   model_genesis=False, clip_only=False, report_embeddings=None, dist=None):
+                   model_genesis=False, clip_only=False, report_embeddings=None, dist=None, pre=None):
     """Same contract as the reference (:685-1076): returns {'segmentation', report keys..., 'overall'}."""
     if model_genesis or clip_only or getattr(args, 'classification_branch', False) or getattr(args, 'multi_ch_tumor', False):
         raise NotImplementedError('model_genesis / clip_only / classification_branch / multi_ch_tumor are baselines outside '
@@ -576,9 +627,13 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
     B, C = label.shape[:2]
     assert len(classes) == C, f'Number of classes in classes: {len(classes)} does not match the number of channels in label: {C}'
     assert len(classes) == heads[0].shape[1], 'Number of classes in result does not match the number of channels in label'
-    label_u8 = _u8(label)
-    unk_u8 = _u8(unk_voxels) if unk_voxels is not None else torch.zeros_like(label_u8)
-    mask_u8 = _u8(chosen_segment_mask) if chosen_segment_mask is not None else torch.zeros_like(label_u8)
+    if pre is not None and pre['u8'][0] is label and pre['u8'][1] is unk_voxels and pre['u8'][2] is chosen_segment_mask:
+        label_u8, unk_u8, mask_u8 = pre['u8'][3:]                        # the tensors prepare_report_supervision keyed its results on
+    else:
+        pre = None
+        label_u8 = _u8(label)
+        unk_u8 = _u8(unk_voxels) if unk_voxels is not None else torch.zeros_like(label_u8)
+        mask_u8 = _u8(chosen_segment_mask) if chosen_segment_mask is not None else torch.zeros_like(label_u8)
     D, H, W = label.shape[2:]
     V = D * H * W
 
@@ -629,7 +684,7 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         if use_ball and L > 0:
             with torch.no_grad():
                 plans = _ball_plans(r.detach(), label_u8, unk_u8, mask_u8, tumor_volumes_report, tumor_diameters, groups,
-                                    float(args.ball_volume_margin))
+                                    float(args.ball_volume_margin), pre=pre)
             for p in plans:
                 if p.kind == 'none':
                     for li, c in enumerate(p.chs):
