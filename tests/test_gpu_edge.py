@@ -1067,6 +1067,45 @@ def test_dispatcher_ops_forward_only_and_autograd_paths_agree():
 
 
 @pytest.mark.gpu
+def test_supervision_prefetch_changes_nothing():
+    """calculate_loss(pre=prepare_report_supervision(...)) == calculate_loss(...): losses and gradient bit for bit, single head and deep supervision;
+    a `pre` made from other tensors is ignored."""
+    from rsuper_amd.training import losses_foundation as lf
+    classes = synth.PANTS_CLASSES
+    S = 48
+    bt = synth.batch(2, S, classes, ['mask', 'report'], seed=21, diam_range=(5.0, 14.0), max_tumors=3)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in bt.items()}
+    lg = torch.from_numpy(synth.logits(2, len(classes), S, seed=22)).to(DEV)
+    for loss_name, deep in (('ball_dice_both', False), ('ball_dice_last', True)):
+        args = argparse.Namespace(loss=loss_name, aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1, volume_loss_tolerance=0.2,
+                                  ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                                  classification_branch=False, ema=True, ema_alpha=0.99)
+
+        def run(mode):
+            x = lg.clone().requires_grad_(True)
+            out = [x, x * 0.5] if deep else x
+            pre = None
+            if mode == 'pre':
+                pre = lf.prepare_report_supervision(t['label'], t['unk_channels'], t['mask'], t['volumes'], t['diameters'], classes, args)
+                assert pre is not None
+            elif mode == 'foreign':                    # prepared from clones: other tensors -> must be ignored, not trusted
+                pre = lf.prepare_report_supervision(t['label'].clone(), t['unk_channels'].clone(), t['mask'].clone(), t['volumes'], t['diameters'],
+                                                    classes, args)
+            res = lf.calculate_loss({'segmentation': out}, t['label'], t['unk_channels'], args, None, t['mask'], t['volumes'], t['diameters'], classes,
+                                    pre=pre)
+            res['overall'].backward()
+            return {k: float(v.detach()) for k, v in res.items()}, x.grad.clone()
+        r0, g0 = run('plain')
+        for mode in ('pre', 'foreign'):
+            r1, g1 = run(mode)
+            assert r0 == r1, (loss_name, mode, r0, r1)
+            assert torch.equal(g0, g1), (loss_name, mode)
+        assert 'ball_loss_bce' in r0 and r0['ball_loss_bce'] > 0
+    a0 = argparse.Namespace(loss='ball_dice_both', report_volume_loss_basic=0.0)
+    assert lf.prepare_report_supervision(t['label'], t['unk_channels'], t['mask'], t['volumes'], t['diameters'], classes, a0) is None
+
+
+@pytest.mark.gpu
 def test_pointwise_prepack_never_serves_a_dead_parameters_fragments():
     """A parameter that dies leaves its address (and a version counter of 0) to the next one: the prepacked fragments of the dead parameter
     must not be served to its heir.  (Round 3: `test_medformer_shipped_config_128_42_classes` failed once in a while after other MedFormer
