@@ -447,6 +447,12 @@ def _ball_inputs(label_u8, unk_u8, mask_u8, volumes, diameters, chs, prefetch):
                 event=ev, keep=srcs)
 
 
+def _volume_flags(label_u8, mseg31, tumor_volumes_report, chs):
+    """(B, 2L) flags [tumour annotated per voxel | segment present] and the (B, 1) report volume of the volume loss (:313, :335)."""
+    flags = torch.stack([_plane_any(label_u8[:, c], 1) for c in chs] + [_plane_any(m, 1) for m in mseg31], 1).float()
+    return flags, tumor_volumes_report.float().sum(-1, keepdim=True)
+
+
 def prepare_report_supervision(label, unk_voxels, chosen_segment_mask, tumor_volumes_report, tumor_diameters, classes, args):
     """Call BEFORE the forward pass of a training step (train_ddp.train_step does): the batch-only inputs of the ball loss -- two dilations and
     three small host reads -- are queued ahead of the network, so that calculate_loss(pre=...) does not start with a blocking copy.  Without
@@ -468,6 +474,16 @@ def prepare_report_supervision(label, unk_voxels, chosen_segment_mask, tumor_vol
     mask_u8 = _u8(chosen_segment_mask)
     with torch.no_grad():
         pre = _ball_inputs(label_u8, unk_u8, mask_u8, tumor_volumes_report, tumor_diameters, chs, True)
+        if 'both' in args.loss and HOST_REPORT_ALGEBRA:                     # the volume loss runs too: its dilated masks and (B, 2L + 1) host flags
+            pre['mseg31'] = [ops.dilate_volume(mask_u8[:, c].contiguous(), 31) for c in chs]
+            fl, rv = _volume_flags(label_u8, pre['mseg31'], tumor_volumes_report, chs)
+            pre['flags'] = torch.empty(fl.shape, dtype=fl.dtype, pin_memory=True)
+            pre['rvol'] = torch.empty(rv.shape, dtype=rv.dtype, pin_memory=True)
+            pre['flags'].copy_(fl, non_blocking=True)
+            pre['rvol'].copy_(rv, non_blocking=True)
+            pre['keep'] = pre['keep'] + (fl, rv)
+            pre['event'] = torch.cuda.Event()
+            pre['event'].record()
     pre['u8'] = (label, unk_voxels, chosen_segment_mask, label_u8, unk_u8, mask_u8)     # calculate_loss reuses the uint8 views (same key)
     return pre
 
@@ -677,7 +693,8 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         terms = [_Term(0, V, B * C, t=label_u8, k=unk5, kinv=True)]
         if use_vol and L > 0:
             if mseg31 is None:
-                mseg31 = [ops.dilate_volume(mask_u8[:, c].contiguous(), 31) for c in chs]   # :308
+                mseg31 = pre['mseg31'] if pre is not None and 'mseg31' in pre else \
+                    [ops.dilate_volume(mask_u8[:, c].contiguous(), 31) for c in chs]   # :308
             for li, c in enumerate(chs):
                 terms.append(_Term(c * V, C * V, B, k=mseg31[li]))
         plans = []
@@ -707,10 +724,13 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         if use_vol and L > 0:
             vhat = torch.stack([sums[ti + li * B:ti + (li + 1) * B, 1] for li in range(L)], dim=1)      # (B, L) sum sig * M
             ti += L * B
-            flags = torch.stack([_plane_any(label_u8[:, c], 1) for c in chs] + [_plane_any(m, 1) for m in mseg31], 1).float()   # (B, 2L)
-            rvol = tumor_volumes_report.float().sum(-1, keepdim=True)
-            if host:
-                flags, rvol = flags.cpu(), rvol.cpu()
+            if host and pre is not None and 'flags' in pre:
+                pre['event'].synchronize()
+                flags, rvol = pre['flags'], pre['rvol']                   # read before the forward pass (prepare_report_supervision)
+            else:
+                flags, rvol = _volume_flags(label_u8, mseg31, tumor_volumes_report, chs)
+                if host:
+                    flags, rvol = flags.cpu(), rvol.cpu()
             lab_any, gate = flags[:, :L], flags[:, L:]                     # per-voxel annotated tumour (:313) / segment present (:335)
             vhat = vhat * (1 - lab_any)
             rv = rvol.expand(B, L) * gate
@@ -755,8 +775,13 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
     loss = {'segmentation': loss_seg_total}
     if rep:
         # key order of the reference: ball keys first, then volume
-        for k in ('ball_loss_bce', 'ball_loss_dice', 'dice_volume_loss'):
-            if k in rep:
+        keys = [k for k in ('ball_loss_bce', 'ball_loss_dice', 'dice_volume_loss') if k in rep]
+        if len(keys) > 1 and all(not rep[k].is_cuda for k in keys):
+            dev_vals = torch.stack([rep[k] for k in keys]).to(loss_seg_total.device)    # host algebra: ONE copy for all keys (and one back in backward)
+            for i, k in enumerate(keys):
+                loss[k] = dev_vals[i]
+        else:
+            for k in keys:
                 loss[k] = rep[k].to(loss_seg_total.device)
     else:
         loss['report'] = rep_scalar
