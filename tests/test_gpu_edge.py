@@ -1067,6 +1067,23 @@ def test_dispatcher_ops_forward_only_and_autograd_paths_agree():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('which', ['unet', 'nopool', 'medformer'])
+def test_no_kernel_reads_an_unwritten_buffer(which):
+    """Three training steps with report supervision while every torch.empty is NaN-filled (torch.utils.deterministic.fill_uninitialized_memory;
+    tools/uninit_hunt.py in its own process -- the switch is global): a kernel that reads an element nobody wrote turns a loss or a gradient
+    into NaN.  UNet (pooled and strided down blocks) and MedFormer (shipped configuration, 128^3, 42 classes)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'uninit_hunt.py'), which, 'bf16'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('step ')]
+    assert r.returncode == 0 and len(lines) == 3, r.stdout[-2000:]
+    for l in lines:
+        assert 'finite True' in l and 'first NaN module: []' in l and 'non-finite gradients: []' in l, l
+
+
+@pytest.mark.gpu
 def test_supervision_prefetch_changes_nothing():
     """calculate_loss(pre=prepare_report_supervision(...)) == calculate_loss(...): losses and gradient bit for bit, single head and deep supervision;
     a `pre` made from other tensors is ignored."""
