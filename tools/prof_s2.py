@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run the strided (parity-class) igemm a few times (for rocprofv3 --pmc).  Usage: prof_s2.py <fwd|dgrad> [S Ca Cout]"""
+"""Run the strided (parity-class) igemm / the strided weight gradient a few times (for rocprofv3 --pmc).  Usage: prof_s2.py <fwd|dgrad|wgrad> [S Ca Cout]"""
 import os, sys, math
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,6 +18,10 @@ if which == 'fwd':
     ys = torch.empty((N, O, O, O, nc), device=dev, dtype=dt)
     part = torch.empty((N, ops._L().rsuper_conv3_s2_part_rows(1, S, S, S), nc, 2), device=dev, dtype=torch.float32)
     fn = lambda: ops.igemm_s2(1, sa, None, wp, nc, dims, ys, part)
+elif which == 'wgrad':
+    dy1 = torch.randn((N, O, O, O, Cout), device=dev).to(dt); dy2 = torch.randn((N, O, O, O, Cout), device=dev).to(dt)
+    dw1 = torch.zeros_like(w1); dws = torch.zeros_like(ws)
+    fn = lambda: ops.wgrad_s2(sa, ops.Src(dy1), ops.Src(dy2), dw1, dws, dims)
 else:
     dy1 = torch.randn((N, O, O, O, Cout), device=dev).to(dt); dy2 = torch.randn((N, O, O, O, Cout), device=dev).to(dt)
     wpd = ops.pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, 64)
