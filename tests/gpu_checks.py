@@ -1039,6 +1039,9 @@ def all_checks(quick=False):
                    (with_strided, (force, check_unet_tiny_nopool, mode))]
     cs += [(check_token_attn, (2, 81, 10, 32)), (check_token_attn, (1, 128, 2, 32)), (check_token_attn, (3, 7, 3, 16)), (check_token_attn, (2, 65, 4, 24)),
            (check_token_attn, (1, 1, 1, 4)), (check_token_attn, (2, 96, 2, 64))]      # fusion transformer's attention core: shipped shape, limits, ragged
+    for m in ('f32', 'bf16'):           # small volumes (the 6^3 level as shipped, ragged shapes, more samples than tiles): tiles mostly empty, fitted igemm kernels, split-K epilogue
+        cs += [(check_conv_bwd, (m, 2, (6, 6, 6), 64, 0, 64, False)), (check_conv_bwd, (m, 2, (6, 6, 6), 32, 0, 48, True)), (check_conv_bwd, (m, 3, (5, 6, 4), 40, 0, 24, True)),
+               (check_conv_bwd, (m, 1, (2, 2, 2), 8, 0, 8, False)), (check_conv_bwd, (m, 9, (3, 2, 7), 16, 0, 16, False)), (check_conv_bwd, (m, 2, (6, 6, 6), 320, 0, 320, False))]
     for m in ('f32', 'bf16'):           # strided weight gradient: even / odd / ragged sizes, one and two dy sources, channel tails, several tiles per split
         cs += [(check_wgrad_s2, (m, 1, (8, 8, 32), 32, 32, 0)), (check_wgrad_s2, (m, 2, (12, 10, 20), 16, 32, 32)), (check_wgrad_s2, (m, 1, (7, 9, 35), 8, 16, 16)),
                (check_wgrad_s2, (m, 2, (5, 17, 66), 40, 24, 24)), (check_wgrad_s2, (m, 1, (2, 3, 5), 8, 8, 8)), (check_wgrad_s2, (m, 3, (24, 24, 24), 64, 128, 128))]
