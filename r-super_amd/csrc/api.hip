@@ -139,13 +139,24 @@ static bool use_pc(int dtype, int epi, int bn, int tiles_total) {
 // (6: shape chosen per volume, 7: the 4x4x4 box) -- test paths.
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
-static const size_t BOXC_WS_BYTES = (size_t)256 * 216 * 32 * 4;    // upper bound of nsplit x N x 216 x n_cols floats (rs_box_nsplit)
+static const size_t BOXC_WS_BYTES = (size_t)256 * 216 * 32 * 4;    // nsplit x N x 216 x n_cols floats while N x ceil(n_cols / 32) <= 256 (rs_box_nsplit)
+// Bytes the split shape writes into the workspace: nsplit x N x voxels x n_cols floats.  rs_box_nsplit deals at most 256 / (N x groups) splits (at least
+// one), so beyond N x groups = 256 the requirement grows with N x n_cols without bound -- the shape is only taken while it fits what the caller registered.
+static size_t boxc_ws_need(int nsplit, int N, int D, int H, int W, int n_cols) {
+    return (size_t)nsplit * (size_t)N * (size_t)(D * H * W) * (size_t)n_cols * sizeof(float);
+}
+static bool boxc_fits(int N, int D, int H, int W, int n_cols) {
+    const int groups = (n_cols + 31) / 32;
+    const long ng = (long)N * groups;
+    const int smax = ng >= 256 ? 1 : (int)(256 / ng);
+    return g_ws && boxc_ws_need(smax, N, D, H, W, n_cols) <= g_ws_bytes;
+}
 static int box_shape(int dtype, int N, int D, int H, int W, int n_cols) {
     if (dtype != RS_BF16) return 0;
     const bool forced = g_variant == 6 || g_variant == 7;
     static const int off = getenv("RSUPER_NO_BOX") ? atoi(getenv("RSUPER_NO_BOX")) : 0;      // 1: no box kernel, 2: no split shape
     if (!forced && (g_variant != 3 || off == 1 || n_cols <= 32)) return 0;
-    if (g_variant != 7 && off != 2 && D <= 6 && H <= 6 && W <= 6 && g_ws && g_ws_bytes >= BOXC_WS_BYTES) return 3;
+    if (g_variant != 7 && off != 2 && D <= 6 && H <= 6 && W <= 6 && boxc_fits(N, D, H, W, n_cols)) return 3;
     if (g_variant == 7) return 2;
     if (!forced && (long)N * rsuper_conv3_tiles(D, H, W) * ((n_cols + 127) / 128) >= 512) return 0;
     return rs_box_config(N, D, H, W, n_cols);
@@ -229,7 +240,10 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     p.ea = {exa, elda, eCa, emra};
     p.eb = {exb, eldb, eCb, emrb};
     p.box = box_for(dtype, bn, N, D, H, W, n_cols);
-    if (p.box == 3) { p.ws = (float*)g_ws; p.nsplit = rs_box_nsplit(N, n_cols, (Ca + 31) / 32 + (Cb + 31) / 32); }
+    if (p.box == 3) {
+        p.ws = (float*)g_ws; p.nsplit = rs_box_nsplit(N, n_cols, (Ca + 31) / 32 + (Cb + 31) / 32);
+        if (!g_ws || boxc_ws_need(p.nsplit, N, D, H, W, n_cols) > g_ws_bytes) return RS_ERR_ARG;      // never write past the registered workspace
+    }
     p.pc = use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0;
     if (p.pc && g_variant == 5) p.pc = 3;
     if (p.pc && bn == 32 && (g_variant == 4 || (g_variant == 3 && (Ca + 31) / 32 + (Cb + 31) / 32 == 1))) p.pc = 2;

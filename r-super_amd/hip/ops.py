@@ -43,11 +43,14 @@ _WS = None
 
 
 def _L():
-    """The C library, with the split-reduction workspace of the 6^3-level convolutions registered on first use on a GPU."""
-    global _WS
+    """The C library, with the split-reduction workspace of the 6^3-level convolutions registered on first use on a GPU.  One device per
+    process (one rank per GPU): the workspace lives on the device the first launch pins (`_stream`), the same one every later launch uses."""
+    global _WS, _DEV_INDEX
     L = _l.lib()
     if _WS is None and torch.cuda.is_available():
-        _WS = torch.empty((L.rsuper_conv3_workspace_bytes(),), device='cuda', dtype=torch.uint8)
+        if _DEV_INDEX is None:
+            _DEV_INDEX = torch.cuda.current_device()
+        _WS = torch.empty((L.rsuper_conv3_workspace_bytes(),), device=torch.device('cuda', _DEV_INDEX), dtype=torch.uint8)
         _l.check(L.rsuper_conv3_set_workspace(_WS.data_ptr(), _WS.numel()), 'conv3_set_workspace')
     return L
 

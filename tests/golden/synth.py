@@ -80,12 +80,14 @@ def _ellipsoid(S, center, radii):
     return d <= 1.0
 
 
-def batch(B, S, classes, kinds, seed=7, diam_range=(5.0, 12.0), max_tumors=2):
+def batch(B, S, classes, kinds, seed=7, diam_range=(5.0, 12.0), max_tumors=2, n_tumors=None, diam_list=None, vol_list=None):
     """Build one synthetic mixed batch.
 
     kinds: list of 'mask' | 'report' | 'healthy' per sample.
     Returns dict of float32/uint8 ndarrays with the reference's batch keys
     (train_ddp.py:247-256): label, unk_channels, mask, volumes, diameters.
+    n_tumors / diam_list / vol_list: fix the number of tumours of every report sample / their diameters / their reported volumes
+    (default: the sphere of the diameter) instead of drawing them.
     """
     C = len(classes)
     g = rng(seed)
@@ -122,11 +124,11 @@ def batch(B, S, classes, kinds, seed=7, diam_range=(5.0, 12.0), max_tumors=2):
         elif kind == 'report':
             unk[b, li] = organ
             mask[b, li] = organ
-            nt = int(g.integers(1, max_tumors + 1))
+            nt = int(g.integers(1, max_tumors + 1)) if n_tumors is None else int(n_tumors)
             for t in range(nt):
-                d = float(g.uniform(*diam_range))
+                d = float(g.uniform(*diam_range)) if diam_list is None else float(diam_list[t])
                 diameters[b, t] = (d, 0.8 * d, 0.7 * d)
-                volumes[b, t] = (4.0 / 3.0) * math.pi * (d / 2.0) ** 3
+                volumes[b, t] = (4.0 / 3.0) * math.pi * (d / 2.0) ** 3 if vol_list is None or vol_list[t] is None else float(vol_list[t])
         elif kind == 'healthy':
             pass
         else:
@@ -251,3 +253,85 @@ def loader_report_rows(name):
 MEDFORMER_TINY = dict(base_chan=8, map_size=[2, 2, 2], conv_num=[2, 0, 0, 0, 0, 0, 2, 2], trans_num=[0, 1, 2, 1, 1, 1, 0, 0],
                       chan_num=[16, 32, 64, 80, 64, 32, 16, 8], num_heads=[1, 2, 4, 5, 4, 2, 1, 1], fusion_depth=1, fusion_dim=80,
                       fusion_heads=5, aux_loss=True, size=32, seed=5)
+
+
+# ---- isolate_tumor / ball_loss at the diameters the benchmark's report batch draws (15-40 mm) ----------------------
+# name -> (volume edge, diameter, reported volume, builder of x).  Volumes: the sphere of that diameter unless a case says otherwise.
+def _sphere_vol(d):
+    return (4.0 / 3.0) * math.pi * (d / 2.0) ** 3
+
+
+def _sig(a):
+    return (1.0 / (1.0 + np.exp(-a))).astype(np.float32)
+
+
+def ball_case(name):
+    """Input of one large-diameter isolate_tumor fixture: (x (S,S,S) float32 >= 0, diameter, tumour volume).
+      d15 / d21 (48^3), d31 / d40 (64^3): smooth probability map with one optimum, ball kernels of edge 19 / 27 / 39 / 51
+      border21: the optimum sits in a corner -> the inserted ball is clipped and the growth loop runs (losses_foundation.py:1450-1461)
+      rewrite15: reported volume below the ball's own voxel count -> volume rewritten to nnz - 1 (:1431-1433)
+      sparse21: only ~30 % of the voxels are positive, the rest exact zeros -> top-k runs out of positive voxels and the dilation round runs
+                (:1513-1522); one round of the 7-ball saturates the masks to the whole inserted ball, so the result does not depend on WHICH
+                zeros torch.topk picked (implementation-defined)
+      organ31: support smaller than the reported tumour (sphere of radius 12 in 64^3, d = 31): the same situation without saturation -- the
+               reference's result here depends on torch.topk's tie order among zeros (its CPU and GPU kernels differ); the fixture keeps it
+               and the tests compare only the tie-independent part (the positive voxels)"""
+    S = 64 if name in ('d31', 'd40', 'organ31') else 48
+    lg = logits(1, 1, S, seed=5)[0, 0]
+    x = _sig(lg)
+    if name in ('d15', 'd21', 'd31', 'd40'):
+        d = float(name[1:])
+        return x, d, _sphere_vol(d)
+    if name == 'border21':
+        xb = (0.01 * x).astype(np.float32)
+        xb[0:6, 0:6, 0:6] = 0.9
+        return xb, 21.0, _sphere_vol(21.0)
+    if name == 'rewrite15':
+        return x, 15.0, 600.0
+    if name == 'sparse21':
+        keep = rng(77).random((S, S, S)) < 0.3
+        return (x * keep).astype(np.float32), 21.0, _sphere_vol(21.0)
+    if name == 'organ31':
+        organ = _ellipsoid(S, (S / 2.0,) * 3, (12.0,) * 3)
+        return (x * organ).astype(np.float32), 31.0, _sphere_vol(31.0)
+    raise KeyError(name)
+
+
+BALL_CASES = ['d15', 'd21', 'd31', 'd40', 'border21', 'rewrite15', 'sparse21', 'organ31']
+
+
+# calculate_loss at 48^3 / 64^3 with three tumours per report sample (tests/golden/gen_golden_ball_large.py)
+BALL_LOSS_CASES = {
+    # tag: (edge, diameters of the three tumours of the report sample, their reported volumes (None: sphere), loss, deep supervision)
+    'c48_both': (48, [31.0, 21.0, 15.0], None, 'ball_dice_both', False),
+    'c48_deep_last': (48, [21.0, 15.0, 17.0], None, 'ball_dice_last', True),
+    'c64_both': (64, [40.0, 21.0, 15.0], None, 'ball_dice_both', False),
+    # a reported volume above what the ball of the reported diameter holds -> the growth loop (:1450-1461) runs inside calculate_loss,
+    # i.e. the speculative device-side search must notice and repeat the sample with the exact search
+    'c48_grow_both': (48, [15.0, 9.0, 21.0], [5000.0, None, None], 'ball_dice_both', False),
+}
+
+
+def ball_loss_case_inputs(tag):
+    S, dl, vl, loss, deep = BALL_LOSS_CASES[tag]
+    classes = TINY_CLASSES
+    bt = batch(2, S, classes, ['mask', 'report'], seed=17, n_tumors=3, diam_list=dl, vol_list=vl)
+    lg0 = logits(2, len(classes), S, seed=299)
+    lg1 = logits(2, len(classes), S, seed=300)
+    return classes, bt, lg0, lg1, loss, deep
+
+
+# full-size cases (96^3, 26 classes): 'bench96' is EXACTLY the batch `bench.py --report` builds on rank 0 (two tumours, d = 18.6 / 24.2);
+# 'full96_d40' has three tumours of d = 40 / 31 / 21 in the report sample
+def fullsize_report_case(tag):
+    classes = PANTS_CLASSES
+    if tag == 'bench96':
+        bt = batch(2, 96, classes, ['mask', 'report'], seed=7, diam_range=(5.0, 40.0), max_tumors=3)
+    elif tag == 'full96_d40':
+        bt = batch(2, 96, classes, ['mask', 'report'], seed=7, n_tumors=3, diam_list=[40.0, 31.0, 21.0])
+    else:
+        raise KeyError(tag)
+    return classes, bt, logits(2, len(classes), 96, seed=12)
+
+
+FULLSIZE_REPORT_CASES = ['bench96', 'full96_d40']

@@ -906,6 +906,65 @@ def check_calculate_loss(tag, akw, deep, seed, cw):
     return result(f'calculate_loss[{tag}]', max(worst, eg), 1e-4, ' '.join(notes))
 
 
+def check_isolate_tumor_large(name):
+    """tests/golden/ball_large.npz part A (reference fixtures at d = 15 ... 40): the default path (separable two-stage correlation, device
+    radix select) must give the reference's masks bit for bit; the speculative search must either agree or report that it cannot decide."""
+    from rsuper_amd.training import losses_foundation as lf
+    g = golden('ball_large')
+    x, d, vol = synth.ball_case(name)
+    sh = x.shape
+    xt = T(x).to(DEV)
+    got3 = lf.isolate_tumor(xt, d, True, 1.5, vol, 0.2, 0.2)
+    tie = bool(int(g[f'iso_{name}_tie_dependent'][0]))
+    pos = x > 0
+    bad, notes = 0, []
+    for got, key in zip(got3, 'msb'):
+        ref = np.unpackbits(g[f'iso_{name}_{key}'])[:x.size].reshape(sh)
+        gn = got.cpu().numpy()
+        dd = int((gn[pos] != ref[pos]).sum()) if tie else int((gn != ref).sum())
+        bad += dd
+        notes.append(f'{key}:{dd}')
+    checks = []
+    r3 = lf.isolate_tumor_spec(xt, d, 1.5, vol, checks, 0.2, 0.2)
+    ok, _ = lf._spec_ok(checks)
+    loops = [int(v) for v in g[f'iso_{name}_loops']]
+    if ok:
+        dd = sum(int((a != b).sum()) for a, b in zip(r3, got3))
+        bad += dd + (1 if any(loops) else 0)          # the reference looped -> the speculation must not have claimed validity
+        notes.append(f'spec:{dd}')
+    else:
+        bad += 0 if any(loops) else 1                 # ... and the other way round
+        notes.append('spec:fallback')
+    return result(f'isolate_tumor[{name}] d={d:.0f} edge {sh[0]} (bit-exact vs reference golden' + (', positive voxels only: tie-dependent case)' if tie else ')'),
+                  bad, 0, ' '.join(notes) + f' reference loops {loops}')
+
+
+def check_calculate_loss_large(tag):
+    """tests/golden/ball_large.npz part B: calculate_loss with three tumours of d = 15 ... 40 per report sample at 48^3 / 64^3."""
+    from rsuper_amd.training import losses_foundation as lf
+    g = golden('ball_large')
+    classes, bt, lg0, lg1, loss, deep = synth.ball_loss_case_inputs(tag)
+    a, b = T(lg0).to(DEV).requires_grad_(True), T(lg1).to(DEV).requires_grad_(True)
+    res = lf.calculate_loss({'segmentation': [a, b] if deep else a}, T(bt['label']).to(DEV), T(bt['unk_channels']).to(DEV), make_args(loss=loss),
+                            None, T(bt['mask']).to(DEV), T(bt['volumes']).to(DEV), T(bt['diameters']).to(DEV), classes)
+    res['overall'].backward()
+    torch.cuda.synchronize()
+    if sorted(res.keys()) != list(g[f'{tag}_keys']):
+        return result(f'calculate_loss_large[{tag}]', float('inf'), 1e-4, f'keys {sorted(res.keys())} vs {list(g[tag + "_keys"])}')
+    notes, worst = [], 0.0
+    for k, v in res.items():
+        dd = abs(float(v.detach()) - float(g[f'{tag}_{k}']))
+        worst = max(worst, dd)
+        notes.append(f'{k}:{dd:.1e}')
+    for t_, key in ((a, 'g0'),) + (((b, 'g1'),) if deep else ()):
+        sub, _ = synth.subsample(t_.grad.cpu().numpy(), 8192)
+        ref = g[f'{tag}_{key}_sub']
+        eg = float(np.abs(sub - ref).max() / max(np.abs(ref).max(), 1e-12))
+        worst = max(worst, eg)
+        notes.append(f'{key}:{eg:.1e}')
+    return result(f'calculate_loss_large[{tag}]', worst, 1e-4, ' '.join(notes))
+
+
 def check_optimizer():
     from rsuper_amd.training.utils import FusedAdamWEMA, clip_grad_norm_
     g = synth.rng(9)
@@ -1042,6 +1101,10 @@ def all_checks(quick=False):
     for m in ('f32', 'bf16'):           # small volumes (the 6^3 level as shipped, ragged shapes, more samples than tiles): tiles mostly empty, fitted igemm kernels, split-K epilogue
         cs += [(check_conv_bwd, (m, 2, (6, 6, 6), 64, 0, 64, False)), (check_conv_bwd, (m, 2, (6, 6, 6), 32, 0, 48, True)), (check_conv_bwd, (m, 3, (5, 6, 4), 40, 0, 24, True)),
                (check_conv_bwd, (m, 1, (2, 2, 2), 8, 0, 8, False)), (check_conv_bwd, (m, 9, (3, 2, 7), 16, 0, 16, False)), (check_conv_bwd, (m, 2, (6, 6, 6), 320, 0, 320, False))]
+    # the split shape of the <= 6^3 box kernel needs nsplit x N x 216 x n_cols floats of workspace; beyond N x ceil(n_cols / 32) = 256
+    # that exceeds what is registered -> these batches must take another shape instead of writing past it (N = 13 / 640 columns is the first such case)
+    cs += [(check_conv_bwd, ('bf16', 32, (6, 6, 6), 320, 0, 320, False)), (check_conv_bwd, ('bf16', 32, (6, 6, 6), 320, 0, 320, True)),
+           (check_conv_bwd, ('bf16', 13, (6, 6, 6), 64, 0, 320, True)), (check_conv_fwd, ('bf16', 26, (6, 6, 6), 64, 0, 320, False, True))]
     for m in ('f32', 'bf16'):           # strided weight gradient: even / odd / ragged sizes, one and two dy sources, channel tails, several tiles per split
         cs += [(check_wgrad_s2, (m, 1, (8, 8, 32), 32, 32, 0)), (check_wgrad_s2, (m, 2, (12, 10, 20), 16, 32, 32)), (check_wgrad_s2, (m, 1, (7, 9, 35), 8, 16, 16)),
                (check_wgrad_s2, (m, 2, (5, 17, 66), 40, 24, 24)), (check_wgrad_s2, (m, 1, (2, 3, 5), 8, 8, 8)), (check_wgrad_s2, (m, 3, (24, 24, 24), 64, 128, 128))]
@@ -1074,6 +1137,7 @@ def all_checks(quick=False):
            (check_plane_partials, ()), (check_seg_from_sums, (2, 26, False, 1)), (check_seg_from_sums, (3, 5, True, 2)),
            (check_seg_from_sums, (1, 300, True, 3)), (check_dilate, ()), (check_isolate_tumor, ()), (check_gwrp, ()), (check_optimizer, ())]
     cs += [(check_calculate_loss, c) for c in LOSS_CASES]
+    cs += [(check_isolate_tumor_large, (n,)) for n in synth.BALL_CASES] + [(check_calculate_loss_large, (t_,)) for t_ in synth.BALL_LOSS_CASES]
     cs += [(check_train_steps, ('f32',)), (check_train_steps, ('bf16',))]
     cs += [(check_cnorm, (8, (6, 7, 9), True)), (check_cnorm, (72, (5, 4, 11), False, 1)), (check_cnorm, (1280, (3, 3, 3), True)),
            (check_cnorm, (256, (24, 24, 24), True, 1))]

@@ -1198,3 +1198,23 @@ def test_accumulators_need_no_memset():
     torch.cuda.synchronize()
     assert bool(torch.isfinite(dx.float()).all()) and float(dx.float().sum()) == float(dy.float().sum())
     assert float(dx[:, 4].float().abs().sum()) == 0.0 and float(dx[:, :, 6].float().abs().sum()) == 0.0 and float(dx[:, :, :, 8].float().abs().sum()) == 0.0
+
+
+def test_box_split_shape_respects_the_registered_workspace():
+    """the split shape of the <= 6^3 box igemm writes nsplit x N x 216 x n_cols floats into the registered workspace; it may
+    only be chosen while that fits (N x ceil(n_cols / 32) <= 256 with the default 7 MB), otherwise the launch takes another shape."""
+    from rsuper_amd.hip import ops, lib
+    L = ops._L()
+    ws_bytes = L.rsuper_conv3_workspace_bytes()
+    for N, cols in [(2, 640), (2, 320), (12, 640), (25, 320), (8, 1024)]:
+        assert N * -(-cols // 32) <= 256
+        assert L.rsuper_conv3_box_bn(lib.BF16, N, 6, 6, 6, cols) == 32, (N, cols)              # split shape (32-column blocks)
+    for N, cols in [(13, 640), (26, 320), (32, 320), (32, 640), (64, 64), (300, 64)]:
+        need1 = N * 216 * cols * 4                                                             # one split already exceeds the workspace?
+        bn = L.rsuper_conv3_box_bn(lib.BF16, N, 6, 6, 6, cols)
+        if need1 > ws_bytes:
+            assert bn != 32, (N, cols, bn)
+    # and the results of such launches are right (they would be even on an overflowing workspace, hence the shape assertions above)
+    for a in [('bf16', 32, (6, 6, 6), 320, 0, 320, True), ('bf16', 13, (6, 6, 6), 64, 0, 320, True)]:
+        r = gc.check_conv_bwd(*a)
+        assert r['ok'], r

@@ -339,3 +339,54 @@ def test_bf16_gradients_of_the_real_loss_align_with_f32(which, cos_min, l2_max):
     lf32, lbf, l2, gl2, cos = (float(v) for v in m.groups())
     assert abs(lf32 - lbf) <= 1e-3 * abs(lf32), line
     assert l2 <= l2_max and cos >= cos_min, line
+
+
+@pytest.mark.parametrize('tag', synth.FULLSIZE_REPORT_CASES)
+def test_report_loss_fullsize_matches_reference_and_oracle(tag):
+    """the exact batch `bench.py --report` builds (96^3, 26 classes, diam_range (5, 40), max_tumors 3; 'bench96') and a
+    three-tumour one with d = 40 / 31 / 21 ('full96_d40') through the HIP calculate_loss on its default path (separable two-stage ball
+    correlation, speculative device-side search) against (a) the reference's own values and input gradient (tests/golden/ball_large.npz,
+    generated by tests/golden/gen_golden_ball_large.py part C) and (b) the oracle evaluated here on the host: every loss key <= 1e-4,
+    input gradient <= 1e-4 of its scale, pseudo masks / enlarged masks / penalised regions BIT-exact."""
+    import os
+    from oracle import losses_oracle as lo
+    from rsuper_amd.training import losses_foundation as lf
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ball_large.npz'))
+    classes, bt, lg = synth.fullsize_report_case(tag)
+    args = _args(loss='ball_dice_both')
+    T = torch.from_numpy
+    dev = {k: T(v).to(DEV) for k, v in bt.items()}
+    a = T(lg).to(DEV).requires_grad_(True)
+    res = lf.calculate_loss({'segmentation': a}, dev['label'], dev['unk_channels'], args, None, dev['mask'], dev['volumes'], dev['diameters'], classes)
+    res['overall'].backward()
+    torch.cuda.synchronize()
+    # (a) the reference's numbers
+    assert sorted(res.keys()) == list(g[f'{tag}_keys'])
+    for k, v in res.items():
+        assert abs(float(v.detach()) - float(g[f'{tag}_{k}'])) <= 1e-4, (k, float(v.detach()), float(g[f'{tag}_{k}']))
+    grad = a.grad.cpu().numpy()
+    li = classes.index('pancreatic_lesion')
+    for sub, ref in ((synth.subsample(grad, 8192)[0], g[f'{tag}_g0_sub']), (synth.subsample(grad[1, li], 8192)[0], g[f'{tag}_g0_lesion_sub'])):
+        assert np.abs(sub - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-12), float(np.abs(sub - ref).max() / np.abs(ref).max())
+    # (b) the oracle on the host: keys, the whole gradient, the masks
+    a2 = T(lg).requires_grad_(True)
+    ores = lo.calculate_loss({'segmentation': a2}, T(bt['label']), T(bt['unk_channels']), args, T(bt['mask']), T(bt['volumes']), T(bt['diameters']), classes)
+    ores['overall'].backward()
+    for k, v in res.items():
+        assert abs(float(v.detach()) - float(ores[k])) <= 1e-4, (k, float(v.detach()), float(ores[k]))
+    og = a2.grad.numpy()
+    assert np.abs(grad - og).max() <= 1e-4 * np.abs(og).max(), float(np.abs(grad - og).max() / np.abs(og).max())
+    _, _, debug = lo.ball_loss(T(lg), T(bt['label']).float(), T(bt['unk_channels']).float(), T(bt['mask']).float(), T(bt['volumes']), T(bt['diameters']),
+                               classes, True, margin=0.2)
+    with torch.no_grad():
+        plans = lf._ball_plans(a.detach(), dev['label'], dev['unk_channels'], dev['mask'], dev['volumes'], dev['diameters'], lf.lesion_groups(classes), 0.2)
+    n_tumor = 0
+    for p, d in zip(plans, debug):
+        assert (p.kind == 'tumor') == (d is not None)
+        if d is None:
+            continue
+        n_tumor += 1
+        for got, key in ((p.pm, 'PM'), (p.big, 'BIG'), (p.penal, 'penal')):
+            ref = d[key].numpy() > 0
+            assert np.array_equal(got.cpu().numpy() > 0, ref), (key, int(((got.cpu().numpy() > 0) != ref).sum()))
+    assert n_tumor == 1

@@ -237,6 +237,51 @@ def test_calculate_loss(golden, tag, akw, deep, seed, cw):
         np.testing.assert_allclose(sub, g[f'{tag}_g1_sub'], atol=1e-8, rtol=2e-3)
 
 
+# ------------------------------------------------------------------ the Ball path at the benchmark's diameters (15-40 mm, three tumours)
+@pytest.mark.parametrize('name', synth.BALL_CASES)
+def test_isolate_tumor_large(golden, name):
+    """tests/golden/gen_golden_ball_large.py part A: ball kernels of edge 19-51, clipped ball + growth loop, volume rewrite, dilation rounds."""
+    g = golden['ball_large']
+    x, d, vol = synth.ball_case(name)
+    m, ms, mb, _ = lo.isolate_tumor(T(x), d, vol, 0.2, 0.2)
+    sh = x.shape
+    if int(g[f'iso_{name}_tie_dependent'][0]):
+        # the reference's result depends on which exact zeros torch.topk picked: only the positive voxels are defined by the algorithm
+        pos = x > 0
+        for got, key in ((m, 'm'), (ms, 's'), (mb, 'b')):
+            assert np.array_equal(got.numpy().astype(np.uint8)[pos], unpack(g[f'iso_{name}_{key}'], sh)[pos]), key
+        return
+    for got, key in ((m, 'm'), (ms, 's'), (mb, 'b')):
+        assert np.array_equal(got.numpy().astype(np.uint8), unpack(g[f'iso_{name}_{key}'], sh)), key
+    assert [m.sum().item(), ms.sum().item(), mb.sum().item()] == list(g[f'iso_{name}_sums'])
+
+
+def test_ball_large_fixture_covers_every_branch(golden):
+    g = golden['ball_large']
+    loops = {n: tuple(int(v) for v in g[f'iso_{n}_loops']) for n in synth.BALL_CASES}
+    assert loops['border21'][0] >= 1 and loops['sparse21'][1] >= 1 and loops['organ31'][1] >= 1     # growth loop, dilation rounds
+    assert int(g['c48_grow_both_loops'][0]) >= 1                                                      # growth loop inside calculate_loss
+    assert [n for n in synth.BALL_CASES if int(g[f'iso_{n}_tie_dependent'][0])] == ['organ31']
+
+
+@pytest.mark.parametrize('tag', list(synth.BALL_LOSS_CASES))
+def test_calculate_loss_large(golden, tag):
+    g = golden['ball_large']
+    classes, bt, lg0, lg1, loss, deep = synth.ball_loss_case_inputs(tag)
+    a, b = T(lg0).requires_grad_(True), T(lg1).requires_grad_(True)
+    res = lo.calculate_loss({'segmentation': [a, b] if deep else a}, T(bt['label']), T(bt['unk_channels']), make_args(loss=loss),
+                            T(bt['mask']), T(bt['volumes']), T(bt['diameters']), classes)
+    res['overall'].backward()
+    assert sorted(res.keys()) == list(g[f'{tag}_keys'])
+    for k, v in res.items():
+        np.testing.assert_allclose(float(v.detach()), float(g[f'{tag}_{k}']), atol=1e-4, err_msg=k)
+    sub, _ = synth.subsample(a.grad.numpy(), 8192)
+    np.testing.assert_allclose(sub, g[f'{tag}_g0_sub'], atol=1e-8, rtol=2e-3)
+    if deep:
+        sub, _ = synth.subsample(b.grad.numpy(), 8192)
+        np.testing.assert_allclose(sub, g[f'{tag}_g1_sub'], atol=1e-8, rtol=2e-3)
+
+
 # ------------------------------------------------------------------ train step
 def test_train_steps(golden):
     g = golden['train_step']
