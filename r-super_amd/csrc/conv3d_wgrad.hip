@@ -218,11 +218,26 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
     };
 
     int cur_n = -1;
-    if ((int)blockIdx.z < tiles) issue(blockIdx.z);
+    // XCD-aware tile order: linear workgroup id b runs on XCD b % 8 (private L2 each), and for a fixed (chunk, row group) the splits z, z + 8, ...
+    // share an XCD.  Class z & 7 owns a contiguous range of tiles and its blocks sweep it together, so the halo rows neighbouring tiles share are
+    // fetched into that L2 once (the grid-stride order put the 8 w / h neighbours of a tile on 8 different XCDs).  Any placement gives the same sums
+    // per slab set; only the assignment of tiles to slabs changes.
+    int tile0, tile_end, tstride;
+    {
+        const int z = blockIdx.z, S = p.splits;
+        if (S >= 8 && tiles >= 64) {
+            const int cls = z & 7, q = S >> 3, rm = S & 7;
+            const int cum0 = cls * q + (cls < rm ? cls : rm), ncl = q + (cls < rm ? 1 : 0);
+            tile0 = (int)((long)tiles * cum0 / S) + (z >> 3);
+            tile_end = (int)((long)tiles * (cum0 + ncl) / S);
+            tstride = ncl;
+        } else { tile0 = z; tile_end = tiles; tstride = S; }
+    }
+    if (tile0 < tile_end) issue(tile0);
 #ifdef RS_WG_PROF
     unsigned long long pf[5] = {0, 0, 0, 0, 0};
 #endif
-    for (int tile = blockIdx.z; tile < tiles; tile += p.splits) {
+    for (int tile = tile0; tile < tile_end; tile += tstride) {
         const int n = tile / (tiles_w * tiles_h * tiles_d);
 #ifdef RS_WG_PROF
         const unsigned long long q0 = __builtin_readcyclecounter();
@@ -248,9 +263,9 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
 #ifdef RS_WG_PROF
         const unsigned long long q3 = __builtin_readcyclecounter();
 #endif
-        const bool has_next = tile + p.splits < tiles;
-        if (sizeof(T) != 2 && has_next) issue(tile + p.splits);  // f32 parity mode: burst; bf16: interleaved with the MFMAs below
-        const IssueTile nt = prepare(has_next ? tile + p.splits : tile);   // last tile: harmless re-load of itself
+        const bool has_next = tile + tstride < tile_end;
+        if (sizeof(T) != 2 && has_next) issue(tile + tstride);   // f32 parity mode: burst; bf16: interleaved with the MFMAs below
+        const IssueTile nt = prepare(has_next ? tile + tstride : tile);    // last tile: harmless re-load of itself
 #ifdef RS_WG_PROF
         const unsigned long long q4 = __builtin_readcyclecounter();
         pf[0] += q1 - q0; pf[1] += q2 - q1; pf[2] += q3 - q2; pf[3] += q4 - q3; pf[4] += 1;
@@ -736,6 +751,11 @@ __global__ __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) void wgrad_pc_ker
         constexpr int NXV2 = PF2 ? NXV : 1, NYV2 = PF2 ? NYV : 1;
         uint4 pxA[NXV], pyA[NYV], pxB[NXV2], pyB[NYV2];
         uint32_t xmA = 0, xmB = 0;
+#ifdef RS_WG_SKIP_PROD                                          // ablation: barriers only (the consumers alone)
+        __syncthreads();
+        for (int it = 0; it < nitems; ++it) __syncthreads();
+        return;
+#endif
         if constexpr (PF2) {
             // even items in set A, odd items in set B; loads are issued two items ahead
             if (nitems > 0) { issue(0, pxA, pyA, xmA); commit(0, pxA, pyA, xmA); }
@@ -807,7 +827,11 @@ __global__ __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) void wgrad_pc_ker
                 if (u + BD < NU) bq[(u + BD) % BR] = fetch_b((u + BD) / TPW, (u + BD) % TPW);
                 if (i == 0 && row + 1 < TD * TH) aq[(row + 1) & 1] = fetch_a(row + 1);
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef RS_WG_SKIP_CONS                                         // ablation: operand fetches without the MFMAs would be optimised away -> skip the whole unit
                 mma32<bf16_t>(acc[i], aq[row & 1], bq[u % BR]);
+#else
+                if (u == 0) mma32<bf16_t>(acc[i], aq[row & 1], bq[u % BR]);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
@@ -1023,6 +1047,12 @@ static int launch_wgrad_impl(const WgradParams& p, int dtype, int use_tr, hipStr
     const int tiles_total = p.N * ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);
     if (dtype == RS_F32) return cfg == 0 ? launch<float, 1, 27, 0, 4>(p, st) : launch<float, 2, 9, 0, 4>(p, st);
+    if (use_tr && cfg != 1 && rs_wgrad_dma_supported(p, dtype)) {      // pre-normalised sources: operands by LDS-DMA (conv3d_wgrad_dma.hip)
+        const int rc = rs_launch_wgrad_dma(p, st);
+        if (rc != RS_OK) return rc;
+        launch_reduce(p, st);
+        return rs_check_launch();
+    }
     if (dtype == RS_BF16) {
         // config 0 runs the producer/consumer kernel (177 -> 131 us on 32->32 @96^3); on configs 1/2 it measured equal or
         // slower (12 waves hit the 168-VGPR cap) and the classic kernel stays

@@ -75,6 +75,9 @@ int rs_launch_token_attn(const float* qkv, float* o, float* p, const float* d_o,
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st, bool reduce = true);
 int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
+// LDS-DMA fed weight gradient for pre-normalised bf16 inputs (conv3d_wgrad_dma.hip); writes the same slabs, the caller runs the reduction
+bool rs_wgrad_dma_supported(const WgradParams& p, int dtype);
+int rs_launch_wgrad_dma(const WgradParams& p, hipStream_t st);
 // stride-2 convolution (conv3d_wgrad_s2.hip): p.N/D/H/W = the FULL-resolution grid of x, dY lives on the ((D+1)/2, (H+1)/2, (W+1)/2) grid; xb unused
 int rs_wgrad_s2_splits(int dtype, int Ca, int Mtot, int N, int D, int H, int W);
 int rs_launch_wgrad_s2(const WgradParams& p, int dtype, hipStream_t st);

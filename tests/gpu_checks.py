@@ -198,6 +198,36 @@ def check_conv_bwd(mode, N, S, Ca, Cb, Cout, fused_sc, seed=0, tr=None):
                   f'g {e_g:.2e} dx {e_dx:.2e} dw {e_w:.2e}')
 
 
+def check_wgrad_xhat(N, S, Ca, Cb, Ya, Yb, seed=0):
+    """Weight gradient on PRE-NORMALISED bf16 sources (no statistics: csrc/conv3d_wgrad_dma.hip, operands by LDS-DMA) against the float64
+    gradient of F.conv3d on exactly the bf16 operands the kernel sees -- f32 accumulation is the only difference, hence the tight bound."""
+    from rsuper_amd.hip import ops
+    D, H, W = S
+    dt = torch.bfloat16
+    xa = torch.relu(_rng_t(seed + 1, (N, Ca, D, H, W)) + 0.3).bfloat16()
+    xb = torch.relu(_rng_t(seed + 2, (N, Cb, D, H, W)) * 1.5 - 0.2).bfloat16() if Cb else None
+    dy1 = _rng_t(seed + 6, (N, Ya, D, H, W)).bfloat16()
+    dy2 = _rng_t(seed + 7, (N, Yb, D, H, W)).bfloat16() if Yb else None
+    xh = (xa if xb is None else torch.cat([xa, xb], 1)).double()
+    refs = []
+    for dy, Y in ((dy1, Ya), (dy2, Yb)):
+        if dy is None:
+            continue
+        w = torch.zeros((Y, Ca + Cb, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+        F.conv3d(xh, w, padding=1).backward(dy.double())
+        refs.append(w.grad.float())
+    sa = ops.Src(to_cl(xa.float(), dt))
+    sb = ops.Src(to_cl(xb.float(), dt)) if Cb else None
+    dw1 = torch.full((Ya, Ca + Cb, 3, 3, 3), float('nan'), device=DEV)
+    dw2 = torch.full((Yb, Ca + Cb, 3, 3, 3), float('nan'), device=DEV) if Yb else None
+    ops.wgrad(sa, sb, ops.Src(to_cl(dy1.float(), dt)), ops.Src(to_cl(dy2.float(), dt)) if Yb else None, dw1, dw2, (N, D, H, W))
+    torch.cuda.synchronize()
+    e = relerr(dw1.cpu(), refs[0])
+    if Yb:
+        e = max(e, relerr(dw2.cpu(), refs[1]))
+    return result(f'wgrad_xhat[bf16 N{N} S{S} {Ca}+{Cb}->{Ya}+{Yb}]', e, 1e-4, f'dw {e:.2e}')
+
+
 def check_wgrad_s2(mode, N, S, Ca, Ya, Yb, seed=0):
     """Strided weight gradient (csrc/conv3d_wgrad_s2.hip) of [conv1 | shortcut] against autograd of F.conv3d(stride=2, padding=1) on the
     normalised + rectified input (float64 reference of the operands the kernel sees)."""
@@ -1105,6 +1135,12 @@ def all_checks(quick=False):
     # that exceeds what is registered -> these batches must take another shape instead of writing past it (N = 13 / 640 columns is the first such case)
     cs += [(check_conv_bwd, ('bf16', 32, (6, 6, 6), 320, 0, 320, False)), (check_conv_bwd, ('bf16', 32, (6, 6, 6), 320, 0, 320, True)),
            (check_conv_bwd, ('bf16', 13, (6, 6, 6), 64, 0, 320, True)), (check_conv_fwd, ('bf16', 26, (6, 6, 6), 64, 0, 320, False, True))]
+    # pre-normalised sources (LDS-DMA fed weight gradient): one / two x sources, one / two dY sources, 32- and 64-row blocks, ragged volumes (zero padding
+    # by out-of-range DMA lanes on every face), channel tails, several tiles per block, both samples in one block's range, >= 128 tiles (XCD-aware order)
+    cs += [(check_wgrad_xhat, (1, (4, 4, 16), 32, 0, 32, 0)), (check_wgrad_xhat, (2, (8, 8, 32), 32, 0, 32, 0, 1)), (check_wgrad_xhat, (1, (5, 6, 7), 8, 16, 8, 8, 2)),
+           (check_wgrad_xhat, (2, (8, 12, 20), 64, 32, 64, 64, 3)), (check_wgrad_xhat, (1, (7, 9, 35), 40, 0, 24, 0, 4)), (check_wgrad_xhat, (2, (16, 16, 64), 32, 32, 32, 32, 5)),
+           (check_wgrad_xhat, (2, (24, 24, 48), 32, 0, 32, 0, 6)), (check_wgrad_xhat, (1, (16, 32, 64), 64, 0, 64, 0, 7)), (check_wgrad_xhat, (2, (12, 12, 12), 128, 0, 128, 0, 8)),
+           (check_wgrad_xhat, (3, (6, 6, 6), 32, 0, 96, 32, 9)), (check_wgrad_xhat, (1, (2, 3, 5), 8, 0, 8, 0, 10))]
     for m in ('f32', 'bf16'):           # strided weight gradient: even / odd / ragged sizes, one and two dy sources, channel tails, several tiles per split
         cs += [(check_wgrad_s2, (m, 1, (8, 8, 32), 32, 32, 0)), (check_wgrad_s2, (m, 2, (12, 10, 20), 16, 32, 32)), (check_wgrad_s2, (m, 1, (7, 9, 35), 8, 16, 16)),
                (check_wgrad_s2, (m, 2, (5, 17, 66), 40, 24, 24)), (check_wgrad_s2, (m, 1, (2, 3, 5), 8, 8, 8)), (check_wgrad_s2, (m, 3, (24, 24, 24), 64, 128, 128))]

@@ -25,7 +25,12 @@ def main():
             line = f"{'PASS' if r['ok'] else 'FAIL'} {r['name']}: err {r['err']:.3e} (tol {r['tol']:.1e}) {r['note']} [{time.time() - t0:.1f}s]"
             npass += r['ok']
             nfail += not r['ok']
-        except Exception as e:  # noqa: BLE001
+        except BaseException as e:  # noqa: BLE001  (pytest.skip raises an OutcomeException, a BaseException)
+            if type(e).__name__ == 'Skipped':
+                print(f'SKIP {label}: {e}', flush=True)
+                continue
+            if isinstance(e, KeyboardInterrupt):
+                raise
             nfail += 1
             line = f'ERROR {label}: {type(e).__name__}: {e}\n' + traceback.format_exc(limit=6)
         print(line, flush=True)

@@ -20,6 +20,8 @@ LAYERS = [('inc 32->32', 96, 32, 0, 32, False), ('up4.0 96->32+sc', 96, 32, 64, 
 
 if os.environ.get('BC_ONLY_S2'):                       # only the strided rows below
     LAYERS = []
+if os.environ.get('BC_ONLY'):                          # only the stride-1 layers whose name contains one of the comma-separated substrings
+    LAYERS = [l for l in LAYERS if any(k in l[0] for k in os.environ['BC_ONLY'].split(','))]
 
 
 def timeit(fn, iters=10):
@@ -68,7 +70,7 @@ for name, S, Ca, Cb, Cout, sc in LAYERS:
 # ---- the strided member (down_block(pool=False)): [conv1 | shortcut] of BasicBlock(Cin, Cout, stride=2) on the parity-class kernel against the
 #      rounds-1/2 evaluation (the stride-1 GEMM at full resolution + rsuper_subsample2 / zero-stuffed dy).  FLOPs = the strided convolution's own.
 print('# stride-2 [conv1 | shortcut]: parity-class kernel (conv3d_igemm_s2.hip) vs stride-1 evaluation at full resolution', flush=True)
-for name, S, Ca, Cout in [('down1.0 s2 32->64+sc', 96, 32, 64), ('down2.0 s2 64->128+sc', 48, 64, 128), ('down3.0 s2 128->256+sc', 24, 128, 256)]:
+for name, S, Ca, Cout in ([] if os.environ.get('BC_ONLY') else [('down1.0 s2 32->64+sc', 96, 32, 64), ('down2.0 s2 64->128+sc', 48, 64, 128), ('down3.0 s2 128->256+sc', 24, 128, 256)]):
     dims = (N, S, S, S); O = (S + 1) // 2
     xa = torch.randn((N, S, S, S, Ca), device=dev).to(dt)
     mra = torch.stack([torch.zeros(N, Ca, device=dev), torch.ones(N, Ca, device=dev)], -1).contiguous()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Run one conv kernel configuration a few times (for rocprofv3 --pmc).  Usage: prof_one.py <layer-index> <fwd|dgrad|wgrad>"""
+"""Run one conv kernel configuration a few times (for rocprofv3 --pmc / --kernel-trace).  Usage: prof_one.py <layer-index> <fwd|dgrad|wgrad> [xhat]
+(xhat: the sources carry no statistics = a pre-normalised input; the weight gradient then runs the LDS-DMA fed kernel)"""
 import os, sys, math
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,6 +21,8 @@ w1 = torch.randn((Cout, Cin, 3, 3, 3), device=dev) / math.sqrt(27 * Cin)
 ws = torch.randn((Cout, Cin, 3, 3, 3), device=dev) / math.sqrt(27 * Cin) if sc else None
 nc = Cout * (2 if sc else 1)
 tiles = ops._L().rsuper_conv3_tiles(S, S, S)
+if len(sys.argv) > 3 and sys.argv[3] == 'xhat':
+    mra = mrb = None
 sa, sb = ops.Src(xa, mr=mra), (ops.Src(xb, mr=mrb) if Cb else None)
 dy1 = torch.randn((N, S, S, S, Cout), device=dev).to(dt)
 dy2 = torch.randn((N, S, S, S, Cout), device=dev).to(dt) if sc else None
@@ -34,6 +37,6 @@ elif which == 'dgrad':
 else:
     dw1 = torch.zeros_like(w1); dws = torch.zeros_like(ws) if sc else None
     fn = lambda: ops.wgrad(sa, sb, ops.Src(dy1), ops.Src(dy2) if sc else None, dw1, dws, dims)
-for _ in range(3):
+for _ in range(int(os.environ.get('PROF_ITERS', '3'))):
     fn()
 torch.cuda.synchronize()
