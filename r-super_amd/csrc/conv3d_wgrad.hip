@@ -1047,6 +1047,12 @@ static int launch_wgrad_impl(const WgradParams& p, int dtype, int use_tr, hipStr
     const int tiles_total = p.N * ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);
     if (dtype == RS_F32) return cfg == 0 ? launch<float, 1, 27, 0, 4>(p, st) : launch<float, 2, 9, 0, 4>(p, st);
+    if (use_tr && cfg != 1 && rs_wgrad2_supported(p, dtype)) {          // operand re-use across taps + double-buffered tiles (conv3d_wgrad2.hip)
+        const int rc = rs_launch_wgrad2(p, st);
+        if (rc != RS_OK) return rc;
+        launch_reduce(p, st);
+        return rs_check_launch();
+    }
     if (use_tr && cfg != 1 && rs_wgrad_dma_supported(p, dtype)) {      // pre-normalised sources: operands by LDS-DMA (conv3d_wgrad_dma.hip)
         const int rc = rs_launch_wgrad_dma(p, st);
         if (rc != RS_OK) return rc;

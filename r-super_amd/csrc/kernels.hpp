@@ -75,6 +75,9 @@ int rs_launch_token_attn(const float* qkv, float* o, float* p, const float* d_o,
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st, bool reduce = true);
 int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
+// second-generation weight gradient (conv3d_wgrad2.hip): bf16, operand re-use across taps + double-buffered tiles; same slabs, the caller reduces
+bool rs_wgrad2_supported(const WgradParams& p, int dtype);
+int rs_launch_wgrad2(const WgradParams& p, hipStream_t st);
 // LDS-DMA fed weight gradient for pre-normalised bf16 inputs (conv3d_wgrad_dma.hip); writes the same slabs, the caller runs the reduction
 bool rs_wgrad_dma_supported(const WgradParams& p, int dtype);
 int rs_launch_wgrad_dma(const WgradParams& p, hipStream_t st);
