@@ -1047,7 +1047,11 @@ static int launch_wgrad_impl(const WgradParams& p, int dtype, int use_tr, hipStr
     const int tiles_total = p.N * ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);
     if (dtype == RS_F32) return cfg == 0 ? launch<float, 1, 27, 0, 4>(p, st) : launch<float, 2, 9, 0, 4>(p, st);
-    if (use_tr && cfg != 1 && rs_wgrad2_supported(p, dtype)) {          // operand re-use across taps + double-buffered tiles (conv3d_wgrad2.hip)
+    // Second-generation kernel (conv3d_wgrad2.hip: operand re-use across taps, double-buffered tiles) where a block sweeps enough tiles to amortise its
+    // heavier prologue (descriptor / constants tables, two tiles staged before the first MFMA): measured same-box against the kernel below, >= 12 tiles
+    // per block 0.81-0.93x (32 -> 32 @96^3, up4.0, up3.0, up2.0), 6.75 tiles per block 1.02-1.08x (64 -> 64 @48^3, 128 -> 128 @24^3, down1.0)
+    static const int w2min = getenv("RSUPER_WGRAD2_MIN_TILES") ? atoi(getenv("RSUPER_WGRAD2_MIN_TILES")) : 12;
+    if (use_tr && cfg != 1 && tiles_total >= w2min * p.splits && rs_wgrad2_supported(p, dtype)) {
         const int rc = rs_launch_wgrad2(p, st);
         if (rc != RS_OK) return rc;
         launch_reduce(p, st);

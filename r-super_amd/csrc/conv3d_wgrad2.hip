@@ -32,7 +32,14 @@ constexpr int TD = 4, TH = 4, TW = 16, HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int XROWS = HD * HH * HW;                              // 648 halo rows of 64 B (32 channels)
 constexpr int XBYTES = XROWS * 64;
 constexpr int YPLANE = 256 * 64;                                 // one 32-row group of dY: 256 voxels x 64 B
-constexpr int NT = 512;
+constexpr int NT = 512, NW = 8;
+
+// dY needs no arithmetic on its way into LDS: `buffer_load_dwordx4 ... lds` copies 1 KB per wave instruction from per-lane global offsets into a
+// lane-linear LDS image (lane l -> M0 + 16 l), out-of-range offsets arrive as zeros; semantics pinned by tools/ubench/lds_dma_probe.hip.  The
+// compiler does not see the instruction: completion is waited for by an explicit counted vmcnt before the tile barrier.
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, uint32_t lds_byte) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(lds_byte), "s"(rs) : "memory", "m0");
+}
 
 // ---- static schedule of one wave's tile: the halo fragments it fetches, in order.  Pair index pidx = kd * 3 + kh; groups 0-2 own pairs 0..6 at kw = G,
 //      group 3 owns pairs 7, 8 = (kd 2, kh 1 / 2) at every kw.  NDL = tile planes handled by the wave (4, or 2 for the depth halves of 32-row blocks).
@@ -64,8 +71,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
     constexpr int NDL = MT == 2 ? 4 : 2;
     constexpr int BUF = XBYTES + MT * YPLANE;
     constexpr int NXV = (XROWS * 4 + NT - 1) / NT;               // 16-byte x vectors per thread (6; the last one on 32 threads only)
-    constexpr int NYV = MT * 256 * 4 / NT;                       // dY vectors per thread (2 / 4), plane = i / 2
-    constexpr int NV = NXV + NYV;
+    constexpr int YK = 16 * MT / NW;                             // dY DMA pieces per wave (2 / 4): piece = one (d, h) line of a 32-row group, 16 voxels x 64 B
+    constexpr int NV = NXV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -106,29 +113,25 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
         xpm[i] = (r < XROWS && x_cok) ? ((1u << hd) | (1u << (6 + hh)) | (1u << (12 + hw))) : (1u << 31);
     }
     const int x_st = s_row * 64 + s_slot * 16;                   // LDS byte of vector 0; vector i at + 8192 i
-    // dY: plane q = rows m0 + 32 q .. + 31 of [ya | yb] (a 32-row group never straddles the two sources: checked by the launcher);
-    // vector i -> plane i / 2, voxel row s_row + 128 (i & 1) of the tile = (d = r >> 6, h = (r >> 4) & 3, w = r & 15)
+    // dY: plane q = rows m0 + 32 q .. + 31 of [ya | yb] (a 32-row group never straddles the two sources: checked by the launcher).  DMA piece y of a tile
+    // = plane y >> 4, line (d, h) = ((y & 15) >> 2, y & 3); lane -> voxel w = lane >> 2, 16-byte slot lane & 3.
+    const int prow = lane >> 2, pslot = lane & 3;
     __amdgpu_buffer_rsrc_t yrs[MT];
-    uint32_t yrowb[MT], ycolb[MT];
+    uint32_t yrowb[MT], yoffb[MT];
     bool yok[MT];
 #pragma unroll
     for (int q = 0; q < MT; ++q) {
         const int mq = m0 + 32 * q;
         const bool inA = mq < p.ya.C;
         const ConvSrc& ys = inA ? p.ya : p.yb;
-        const int ch = (inA ? mq : mq - p.ya.C) + s_slot * 8;
+        const int ch = (inA ? mq : mq - p.ya.C) + pslot * 8;
         yok[q] = mq < Mtot && ch < ys.C;
         yrowb[q] = (uint32_t)ys.ld * 2u;
-        ycolb[q] = (uint32_t)ch * 2u;
+        yoffb[q] = (uint32_t)prow * yrowb[q] + (uint32_t)ch * 2u;
         yrs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)ys.x, 0, nvox_total * yrowb[q], 0x00020000);
     }
-    uint32_t ydelta[2], ypm[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = s_row + 128 * j;
-        ydelta[j] = (uint32_t)(((r >> 6) * p.H + ((r >> 4) & 3)) * p.W + (r & 15));
-        ypm[j] = (1u << (r >> 6)) | (1u << (4 + ((r >> 4) & 3))) | (1u << (8 + (r & 15)));
-    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the dynamic region
+    const uint32_t ywbit = 1u << (8 + prow);                     // this lane's w position in the tile's validity mask
 
     // XCD-aware tile order (see conv3d_wgrad.hip): class z & 7 owns a contiguous range of tiles and its blocks sweep it together
     int tile0, tile_end, tstride;
@@ -175,23 +178,25 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
         t.ybad = w & 0xFFFFu; t.n = (int)(w >> 16);
         return t;
     };
-    uint4 px[NXV], py[NYV];
+    uint4 px[NXV];
     auto ld16 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t off) {
         const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);      // out-of-range offsets return zeros
         return make_uint4(q[0], q[1], q[2], q[3]);
     };
     auto issue_v = [&](const IssueTile& t, int i) {              // i static
-        if (i < NXV) {
-            const bool ok = (xpm[i] & t.xbad) == 0u;
-            px[i] = ld16(xrs, ok ? t.baseb + xoffb[i] : 0xFFFFFFF0u);
-        } else {
-            const int j = i - NXV, q = j >> 1;
-            const bool ok = yok[q] && (ypm[j & 1] & t.ybad) == 0u;
-            py[j] = ld16(yrs[q], ok ? (t.ybase + ydelta[j & 1]) * yrowb[q] + ycolb[q] : 0xFFFFFFF0u);
-        }
+        const bool ok = (xpm[i] & t.xbad) == 0u;
+        px[i] = ld16(xrs, ok ? t.baseb + xoffb[i] : 0xFFFFFFF0u);
     };
-    // x_hat = max(x * rstd - mean * rstd, 0): the constants of every (sample, channel pair) live in LDS as float4 (sc0, sc1, nb0, nb1) -- a vector's commit
-    // reads its four entries (16 VGPRs of per-thread constants would not fit beside 112 accumulators + the resident dY fragments)
+    auto dma_y = [&](const IssueTile& t, int k, uint32_t buf) {  // k static: this wave's k-th dY piece of tile t -> tile buffer at LDS byte offset buf
+        const int y = wave + NW * k;
+        const int q = MT == 1 ? 0 : (y >> 4), line = y & 15, d = line >> 2, h = line & 3;
+        const uint32_t lbit = (1u << d) | (1u << (4 + h)) | ywbit;
+        const bool ok = yok[q] && (lbit & t.ybad) == 0u;
+        const uint32_t voff = ok ? (t.ybase + (uint32_t)((d * p.H + h) * p.W)) * yrowb[q] + yoffb[q] : 0xFFFFFFF0u;
+        dma16(MT == 1 ? yrs[0] : (q ? yrs[MT - 1] : yrs[0]), voff, lds0 + buf + XBYTES + (uint32_t)y * 1024u);
+    };
+    // x_hat = max(x * rstd - mean * rstd, 0): constants of this thread's 8 channels as (sc0, sc1, nb0, nb1) per pair, re-read from a per-sample LDS table
+    // when the sample changes (the dY vectors travel by DMA, which frees the registers these need)
     float4* ntab = (float4*)(smem + 2 * BUF);                    // [N][4 slots][4 pairs]
     if (norm) {
         for (int e = tid; e < p.N * 16; e += NT) {
@@ -202,8 +207,16 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
         }
     }
     const float4* nrow = ntab + s_slot * 4;                      // + 16 n
-    auto commit_v = [&](char* buf, int i, const IssueTile& t) {  // i static: normalise (x) and write vector i of the tile `t` held in px / py
-        if (i < NXV) {
+    float4 ncst[4];
+    int cur_n = -1;
+    auto load_norm = [&](int n) {
+        if (!norm || n == cur_n) return;
+        cur_n = n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ncst[j] = nrow[16 * n + j];
+    };
+    auto commit_v = [&](char* buf, int i, const IssueTile& t) {  // i static: normalise and write x vector i of the tile `t` held in px
+        {
             uint4 q = px[i];
             if (norm) {
                 const uint32_t w[4] = {q.x, q.y, q.z, q.w};
@@ -211,11 +224,19 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
                 const uint32_t m = (xpm[i] & t.xbad) == 0u ? 0xFFFFFFFFu : 0u;        // padding stays zero AFTER the activation
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float4 c = nrow[16 * t.n + j];
+                    const float4 c = ncst[j];
+#ifndef WG2_PKFMA
+                    // two v_fma_f32, not one v_pk_fma_f32: beside MFMAs the packed f32 forms cost ~22 cycles more per instruction (MI355X_MICROARCH.md, filler prices)
+                    float x0, x1;
+                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(__uint_as_float(w[j] << 16)), "v"(c.x), "v"(c.z));
+                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(__uint_as_float(w[j] & 0xffff0000u)), "v"(c.y), "v"(c.w));
+                    i16x2_t v = __builtin_bit_cast(i16x2_t, f2bf2(x0, x1));
+#else
                     f32x2_t x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
                     const f32x2_t s2 = {c.x, c.y}, b2 = {c.z, c.w};
                     x = __builtin_elementwise_fma(x, s2, b2);
                     i16x2_t v = __builtin_bit_cast(i16x2_t, f2bf2(x[0], x[1]));
+#endif
                     const i16x2_t z = {0, 0};
                     v = __builtin_elementwise_max(v, z);
                     o[j] = __builtin_bit_cast(uint32_t, v) & m;
@@ -223,9 +244,6 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
                 q = make_uint4(o[0], o[1], o[2], o[3]);
             }
             if (s_row + 128 * i < XROWS) *(uint4*)(buf + x_st + i * 8192) = q;
-        } else {
-            const int j = i - NXV;
-            *(uint4*)(buf + XBYTES + (j >> 1) * YPLANE + x_st + (j & 1) * 8192) = py[j];
         }
     };
 
@@ -234,6 +252,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
         constexpr Sched S = make_sched(G, NDL);
         constexpr int KDMIN = G < 3 ? 0 : 2;                     // first halo plane that uses dY plane 0
         constexpr int AP = NDL < 3 ? NDL : 3;                    // dY planes held in registers (ring)
+#ifndef WG2_NOSTAGGER
+        constexpr int HOFF = G >= 2 ? S.n / (2 * NV) : 0;        // the two waves of a SIMD (tap groups g, g + 2) run their staging hooks half an interval apart
+#else
+        constexpr int HOFF = 0;
+#endif
         f32x16_t acc[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i)
@@ -246,12 +269,16 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
         {
             const IssueTile t0 = fetch_desc(0);
 #pragma unroll
+            for (int k = 0; k < YK; ++k) dma_y(t0, k, 0);
+#pragma unroll
             for (int i = 0; i < NV; ++i) issue_v(t0, i);
+            load_norm(t0.n);
 #pragma unroll
             for (int i = 0; i < NV; ++i) commit_v(smem, i, t0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) issue_v(t1, i);
         }
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NV) : "memory");      // the dY pieces of tile 0 (the x loads of tile 1 stay in flight)
         __syncthreads();
 
         int it = 0;
@@ -259,6 +286,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
             const char* buf = smem + (it & 1) * BUF;
             char* nxt = smem + ((it + 1) & 1) * BUF;
             const IssueTile t2 = fetch_desc(it + 2);             // t1: the tile committed during this one; t2: the tile whose loads are issued during it
+            load_norm(t1.n);
+#ifndef WG2_SKIP_STAGE
+#pragma unroll
+            for (int k = 0; k < YK; ++k) dma_y(t1, k, (uint32_t)((it + 1) & 1) * BUF);      // first VMEM operations of the tile: NV x loads follow
+#endif
             auto fetch_a = [&](int row) { return frag_bf16<1>(buf + ya_off + (row * TW) * 64, 64); };
             auto fetch_b = [&](int s) { return frag_bf16<1>(buf + x_off + ((S.dp[s] * HH + S.hp[s]) * HW + S.kw[s]) * 64, 64); };
             constexpr int BR = BD + 1;
@@ -299,10 +331,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
                 // staging hooks: vector i of tile t + 1 is normalised + written into the other buffer, then its register takes the load of tile t + 2
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    if (s == (i * S.n) / NV) { commit_v(nxt, i, t1); issue_v(t2, i); }
+                    if (s == (i * S.n) / NV + HOFF) { commit_v(nxt, i, t1); issue_v(t2, i); }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifndef WG2_SKIP_STAGE
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NV) : "memory");  // this tile's dY pieces have landed; the NV x loads issued after them stay in flight
+#endif
             __syncthreads();                                     // tile t consumed, tile t + 1 complete in the other buffer
             t1 = t2;
         }
