@@ -67,8 +67,6 @@ int rsuper_conv3_tiles(int D, int H, int W);
  * K-split kernel (rsuper_conv3_box_bn) forced for every bf16 64-column launch (6: box shape per volume, 7: the 4x4x4 box).
  * v < 0 queries.  Returns the variant in effect. */
 int rsuper_conv3_variant(int v);
-/* 1 when the library was built with `make EXPERIMENTAL=1` (kernel variants that measured no faster: igemm variant 5, RSUPER_WGRAD_DB, RSUPER_PC64_ALT) */
-int rsuper_has_experimental(void);
 
 /* Launches whose volume cannot fill the chip with 4x4x16-voxel tiles (the 24^3 / 12^3 levels of the UNet at batch 2:
  * model/dim3/unet.py:49-58 after three / four poolings) run a volume-fitted kernel under the default variant: boxes of

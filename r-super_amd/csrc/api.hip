@@ -106,16 +106,8 @@ int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, cons
 int rsuper_conv3_tiles(int D, int H, int W) { return ((D + 3) / 4) * ((H + 3) / 4) * ((W + 15) / 16); }
 
 static int g_variant = 3;
-int rsuper_has_experimental(void) {
-#ifdef RS_EXPERIMENTAL
-    return 1;
-#else
-    return 0;
-#endif
-}
 int rsuper_conv3_variant(int v) {
-    if (v == 5 && !rsuper_has_experimental()) return g_variant;      // variant 5 only exists in `make EXPERIMENTAL=1` builds
-    if (v >= 0 && v <= 7) g_variant = v;
+    if (v >= 0 && v <= 7 && v != 5) g_variant = v;                   // 5 was the second-generation producer/consumer kernel (measured equal, removed)
     return g_variant;
 }
 // variant 2 (auto, default): producer/consumer kernel where it measured faster on MI355X -- data-gradient launches with
@@ -127,7 +119,6 @@ int rsuper_conv3_variant(int v) {
 static bool use_pc(int dtype, int epi, int bn, int tiles_total) {
     if (dtype != RS_BF16) return false;
     if (g_variant == 4) return bn == 32 || (bn <= 64 && (epi == 1 || tiles_total <= 1024));
-    if (g_variant == 5) return bn <= 64;
     if (g_variant == 2 || g_variant == 3) return bn <= 64 && (epi == 1 || bn == 32 || tiles_total <= 1024);
     return g_variant == 1;
 }
@@ -245,7 +236,6 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
         if (!g_ws || boxc_ws_need(p.nsplit, N, D, H, W, n_cols) > g_ws_bytes) return RS_ERR_ARG;      // never write past the registered workspace
     }
     p.pc = use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0;
-    if (p.pc && g_variant == 5) p.pc = 3;
     if (p.pc && bn == 32 && (g_variant == 4 || (g_variant == 3 && (Ca + 31) / 32 + (Cb + 31) / 32 == 1))) p.pc = 2;
     return rs_launch_igemm(p, dtype, epi, ST(stream));
 }

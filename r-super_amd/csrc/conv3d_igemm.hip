@@ -875,39 +875,20 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(PackBatch b, T* out) {
 
 }  // namespace
 
-// bn = 64 on the producer/consumer kernel: 0 = 2 x 2 waves, each 4 M-fragments x 1 N-fragment (A fragment used once, B four times);
-// 1 = 4 x 1 waves, each 2 M-fragments x 2 N-fragments (A and B fragments used twice each: half the LDS reads per MFMA).
-// (EXPERIMENTAL build only: tiling 1 measured slower -- up3.0 data gradient 253 -> 311 us)
-static int pc64_alt() {
-#ifdef RS_EXPERIMENTAL
-    static const int v = getenv("RSUPER_PC64_ALT") ? atoi(getenv("RSUPER_PC64_ALT")) : 0;
-    return v;
-#else
-    return 0;
-#endif
-}
-
 int rs_igemm_part_rows(int bn, int pc, int tiles, int n_cols, int N) {
     if (!pc) return tiles;                                            // classic kernel: one row per tile
     const int gy = (n_cols + bn - 1) / bn;                            // producer/consumer: one row per (persistent block, wm)
-    return pc_grid_x(tiles, gy, N) * ((bn == 32 || (bn == 64 && pc == 1 && pc64_alt())) ? 4 : 2);
+    return pc_grid_x(tiles, gy, N) * (bn == 32 ? 4 : 2);
 }
 
 int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st) {
     if (p.box > 0 && dtype == RS_BF16) return rs_launch_igemm_box(p, p.box, epi, st);
     if (p.pc == 2 && rs_igemm_ws_supported(p, dtype, epi)) return rs_launch_igemm_ws(p, epi, st);
-#ifdef RS_EXPERIMENTAL
-    if (p.pc == 3 && dtype == RS_BF16 && (p.bn == 32 || (p.bn == 64 && p.ntiles % 2 == 0))) return rs_launch_igemm_pc2(p, epi, st);
-#endif
     if (dtype == RS_BF16 && p.pc) {
         if (p.ntiles % (p.bn / 32)) return RS_ERR_ARG;
         switch (p.bn) {
             case 32: return launch_pc<bf16_t, 4, 2, 1, 1>(p, epi, st);
-#ifdef RS_EXPERIMENTAL
-            case 64: return pc64_alt() ? launch_pc<bf16_t, 4, 2, 1, 2>(p, epi, st) : launch_pc<bf16_t, 2, 4, 2, 1>(p, epi, st);
-#else
             case 64: return launch_pc<bf16_t, 2, 4, 2, 1>(p, epi, st);
-#endif
             case 128: return launch_pc<bf16_t, 2, 4, 2, 2>(p, epi, st);
         }
         return RS_ERR_ARG;

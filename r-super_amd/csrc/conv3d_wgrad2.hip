@@ -23,10 +23,15 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "wgrad_frag.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
+
+#ifdef WG2_PROF
+__device__ unsigned long long g_wg2_prof[8 * 4];                 // block 0: [wave][loop cycles, barrier cycles, tiles, -]
+#endif
 
 constexpr int TD = 4, TH = 4, TW = 16, HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int XROWS = HD * HH * HW;                              // 648 halo rows of 64 B (32 channels)
@@ -252,11 +257,16 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
         constexpr Sched S = make_sched(G, NDL);
         constexpr int KDMIN = G < 3 ? 0 : 2;                     // first halo plane that uses dY plane 0
         constexpr int AP = NDL < 3 ? NDL : 3;                    // dY planes held in registers (ring)
-#ifndef WG2_NOSTAGGER
-        constexpr int HOFF = G >= 2 ? S.n / (2 * NV) : 0;        // the two waves of a SIMD (tap groups g, g + 2) run their staging hooks half an interval apart
-#else
-        constexpr int HOFF = 0;
+        // The two waves of a SIMD are the tap groups g and g + 2 (waves w, w + 4).  The SIMD arbitrates by age: the older wave runs nearly unimpeded and the
+        // younger one gets what is left (cycle stamps, 32 -> 32 @96^3, staging off: older wave 2.0 k cycles for its 56 MFMAs, then 1.8 k at the barrier;
+        // younger 3.7 k).  So the two programs are made complementary instead of identical: the older wave multiplies first and stages in the second
+        // half of its steps, the younger one stages in the first half (while the matrix pipe belongs to its partner) and multiplies after.
+#ifndef WG2_HOOK_MODE
+#define WG2_HOOK_MODE 1
 #endif
+        constexpr int HMODE = WG2_HOOK_MODE;                     // 0: hooks spread evenly; 1: complementary halves; 2: the other way round
+        constexpr bool late = HMODE == 0 ? false : ((G < 2) == (HMODE == 1));
+        auto hook_step = [&](int i) constexpr { return HMODE == 0 ? (i * S.n) / NV : (late ? S.n / 2 : 0) + (i * (S.n / 2)) / NV; };
         f32x16_t acc[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i)
@@ -281,8 +291,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
         asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NV) : "memory");      // the dY pieces of tile 0 (the x loads of tile 1 stay in flight)
         __syncthreads();
 
+#ifdef WG2_PROF
+        unsigned long long pf_loop = 0, pf_bar = 0;
+#endif
         int it = 0;
         for (int tile = tile0; tile < tile_end; tile += tstride, ++it) {
+#ifdef WG2_PROF
+            const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
             const char* buf = smem + (it & 1) * BUF;
             char* nxt = smem + ((it + 1) & 1) * BUF;
             const IssueTile t2 = fetch_desc(it + 2);             // t1: the tile committed during this one; t2: the tile whose loads are issued during it
@@ -331,17 +347,27 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
                 // staging hooks: vector i of tile t + 1 is normalised + written into the other buffer, then its register takes the load of tile t + 2
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    if (s == (i * S.n) / NV + HOFF) { commit_v(nxt, i, t1); issue_v(t2, i); }
+                    if (s == hook_step(i)) { commit_v(nxt, i, t1); issue_v(t2, i); }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef WG2_PROF
+            const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
 #ifndef WG2_SKIP_STAGE
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NV) : "memory");  // this tile's dY pieces have landed; the NV x loads issued after them stay in flight
 #endif
-            __syncthreads();                                     // tile t consumed, tile t + 1 complete in the other buffer
+            __syncthreads();
+#ifdef WG2_PROF
+            const unsigned long long q2 = __builtin_readcyclecounter();
+            pf_loop += q1 - q0; pf_bar += q2 - q1;
+#endif                                     // tile t consumed, tile t + 1 complete in the other buffer
             t1 = t2;
         }
 
+#ifdef WG2_PROF
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) { g_wg2_prof[wave * 4] = pf_loop; g_wg2_prof[wave * 4 + 1] = pf_bar; g_wg2_prof[wave * 4 + 2] = (unsigned long long)it; }
+#endif
         // ---- 32-row blocks: the two depth halves meet in LDS (the tile buffers are free now); wave wsel = 0 of each pair holds the sum
         if constexpr (MT == 1) {
             float* red = (float*)smem + (size_t)g * 7 * 16 * 64 + lane;
@@ -396,6 +422,16 @@ int launch2(const WgradParams& p, hipStream_t st) {
     auto k = wgrad2_kernel<MT, BD, NORM>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
+#ifdef WG2_PROF
+    if (getenv("RSUPER_WG2_PROF")) {
+        unsigned long long h[32];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wg2_prof), sizeof(h));
+        fprintf(stderr, "wg2_prof MT%d norm%d:", MT, (int)NORM);
+        for (int w = 0; w < 8; ++w) fprintf(stderr, " w%d(g%d) loop %.0f bar %.0f |", w, w >> 1, (double)h[w * 4] / h[w * 4 + 2], (double)h[w * 4 + 1] / h[w * 4 + 2]);
+        fprintf(stderr, " tiles %llu\n", h[2]);
+    }
+#endif
     return RS_OK;
 }
 

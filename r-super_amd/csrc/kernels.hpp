@@ -22,7 +22,7 @@ struct IgemmParams {
     void* out; int ldo;
     const void* res; int ldr;   // EPI 0: optional residual added before store
     float* part;           // per-block partial sums [N][rows][Cout][2] or nullptr (rows = rs_igemm_part_rows)
-    int pc;                // 1: producer/consumer persistent kernel (bf16); 2: weight-stationary kernel (bf16, bn 32); 3: producer/consumer v2 (bf16, bn <= 64)
+    int pc;                // 1: producer/consumer persistent kernel (bf16); 2: weight-stationary kernel (bf16, bn 32)
     ConvSrc ea, eb;        // EPI 1: forward inputs (with mr) whose relu mask / x_n the data-gradient needs
     int box;               // > 0: volume-fitted K-split kernel (conv3d_igemm_box.hip), value = rs_box_config (3: one box per sample, reduction split over blocks)
     float* ws; int nsplit; // box == 3: f32 workspace [nsplit][N * D * H * W][Cout] and the number of chunk ranges
@@ -58,8 +58,6 @@ int rs_igemm_part_rows(int bn, int pc, int tiles, int n_cols, int N);
 // weight-stationary variant (conv3d_igemm_ws.hip): bf16, bn 32 / 64; same partial-row count as the producer/consumer kernel
 bool rs_igemm_ws_supported(const IgemmParams& p, int dtype, int epi);
 int rs_launch_igemm_ws(const IgemmParams& p, int epi, hipStream_t st);
-// second-generation producer/consumer kernel (conv3d_igemm_pc2.hip): bf16, bn 32 / 64, partial rows as igemm_pc_kernel
-int rs_launch_igemm_pc2(const IgemmParams& p, int epi, hipStream_t st);
 // volume-fitted in-block K-split kernel for under-filled (low-resolution) launches (conv3d_igemm_box.hip): bf16, bn 64
 int rs_box_config(int N, int D, int H, int W, int n_cols);
 int rs_box_part_rows(int cfg, int D, int H, int W);
@@ -78,9 +76,6 @@ int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
 // second-generation weight gradient (conv3d_wgrad2.hip): bf16, operand re-use across taps + double-buffered tiles; same slabs, the caller reduces
 bool rs_wgrad2_supported(const WgradParams& p, int dtype);
 int rs_launch_wgrad2(const WgradParams& p, hipStream_t st);
-// LDS-DMA fed weight gradient for pre-normalised bf16 inputs (conv3d_wgrad_dma.hip); writes the same slabs, the caller runs the reduction
-bool rs_wgrad_dma_supported(const WgradParams& p, int dtype);
-int rs_launch_wgrad_dma(const WgradParams& p, hipStream_t st);
 // stride-2 convolution (conv3d_wgrad_s2.hip): p.N/D/H/W = the FULL-resolution grid of x, dY lives on the ((D+1)/2, (H+1)/2, (W+1)/2) grid; xb unused
 int rs_wgrad_s2_splits(int dtype, int Ca, int Mtot, int N, int D, int H, int W);
 int rs_launch_wgrad_s2(const WgradParams& p, int dtype, hipStream_t st);

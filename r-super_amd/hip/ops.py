@@ -72,8 +72,6 @@ def pick_bn(n_cols, dtype, tiles_total=None, dims=None):
         return 32
     if dtype != torch.float32 and _L().rsuper_conv3_variant(-1) == 4:
         return 32         # forced weight-stationary kernel (tests / experiments): 32-column blocks, Cout / 32 of them in grid.y
-    if dtype != torch.float32 and _L().rsuper_conv3_variant(-1) == 5:
-        return 64 if n_cols % 64 == 0 else 32      # producer/consumer v2: 64-column blocks where they waste no column tile
     fill = int(os.environ.get('RSUPER_BN_FILL', '512'))       # two resident blocks per CU (measured 128 / 256 / 512: 13.89 / - / 13.80 ms per step)
     if tiles_total is not None and tiles_total * -(-n_cols // 128) < fill:
         for bn in reversed(cands):

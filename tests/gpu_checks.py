@@ -1083,13 +1083,10 @@ def with_strided(force, fn, *a):
 
 def with_variant(variant, fn, *a):
     """Run a conv check under a forced igemm kernel variant (0 classic, 1 producer/consumer, 2 = round-1 auto choice,
-    4 = weight-stationary kernel on every 32-column launch, 5 = producer/consumer v2, 6 / 7 = volume-fitted K-split kernel with the box
+    4 = weight-stationary kernel on every 32-column launch, 6 / 7 = volume-fitted K-split kernel with the box
     chosen per volume / the 4x4x4 box); restores the default (3)."""
     from rsuper_amd.hip import ops
     L = ops._L()
-    if variant == 5 and not L.rsuper_has_experimental():          # only in `make EXPERIMENTAL=1` builds of the library
-        import pytest
-        pytest.skip('igemm variant 5 (producer/consumer v2) is compiled under `make EXPERIMENTAL=1` only')
     L.rsuper_conv3_variant(variant)
     try:
         r = fn(*a)
@@ -1148,7 +1145,7 @@ def all_checks(quick=False):
         cs += [(check_pointwise, (m, 27648, 128, 512, False)), (check_pointwise, (m, 13824, 512, 128, True)), (check_pointwise, (m, 3456, 256, 1024, False)),
                (check_pointwise, (m, 3456, 1024, 256, True)), (check_pointwise, (m, 432, 320, 1280, False)),       # reduction split over the waves
                (check_pointwise, (m, 100, 36, 20, True)), (check_pointwise, (m, 33, 4, 4, False)), (check_pointwise, (m, 1000, 72, 260, True))]
-    for variant in (0, 1, 4, 5, 6, 7):  # every bf16 igemm kernel on every conv case (6 / 7: the volume-fitted K-split kernel, incl. its split-reduction shape) (the default picks per launch)
+    for variant in (0, 1, 4, 6, 7):  # every bf16 igemm kernel on every conv case (6 / 7: the volume-fitted K-split kernel, incl. its split-reduction shape) (the default picks per launch)
         cs += [(with_variant, (variant, fn) + a) for fn, a in list(cs) if fn in (check_conv_fwd, check_conv_bwd) and a[0] == 'bf16']
     cs += [(with_variant, (1, check_conv_fwd, 'bf16', 2, (8, 24, 32), 32, 0, 32, False, True)),       # persistent: several tiles per block
            (with_variant, (1, check_conv_fwd, 'bf16', 1, (12, 20, 48), 64, 64, 128, True, False)),    # 128 columns, 4 chunks, 2 sources
@@ -1159,13 +1156,7 @@ def all_checks(quick=False):
            (with_variant, (4, check_conv_fwd, 'bf16', 2, (16, 32, 64), 64, 0, 64, False, True)),      # 64-column blocks with residual
            (with_variant, (4, check_conv_bwd, 'bf16', 2, (8, 24, 32), 64, 64, 64, True)),
            (with_variant, (4, check_conv_bwd, 'bf16', 1, (12, 20, 48), 128, 0, 128, False)),
-           (with_variant, (4, check_conv_bwd, 'bf16', 2, (16, 32, 64), 32, 64, 32, True)),            # 96-column data gradient (three 32-column tiles)
-           (with_variant, (5, check_conv_fwd, 'bf16', 2, (8, 24, 32), 32, 0, 32, False, True)),       # producer/consumer v2: the same stress cases
-           (with_variant, (5, check_conv_fwd, 'bf16', 1, (12, 20, 48), 64, 64, 128, True, False)),
-           (with_variant, (5, check_conv_fwd, 'bf16', 2, (16, 32, 64), 64, 0, 64, False, True)),
-           (with_variant, (5, check_conv_bwd, 'bf16', 2, (8, 24, 32), 64, 64, 64, True)),
-           (with_variant, (5, check_conv_bwd, 'bf16', 1, (12, 20, 48), 128, 0, 128, False)),
-           (with_variant, (5, check_conv_bwd, 'bf16', 2, (16, 32, 64), 32, 64, 32, True))]
+           (with_variant, (4, check_conv_bwd, 'bf16', 2, (16, 32, 64), 32, 64, 32, True))]            # 96-column data gradient (three 32-column tiles)]
     cs += [(check_conv_bwd, ('bf16', 2, (16, 16, 64), 32, 32, 64, True)),      # >= 128 tiles, M = 128: 27-tap / 8-wave weight-gradient config
            (check_conv_bwd, ('bf16', 1, (16, 32, 64), 64, 0, 64, False))]
     cs += [(check_conv_bwd, ('bf16', 1, (4, 4, 16), 32, 0, 32, False, 0, 0)), (check_conv_bwd, ('bf16', 1, (8, 12, 20), 64, 32, 64, True, 0, 0)),

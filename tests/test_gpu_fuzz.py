@@ -33,7 +33,7 @@ def _cases(n, seed):
 CASES = _cases(10, 2026)
 
 
-@pytest.mark.parametrize('variant', [3, 4, 5, 0, 1, 6, 7])
+@pytest.mark.parametrize('variant', [3, 4, 0, 1, 6, 7])
 @pytest.mark.parametrize('case', CASES, ids=[f'N{c[0]}_S{"x".join(map(str, c[1]))}_{c[2]}+{c[3]}to{c[4]}_sc{int(c[5])}' for c in CASES])
 def test_conv_fuzz_bf16(case, variant):
     N, S, Ca, Cb, Cout, sc = case
