@@ -63,10 +63,14 @@ int rsuper_conv3_tiles(int D, int H, int W);
  * producer/consumer persistent kernel (bf16), 2 = per-launch choice between the two (round-1 default), 3 (default) = as 2,
  * with the weight-stationary 8-wave kernel (weights in registers, activation fragments re-used across taps, epilogue
  * straight from the accumulators) for 32-column launches over a single 32-channel K chunk, 4 = weight-stationary kernel
- * for every bf16 32-column launch, 5 = second-generation producer/consumer kernel for bn <= 64, 6 / 7 = the volume-fitted
+ * for every bf16 32-column launch, 6 / 7 = the volume-fitted
  * K-split kernel (rsuper_conv3_box_bn) forced for every bf16 64-column launch (6: box shape per volume, 7: the 4x4x4 box).
  * v < 0 queries.  Returns the variant in effect. */
 int rsuper_conv3_variant(int v);
+/* bf16 weight gradients (rsuper_conv3_wgrad) run the second-generation kernel (operand re-use across taps, double-buffered tiles) when a block
+ * sweeps at least `t` spatial tiles -- default 12, the measured break-even against the round-3 kernel; 0 = every supported launch (tests),
+ * a large value = never.  t < 0 queries.  Returns the threshold in effect. */
+int rsuper_conv3_wgrad2_min_tiles(int t);
 
 /* Launches whose volume cannot fill the chip with 4x4x16-voxel tiles (the 24^3 / 12^3 levels of the UNet at batch 2:
  * model/dim3/unet.py:49-58 after three / four poolings) run a volume-fitted kernel under the default variant: boxes of

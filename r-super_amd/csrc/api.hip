@@ -106,6 +106,8 @@ int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, cons
 int rsuper_conv3_tiles(int D, int H, int W) { return ((D + 3) / 4) * ((H + 3) / 4) * ((W + 15) / 16); }
 
 static int g_variant = 3;
+int rsuper_conv3_wgrad2_min_tiles(int t) { return rs_wgrad2_min_tiles(t); }
+
 int rsuper_conv3_variant(int v) {
     if (v >= 0 && v <= 7 && v != 5) g_variant = v;                   // 5 was the second-generation producer/consumer kernel (measured equal, removed)
     return g_variant;

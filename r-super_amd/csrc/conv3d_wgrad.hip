@@ -484,6 +484,12 @@ int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total) {
     return s < 1 ? 1 : s;
 }
 
+int rs_wgrad2_min_tiles(int t) {
+    static int v = getenv("RSUPER_WGRAD2_MIN_TILES") ? atoi(getenv("RSUPER_WGRAD2_MIN_TILES")) : 12;
+    if (t >= 0) v = t;
+    return v;
+}
+
 int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st) {
     launch_reduce_now(p, st);
     return rs_check_launch();
@@ -506,8 +512,7 @@ static int launch_wgrad_impl(const WgradParams& p, int dtype, int use_tr, hipStr
     // Second-generation kernel (conv3d_wgrad2.hip: operand re-use across taps, double-buffered tiles) where a block sweeps enough tiles to amortise its
     // heavier prologue (descriptor / constants tables, two tiles staged before the first MFMA): measured same-box against the kernel below, >= 12 tiles
     // per block 0.81-0.93x (32 -> 32 @96^3, up4.0, up3.0, up2.0), 6.75 tiles per block 1.02-1.08x (64 -> 64 @48^3, 128 -> 128 @24^3, down1.0)
-    static const int w2min = getenv("RSUPER_WGRAD2_MIN_TILES") ? atoi(getenv("RSUPER_WGRAD2_MIN_TILES")) : 12;
-    if (use_tr && cfg != 1 && tiles_total >= w2min * p.splits && rs_wgrad2_supported(p, dtype)) {
+    if (use_tr && cfg != 1 && (long)tiles_total >= (long)rs_wgrad2_min_tiles(-1) * p.splits && rs_wgrad2_supported(p, dtype)) {
         const int rc = rs_launch_wgrad2(p, st);
         if (rc != RS_OK) return rc;
         launch_reduce(p, st);

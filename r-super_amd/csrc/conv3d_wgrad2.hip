@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
     // cycles at the top of every tile with all matrix pipes idle: 108 of 613 us on up4.0): entry k = k-th tile of the block, entries past the
     // last tile describe "nothing to load" (every vector out of range: zeros).
     struct IssueTile { uint32_t baseb, ybase; uint32_t xbad, ybad; int n; };
-    uint4* dtab = (uint4*)(smem + 2 * BUF + p.N * 256);          // [ntile + 3] x (baseb, ybase, xbad, ybad); the sample index rides in ybad's upper half
+    uint4* dtab = (uint4*)(smem + 2 * BUF + p.N * 256);          // [ntile + 3] x (baseb, ybase, xbad, ybad); ybad uses 24 bits (4 d, 4 h, 16 w), the sample index rides in its top byte
     const int ntile = tile0 < tile_end ? (tile_end - 1 - tile0) / tstride + 1 : 0;
     for (int k = tid; k < ntile + 3; k += NT) {
         const bool live = k < ntile;
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
             return hi_ < lo ? 0u : (((2u << hi_) - 1u) & ~((1u << lo) - 1u));
         };
         const uint32_t xbad = live ? ~(range(d0 - 1, p.D, HD) | (range(h0 - 1, p.H, HH) << 6) | (range(w0 - 1, p.W, HW) << 12)) : 0xFFFFFFFFu;
-        const uint32_t ybad = live ? (~(range(d0, p.D, TD) | (range(h0, p.H, TH) << 4) | (range(w0, p.W, TW) << 8)) & 0xFFFFu) : 0xFFFFu;
+        const uint32_t ybad = live ? (~(range(d0, p.D, TD) | (range(h0, p.H, TH) << 4) | (range(w0, p.W, TW) << 8)) & 0xFFFFFFu) : 0xFFFFFFu;
         dtab[k] = make_uint4((uint32_t)(((n * p.D + d0 - 1) * p.H + (h0 - 1)) * p.W + (w0 - 1)) * xrowb,
-                             (uint32_t)(((n * p.D + d0) * p.H + h0) * p.W + w0), xbad, ybad | ((uint32_t)n << 16));
+                             (uint32_t)(((n * p.D + d0) * p.H + h0) * p.W + w0), xbad, ybad | ((uint32_t)n << 24));
     }
     auto fetch_desc = [&](int k) {                               // wave-uniform: one broadcast LDS read + readfirstlanes
         const uint4 v = dtab[k];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
         t.baseb = __builtin_amdgcn_readfirstlane(v.x); t.ybase = __builtin_amdgcn_readfirstlane(v.y);
         t.xbad = __builtin_amdgcn_readfirstlane(v.z);
         const uint32_t w = __builtin_amdgcn_readfirstlane(v.w);
-        t.ybad = w & 0xFFFFu; t.n = (int)(w >> 16);
+        t.ybad = w & 0xFFFFFFu; t.n = (int)(w >> 24);
         return t;
     };
     uint4 px[NXV];

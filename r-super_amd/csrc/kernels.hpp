@@ -75,6 +75,7 @@ int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
 // second-generation weight gradient (conv3d_wgrad2.hip): bf16, operand re-use across taps + double-buffered tiles; same slabs, the caller reduces
 bool rs_wgrad2_supported(const WgradParams& p, int dtype);
+int rs_wgrad2_min_tiles(int t);     // tiles per block from which bf16 launches take it (t < 0: query)
 int rs_launch_wgrad2(const WgradParams& p, hipStream_t st);
 // stride-2 convolution (conv3d_wgrad_s2.hip): p.N/D/H/W = the FULL-resolution grid of x, dY lives on the ((D+1)/2, (H+1)/2, (W+1)/2) grid; xb unused
 int rs_wgrad_s2_splits(int dtype, int Ca, int Mtot, int N, int D, int H, int W);

@@ -22,6 +22,7 @@ _SIGS = {
     'rsuper_conv3_pack_weights_batch': (c_int, [c_int, c_int, P, P, P, P, P, P]),
     'rsuper_conv3_tiles': (c_int, [c_int] * 3),
     'rsuper_conv3_variant': (c_int, [c_int]),
+    'rsuper_conv3_wgrad2_min_tiles': (c_int, [c_int]),
     'rsuper_conv3_box_bn': (c_int, [c_int] * 6),
     'rsuper_conv3_set_workspace': (c_int, [P, c_size_t]),
     'rsuper_conv3_workspace_bytes': (c_size_t, []),

@@ -9,6 +9,10 @@ registered as custom HIP ops behind the repo's existing model/ and training/ int
     torch.ops.rsuper.conv3(x, w) -> y                          torch.ops.rsuper.channel_norm(x, eps, relu) -> y
     torch.ops.rsuper.depthwise_conv3(x, w) -> y                torch.ops.rsuper.squeeze_excite(x, w1, b1, w2, b2) -> y
     torch.ops.rsuper.bidir_attention(fqv, mqv, heads, scale) -> (f_out, m_out)      torch.ops.rsuper.cl_planar(x, K) -> planes
+loss ops (training/losses_foundation.py; reference call sites rsuper_train/training/losses_foundation.py:945-956, 541-607, 22-99, 1387-1532):
+    torch.ops.rsuper.plane_partials(logits, x_off, xstride, planes, kinv, t, k, w1, w2) -> (sums of term 0, sums of the other terms)
+    torch.ops.rsuper.seg_from_sums(sums, cw, B, C, V, scale) -> loss
+    torch.ops.rsuper.dilate_volume(vol, kernel_size) -> vol      torch.ops.rsuper.ball_search(x, diameter, sigma) -> key   (no derivative: masks / indices)
 
 Only a "CUDA" kernel is registered: a CPU tensor reaches no kernel and raises (the product path has no CPU fallback).
 
@@ -40,6 +44,13 @@ class _Ctx:
 
     def set_materialize_grads(self, v):
         pass
+
+
+def _register_plain(name, schema, fn):
+    """Define rsuper::<name> for an operator without a derivative (uint8 masks, indices): one kernel at the CUDA key."""
+    LIB.define(name + schema)
+    LIB.impl(name, fn, 'CUDA')
+    return getattr(torch.ops.rsuper, name)
 
 
 def _register(name, schema, Fn, to_fn_args=None):
@@ -104,3 +115,29 @@ def install():
         setattr(_ops, '_' + cls, Fn)                              # the kernel pair itself stays reachable (tests, tools)
         setattr(_ops, cls, _Apply(op, adapt, Fn.__doc__))
     _ops._LIBRARY_INSTALLED = True
+
+
+def install_loss_ops(lf):
+    """Register the loss operators of training/losses_foundation.py (called at the end of that module; idempotent): the fused plane sums and
+    the segmentation loss from them with their derivatives, the ball dilation and the ball search as plain CUDA kernels."""
+    if getattr(lf, '_LIBRARY_INSTALLED', False):
+        return
+
+    def pp_to_fn(logits, x_off, xstride, planes, kinv, t, k, w1, w2):
+        return logits, [lf._Term(x_off[i], xstride[i], planes[i], t[i], k[i], w1[i], w2[i], kinv[i]) for i in range(len(planes))]
+
+    def pp_adapt(logits, terms):
+        return (logits, [tm.x_off for tm in terms], [tm.xstride for tm in terms], [tm.planes for tm in terms], [tm.kinv for tm in terms],
+                [tm.t for tm in terms], [tm.k for tm in terms], [tm.w1 for tm in terms], [tm.w2 for tm in terms])
+
+    pp = _register('plane_partials', '(Tensor logits, int[] x_off, int[] xstride, int[] planes, bool[] kinv, Tensor?[] t, Tensor?[] k, '
+                   'Tensor?[] w1, Tensor?[] w2) -> (Tensor, Tensor)', lf._PartialsFn, pp_to_fn)
+    sf = _register('seg_from_sums', '(Tensor sums, Tensor? cw, int B, int C, int V, float scale) -> Tensor', lf._SegFromSums)
+    dv = _register_plain('dilate_volume', '(Tensor vol, int kernel_size) -> Tensor', _ops.dilate_volume)
+    bs = _register_plain('ball_search', '(Tensor x, int diameter, float sigma) -> Tensor', _ops.ball_search)
+    lf._PartialsFnImpl, lf._SegFromSumsImpl = lf._PartialsFn, lf._SegFromSums
+    lf._PartialsFn = _Apply(pp, pp_adapt, lf._PartialsFnImpl.__doc__)
+    lf._SegFromSums = _Apply(sf, None, lf._SegFromSumsImpl.__doc__)
+    _ops._dilate_volume_impl, _ops._ball_search_impl = _ops.dilate_volume, _ops.ball_search
+    _ops.dilate_volume, _ops.ball_search = dv, bs
+    lf._LIBRARY_INSTALLED = True

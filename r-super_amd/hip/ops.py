@@ -1099,6 +1099,19 @@ class DepthwiseConvFn(torch.autograd.Function):
         return dx, dw
 
 
+def ball_search(x, diameter, sigma):
+    """Gaussian-ball correlation of a non-negative (D, H, W) f32 map with the ball kernel of odd `diameter` + first arg-max
+    (training/losses_foundation.py:1435-1446: F.conv3d + torch.argmax): returns an int64[1] key on the device, value bits in the upper and
+    0xFFFFFFFF - linear index in the lower half.  Separable two-stage form from diameter 5 (k^2 gathers per voxel instead of k^3 taps)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()
+    D, H, W = x.shape
+    best = torch.zeros(1, device=x.device, dtype=torch.int64)
+    ws = (torch.empty((_L().rsuper_ball_workspace_floats(D, H, W, int(diameter)),), device=x.device, dtype=torch.float32)
+          if (diameter >= 5 and os.environ.get('RSUPER_BALL_DIRECT', '0') != '1') else None)
+    _l.check(_L().rsuper_ball_conv_argmax(_ptr(x), D, H, W, int(diameter), float(sigma), _ptr(best), None, _ptr(ws), _stream()), 'ball_conv_argmax')
+    return best
+
+
 def dilate_volume(vol_u8, kernel_size):
     """dilate_volume (training/losses_foundation.py:22-46) on a uint8 0/1 tensor (..., D, H, W)."""
     v = vol_u8.contiguous()

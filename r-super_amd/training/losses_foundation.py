@@ -274,12 +274,7 @@ def isolate_tumor(x, diameter, gaussian, gaussian_std, tumor_volume, diameter_ma
     D, H, W = x.shape
     V = x.numel()
     diameter, vol, ks = _isolate_params(diameter, tumor_volume, V, volume_margin)
-    best = torch.zeros(1, device=x.device, dtype=torch.int64)
-    # separable two-stage correlation (k^2 gathers per voxel instead of k^3 taps); direct form for tiny balls
-    ws = (torch.empty((_L().rsuper_ball_workspace_floats(D, H, W, diameter),), device=x.device, dtype=torch.float32)
-          if (diameter >= 5 and os.environ.get('RSUPER_BALL_DIRECT', '0') != '1') else None)
-    _l.check(_L().rsuper_ball_conv_argmax(_ptr(x), D, H, W, diameter, float(gaussian_std * (diameter / 2.0)), _ptr(best), None, _ptr(ws), _stream()),
-              'ball_conv_argmax')
+    best = ops.ball_search(x, diameter, float(gaussian_std * (diameter / 2.0)))      # rsuper::ball_search (separable two-stage correlation + arg-max)
     key = int(best.item()) & 0xFFFFFFFFFFFFFFFF
     idx = 0xFFFFFFFF - (key & 0xFFFFFFFF)
     center = np.unravel_index(idx, (D, H, W))
@@ -333,11 +328,7 @@ def isolate_tumor_spec(x, diameter, gaussian_std, tumor_volume, checks, diameter
     if min(ks) <= 0 or os.environ.get('RSUPER_TOPK_HOST', '0') == '1':
         return None
     import ctypes
-    best = torch.zeros(1, device=x.device, dtype=torch.int64)
-    ws = (torch.empty((_L().rsuper_ball_workspace_floats(D, H, W, diameter),), device=x.device, dtype=torch.float32)
-          if (diameter >= 5 and os.environ.get('RSUPER_BALL_DIRECT', '0') != '1') else None)
-    _l.check(_L().rsuper_ball_conv_argmax(_ptr(x), D, H, W, diameter, float(gaussian_std * (diameter / 2.0)), _ptr(best), None, _ptr(ws), _stream()),
-              'ball_conv_argmax')
+    best = ops.ball_search(x, diameter, float(gaussian_std * (diameter / 2.0)))
     d_odd, kedge = ball_kernel_geometry(diameter * (1 + diameter_margin))
     ball = torch.empty((D, H, W), device=x.device, dtype=torch.uint8)
     cnts = torch.zeros(2, device=x.device, dtype=torch.int32)          # [ball voxels, voxels of the top-k mask inside the ball]
@@ -793,3 +784,9 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         raise ValueError('loss is nan, propagating this can destroy the network weights, STOP!')
     assert overall.requires_grad, 'Loss overall should require grad'
     return loss
+
+
+# the loss operators as dispatcher ops rsuper::plane_partials / seg_from_sums / dilate_volume / ball_search (hip/library.py)
+if os.environ.get('RSUPER_NO_TORCH_LIBRARY', '0') != '1':
+    from ..hip import library as _library
+    _library.install_loss_ops(__import__(__name__, fromlist=['_']))

@@ -1096,6 +1096,45 @@ def with_variant(variant, fn, *a):
     return r
 
 
+def with_wgrad2(fn, *a):
+    """Run a check with EVERY supported bf16 weight gradient on the second-generation kernel (csrc/conv3d_wgrad2.hip), whatever the number of tiles
+    per block (the default takes it from 12 tiles per block: the small test volumes would never reach it)."""
+    from rsuper_amd.hip import ops
+    L = ops._L()
+    old = L.rsuper_conv3_wgrad2_min_tiles(-1)
+    L.rsuper_conv3_wgrad2_min_tiles(0)
+    try:
+        r = fn(*a)
+    finally:
+        L.rsuper_conv3_wgrad2_min_tiles(old)
+    r['name'] = f"wgrad2:{r['name']}"
+    return r
+
+
+def check_wgrad_sliced_dy(N, S, Ca, Cout, seed=0):
+    """Weight gradient with the two dY sources given as channel slices of ONE tensor (ld = 2 Cout, the layout the zero-stuffed evaluation of the strided
+    block and BasicBlockFn's [dY1 | dOut] use) and a normalised x source, against the float64 gradient on the bf16 operands the kernel sees."""
+    from rsuper_amd.hip import ops
+    D, H, W = S
+    dt = torch.bfloat16
+    xa = rnd(_rng_t(seed + 1, (N, Ca, D, H, W)) + 0.3, 'bf16')
+    mr = stats_ref(xa)
+    xh = torch.relu((xa.double() - mr[:, :, 0].double()[:, :, None, None, None]) * mr[:, :, 1].double()[:, :, None, None, None]).float().bfloat16().double()
+    dy = _rng_t(seed + 6, (N, 2 * Cout, D, H, W)).bfloat16()
+    refs = []
+    for part in (dy[:, :Cout], dy[:, Cout:]):
+        w = torch.zeros((Cout, Ca, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+        F.conv3d(xh, w, padding=1).backward(part.double())
+        refs.append(w.grad.float())
+    dfull = to_cl(dy.float(), dt)
+    dw1 = torch.full((Cout, Ca, 3, 3, 3), float('nan'), device=DEV)
+    dw2 = torch.full((Cout, Ca, 3, 3, 3), float('nan'), device=DEV)
+    ops.wgrad(ops.Src(to_cl(xa, dt), mr=mr.to(DEV)), None, ops.Src(dfull, C=Cout), ops.Src(dfull, C=Cout, off=Cout), dw1, dw2, (N, D, H, W))
+    torch.cuda.synchronize()
+    e = max(relerr(dw1.cpu(), refs[0]), relerr(dw2.cpu(), refs[1]))
+    return result(f'wgrad_sliced_dy[bf16 N{N} S{S} {Ca}->2x{Cout}]', e, 3e-3, f'dw {e:.2e}')
+
+
 def all_checks(quick=False):
     cs = []
     for mode in ('f32', 'bf16'):
@@ -1138,6 +1177,15 @@ def all_checks(quick=False):
            (check_wgrad_xhat, (2, (8, 12, 20), 64, 32, 64, 64, 3)), (check_wgrad_xhat, (1, (7, 9, 35), 40, 0, 24, 0, 4)), (check_wgrad_xhat, (2, (16, 16, 64), 32, 32, 32, 32, 5)),
            (check_wgrad_xhat, (2, (24, 24, 48), 32, 0, 32, 0, 6)), (check_wgrad_xhat, (1, (16, 32, 64), 64, 0, 64, 0, 7)), (check_wgrad_xhat, (2, (12, 12, 12), 128, 0, 128, 0, 8)),
            (check_wgrad_xhat, (3, (6, 6, 6), 32, 0, 96, 32, 9)), (check_wgrad_xhat, (1, (2, 3, 5), 8, 0, 8, 0, 10))]
+    # the second-generation weight gradient on every bf16 backward case and on the pre-normalised ones (the default dispatch needs >= 12 tiles per block)
+    cs += [(with_wgrad2, (fn,) + a) for fn, a in list(cs) if fn in (check_conv_bwd, check_wgrad_xhat) and (fn is check_wgrad_xhat or a[0] == 'bf16')]
+    cs += [(with_wgrad2, (check_conv_bwd, 'bf16', 2, (16, 16, 64), 32, 32, 64, True)), (with_wgrad2, (check_conv_bwd, 'bf16', 1, (16, 32, 64), 64, 0, 64, False)),
+           (with_wgrad2, (check_conv_bwd, 'bf16', 2, (24, 24, 48), 32, 0, 32, False)),
+           (check_wgrad_sliced_dy, (1, (23, 23, 23), 64, 128)), (with_wgrad2, (check_wgrad_sliced_dy, 1, (23, 23, 23), 64, 128)),
+           (with_wgrad2, (check_wgrad_sliced_dy, 2, (9, 10, 19), 32, 32, 1)), (check_wgrad_sliced_dy, (1, (47, 47, 47), 64, 128, 2)),
+           # last w tile with its first invalid voxel at positions 8 .. 15 (W mod 16 >= 8: the validity bits of the upper half of a tile row), several tiles per block
+           (with_wgrad2, (check_wgrad_sliced_dy, 1, (9, 9, 31), 64, 128, 3)), (with_wgrad2, (check_wgrad_sliced_dy, 2, (6, 7, 25), 32, 32, 4)),
+           (with_wgrad2, (check_wgrad_sliced_dy, 2, (10, 12, 47), 128, 128, 5)), (with_wgrad2, (check_wgrad_xhat, 2, (11, 9, 29), 64, 64, 64, 64, 11))]
     for m in ('f32', 'bf16'):           # strided weight gradient: even / odd / ragged sizes, one and two dy sources, channel tails, several tiles per split
         cs += [(check_wgrad_s2, (m, 1, (8, 8, 32), 32, 32, 0)), (check_wgrad_s2, (m, 2, (12, 10, 20), 16, 32, 32)), (check_wgrad_s2, (m, 1, (7, 9, 35), 8, 16, 16)),
                (check_wgrad_s2, (m, 2, (5, 17, 66), 40, 24, 24)), (check_wgrad_s2, (m, 1, (2, 3, 5), 8, 8, 8)), (check_wgrad_s2, (m, 3, (24, 24, 24), 64, 128, 128))]

@@ -252,3 +252,15 @@ def test_ops_are_registered_with_the_dispatcher():
     with pytest.raises(NotImplementedError):
         torch.ops.rsuper.maxpool2(torch.zeros(1, 2, 2, 2, 8))
     assert ops.MaxPoolFn.apply.__self__.op is torch.ops.rsuper.maxpool2          # the modules' call sites go through the dispatcher
+    # ... and the loss operators (training/losses_foundation.py): fused plane sums + segmentation loss with derivatives, dilation + ball search without
+    from rsuper_amd.training import losses_foundation as lf
+    for n, autograd in [('plane_partials', True), ('seg_from_sums', True), ('dilate_volume', False), ('ball_search', False)]:
+        schema = getattr(torch.ops.rsuper, n).default._schema
+        assert schema.name == f'rsuper::{n}'
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f'rsuper::{n}', 'CUDA')
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f'rsuper::{n}', 'AutogradCUDA') == autograd
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f'rsuper::{n}', 'CPU')
+    assert lf._PartialsFn.op is torch.ops.rsuper.plane_partials and lf._SegFromSums.op is torch.ops.rsuper.seg_from_sums
+    assert ops.dilate_volume is torch.ops.rsuper.dilate_volume and ops.ball_search is torch.ops.rsuper.ball_search
+    with pytest.raises(NotImplementedError):
+        ops.dilate_volume(torch.zeros(4, 4, 4, dtype=torch.uint8), 3)
