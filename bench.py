@@ -69,40 +69,43 @@ def loss_args(report):
 
 
 def cpu_baseline(args, classes):
-    """Oracle (CPU restatement of the reference, kind='port') timed on the host cores on a bounded sample: one complete
-    training step (fwd + seg loss + bwd + clip + AdamW + EMA) at B=1 after a small warm-up step that pages the ATen CPU
-    kernels in."""
+    """Oracle (CPU restatement of the reference, kind='port') timed on the host cores as BASELINE.md section 3 prescribes: the complete training
+    step of train_epoch (train_ddp.py:308-357: zero_grad, forward, seg loss, backward, clip, AdamW, EMA) on the bench's own configuration (batch
+    `--batch`, `--size`^3, base, classes) with the batch resident in memory, one warm-up step of the same shape, then >= 3 timed steps."""
     from oracle import unet_oracle as uo, losses_oracle as lo, train_oracle as to
     import synth
     ncores = min(os.cpu_count(), 32)      # ATen CPU conv3d stops scaling (and thrashes) far below 256 threads
     torch.set_num_threads(ncores)
     la = loss_args(False)
+    B, S, base, nsteps = args.batch, args.size, args.base, max(3, args.cpu_baseline_steps)
+    shapes = uo.unet_param_shapes(1, base, len(classes))
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes, 3).items()}
+    params = list(sd.values())
+    ema = [p.detach().clone() for p in params]
+    opt = to.AdamW([p.detach() for p in params], lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
+    img = torch.from_numpy(synth.image(B, S, seed=1234))
+    bt = {k: torch.from_numpy(v) for k, v in synth.batch(B, S, classes, ['mask'] * B, seed=7).items()}
 
-    def step(B, S, base):
-        shapes = uo.unet_param_shapes(1, base, len(classes))
-        sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes, 3).items()}
-        params = list(sd.values())
-        ema = [p.detach().clone() for p in params]
-        opt = to.AdamW([p.detach() for p in params], lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
-        img = torch.from_numpy(synth.image(B, S, seed=1234))
-        bt = synth.batch(B, S, classes, ['mask'] * B, seed=7)
+    def step(i):
         t0 = time.time()
+        for p_ in params:
+            p_.grad = None
         r = uo.unet_forward(sd, img)
-        res = lo.calculate_loss({'segmentation': r}, torch.from_numpy(bt['label']), torch.from_numpy(bt['unk_channels']), la,
-                                torch.from_numpy(bt['mask']), torch.from_numpy(bt['volumes']), torch.from_numpy(bt['diameters']), classes)
+        res = lo.calculate_loss({'segmentation': r}, bt['label'], bt['unk_channels'], la, bt['mask'], bt['volumes'], bt['diameters'], classes)
         res['overall'].backward()
-        grads = [p.grad for p in params]
+        grads = [p_.grad for p_ in params]
         with torch.no_grad():
             to.clip_grad_norm_(grads, 1.0)
             opt.step(grads)
-            to.update_ema(opt.params, ema, 0.99, 0)
+            to.update_ema(opt.params, ema, 0.99, i)
         return time.time() - t0
-    step(1, 32, 8)                         # warm-up (thread pool, oneDNN primitives)
-    B, S = 1, args.size
-    dt = step(B, S, args.base)
+    t_warm = step(0)
+    ts = [step(i + 1) for i in range(nsteps)]
+    dt = sum(ts) / len(ts)
     return {'value': B * S ** 3 / dt, 'unit': 'voxels/s', 'cores': ncores, 'kind': 'port',
-            'sample': f'1 full training step (fwd + seg loss + bwd + clip + AdamW + EMA) of the fp32 torch-CPU oracle after a 32^3 warm-up '
-                      f'step, B={B}, {S}^3, base {args.base}, {len(classes)} classes, {ncores} threads, {dt:.1f} s'}
+            'sample': f'{nsteps} timed full training steps (fwd + seg loss + bwd + clip + AdamW + EMA) of the fp32 torch-CPU oracle after 1 warm-up step of the '
+                      f'same shape, B={B}, {S}^3, base {base}, {len(classes)} classes, {ncores} threads: mean {dt:.1f} s/step '
+                      f'(min {min(ts):.1f}, max {max(ts):.1f}, warm-up {t_warm:.1f})'}
 
 
 def respawn_under_torchrun(args):
@@ -153,10 +156,16 @@ class Leg:
         self.world = world
         self.last = None
         self.graphed = None
+        self.sanity = False
 
     def run(self, n):
         from rsuper_amd.train_ddp import train_step
         for _ in range(n):
+            if self.sanity:        # the reference's per-step guards, as train_epoch runs them (train_ddp.py:311-313; the loss's own at losses_foundation.py:864-869, 1070-1071)
+                img = self.batch['image']
+                assert not torch.isnan(img).any(), 'Input is nan'
+                assert torch.max(img) <= 100, f'Input is bigger than 100: {torch.max(img)}'
+                assert torch.min(img) >= -100, f'Input is smaller than -100: {torch.min(img)}'
             if self.graphed is not None:
                 self.last = self.graphed(self.batch, self.step)
             else:
@@ -227,6 +236,21 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         sec['config3_final_loss'] = l3.loss()
         sec['config3_workload'] = 'same UNet + Volume + Ball report losses (ball_dice_both, weight 0.1, 50/50 mask/report batch), BASELINE configs[2]'
         l3.close()
+
+    def sanity_on():
+        # the headline step with the reference's per-step guards active (input NaN / range asserts, the mask / volume consistency checks and the
+        # NaN guard on the loss): each is a device -> host read that drains the launch queue; the headline keeps them outside the timed region
+        from rsuper_amd.training import losses_foundation as lf
+        ls = leg_of(args.dtype, False)
+        ls.sanity = True
+        lf.SANITY_CHECKS = True
+        try:
+            sec['sanity_on_ms_per_step'] = ls.timed(n2, w2) / n2 * 1e3
+            sec['sanity_on_note'] = ('headline workload with SANITY_CHECKS on: isnan / max / min of the input (train_ddp.py:311-313), unk / volume consistency '
+                                     '(losses_foundation.py:864-869) and the loss NaN guard that raises (:1070-1071) inside every timed step')
+        finally:
+            lf.SANITY_CHECKS = False
+        ls.close()
 
     def graph():
         # the same step replayed from a hipGraph (one host launch per step instead of ~330); results are bit-identical to the eager step
@@ -326,6 +350,7 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         lf32.close()
 
     if not args.report:
+        guarded('sanity_on', sanity_on)
         guarded('config3', config3)
         guarded('graph', graph)
         if args.base == 32:
@@ -347,6 +372,7 @@ def main():
     ap.add_argument('--batch', type=int, default=2, help='per-GPU batch (bs=2/GPU in BASELINE.json)')
     ap.add_argument('--base', type=int, default=32)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--cpu-baseline-steps', type=int, default=3, help='timed CPU steps of the baseline leg (>= 3, BASELINE.md section 3)')
     ap.add_argument('--report', action='store_true', help='config 3: report supervision on (ball_dice_both, 50/50 mask/report batch)')
     ap.add_argument('--no-pool', action='store_true', help="variant (not the headline): down_block(pool=False) -- the strided BasicBlock members (SURVEY 8 row g)")
     ap.add_argument('--no-cpu-baseline', action='store_true')

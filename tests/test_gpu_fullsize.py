@@ -373,7 +373,7 @@ def test_report_loss_fullsize_matches_reference_and_oracle(tag):
     ores = lo.calculate_loss({'segmentation': a2}, T(bt['label']), T(bt['unk_channels']), args, T(bt['mask']), T(bt['volumes']), T(bt['diameters']), classes)
     ores['overall'].backward()
     for k, v in res.items():
-        assert abs(float(v.detach()) - float(ores[k])) <= 1e-4, (k, float(v.detach()), float(ores[k]))
+        assert abs(float(v.detach()) - float(ores[k].detach())) <= 1e-4, (k, float(v.detach()), float(ores[k].detach()))
     og = a2.grad.numpy()
     assert np.abs(grad - og).max() <= 1e-4 * np.abs(og).max(), float(np.abs(grad - og).max() / np.abs(og).max())
     _, _, debug = lo.ball_loss(T(lg), T(bt['label']).float(), T(bt['unk_channels']).float(), T(bt['mask']).float(), T(bt['volumes']), T(bt['diameters']),
