@@ -140,6 +140,11 @@ int rsuper_conv3_wgrad_partial(int dtype, int use_tr, const void* xa, int lda, i
                                const void* ya, int ldya, int Ya, const void* yb, int ldyb, int Yb,
                                float* workspace, int N, int D, int H, int W, int splits, void* stream);
 int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Ya, int Yb, float* dwa, float* dwb, void* stream);
+/* _reduce for n weight gradients in ONE launch (arrays of length n: the workspaces written by _partial, their splits, Cin = Ca + Cb, Ya, Yb and the
+ * destinations): the per-layer reduction is a ~10 us launch at the dependent-launch floor and the hot loop has 34 of them per step
+ * (loss.backward(), train_ddp.py:349 -- every nn.Conv3d weight gradient); nothing but the optimiser / the gradient exchange reads dW. */
+int rsuper_conv3_wgrad_reduce_batch(int n, const void* const* workspaces, const int* splits, const int* Cin, const int* Ya, const int* Yb,
+                                    void* const* dwa, void* const* dwb, void* stream);
 
 /* Weight gradient of the STRIDED member (Conv3d(k=3, stride=2, pad=1): BasicBlock(stride=2) conv1 + shortcut of down_block(pool=False),
  * unet_utils.py:18-33, conv_layers.py:60-94):  dW[co][ci][t] = sum_o dy[o][co] * x_hat[2o + t - 1][ci].

@@ -291,6 +291,24 @@ int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Y
     return rs_launch_wgrad_reduce(p, ST(stream));
 }
 
+int rsuper_conv3_wgrad_reduce_batch(int n, const void* const* workspaces, const int* splits, const int* Cin, const int* Ya, const int* Yb,
+                                     void* const* dwa, void* const* dwb, void* stream) {
+    if (n < 0 || (n > 0 && (!workspaces || !splits || !Cin || !Ya || !Yb || !dwa || !dwb))) return RS_ERR_ARG;
+    for (int i0 = 0; i0 < n; i0 += RS_REDUCE_BATCH_MAX) {
+        ReduceBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n - i0 < RS_REDUCE_BATCH_MAX ? n - i0 : RS_REDUCE_BATCH_MAX;
+        for (int j = 0; j < b.n; ++j) {
+            const int i = i0 + j;
+            if (!workspaces[i] || splits[i] <= 0 || Cin[i] <= 0 || (Cin[i] % 8) || Ya[i] <= 0 || Yb[i] < 0 || !dwa[i] || (Yb[i] > 0 && !dwb[i])) return RS_ERR_ARG;
+            b.e[j] = {(const float*)workspaces[i], (float*)dwa[i], (float*)dwb[i], splits[i], Ya[i] + Yb[i], Ya[i], Cin[i], 0u};
+        }
+        const int rc = rs_launch_wgrad_reduce_batch(b, ST(stream));
+        if (rc) return rc;
+    }
+    return RS_OK;
+}
+
 int rsuper_conv3_wgrad_s2_splits(int dtype, int Ca, int Mtot, int N, int FD, int FH, int FW) {
     if (!dt_ok(dtype) || Ca <= 0 || Mtot <= 0 || N <= 0 || FD <= 0 || FH <= 0 || FW <= 0) return -1;
     return rs_wgrad_s2_splits(dtype, Ca, Mtot, N, FD, FH, FW);

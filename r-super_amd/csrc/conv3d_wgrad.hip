@@ -419,6 +419,81 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
     for (int i = threadIdx.x; i < nc * 27; i += 256) dst[i] = tile[i];
 }
 
+// Both reductions above for a LIST of weight gradients in one launch: block -> (entry, block index inside the entry); entries with at least 16
+// slabs take the element-parallel form (8 split groups), the others the row form.  Sums are formed in exactly the order of the single-entry
+// kernels of the same form (bit-identical results for < 16 and for 16 .. 127 slabs; >= 128 slabs sum in 8 instead of 32 groups).
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(ReduceBatch b) {
+    __shared__ float4 part[8][32];
+    __shared__ float tile[64 * 27 + 64];
+    int ei = 0;
+    for (int i = 1; i < b.n; ++i) ei = blockIdx.x >= b.e[i].blk_start ? i : ei;      // entries are few: linear scan in scalar registers
+    const ReduceBatch::Entry& en = b.e[ei];
+    const unsigned blk = blockIdx.x - en.blk_start;
+    const float* __restrict__ ws = en.ws;
+    const int splits = en.splits, Mtot = en.Mtot, Ya = en.Ya, Cin = en.Cin;
+    const size_t E = (size_t)27 * Mtot * Cin;
+    if (splits >= 16) {
+        constexpr int SG = 8, UN = 8;
+        const int el = threadIdx.x & 31, sg = threadIdx.x >> 5;
+        const size_t e = ((size_t)blk * 32 + el) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < E) {
+            for (int s0 = sg; s0 < splits; s0 += SG * UN) {
+                float4 v[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int s = s0 + u * SG;
+                    v[u] = s < splits ? *(const float4*)(ws + (size_t)s * E + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+        }
+        part[sg][el] = acc;
+        __syncthreads();
+        if (sg == 0 && e < E) {
+            float4 v = part[0][el];
+#pragma unroll
+            for (int k = 1; k < SG; ++k) { const float4 t = part[k][el]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            const int c = (int)(e % Cin);
+            const size_t r = e / Cin;
+            const int m = (int)(r % Mtot), tap = (int)(r / Mtot);
+            float* dst = (m < Ya ? en.dwa + ((size_t)m * Cin + c) * 27 : en.dwb + ((size_t)(m - Ya) * Cin + c) * 27) + tap;
+            dst[0] = v.x; dst[27] = v.y; dst[54] = v.z; dst[81] = v.w;
+        }
+        return;
+    }
+    const int cchunks = (Cin + 63) / 64;
+    const int m = blk / cchunks, c0 = (blk % cchunks) * 64;
+    const int nc = min(64, Cin - c0);
+    constexpr int NI = (27 * 64 + 255) / 256;
+    float a[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) a[q] = 0.f;
+    for (int s0 = 0; s0 < splits; s0 += 4) {
+        float v[NI][4];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int i = threadIdx.x + q * 256;
+            const int tap = i >> 6, c = i & 63;
+            const bool ok = i < 27 * 64 && c < nc;
+            const size_t e = ((size_t)(ok ? tap : 0) * Mtot + m) * Cin + c0 + (ok ? c : 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[q][u] = (ok && s0 + u < splits) ? ws[(size_t)(s0 + u) * E + e] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NI; ++q) a[q] += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+    }
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        const int i = threadIdx.x + q * 256;
+        if (i < 27 * 64) tile[(i & 63) * 27 + (i >> 6)] = a[q];
+    }
+    __syncthreads();
+    float* dst = m < Ya ? en.dwa + ((size_t)m * Cin + c0) * 27 : en.dwb + ((size_t)(m - Ya) * Cin + c0) * 27;
+    for (int i = threadIdx.x; i < nc * 27; i += 256) dst[i] = tile[i];
+}
+
 static bool g_skip_reduce = false;                               // set by rs_launch_wgrad for the duration of one launch call
 static void launch_reduce_now(const WgradParams& p, hipStream_t st);
 static void launch_reduce(const WgradParams& p, hipStream_t st) { if (!g_skip_reduce) launch_reduce_now(p, st); }
@@ -482,6 +557,20 @@ int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total) {
     int s = target / (nch * gy > 0 ? nch * gy : 1);
     if (s > tiles_total) s = tiles_total;
     return s < 1 ? 1 : s;
+}
+
+int rs_launch_wgrad_reduce_batch(ReduceBatch& b, hipStream_t st) {
+    if (b.n <= 0) return RS_OK;
+    unsigned blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+        ReduceBatch::Entry& e = b.e[i];
+        e.blk_start = blocks;
+        const size_t elems = (size_t)27 * e.Mtot * e.Cin;
+        blocks += e.splits >= 16 ? (unsigned)((elems + 127) / 128) : (unsigned)(e.Mtot * ((e.Cin + 63) / 64));
+    }
+    b.blocks = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
+    return rs_check_launch();
 }
 
 int rs_wgrad2_min_tiles(int t) {

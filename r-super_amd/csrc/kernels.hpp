@@ -72,6 +72,14 @@ int rs_token_attn_supported(int L, int Dh);
 int rs_launch_token_attn(const float* qkv, float* o, float* p, const float* d_o, float* d_qkv, int B, int L, int H, int Dh, float scale, hipStream_t st);
 int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st, bool reduce = true);
 int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st);
+// slab reductions of several weight gradients in ONE launch (the per-layer reduce is a ~10 us launch at the dependent-launch floor, 34 per step)
+#define RS_REDUCE_BATCH_MAX 48
+struct ReduceBatch {
+    int n;
+    struct Entry { const float* ws; float* dwa; float* dwb; int splits, Mtot, Ya, Cin; unsigned blk_start; } e[RS_REDUCE_BATCH_MAX];
+    unsigned blocks;
+};
+int rs_launch_wgrad_reduce_batch(ReduceBatch& b, hipStream_t st);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
 // second-generation weight gradient (conv3d_wgrad2.hip): bf16, operand re-use across taps + double-buffered tiles; same slabs, the caller reduces
 bool rs_wgrad2_supported(const WgradParams& p, int dtype);

@@ -382,9 +382,43 @@ def reduce_side_enabled():
     return os.environ.get('RSUPER_WGRAD_REDUCE_SIDE', '0') == '1'
 
 
-def wgrad(xa, xb, ya, yb, dwa, dwb, dims, side_reduce=False):
+# Deferred slab reductions: the two weight gradients of a BasicBlock's backward (conv2; conv1 + shortcut) only write their per-split slabs, and ONE
+# batched launch at the end of the block's backward sums both -- the per-layer reduction is a ~10 us launch at the dependent-launch floor (34 per UNet
+# step).  Deferring ALL of them to the end of the backward pass was measured too (one launch of 333 us instead of 34 x 11 us: the 1.5 GB of slabs
+# are then read cold from HBM instead of hot from L2 / Infinity Cache -- no gain, and the slabs stay allocated), hence per block.
+# RSUPER_WGRAD_DEFER=0 restores the per-layer launches.
+_DEFERRED = []
+DEFER_WGRAD_REDUCE = os.environ.get('RSUPER_WGRAD_DEFER', '1') == '1'
+
+
+def flush_wgrad_reduces():
+    """Sum the slabs of every weight gradient whose reduction was deferred (one launch on the current stream).  Idempotent."""
+    if not _DEFERRED:
+        return
+    import ctypes
+    ents = list(_DEFERRED)
+    del _DEFERRED[:]
+    n = len(ents)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    args = (n, PA(*[_ptr(e[0]) for e in ents]), IA(*[e[1] for e in ents]), IA(*[e[2] for e in ents]), IA(*[e[3] for e in ents]),
+            IA(*[e[4] for e in ents]), PA(*[_ptr(e[5]) for e in ents]), PA(*[_ptr(e[6]) for e in ents]))
+
+    def run():
+        _l.check(_L().rsuper_conv3_wgrad_reduce_batch(*args, _stream()), 'conv3_wgrad_reduce_batch')
+    if TIMER is not None:
+        TIMER.launch('conv3d_wgrad_reduce', 0.0, run)
+    else:
+        run()
+
+
+def _defer_reduce(ws, splits, Cin_t, Ya, Yb, dwa, dwb):
+    _DEFERRED.append((ws, splits, Cin_t, Ya, Yb, dwa, dwb))
+
+
+def wgrad(xa, xb, ya, yb, dwa, dwb, dims, side_reduce=False, defer=False):
     """side_reduce (only from inside an autograd backward, where the join callback can be queued): partial slabs on the current
-    stream, their reduction into dwa / dwb on the side stream."""
+    stream, their reduction into dwa / dwb on the side stream.  defer: partial slabs now, the reduction in the batched launch of the caller's
+    flush_wgrad_reduces() (before dwa / dwb leave the caller)."""
     dt = _DT[xa.t.dtype]
     N, D, H, W = dims
     Mtot = ya.C + (yb.C if yb is not None else 0)
@@ -395,6 +429,17 @@ def wgrad(xa, xb, ya, yb, dwa, dwb, dims, side_reduce=False):
     ws = torch.empty((splits * 27 * Mtot * Cin_t,), device=dwa.device, dtype=torch.float32)
     flops = 2.0 * N * D * H * W * Mtot * Cin_t * 27
 
+    if defer and not side_reduce:
+        def run_partial_only():
+            _l.check(_L().rsuper_conv3_wgrad_partial(dt, use_tr(), *xa.args(), *(xb.args() if xb is not None else _NONE),
+                                                     _ptr(ya.t, ya.off), ya.ld, ya.C, *yb_args, _ptr(ws), N, D, H, W, splits, _stream()),
+                     'conv3_wgrad_partial')
+        if TIMER is not None:
+            TIMER.launch('conv3d_wgrad', flops, run_partial_only)
+        else:
+            run_partial_only()
+        _defer_reduce(ws, splits, Cin_t, ya.C, yb.C if yb is not None else 0, dwa, dwb)
+        return
     if not side_reduce:
         def run():
             _l.check(_L().rsuper_conv3_wgrad(dt, use_tr(), *xa.args(), *(xb.args() if xb is not None else _NONE),
@@ -639,7 +684,7 @@ class BasicBlockFn(torch.autograd.Function):
         sr = reduce_side_enabled() and fresh and not ov
         dw2 = grad_dest(w2)
         with _Side(ov, (ys, mr_y1, dout, dw2)):
-            wgrad(y1, None, sdo, None, dw2, None, dims, side_reduce=sr)
+            wgrad(y1, None, sdo, None, dw2, None, dims, side_reduce=sr, defer=DEFER_WGRAD_REDUCE and not ov)
         dy1 = in_bwd_finalize(Src(g1), y1, gm1, Cout)
         # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
         sa = Src(xa, mr=mra)
@@ -652,13 +697,14 @@ class BasicBlockFn(torch.autograd.Function):
         dw1 = grad_dest(w1)
         dws = grad_dest(ws) if has_sc else None
         with _Side(ov, (xa, mra, xb, mrb, dy1, dout, dw1, dws)):
-            wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims, side_reduce=sr)
+            wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims, side_reduce=sr, defer=DEFER_WGRAD_REDUCE and not ov)
         if xb is None:
             dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca, add1=None if has_sc else dout)
             dxb = None
         else:
             dxa = in_bwd_finalize(Src(g0, C=Ca), sa, gm0[0], Ca)
             dxb = in_bwd_finalize(Src(g0, C=Cb, off=Ca), sb, gm0[1], Cb)
+        flush_wgrad_reduces()                 # both weight gradients of the block: one reduction launch, slabs still hot in L2
         if (ov or sr) and _join_per_block():
             join_side()
         return dxa, None, dxb, None, dw1, dw2, dws, None, None

@@ -335,3 +335,8 @@ def fullsize_report_case(tag):
 
 
 FULLSIZE_REPORT_CASES = ['bench96', 'full96_d40']
+
+
+# two data-parallel ranks of the tiny training step, each on its own batch (tests/golden/gen_golden_ddp.py)
+def ddp_rank_batch(rank, S=32):
+    return image(2, S, seed=4321 + rank), batch(2, S, TINY_CLASSES, ['mask', 'report'], seed=7 + rank, diam_range=(5.0, 9.0), max_tumors=2)

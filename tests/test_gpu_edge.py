@@ -412,6 +412,22 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert d['value'] > 0 and np.isfinite(d['config']['final_loss'])
 
 
+def test_two_ranks_match_two_reference_ranks_averaged():
+    """N-GPU parity = N independent reference ranks averaged.  Two ranks (one process each, sharing this GPU through gloo) run
+    the HIP forward / loss / backward of the tiny UNet on their own batches under wrap_ddp; after GradReducer.finish() every parameter gradient equals
+    the mean of the unmodified reference's two ranks (tests/golden/ddp2.npz) and each rank's loss values equal its reference rank's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSUPER_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29575', os.path.join(root, 'tests', 'ddp_fixture_gpu_worker.py')], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert 'DDP_FIXTURE_GPU_OK' in r.stdout
+
+
 @pytest.mark.gpu
 def test_bench_self_spawns_two_ranks():
     """`python bench.py --gpus 2` with NO launcher environment (how the driver ran N = 1 in round 1): bench.py re-executes

@@ -223,6 +223,18 @@ def test_grad_reducer_world2_gloo_cpu():
     assert 'REDUCER_OK' in r.stdout
 
 
+def test_ddp_world2_matches_two_reference_ranks_averaged():
+    """SURVEY.md section 8(e) parity definition: "N independent reference ranks averaged".  Two gloo ranks run the tiny training step on their OWN
+    batches (oracle as the model on CPU), the product's GradReducer exchanges the gradients, and every parameter's exchanged gradient equals the
+    mean of the UNMODIFIED reference's two ranks (tests/golden/ddp2.npz from gen_golden_ddp.py; train_ddp.py:623-668, sampler.py:132)."""
+    script = os.path.join(ROOT, 'tests', 'ddp_fixture_gloo_worker.py')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29545', OMP_NUM_THREADS='4')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29545', script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'DDP_FIXTURE_OK' in r.stdout
+
+
 def test_graph_gradient_exchange_world2_gloo_cpu():
     """rsuper_amd.graph.exchange_gradients (what GraphedNetwork runs after its backward replay in a distributed run) on two gloo ranks:
     in-place mean over several flat buckets."""
