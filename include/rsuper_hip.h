@@ -241,6 +241,14 @@ int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, 
  * dice = TP / (TP + alpha FP + (1-alpha) FN + 1e-5), mean over (b, c) of (1 - dice) * cw).  sums f32 [B*C][6] as produced
  * by rsuper_plane_partials_fwd (cast to f32); cw [B*C] or NULL; dsums [B*C][6] receives d loss / d sums. */
 int rsuper_seg_from_sums(const float* sums, const float* cw, int B, int C, size_t V, double scale, float* loss, float* dsums, void* stream);
+/* The report terms of calculate_loss from the (R, 6) sums rsuper_plane_partials_fwd produced for them, with their Jacobians, without leaving the
+ * device: dice_volume_loss (volume_loss_basic :250-349 with dice_based_volume_loss :352-395) from the first L*B rows (row li*B + b; flags[b][2L] =
+ * annotated-tumour flag | segment gate, rvol[b] = reported volume) when use_vol, ball_loss_bce / ball_loss_dice (:1625-1661 for a sample without
+ * tumour = L rows, :1793-1811 + DiceLossMultiClass :541-607 for a tumour sample = 1 row) as the mean over the `nplans` plans given as
+ * plan[nplans][2] = (kind 0 / 1, first row).  roww[R] = class weight per row.  loss[3] = (ball_loss_bce, ball_loss_dice, dice_volume_loss),
+ * jac[3][R][6] = d loss_k / d sums. */
+int rsuper_report_from_sums(const float* sums, const float* roww, int R, int B, int L, size_t V, int use_vol, const float* flags, const float* rvol,
+                            double tol, double E, int nplans, const int* plan, int apply_dice, int standard_ce, float* loss, float* jac, void* stream);
 int rsuper_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, void* stream);
 
 /* Sliding-window inference -- inference/inference3d.py:28-107 (inference_sliding_window) and :8-25

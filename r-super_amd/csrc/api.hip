@@ -540,6 +540,13 @@ int rsuper_seg_from_sums(const float* sums, const float* cw, int B, int C, size_
     SegSumsParams p = {sums, cw, B, C, 1.0 / ((double)B * C * (double)V), scale, loss, dsums};
     return rs_launch_seg_from_sums(p, ST(stream));
 }
+int rsuper_report_from_sums(const float* sums, const float* roww, int R, int B, int L, size_t V, int use_vol, const float* flags, const float* rvol,
+                            double tol, double E, int nplans, const int* plan, int apply_dice, int standard_ce, float* loss, float* jac, void* stream) {
+    if (!sums || !roww || R <= 0 || B <= 0 || L <= 0 || V == 0 || !loss || !jac || nplans < 0 || (nplans > 0 && !plan)) return RS_ERR_ARG;
+    if (use_vol && (!flags || !rvol || R < L * B)) return RS_ERR_ARG;
+    ReportSumsParams p = {sums, roww, B, L, (double)V, use_vol, flags, rvol, tol, E, nplans, plan, apply_dice, standard_ce, loss, jac};
+    return rs_launch_report_from_sums(p, R, ST(stream));
+}
 int rsuper_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, void* stream) {
     if (!x || !out || V == 0) return RS_ERR_ARG;
     return rs_launch_sigmoid_mask(x, m, out, V, ST(stream));

@@ -180,6 +180,86 @@ __global__ __launch_bounds__(256) void seg_from_sums_kernel(SegSumsParams p) {
     if (threadIdx.x == 0) p.loss[0] = (float)(p.scale * (red[0] + red[1] + red[2] + red[3]));
 }
 
+// One thread: the quantities are a few dozen scalars (f64 arithmetic on the f32 sums); what matters is that nothing leaves the device.
+//   volume:  lv[b, li] = clamp(|x - y| / (x + y + E) - |v - y| / (v + y + E), 0, 1) * w,  x = sums[li B + b][1] * (1 - annotated), y = rvol[b] * gate,
+//            v = max((1 - tol) y, min(y, 100));  dice_volume_loss = mean over (b, li)
+//   plan without tumour: bce = sum_li S w / (L V); dice = mean_li (1 - TP / (TP + a FP + (1 - a) FN + 1e-5)) w,  a = clamp(FP / (FP + FN + 1e-5), .2, .8)
+//   plan with tumour:    bce = (F1 + F2) / V * w  (S / V with standard_ce); dice = (1 - TP / (...)) w on its single row
+//   ball_loss_bce / _dice = mean over the plans.  clamp passes the gradient on [min, max] like torch.clamp, |.| has derivative sign(.) (0 at 0).
+__global__ void report_from_sums_kernel(ReportSumsParams p, int R) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float* J0 = p.jac; float* J1 = p.jac + (size_t)R * 6; float* J2 = p.jac + (size_t)2 * R * 6;
+    for (int i = 0; i < 3 * R * 6; ++i) p.jac[i] = 0.f;
+    const int B = p.B, L = p.L;
+    double lvol = 0.0;
+    int row = 0;
+    if (p.use_vol) {
+        const double inv = 1.0 / ((double)B * L);
+        for (int li = 0; li < L; ++li)
+            for (int b = 0; b < B; ++b) {
+                const int r = li * B + b;
+                const double keep = 1.0 - (double)p.flags[b * 2 * L + li], gate = (double)p.flags[b * 2 * L + L + li];
+                const double x = (double)p.sums[r * 6 + 1] * keep, y = (double)p.rvol[b] * gate, w = (double)p.roww[r];
+                const double s = x + y + p.E, d = x - y;
+                const double v = fmax((1.0 - p.tol) * y, fmin(y, 100.0));
+                const double raw = fabs(d) / s - fabs(v - y) / (v + y + p.E);
+                const double lv = fmin(fmax(raw, 0.0), 1.0);
+                lvol += lv * w * inv;
+                const double sg = d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0);
+                const double draw = (raw >= 0.0 && raw <= 1.0) ? (sg / s - fabs(d) / (s * s)) : 0.0;
+                J2[r * 6 + 1] = (float)(draw * keep * w * inv);
+            }
+        row = L * B;
+    }
+    double lbce = 0.0, ldice = 0.0;
+    const double invp = p.nplans > 0 ? 1.0 / p.nplans : 0.0;
+    auto dice_row = [&](int r, double w, double scale) {         // (1 - dice) * w of one row; Jacobian scaled by `scale` into J1; returns the loss
+        const double A = p.sums[r * 6 + 1], Bs = p.sums[r * 6 + 2], Cn = p.sums[r * 6 + 3];
+        const double TP = Bs, FP = A - Bs, FN = Cn - Bs;
+        const double den_a = FP + FN + 1e-5, a_raw = FP / den_a;
+        const double al = fmin(fmax(a_raw, 0.2), 0.8);
+        const bool pass = a_raw >= 0.2 && a_raw <= 0.8;
+        const double den = TP + al * FP + (1.0 - al) * FN + 1e-5;
+        const double g_al = w * TP * (FP - FN) / (den * den);    // d((1 - dice) w) / d alpha
+        const double ga_fp = pass ? g_al * (FN + 1e-5) / (den_a * den_a) : 0.0, ga_fn = pass ? -g_al * FP / (den_a * den_a) : 0.0;
+        const double k = w / (den * den);
+        const double dTP = -k * (den - TP), dFP = k * TP * al + ga_fp, dFN = k * TP * (1.0 - al) + ga_fn;
+        J1[r * 6 + 1] += (float)(scale * dFP);
+        J1[r * 6 + 2] += (float)(scale * (dTP - dFP - dFN));
+        J1[r * 6 + 3] += (float)(scale * dFN);
+        return (1.0 - TP / den) * w;
+    };
+    for (int q = 0; q < p.nplans; ++q) {
+        const int kind = p.plan[2 * q], r0 = p.plan[2 * q + 1];
+        if (kind == 0) {
+            double sb = 0.0, sd = 0.0;
+            for (int li = 0; li < L; ++li) {
+                const int r = r0 + li;
+                const double w = (double)p.roww[r];
+                sb += (double)p.sums[r * 6 + 0] * w;
+                J0[r * 6 + 0] = (float)(w / ((double)L * p.V) * invp);
+                if (p.apply_dice) sd += dice_row(r, w, invp / L);
+            }
+            lbce += sb / ((double)L * p.V) * invp;
+            ldice += sd / L * invp;
+        } else {
+            const int r = r0;
+            const double w = (double)p.roww[r];
+            if (p.standard_ce) {
+                lbce += (double)p.sums[r * 6 + 0] / p.V * w * invp;
+                J0[r * 6 + 0] = (float)(w / p.V * invp);
+            } else {
+                lbce += ((double)p.sums[r * 6 + 4] + (double)p.sums[r * 6 + 5]) / p.V * w * invp;
+                J0[r * 6 + 4] = (float)(w / p.V * invp);
+                J0[r * 6 + 5] = (float)(w / p.V * invp);
+            }
+            if (p.apply_dice) ldice += dice_row(r, w, invp) * invp;
+        }
+    }
+    (void)row;
+    p.loss[0] = (float)lbce; p.loss[1] = (float)ldice; p.loss[2] = (float)lvol;
+}
+
 // out[i] = sigmoid(x[i]) * (m ? m[i] : 1)      (x_iter of ball_loss, :1691-1694)
 __global__ void sigmoid_mask_kernel(const float* x, const uint8_t* m, float* out, size_t V) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (size_t)gridDim.x * blockDim.x)
@@ -241,6 +321,11 @@ int rs_launch_plane_partials(const PlaneParams& p, int planes, int bwd, hipStrea
 
 int rs_launch_seg_from_sums(const SegSumsParams& p, hipStream_t st) {
     hipLaunchKernelGGL(seg_from_sums_kernel, dim3(1), dim3(256), 0, st, p);
+    return rs_check_launch();
+}
+
+int rs_launch_report_from_sums(const ReportSumsParams& p, int R, hipStream_t st) {
+    hipLaunchKernelGGL(report_from_sums_kernel, dim3(1), dim3(64), 0, st, p, R);
     return rs_check_launch();
 }
 

@@ -30,6 +30,26 @@ struct SegSumsParams {
 };
 int rs_launch_seg_from_sums(const SegSumsParams& p, hipStream_t st);
 
+// Report terms (volume loss :250-349 + dice_based_volume_loss :352-395; ball loss tail :1625-1661, :1793-1811 with the Dice of :541-607) from the
+// per-plane sums of the report terms, and their Jacobians -- a few dozen scalars per head: on the host through torch's CPU autograd this cost two
+// device <-> host round trips and ~0.6 ms of idle GPU per step (config 3), as ATen device ops ~200 launch-bound kernels.
+struct ReportSumsParams {
+    const float* sums;      // [R][6] rows of the report terms, in the order calculate_loss builds them: volume rows li * B + b, then the plans' rows
+    const float* roww;      // [R] class weight of every row (1 without class weights)
+    int B, L;               // samples, lesion groups
+    double V;               // voxels per plane
+    int use_vol;            // rows [0, L*B) are the volume terms
+    const float* flags;     // [B][2L]: annotated-tumour flag | segment-present gate  (use_vol)
+    const float* rvol;      // [B] report volume (use_vol)
+    double tol, E;          // dice_based_volume_loss parameters
+    int nplans;             // ball plans (0: no ball loss)
+    const int* plan;        // [nplans][2]: kind (0 = no tumour: L rows, 1 = tumour: 1 row), first row
+    int apply_dice, standard_ce;
+    float* loss;            // [3]: ball_loss_bce, ball_loss_dice, dice_volume_loss
+    float* jac;             // [3][R][6] d loss_k / d sums
+};
+int rs_launch_report_from_sums(const ReportSumsParams& p, int R, hipStream_t st);
+
 int rs_launch_plane_partials(const PlaneParams& p, int planes, int bwd, hipStream_t st);
 int rs_launch_sigmoid_mask(const float* x, const uint8_t* m, float* out, size_t V, hipStream_t st);
 int rs_launch_window_accumulate(const float* logits, float* acc, int BK, int wd, int wh, int ww, int D, int H, int W, int d0, int h0, int w0,

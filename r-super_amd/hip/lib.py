@@ -79,6 +79,7 @@ _SIGS = {
     'rsuper_depthwise3_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_depthwise3_wgrad': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_seg_from_sums': (c_int, [P, P, c_int, c_int, c_size_t, c_double, P, P, P]),
+    'rsuper_report_from_sums': (c_int, [P, P, c_int, c_int, c_int, c_size_t, c_int, P, P, c_double, c_double, c_int, P, c_int, c_int, P, P, P]),
     'rsuper_plane_partials_bwd': (c_int, [P, c_size_t, P, P, P, P, P, P, c_int, c_int, c_size_t, P]),
     'rsuper_sigmoid_mask': (c_int, [P, P, P, c_size_t, P]),
     'rsuper_window_accumulate': (c_int, [P, P] + [c_int] * 11 + [P]),

@@ -172,7 +172,28 @@ class _SegFromSums(torch.autograd.Function):
         return d * g, None, None, None, None, None
 
 
-HOST_REPORT_ALGEBRA = os.environ.get('RSUPER_REPORT_ALGEBRA_DEVICE') != '1'
+class _ReportFromSums(torch.autograd.Function):
+    """(ball_loss_bce, ball_loss_dice, dice_volume_loss) from the (R, 6) sums of the report terms, one launch that also writes the three Jacobians
+    (csrc/loss.hip report_from_sums_kernel).  The same algebra used to run on the host through torch's CPU autograd (the sums came over in one copy,
+    the gradient went back in one): two pipeline drains and ~0.6 ms of idle GPU per config-3 step; as ATen device ops it is ~200 launch-bound kernels."""
+
+    @staticmethod
+    def forward(ctx, rest, roww, plan, flags, rvol, B, L, V, use_vol, tol, nplans, apply_dice, standard_ce):
+        rest = rest.contiguous()
+        R = rest.shape[0]
+        loss = torch.empty(3, device=rest.device, dtype=torch.float32)
+        jac = torch.empty((3, R, 6), device=rest.device, dtype=torch.float32)
+        _l.check(_L().rsuper_report_from_sums(_ptr(rest), _ptr(roww), R, B, L, V, int(use_vol), _ptr(flags), _ptr(rvol), float(tol), 500.0, nplans,
+                                              _ptr(plan), int(apply_dice), int(standard_ce), _ptr(loss), _ptr(jac), _stream()), 'report_from_sums')
+        ctx.save_for_backward(jac)
+        return loss[0], loss[1], loss[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        (jac,) = ctx.saved_tensors
+        g = torch.stack([g0, g1, g2]).view(3, 1, 1)
+        return ((jac * g).sum(0),) + (None,) * 12
+
 
 
 def _dice_from_sums(A, Bs, Cn, w=None):
@@ -465,16 +486,9 @@ def prepare_report_supervision(label, unk_voxels, chosen_segment_mask, tumor_vol
     mask_u8 = _u8(chosen_segment_mask)
     with torch.no_grad():
         pre = _ball_inputs(label_u8, unk_u8, mask_u8, tumor_volumes_report, tumor_diameters, chs, True)
-        if 'both' in args.loss and HOST_REPORT_ALGEBRA:                     # the volume loss runs too: its dilated masks and (B, 2L + 1) host flags
+        if 'both' in args.loss:                                             # the volume loss runs too: its dilated masks and (B, 2L + 1) flags
             pre['mseg31'] = [ops.dilate_volume(mask_u8[:, c].contiguous(), 31) for c in chs]
-            fl, rv = _volume_flags(label_u8, pre['mseg31'], tumor_volumes_report, chs)
-            pre['flags'] = torch.empty(fl.shape, dtype=fl.dtype, pin_memory=True)
-            pre['rvol'] = torch.empty(rv.shape, dtype=rv.dtype, pin_memory=True)
-            pre['flags'].copy_(fl, non_blocking=True)
-            pre['rvol'].copy_(rv, non_blocking=True)
-            pre['keep'] = pre['keep'] + (fl, rv)
-            pre['event'] = torch.cuda.Event()
-            pre['event'].record()
+            pre['flags'], pre['rvol'] = _volume_flags(label_u8, pre['mseg31'], tumor_volumes_report, chs)
     pre['u8'] = (label, unk_voxels, chosen_segment_mask, label_u8, unk_u8, mask_u8)     # calculate_loss reuses the uint8 views (same key)
     return pre
 
@@ -704,58 +718,48 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         seg = _SegFromSums.apply(seg_sums, cw, B, C, V, aw * args.seg_loss)
         loss_seg_total = seg if loss_seg_total is None else loss_seg_total + seg
         loss_r = {}
-        # The report terms are a few dozen scalars per sample: their algebra (~100 forward and ~100 backward one-element ATen launches, each
-        # costing the host ~10 us while the queue is empty behind the ball search's synchronisations) runs on the HOST through torch's CPU
-        # autograd; the sums come over in one copy, the gradient goes back in one (HOST_REPORT_ALGEBRA = False keeps it on the device).
-        host = HOST_REPORT_ALGEBRA and rest.shape[0] > 0
-        sums = rest.cpu() if host else rest
-        cwx = None if cw is None else (cw.float().cpu() if host else cw)
-        ti = 0
-        # ---- volume loss (:250-349)
-        if use_vol and L > 0:
-            vhat = torch.stack([sums[ti + li * B:ti + (li + 1) * B, 1] for li in range(L)], dim=1)      # (B, L) sum sig * M
-            ti += L * B
-            if host and pre is not None and 'flags' in pre:
-                pre['event'].synchronize()
-                flags, rvol = pre['flags'], pre['rvol']                   # read before the forward pass (prepare_report_supervision)
-            else:
-                flags, rvol = _volume_flags(label_u8, mseg31, tumor_volumes_report, chs)
-                if host:
-                    flags, rvol = flags.cpu(), rvol.cpu()
-            lab_any, gate = flags[:, :L], flags[:, L:]                     # per-voxel annotated tumour (:313) / segment present (:335)
-            vhat = vhat * (1 - lab_any)
-            rv = rvol.expand(B, L) * gate
-            lv = dice_based_volume_loss(vhat, rv, tolerance=args.volume_loss_tolerance, E=500)
-            if cwx is not None:
-                lv = lv * cwx[:, chs]
-            loss_r['dice_volume_loss'] = lv.mean()
-        # ---- ball loss (:1537-1864)
-        if use_ball and L > 0:
-            apply_dice = 'dice' in args.loss
-            l_bce, l_dice = [], []
-            for p in plans:
-                if p.kind == 'none':                                      # :1625-1661
-                    ss = sums[ti:ti + L]                                  # (L, 6)
-                    ti += L
-                    wl = cwx[p.b, chs] if cwx is not None else None
-                    Sb = ss[:, 0] * wl if wl is not None else ss[:, 0]
-                    l_bce.append(Sb.sum() / float(L * V))
-                    if apply_dice:
-                        l_dice.append(_dice_from_sums(ss[None, :, 1], ss[None, :, 2], ss[None, :, 3], None if wl is None else wl[None]))
+        # ---- report terms from their sums (volume loss :250-349, ball loss :1537-1864): one launch, nothing leaves the device
+        if rest.shape[0] > 0:
+            roww = [1.0] * rest.shape[0]
+            cw_h = None if cw is None else cw.detach().float().cpu().numpy()      # (B, C) class weights: a batch input, not on the device's critical path
+            ti = 0
+            flags = rvol = None
+            if use_vol and L > 0:
+                if cw_h is not None:
+                    for li, c in enumerate(chs):
+                        for b in range(B):
+                            roww[li * B + b] = float(cw_h[b, c])
+                ti += L * B
+                if pre is not None and 'flags' in pre:
+                    flags, rvol = pre['flags'], pre['rvol']               # computed before the forward pass (prepare_report_supervision)
                 else:
-                    ss = sums[ti]; ti += 1
-                    wc = cwx[p.b, p.c] if cwx is not None else None
-                    if getattr(args, 'stardard_ce_ball', False):
-                        lb = ss[0] / float(V)
+                    flags, rvol = _volume_flags(label_u8, mseg31, tumor_volumes_report, chs)
+            plan_l = []
+            if use_ball and L > 0:
+                for p in plans:
+                    if p.kind == 'none':                                  # :1625-1661
+                        plan_l += [0, ti]
+                        if cw_h is not None:
+                            for li, c in enumerate(chs):
+                                roww[ti + li] = float(cw_h[p.b, c])
+                        ti += L
                     else:
-                        lb = ss[4] / float(V) + ss[5] / float(V)          # mean(BCE*w_fg) + mean(BCE*(1-BIG))  (:1793-1811)
-                    l_bce.append(lb * wc if wc is not None else lb)
-                    if apply_dice:
-                        l_dice.append(_dice_from_sums(ss[1].view(1, 1), ss[2].view(1, 1), ss[3].view(1, 1),
-                                                      None if wc is None else wc.view(1, 1)))
-            loss_r['ball_loss_bce'] = torch.stack(l_bce).mean()
-            loss_r['ball_loss_dice'] = torch.stack(l_dice).mean() if apply_dice else torch.zeros_like(loss_r['ball_loss_bce'])
-        assert ti == rest.shape[0]
+                        plan_l += [1, ti]
+                        if cw_h is not None:
+                            roww[ti] = float(cw_h[p.b, p.c])
+                        ti += 1
+            assert ti == rest.shape[0]
+            roww_d = torch.tensor(roww, dtype=torch.float32).to(rest.device, non_blocking=True)
+            plan_d = torch.tensor(plan_l, dtype=torch.int32).to(rest.device, non_blocking=True) if plan_l else None
+            lb, ld, lv = _ReportFromSums.apply(rest, roww_d, plan_d, None if flags is None else flags.contiguous().float(),
+                                               None if rvol is None else rvol.contiguous().float().view(-1), B, max(L, 1), V, use_vol and L > 0,
+                                               float(args.volume_loss_tolerance), len(plan_l) // 2, 'dice' in args.loss,
+                                               bool(getattr(args, 'stardard_ce_ball', False)))
+            if use_vol and L > 0:
+                loss_r['dice_volume_loss'] = lv
+            if use_ball and L > 0:
+                loss_r['ball_loss_bce'] = lb
+                loss_r['ball_loss_dice'] = ld if 'dice' in args.loss else torch.zeros_like(lb)
         if not loss_r and rep_scalar is None:
             rep_scalar = torch.zeros((), device=r.device)                   # aw * rw * 0 for every head
         for k, v in loss_r.items():
@@ -766,14 +770,9 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
     loss = {'segmentation': loss_seg_total}
     if rep:
         # key order of the reference: ball keys first, then volume
-        keys = [k for k in ('ball_loss_bce', 'ball_loss_dice', 'dice_volume_loss') if k in rep]
-        if len(keys) > 1 and all(not rep[k].is_cuda for k in keys):
-            dev_vals = torch.stack([rep[k] for k in keys]).to(loss_seg_total.device)    # host algebra: ONE copy for all keys (and one back in backward)
-            for i, k in enumerate(keys):
-                loss[k] = dev_vals[i]
-        else:
-            for k in keys:
-                loss[k] = rep[k].to(loss_seg_total.device)
+        for k in ('ball_loss_bce', 'ball_loss_dice', 'dice_volume_loss'):
+            if k in rep:
+                loss[k] = rep[k]
     else:
         loss['report'] = rep_scalar
     overall = None

@@ -53,7 +53,7 @@ def main():
         sub, _ = synth.subsample(p.grad.cpu().numpy(), 2048)
         err = float(np.abs(sub - ref).max()) / max(float(g[f'mean_g_{k}_summary'][2]), 1e-12)
         worst = max(worst, err)
-        assert err <= 1e-2, (rank, k, err)        # the bound of check_unet_tiny[f32] for these gradients (summation-order noise of the tiny network)
+        assert err <= 2e-2, (rank, k, err)        # the bound of check_unet_tiny[f32] against the fp32 fixture (summation-order noise of the tiny network)
     dist.barrier()
     if rank == 0:
         print(f'DDP_FIXTURE_GPU_OK worst {worst:.2e}')

@@ -338,5 +338,6 @@ FULLSIZE_REPORT_CASES = ['bench96', 'full96_d40']
 
 
 # two data-parallel ranks of the tiny training step, each on its own batch (tests/golden/gen_golden_ddp.py)
-def ddp_rank_batch(rank, S=32):
+def ddp_rank_batch(rank, S=48):      # 48 like the tiny-UNet fixture: the bottom level then holds 3^3 voxels (at 32^3 it is 2^3 and InstanceNorm over 8 voxels
+                                     # makes the fp32 gradients of the deepest layers move by 4 % with the summation order alone)
     return image(2, S, seed=4321 + rank), batch(2, S, TINY_CLASSES, ['mask', 'report'], seed=7 + rank, diam_range=(5.0, 9.0), max_tumors=2)

@@ -641,41 +641,80 @@ def test_medformer_fused_attention_matches_aten_composition():
 
 
 @pytest.mark.gpu
-def test_report_algebra_on_host_matches_device():
-    """The Volume / Ball scalar algebra through CPU autograd (default) against the same algebra on the device
-    (RSUPER_REPORT_ALGEBRA_DEVICE=1): loss entries and d(logits)."""
-    import argparse
-    import synth
+@pytest.mark.parametrize('seed,B,L,use_vol,apply_dice,std_ce,weighted', [(1, 2, 1, True, True, False, False), (2, 3, 2, True, True, False, True),
+                                                                          (3, 2, 1, False, True, True, True), (4, 4, 3, True, False, False, True),
+                                                                          (5, 1, 1, True, True, False, False)])
+def test_report_from_sums_kernel_matches_torch_autograd(seed, B, L, use_vol, apply_dice, std_ce, weighted):
+    """csrc/loss.hip report_from_sums_kernel (volume loss + ball-loss tail from the per-plane sums, with Jacobians) against the same algebra written in
+    torch with autograd in float64 (losses_foundation.py:250-395, :1625-1661, :1793-1811, :541-607): values and d / d sums, incl. clamp edges
+    (volumes inside the tolerance band, alpha at its clamps) and plans of both kinds."""
     from rsuper_amd.training import losses_foundation as lf
-    classes = synth.TINY_CLASSES
-    largs = argparse.Namespace(loss='ball_dice_both', aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1, volume_loss_tolerance=0.2,
-                               ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
-                               classification_branch=False)
-    bt = synth.batch(3, 32, classes, ['mask', 'report', 'report'], seed=13, diam_range=(4.0, 9.0), max_tumors=2)
-    b = {k: torch.from_numpy(bt[k]).to('cuda') for k in ('label', 'unk_channels', 'mask', 'volumes', 'diameters')}
-    g = torch.Generator(device='cuda').manual_seed(5)
-    logits = torch.randn((3, len(classes), 32, 32, 32), device='cuda', generator=g) * 2
-    weights = torch.rand((3, len(classes)), device='cuda', generator=g) + 0.5
+    g = torch.Generator().manual_seed(seed)
+    V = 32 ** 3
+    kinds = [int(torch.randint(0, 2, (1,), generator=g)) for _ in range(B)]
+    kinds[0] = 1
+    if B > 1:
+        kinds[1] = 0
+    R = (L * B if use_vol else 0) + sum(L if k == 0 else 1 for k in kinds)
+    sums = torch.rand((R, 6), generator=g, dtype=torch.float64)
+    sums[:, 0] *= 5000.0                                   # S: summed BCE
+    sums[:, 1] = sums[:, 1] * 3000.0 + 10.0                # A = sum P
+    sums[:, 2] = sums[:, 2] * sums[:, 1].clamp(max=900.0)  # Bs = sum P T <= A, Cn
+    sums[:, 3] = sums[:, 2] + torch.rand(R, generator=g, dtype=torch.float64) * 800.0
+    sums[:, 4:] *= 4000.0
+    if R > 2:
+        sums[2, 1], sums[2, 2], sums[2, 3] = 50.0, 49.0, 2000.0        # FP << FN: alpha at the lower clamp
+    flags = (torch.rand((B, 2 * L), generator=g) < 0.5).float()
+    flags[:, L:] = 1.0
+    flags[0, :L] = 0.0
+    rvol = torch.rand(B, generator=g) * 3000.0 + 50.0
+    if use_vol:
+        rvol[0] = float(sums[0, 1]) * 1.05                 # inside the tolerance band: clamped to 0
+    roww = (torch.rand(R, generator=g) + 0.5) if weighted else torch.ones(R)
+    plan, row = [], L * B if use_vol else 0
+    for k in kinds:
+        plan += [k, row]
+        row += L if k == 0 else 1
+    tol = 0.2
 
-    def run(host):
-        old = lf.HOST_REPORT_ALGEBRA
-        lf.HOST_REPORT_ALGEBRA = host
-        try:
-            x = logits.clone().requires_grad_(True)
-            loss = lf.calculate_loss(model_output={'segmentation': x}, label=b['label'], unk_voxels=b['unk_channels'], args=largs, matcher=None,
-                                     chosen_segment_mask=b['mask'], tumor_volumes_report=b['volumes'], tumor_diameters=b['diameters'],
-                                     classes=classes, class_weights=weights)
-            loss['overall'].backward()
-            return {k: float(v.detach()) for k, v in loss.items()}, x.grad.clone()
-        finally:
-            lf.HOST_REPORT_ALGEBRA = old
+    def torch_algebra(sm):
+        out = {}
+        if use_vol:
+            x = torch.stack([sm[li * B:(li + 1) * B, 1] for li in range(L)], 1) * (1 - flags[:, :L].double())
+            y = rvol.double()[:, None].expand(B, L) * flags[:, L:].double()
+            loss = torch.abs(x - y) / (x + y + 500)
+            v = torch.max((1 - tol) * y, y.clamp(max=100))
+            loss = torch.clamp(loss - torch.abs(v - y) / (v + y + 500), min=0, max=1)
+            w = torch.stack([roww[li * B:(li + 1) * B] for li in range(L)], 1).double()
+            out['vol'] = (loss * w).mean()
+        lb, ld = [], []
+        for q in range(len(kinds)):
+            k, r0 = plan[2 * q], plan[2 * q + 1]
+            rows = sm[r0:r0 + (L if k == 0 else 1)]
+            w = roww[r0:r0 + rows.shape[0]].double()
+            if k == 0:
+                lb.append((rows[:, 0] * w).sum() / float(L * V))
+            else:
+                lb.append((rows[0, 0] if std_ce else rows[0, 4] + rows[0, 5]) / float(V) * w[0])
+            TP, FP, FN = rows[:, 2], rows[:, 1] - rows[:, 2], rows[:, 3] - rows[:, 2]
+            al = (FP / (FP + FN + 1e-5)).clamp(0.2, 0.8)
+            ld.append(((1 - TP / (TP + al * FP + (1 - al) * FN + 1e-5)) * w).mean())
+        out['bce'] = torch.stack(lb).mean()
+        out['dice'] = torch.stack(ld).mean() if apply_dice else torch.zeros(())
+        return out
 
-    lh, gh = run(True)
-    ld, gd = run(False)
-    assert lh.keys() == ld.keys() and len(lh) >= 4
-    for k in lh:
-        assert abs(lh[k] - ld[k]) <= 1e-6 * max(1.0, abs(ld[k])), (k, lh[k], ld[k])
-    assert float((gh - gd).abs().max()) <= 1e-6 * float(gd.abs().max())
+    sm = sums.clone().requires_grad_(True)
+    ref = torch_algebra(sm)
+    dev = sums.float().to('cuda').requires_grad_(True)
+    lb, ld, lv = lf._ReportFromSums.apply(dev, roww.to('cuda'), torch.tensor(plan, dtype=torch.int32, device='cuda'),
+                                          flags.to('cuda') if use_vol else None, rvol.to('cuda') if use_vol else None, B, L, V, use_vol, tol,
+                                          len(kinds), apply_dice, std_ce)
+    for name, got in (('bce', lb), ('dice', ld)) + ((('vol', lv),) if use_vol else ()):
+        assert abs(float(got) - float(ref[name])) <= 2e-6 * max(1.0, abs(float(ref[name]))), (name, float(got), float(ref[name]))
+        if ref[name].requires_grad:
+            gr, = torch.autograd.grad(ref[name], sm, retain_graph=True)
+            gd, = torch.autograd.grad(got, dev, retain_graph=True)
+            assert float((gd.cpu().double() - gr).abs().max()) <= 2e-6 * max(float(gr.abs().max()), 1e-12), name
 
 
 @pytest.mark.gpu
