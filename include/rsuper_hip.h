@@ -69,7 +69,8 @@ int rsuper_conv3_tiles(int D, int H, int W);
 int rsuper_conv3_variant(int v);
 /* bf16 weight gradients (rsuper_conv3_wgrad) run the second-generation kernel (operand re-use across taps, double-buffered tiles) when a block
  * sweeps at least `t` spatial tiles -- default 12, the measured break-even against the round-3 kernel; 0 = every supported launch (tests),
- * a large value = never.  t < 0 queries.  Returns the threshold in effect. */
+ * >= 2^20 = never.  Both extremes also switch the small-volume kernel off (batches of at most 64 tiles whose depth slabs fit LDS otherwise run
+ * conv3d_wgrad_sv.hip), so that the tests can pin each tile-streaming kernel on small volumes.  t < 0 queries.  Returns the threshold in effect. */
 int rsuper_conv3_wgrad2_min_tiles(int t);
 
 /* Launches whose volume cannot fill the chip with 4x4x16-voxel tiles (the 24^3 / 12^3 levels of the UNet at batch 2:

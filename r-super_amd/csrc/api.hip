@@ -244,7 +244,9 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
 
 int rsuper_conv3_wgrad_splits(int dtype, int Ca, int Cb, int Mtot, int N, int D, int H, int W) {
     if (!dt_ok(dtype) || Ca <= 0 || Cb < 0 || Mtot <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return -1;
-    return rs_wgrad_splits(dtype, Mtot, (Ca + 31) / 32 + (Cb + 31) / 32, N * rsuper_conv3_tiles(D, H, W));
+    const int nch = (Ca + 31) / 32 + (Cb + 31) / 32;
+    if (const int sv = rs_wgrad_sv_splits(dtype, Mtot, Mtot, nch, N, D, H, W)) return sv;      // small volumes: N x (depth parts per sample)
+    return rs_wgrad_splits(dtype, Mtot, nch, N * rsuper_conv3_tiles(D, H, W));
 }
 
 static int conv3_wgrad_impl(int reduce, int dtype, int use_tr, const void* xa, int lda, int Ca, const float* mra,

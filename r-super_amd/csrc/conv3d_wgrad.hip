@@ -598,6 +598,16 @@ static int launch_wgrad_impl(const WgradParams& p, int dtype, int use_tr, hipStr
     const int tiles_total = p.N * ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);
     if (dtype == RS_F32) return cfg == 0 ? launch<float, 1, 27, 0, 4>(p, st) : launch<float, 2, 9, 0, 4>(p, st);
+    {   // small volumes (12^3 / 6^3 levels): one depth slab of a sample whole in LDS (conv3d_wgrad_sv.hip); the caller sized `splits` for it
+        const int nch = (p.xa.C + 31) / 32 + (p.xb.C + 31) / 32;
+        const int sv = use_tr ? rs_wgrad_sv_splits(dtype, Mtot, p.ya.C, nch, p.N, p.D, p.H, p.W) : 0;
+        if (sv > 0 && sv == p.splits) {
+            const int rc = rs_launch_wgrad_sv(p, st);
+            if (rc != RS_OK) return rc;
+            launch_reduce(p, st);
+            return rs_check_launch();
+        }
+    }
     // Second-generation kernel (conv3d_wgrad2.hip: operand re-use across taps, double-buffered tiles) where a block sweeps enough tiles to amortise its
     // heavier prologue (descriptor / constants tables, two tiles staged before the first MFMA): measured same-box against the kernel below, >= 12 tiles
     // per block 0.81-0.93x (32 -> 32 @96^3, up4.0, up3.0, up2.0), 6.75 tiles per block 1.02-1.08x (64 -> 64 @48^3, 128 -> 128 @24^3, down1.0)

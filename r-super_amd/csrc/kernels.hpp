@@ -81,6 +81,9 @@ struct ReduceBatch {
 };
 int rs_launch_wgrad_reduce_batch(ReduceBatch& b, hipStream_t st);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
+// small-volume weight gradient (conv3d_wgrad_sv.hip): a depth slab of one sample whole in LDS, flat-voxel reduction; splits = 0: does not apply
+int rs_wgrad_sv_splits(int dtype, int Mtot, int Ya, int nch, int N, int D, int H, int W);
+int rs_launch_wgrad_sv(const WgradParams& p, hipStream_t st);
 // second-generation weight gradient (conv3d_wgrad2.hip): bf16, operand re-use across taps + double-buffered tiles; same slabs, the caller reduces
 bool rs_wgrad2_supported(const WgradParams& p, int dtype);
 int rs_wgrad2_min_tiles(int t);     // tiles per block from which bf16 launches take it (t < 0: query)

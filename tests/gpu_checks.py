@@ -1111,6 +1111,21 @@ def with_wgrad2(fn, *a):
     return r
 
 
+def with_wgrad_classic(fn, *a):
+    """Run a check with the round-1..3 tile-streaming weight gradient (csrc/conv3d_wgrad.hip) for every bf16 launch: neither the second-generation nor the
+    small-volume kernel (the default takes one of the two for most shapes)."""
+    from rsuper_amd.hip import ops
+    L = ops._L()
+    old = L.rsuper_conv3_wgrad2_min_tiles(-1)
+    L.rsuper_conv3_wgrad2_min_tiles(1 << 20)
+    try:
+        r = fn(*a)
+    finally:
+        L.rsuper_conv3_wgrad2_min_tiles(old)
+    r['name'] = f"wgrad-classic:{r['name']}"
+    return r
+
+
 def check_wgrad_sliced_dy(N, S, Ca, Cout, seed=0):
     """Weight gradient with the two dY sources given as channel slices of ONE tensor (ld = 2 Cout, the layout the zero-stuffed evaluation of the strided
     block and BasicBlockFn's [dY1 | dOut] use) and a normalised x source, against the float64 gradient on the bf16 operands the kernel sees."""
@@ -1179,6 +1194,11 @@ def all_checks(quick=False):
            (check_wgrad_xhat, (3, (6, 6, 6), 32, 0, 96, 32, 9)), (check_wgrad_xhat, (1, (2, 3, 5), 8, 0, 8, 0, 10))]
     # the second-generation weight gradient on every bf16 backward case and on the pre-normalised ones (the default dispatch needs >= 12 tiles per block)
     cs += [(with_wgrad2, (fn,) + a) for fn, a in list(cs) if fn in (check_conv_bwd, check_wgrad_xhat) and (fn is check_wgrad_xhat or a[0] == 'bf16')]
+    cs += [(with_wgrad_classic, (fn,) + a) for fn, a in list(cs) if fn is check_conv_bwd and a[0] == 'bf16']
+    # small volumes as the UNet has them (12^3 with 2 depth parts, 6^3 whole, ragged, two x / dY sources, channel tails): csrc/conv3d_wgrad_sv.hip by default
+    cs += [(check_conv_bwd, ('bf16', 2, (12, 12, 12), 64, 0, 64, False)), (check_conv_bwd, ('bf16', 2, (12, 12, 12), 32, 64, 32, True)),
+           (check_conv_bwd, ('bf16', 1, (11, 9, 13), 40, 0, 24, True)), (check_wgrad_sliced_dy, (2, (12, 12, 12), 64, 64, 6)),
+           (check_wgrad_xhat, (2, (12, 12, 12), 96, 32, 64, 32, 12)), (check_wgrad_xhat, (4, (6, 6, 6), 64, 0, 96, 0, 13))]
     cs += [(with_wgrad2, (check_conv_bwd, 'bf16', 2, (16, 16, 64), 32, 32, 64, True)), (with_wgrad2, (check_conv_bwd, 'bf16', 1, (16, 32, 64), 64, 0, 64, False)),
            (with_wgrad2, (check_conv_bwd, 'bf16', 2, (24, 24, 48), 32, 0, 32, False)),
            (check_wgrad_sliced_dy, (1, (23, 23, 23), 64, 128)), (with_wgrad2, (check_wgrad_sliced_dy, 1, (23, 23, 23), 64, 128)),
