@@ -45,7 +45,7 @@ SvGeom sv_geometry(int N, int D, int H, int W, int nch, int Mtot) {
     return g;
 }
 
-__global__ __launch_bounds__(NT, 1) void wgrad_sv_kernel(WgradParams p, int P, int dr, int rows_x, int nks) {
+__global__ __launch_bounds__(NT, 2) void wgrad_sv_kernel(WgradParams p, int P, int dr, int rows_x, int nks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xim = smem;                                             // x_hat image
     char* yim = smem + (size_t)rows_x * 64;                       // dY image: nks * 16 rows
@@ -163,22 +163,26 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sv_kernel(WgradParams p, int P, i
     // lane part of a transposing fragment read (wgrad_frag.hpp): rows r1 = (g >> 1) * 8 + (q >> 2) and r1 + 4, byte column ((g & 1) * 16 + (q & 3) * 4) * 2
     const int q_ = lane & 15, g_ = lane >> 4;
     const int r1 = (g_ >> 1) * 8 + (q_ >> 2), colb = ((g_ & 1) * 16 + (q_ & 3) * 4) * 2;
+    // LDS addresses as 32-bit integers: a generic pointer + per-lane offset costs a 64-bit add and an address-space conversion (null check + select)
+    // per read -- 30 VALU instructions per MFMA in the first version of this loop (rocprofv3 SQ_INSTS_VALU), MFMA pipe 10 % busy
     typedef __attribute__((address_space(3))) v4s_t* lds_v4;
-    auto tr8 = [&](const char* a) {
+    auto tr8 = [&](uint32_t a) {
         union { v4s_t v; uint2 u; } t;
-        t.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a));
+        t.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)a);
         return t.u;
     };
-    const char* ya = yim + (size_t)r1 * 64 + colb;
-    const char* xb = xim + colb;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t ya = lds0 + (uint32_t)(yim - smem) + (uint32_t)(r1 * 64 + colb);
+    const uint32_t xb = lds0 + (uint32_t)(xim - smem) + (uint32_t)colb;
+    const uint32_t* ra = rowaddr + r1;
     struct Ops { uint4 a; uint4 b[TPW]; };
     auto load_ops = [&](int ks, Ops& o) {
-        const uint32_t o1 = rowaddr[ks * 16 + r1], o2 = rowaddr[ks * 16 + r1 + 4];
-        const uint2 a_lo = tr8(ya + (size_t)ks * 1024), a_hi = tr8(ya + (size_t)ks * 1024 + 256);
+        const uint32_t o1 = xb + ra[ks * 16], o2 = xb + ra[ks * 16 + 4];
+        const uint2 a_lo = tr8(ya + (uint32_t)ks * 1024u), a_hi = tr8(ya + (uint32_t)ks * 1024u + 256u);
         o.a = make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const uint2 lo = tr8(xb + o1 + tapoff[i]), hi = tr8(xb + o2 + tapoff[i]);
+            const uint2 lo = tr8(o1 + (uint32_t)tapoff[i]), hi = tr8(o2 + (uint32_t)tapoff[i]);
             o.b[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
     };
@@ -213,6 +217,9 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sv_kernel(WgradParams p, int P, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + cd_row32(r, lane);
+#ifdef WGSV_SKIP_STORE
+            if (acc[i][r] == 12345.678f)
+#endif
             if (m < Mtot && ci < xs.C) slab[((size_t)tl * Mtot + m) * cin_total + cin_base + (lane & 31)] = acc[i][r];
         }
     }
