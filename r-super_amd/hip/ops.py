@@ -1183,6 +1183,7 @@ _PW_SEEN = {}      # (data_ptr, mode) -> weakref of a weight pointwise_gemm had 
 _PW_PACKED = {}    # (data_ptr, mode, dtype code) -> (validity key, arena, byte offset)
 _PW_TABLES = {}    # dtype code -> (device table, total items, arena, entries)
 _PW_SEEN_DIRTY = False
+_PW_CAPTURED = []  # (table, arena) pairs a hipGraph capture recorded pointers to: never freed (see pointwise_prepack)
 
 
 def _pw_key(w):
@@ -1234,6 +1235,12 @@ def pointwise_prepack(compute):
             _PW_PACKED.clear()                                   # ... and every fragment set packed from it: a new parameter at a recycled address with
             _PW_SEEN_DIRTY = True                                # the same (epoch, version) would otherwise multiply with the dead one's fragments
             return
+    if torch.cuda.is_current_stream_capturing() and not any(t is table for t, _ in _PW_CAPTURED):
+        # the graph being captured keeps raw pointers to this table and arena (this launch and every GEMM that reads its fragments from the
+        # arena); the cache above drops them when another set of weights shows up (an EMA copy, a second model) or a parameter dies --
+        # a later replay would then read a freed descriptor table and write fragments into somebody else's memory.  Captured tables stay
+        # alive for the life of the process (a few MB per captured model).
+        _PW_CAPTURED.append((table, arena))
     _l.check(_L().rsuper_pointwise_pack_batch(dt, _ptr(table), len(entries), total, _ptr(arena), _stream()), 'pointwise_pack_batch')
     ep = WEIGHTS_EPOCH
     for key, off, ref in entries:

@@ -136,6 +136,8 @@ class GradReducer:
             b.handle = None
             if self.wire_dtype is not None:
                 b.flat.copy_(b.wire)                            # back into the f32 bucket the optimiser reads (after the wait: stream-ordered)
+                if b.wire.is_cuda:                              # allocated on the side stream, read here on the current one: the caching
+                    b.wire.record_stream(torch.cuda.current_stream())   # allocator must not recycle it for a side-stream tensor before this copy ran
                 b.wire = None
             if self.backend != 'nccl':
                 b.flat.div_(self.world)

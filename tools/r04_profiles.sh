@@ -17,3 +17,7 @@ rm -rf /tmp/ddp_tr; timeout 300 rocprofv3 --kernel-trace --output-format csv -d 
 python tools/ddp_overlap.py $(ls /tmp/ddp_tr/*kernel_trace.csv | head -1) > gpurun_out/r04_ddp_overlap.txt 2>&1
 timeout 1500 python bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.err
 tail -c 300 gpurun_out/r04_bench_default.json
+timeout 300 python tools/ddp_bucket_timeline.py 6 > gpurun_out/r04_ddp_bucket_timeline.txt 2>&1
+timeout 300 python tools/xhat_probe.py > gpurun_out/r04_xhat_probe.txt 2>&1
+timeout 300 bash tools/wg2_prof.sh "-DWG2_SKIP_STAGE" > /dev/null 2>&1; cp gpurun_out/wg2_prof.txt gpurun_out/r04_wg2_prof.txt
+timeout 600 bash tools/mf_kstats.sh > /dev/null 2>&1
