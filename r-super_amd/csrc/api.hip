@@ -409,7 +409,6 @@ int rsuper_upsample_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx,
     UpParams p = {nullptr, 0, (void*)dy, lddy, dx, lddx, nullptr, N, ID, IH, IW, OD, OH, OW, C};
     return rs_launch_upsample(p, dtype, 1, 1, ST(stream));
 }
-
 int rsuper_stem_fwd(int dtype, const float* x, const float* w, void* y, int ldy, float* part,
                     int N, int D, int H, int W, int C, void* stream) {
     if (!dt_ok(dtype) || !x || !w || !y || !part || !ch_ok(C, ldy)) return RS_ERR_ARG;

@@ -268,7 +268,7 @@ __global__ void subsample_bwd_kernel(PoolParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ trilinear, align_corners
-__device__ __forceinline__ void lin_coord(int o, float scale, int I, int& i0, int& i1, float& l1) {
+__host__ __device__ __forceinline__ void lin_coord(int o, float scale, int I, int& i0, int& i1, float& l1) {
     // ATen area_pixel_compute_source_index(align_corners=True): src = scale * dst (float32)
     const float src = scale * (float)o;
     i0 = (int)src;
@@ -341,14 +341,14 @@ __global__ void upsample_fwd_kernel(UpParams p) {
 }
 
 // contribution range of input index i along one axis: outputs o whose i0(o)==i or i1(o)==i
-__device__ __forceinline__ void up_range(int i, float scale, int O, int& lo, int& hi) {
+__host__ __device__ __forceinline__ void up_range(int i, float scale, int O, int& lo, int& hi) {
     if (scale <= 0.f) { lo = 0; hi = O - 1; return; }
     lo = (int)floorf((float)(i - 1) / scale) - 1;
     hi = (int)ceilf((float)(i + 1) / scale) + 1;
     if (lo < 0) lo = 0;
     if (hi > O - 1) hi = O - 1;
 }
-__device__ __forceinline__ float up_weight(int o, int i, float scale, int I) {
+__host__ __device__ __forceinline__ float up_weight(int o, int i, float scale, int I) {
     int i0, i1; float l1;
     lin_coord(o, scale, I, i0, i1, l1);
     float w = 0.f;
@@ -591,6 +591,187 @@ __global__ __launch_bounds__(256) void upsample_bwd2_kernel(UpParams p) {
     if (nwmax <= 4) up_bwd_rows<T, 4>(p, td, th, tw, blockIdx.y, i0, total, stride);
     else if (nwmax <= 6) up_bwd_rows<T, 6>(p, td, th, tw, blockIdx.y, i0, total, stride);
     else up_bwd_rows<T, UP_MAXW>(p, td, th, tw, blockIdx.y, i0, total, stride);
+}
+
+// ---- third-generation backward (round 4): the row reduction along w is done ONCE per output row and shared by a 2 x 2 (d, h) tile of input voxels.
+// upsample_bwd2 gathers 4 x 4 x 4 output vectors per input vector (906 MB of L1 requests for 226 MB of data at 96^3 x 64 channels: 124-143 us).
+// Here a thread owns (iw, 8 channels) of a 2 x 2 tile of (id, ih): it walks the output rows (od, oh) the tile receives from (about 5.5 x 5.5),
+// reduces each row along w (t = sum_c wc * dy[od, oh, wlo + c]: NT coalesced 16-byte buffer loads whose row offset is a wave-uniform SGPR -- all 8
+// channel groups of a voxel are read by adjacent lanes) and adds (wd * wh) * t to the four tile voxels through a per-row weight table: ~30 loads per
+// output vector instead of 64, no integer division or 64-bit address arithmetic in the loop.  Association differs from upsample_bwd2
+// ((wd * wh) * sum_c wc g  vs  sum of (wd * wh * wc) g): results agree to f32 rounding, not bit for bit.  The weights come from up_weight -- the same
+// values as everywhere.  96^3 x 64 channels 124 -> 86 us, 48^3 x 128 43 -> 29 us (tools/bench_up.py).
+// Measured and not kept: (i) the output-gradient tile staged through LDS per 8-channel chunk (16-byte accesses to 128-byte lines: request-rate bound,
+// 465 us); (ii) the InstanceNorm backward tail of the producing block fused into this kernel (the tail is linear in its two tensors, so the row
+// reduction ran on g and x separately): 268-274 us against 153 + 93 for the two launches -- twice the loads and registers (202 VGPRs, two waves per
+// SIMD) cost more than the 226 MB write + read the fusion saves; deeper load pipelines (3-5 rows in flight) 92-236 us: the loop is issue-bound.
+struct UpInParams {
+    const void* g; int ldg;        // output gradient, channels-last on the (OD, OH, OW) grid
+    void* dx; int lddx;
+    int N, ID, IH, IW, OD, OH, OW, C;
+};
+#ifndef UP4_SL
+#define UP4_SL 2
+#endif
+constexpr int UP4_ROWS = 16;       // candidate output rows of a pair of input indices (up_range of the first .. of the second): <= 2 * 2 / scale + 6
+template <int NT>
+__global__ __launch_bounds__(256, 3) void upsample_bwd4_kernel(UpInParams p, int nbx) {
+    typedef bf16_t T;
+    constexpr int CPT = 8, NWD = CPT / 2;                        // channels per thread (one 16-byte vector), 32-bit words of it
+    constexpr int SL = UP4_SL;                                   // row slots: SL - 1 rows of loads in flight behind the one being reduced
+    __shared__ float Wd[UP4_ROWS][2], Wh[UP4_ROWS][2];
+    __shared__ float4 W4[UP4_ROWS * UP4_ROWS];                   // row (a, b) -> (wd0 wh0, wd0 wh1, wd1 wh0, wd1 wh1)
+    __shared__ int span[4];                                      // od0, rd, oh0, rh
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int CV = p.C / CPT, tiles_h = (p.IH + 1) / 2;
+    // XCD-aware order: linear block b runs on XCD b % 8; every XCD gets a contiguous run of (tile, lane block) items so that the output rows shared
+    // by neighbouring tiles are fetched into one L2
+    int L;
+    {
+        const int nt = gridDim.x, b = blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = b & 7, k = b >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int bx = L % nbx, tile = L / nbx;
+    const int id0 = (tile / tiles_h) * 2, ih0 = (tile % tiles_h) * 2;
+    const float sd = p.OD > 1 ? (float)(p.ID - 1) / (float)(p.OD - 1) : 0.f;
+    const float sh = p.OH > 1 ? (float)(p.IH - 1) / (float)(p.OH - 1) : 0.f;
+    const float sw = p.OW > 1 ? (float)(p.IW - 1) / (float)(p.OW - 1) : 0.f;
+    // dense weight tables of the tile: row r of axis d = output od_lo + r, column i = input id0 + i (zero where the output does not reach the input);
+    // wave 0 builds d, wave 1 builds h; the span is trimmed to the rows with a non-zero weight
+    if (tid < 128) {
+        const int axis = tid >> 6, r = tid & 63;
+        const int i0 = axis ? ih0 : id0, I = axis ? p.IH : p.ID, O = axis ? p.OH : p.OD;
+        const float sc = axis ? sh : sd;
+        int lo, hi, lo2, hi2;
+        up_range(i0, sc, O, lo, hi);
+        if (i0 + 1 < I) { up_range(i0 + 1, sc, O, lo2, hi2); if (hi2 > hi) hi = hi2; }
+        const int o = lo + r;
+        float w0 = 0.f, w1 = 0.f;
+        if (r < UP4_ROWS && o <= hi) { w0 = up_weight(o, i0, sc, I); if (i0 + 1 < I) w1 = up_weight(o, i0 + 1, sc, I); }
+        const unsigned long long nz = __ballot(w0 != 0.f || w1 != 0.f);
+        const int first = nz ? __builtin_ctzll(nz) : 0, last = nz ? 63 - __builtin_clzll(nz) : -1;
+        if (hi - lo + 1 > UP4_ROWS) __builtin_trap();            // the launcher admits scales whose candidate window fits
+        if (r >= first && r <= last) { float (*Wt)[2] = axis ? Wh : Wd; Wt[r - first][0] = w0; Wt[r - first][1] = w1; }
+        if (r == 0) { span[axis * 2] = lo + first; span[axis * 2 + 1] = last - first + 1; }
+    }
+    __syncthreads();
+    const int od0 = span[0], rd = span[1], oh0 = span[2], rh = span[3];
+    const int nrow = rd * rh;
+    if (tid < nrow) { const int a = tid / rh, b = tid - a * rh; W4[tid] = make_float4(Wd[a][0] * Wh[b][0], Wd[a][0] * Wh[b][1], Wd[a][1] * Wh[b][0], Wd[a][1] * Wh[b][1]); }
+    __syncthreads();
+    const int flat = bx * 256 + tid;
+    if (flat >= p.IW * CV) return;
+    const int iw = flat / CV, s = flat - iw * CV;
+    // this thread's w entry: first contributing output and NT weights
+    int wlo;
+    float wc[NT];
+    {
+        int lo, hi;
+        up_range(iw, sw, p.OW, lo, hi);
+        int first = -1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (first < 0 && lo + k <= hi && up_weight(lo + k, iw, sw, p.IW) != 0.f) first = k;
+        wlo = lo + (first < 0 ? 0 : first);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) wc[c] = (first >= 0 && wlo + c <= hi) ? up_weight(wlo + c, iw, sw, p.IW) : 0.f;
+        if (first >= 0 && wlo + NT <= hi && up_weight(wlo + NT, iw, sw, p.IW) != 0.f) __builtin_trap();      // the launcher sized NT (up_max_count)
+    }
+    // operand loads: buffer resources on the sample's tensors, per-lane byte offset of tap c (constant for the whole loop: a tap past the entry re-reads
+    // tap 0 with weight 0), wave-uniform row offset in an SGPR -> no address arithmetic per load
+    const uint32_t ovox = (uint32_t)(p.OD * p.OH * p.OW);
+    const uint32_t grow = (uint32_t)p.ldg * 2u;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.g + (size_t)n * ovox * p.ldg), 0, ovox * grow, 0x00020000);
+    uint32_t goff[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const uint32_t v = (uint32_t)(wlo + (wc[c] != 0.f ? c : 0));
+        goff[c] = v * grow + (uint32_t)s * 16u;
+    }
+    float acc[4][CPT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) acc[i][k] = 0.f;
+    uint4 gq[SL][NT];
+    int ia = 0, ib = 0;                                          // (a, b) of the next row to issue
+    auto issue = [&](int slot) {
+        const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane(((od0 + ia) * p.OH + (oh0 + ib)) * p.OW);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(grs, goff[c], row * grow, 0);
+            gq[slot][c] = make_uint4(q[0], q[1], q[2], q[3]);
+        }
+        if (++ib == rh) { ib = 0; ++ia; }
+    };
+#pragma unroll
+    for (int h = 0; h < SL - 1; ++h) if (h < nrow) issue(h);
+    for (int r = 0; r < nrow; r += SL) {
+#pragma unroll
+        for (int h = 0; h < SL; ++h) {                           // static register slots: row r + h lives in slot h
+            const int rr = r + h;
+            if (rr >= nrow) break;
+            if (rr + SL - 1 < nrow) issue((h + SL - 1) % SL);
+            f32x2_t tg[NWD];
+#pragma unroll
+            for (int j = 0; j < NWD; ++j) tg[j] = f32x2_t{0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const f32x2_t w2 = {wc[c], wc[c]};
+                const uint32_t wq[4] = {gq[h][c].x, gq[h][c].y, gq[h][c].z, gq[h][c].w};
+#pragma unroll
+                for (int j = 0; j < NWD; ++j) {
+                    const f32x2_t v2 = {__uint_as_float(wq[j] << 16), __uint_as_float(wq[j] & 0xffff0000u)};
+                    tg[j] = __builtin_elementwise_fma(w2, v2, tg[j]);
+                }
+            }
+            float t[CPT];
+#pragma unroll
+            for (int j = 0; j < NWD; ++j) { t[2 * j] = tg[j][0]; t[2 * j + 1] = tg[j][1]; }
+            const float4 w4 = W4[rr];                            // a zero weight adds exactly nothing (fma(0, t, acc) == acc for finite t)
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) acc[i][k] = fmaf(wv[i], t[k], acc[i][k]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = id0 + (i >> 1), ih = ih0 + (i & 1);
+        if (id < p.ID && ih < p.IH)
+            *(uint4*)((T*)p.dx + ((size_t)((n * p.ID + id) * p.IH + ih) * p.IW + iw) * p.lddx + s * CPT) = pack16<T>(acc[i]);
+    }
+}
+// largest number of contributing outputs of any input index of one axis (+1 per side where the device's contracted multiply-add may see one more: a
+// candidate whose source coordinate rounds to an exact integer has weight 0 on the host and may have a tiny non-zero weight on the device)
+static int up_max_count(int I, int O) {
+    const float sc = O > 1 ? (float)(I - 1) / (float)(O - 1) : 0.f;
+    int m = 1;
+    for (int i = 0; i < I; ++i) {
+        int lo, hi;
+        up_range(i, sc, O, lo, hi);
+        int first = -1, last = -2;
+        for (int o = lo; o <= hi; ++o) {
+            const float src = sc * (float)o;
+            const bool exact = src == (float)(int)src && ((int)src == i || (int)src == i - 1 || (int)src == i + 1);
+            if (up_weight(o, i, sc, I) != 0.f || exact) { if (first < 0) first = o; last = o; }
+        }
+        if (last - first + 1 > m) m = last - first + 1;
+    }
+    return m;
+}
+static int up_pair_window(int I, int O) {                        // widest candidate window (up_range) of an aligned pair of input indices
+    const float sc = O > 1 ? (float)(I - 1) / (float)(O - 1) : 0.f;
+    int m = 1;
+    for (int i = 0; i < I; i += 2) {
+        int lo, hi, lo2, hi2;
+        up_range(i, sc, O, lo, hi);
+        if (i + 1 < I) { up_range(i + 1, sc, O, lo2, hi2); if (hi2 > hi) hi = hi2; }
+        if (hi - lo + 1 > m) m = hi - lo + 1;
+    }
+    return m;
 }
 
 // ------------------------------------------------------------------------------------------------ stem: Conv3d(1 -> C, 3x3x3)
@@ -967,6 +1148,22 @@ int rs_launch_subsample(const PoolParams& p, int dtype, int bwd, int blocks, hip
     return rs_check_launch();
 }
 
+// trilinear backward on the row-sharing kernel (bf16); RS_ERR_UNSUPPORTED for scales its tile tables do not hold (the caller runs upsample_bwd2 then)
+static int launch_upsample_bwd4(const void* g, int ldg, void* dx, int lddx, int N, int ID, int IH, int IW, int OD, int OH, int OW, int C, hipStream_t st) {
+    static const bool off = getenv("RSUPER_UPSAMPLE_BWD4") && atoi(getenv("RSUPER_UPSAMPLE_BWD4")) == 0;
+    if (off || (C % 8) || N > 65535) return RS_ERR_UNSUPPORTED;
+    if ((size_t)OD * OH * OW * (size_t)ldg * 2 >= 0xFFFFFFFFull) return RS_ERR_UNSUPPORTED;                    // 32-bit byte offsets
+    if (up_pair_window(ID, OD) > UP4_ROWS || up_pair_window(IH, OH) > UP4_ROWS) return RS_ERR_UNSUPPORTED;
+    const int nmax = up_max_count(IW, OW);
+    if (nmax > 6) return RS_ERR_UNSUPPORTED;
+    UpInParams p = {g, ldg, dx, lddx, N, ID, IH, IW, OD, OH, OW, C};
+    const int nbx = (IW * (C / 8) + 255) / 256;
+    const unsigned blocks = (unsigned)(((ID + 1) / 2) * ((IH + 1) / 2) * nbx);
+    if (nmax <= 4) hipLaunchKernelGGL((upsample_bwd4_kernel<4>), dim3(blocks, N), dim3(256), 0, st, p, nbx);
+    else hipLaunchKernelGGL((upsample_bwd4_kernel<6>), dim3(blocks, N), dim3(256), 0, st, p, nbx);
+    return rs_check_launch();
+}
+
 int rs_launch_upsample(const UpParams& p, int dtype, int bwd, int blocks, hipStream_t st) {
     const int KP = dtype == RS_F32 ? 4 : 8;
     const int CV = p.C / KP;
@@ -992,6 +1189,10 @@ int rs_launch_upsample(const UpParams& p, int dtype, int bwd, int blocks, hipStr
         const int b = rs_elem_blocks((size_t)p.ID * p.IH * p.IW * CV);
         const size_t tab = (size_t)(p.ID + p.IH + p.IW) * sizeof(UpEnt);
         const bool small = (size_t)p.OD * p.OH * p.OW * p.ldy * (dtype == RS_F32 ? 4 : 2) < 0xFFFFFFFFull && (size_t)p.ID * p.IH * p.IW * CV < 0xFFFFFFFFull && tab <= 48 * 1024;
+        if (!v1 && dtype == RS_BF16) {                           // row-sharing kernel (upsample_bwd4_kernel)
+            const int rc = launch_upsample_bwd4(p.y, p.ldy, p.dx, p.lddx, p.N, p.ID, p.IH, p.IW, p.OD, p.OH, p.OW, p.C, st);
+            if (rc != RS_ERR_UNSUPPORTED) return rc;
+        }
         if (v1 || !small) {
             if (dtype == RS_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(b, p.N), dim3(256), 0, st, p);
             else hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(b, p.N), dim3(256), 0, st, p);

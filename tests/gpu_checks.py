@@ -324,6 +324,23 @@ def check_upsample(mode, Cin=8, I=3, O=6, seed=63):
     return result(f'upsample[{mode} {I}->{O} C{Cin}]', max(e, e2 * 0.1), 2e-5 if mode == 'f32' else 2e-2, f'val/grad {e:.2e} rstd {e2:.2e}')
 
 
+def check_upsample_bwd(N, I, O, C, seed=80):
+    """rsuper_upsample_bwd (bf16: the row-sharing kernel, csrc/unet_misc.hip upsample_bwd4_kernel) on a random gradient against a float64 evaluation
+    (autograd of F.interpolate) at the UNet's shapes scaled down, odd / ragged sizes, scale 1 and ~3 (the latter falls to the gather kernel).
+    I / O: (d, h, w) sizes.  Tolerance: the bf16 rounding of the result."""
+    from rsuper_amd.hip import ops
+    from rsuper_amd.hip import lib as _lib
+    dt = torch.bfloat16
+    dy = T(synth.rng(seed).standard_normal((N,) + tuple(O) + (C,)).astype(np.float32)).to(DEV).to(dt)
+    got = torch.full((N,) + tuple(I) + (C,), float('nan'), device=DEV, dtype=dt)
+    _lib.check(ops._L().rsuper_upsample_bwd(1, ops._ptr(dy), C, ops._ptr(got), C, N, *I, *O, C, ops._stream()), 'upsample_bwd')
+    torch.cuda.synchronize()
+    xin = torch.zeros((N, C) + tuple(I), dtype=torch.float64, requires_grad=True)
+    F.interpolate(xin, size=tuple(O), mode='trilinear', align_corners=True).backward(dy.cpu().double().permute(0, 4, 1, 2, 3).contiguous())
+    e = relerr(got.float().cpu(), xin.grad.permute(0, 2, 3, 4, 1).float())
+    return result(f'upsample_bwd[bf16 N{N} {I}->{O} C{C}]', e, 1e-2)
+
+
 def check_stem(mode, C=8, S=12):
     from rsuper_amd.hip import ops
     dt = DT[mode]
@@ -1209,6 +1226,11 @@ def all_checks(quick=False):
     for m in ('f32', 'bf16'):           # strided weight gradient: even / odd / ragged sizes, one and two dy sources, channel tails, several tiles per split
         cs += [(check_wgrad_s2, (m, 1, (8, 8, 32), 32, 32, 0)), (check_wgrad_s2, (m, 2, (12, 10, 20), 16, 32, 32)), (check_wgrad_s2, (m, 1, (7, 9, 35), 8, 16, 16)),
                (check_wgrad_s2, (m, 2, (5, 17, 66), 40, 24, 24)), (check_wgrad_s2, (m, 1, (2, 3, 5), 8, 8, 8)), (check_wgrad_s2, (m, 3, (24, 24, 24), 64, 128, 128))]
+    # trilinear backward, row-sharing kernel: the UNet's shapes (scaled down), odd / ragged sizes, scale 1 and ~3, many channels
+    cs += [(check_upsample_bwd, (2, (6, 6, 6), (12, 12, 12), 64)), (check_upsample_bwd, (1, (12, 12, 12), (24, 24, 24), 16, 81)),
+           (check_upsample_bwd, (2, (3, 5, 7), (6, 9, 13), 8, 82)), (check_upsample_bwd, (1, (5, 4, 3), (5, 4, 3), 8, 83)),
+           (check_upsample_bwd, (1, (3, 3, 4), (8, 9, 10), 24, 84)), (check_upsample_bwd, (1, (1, 2, 3), (2, 4, 6), 8, 85)),
+           (check_upsample_bwd, (2, (24, 24, 24), (48, 48, 48), 16, 86)), (check_upsample_bwd, (1, (6, 6, 6), (12, 12, 12), 320, 87))]
     for m in ('f32', 'bf16'):           # 1x1x1 convolutions of MedFormer's attention stages on MFMA: shipped shapes, ragged rows / channels
         cs += [(check_pointwise, (m, 27648, 128, 512, False)), (check_pointwise, (m, 13824, 512, 128, True)), (check_pointwise, (m, 3456, 256, 1024, False)),
                (check_pointwise, (m, 3456, 1024, 256, True)), (check_pointwise, (m, 432, 320, 1280, False)),       # reduction split over the waves
