@@ -225,6 +225,11 @@ int rsuper_head_fwd(int dtype, const void* x, int ldx, const float* w, const flo
 int rsuper_head_bwd_data(int dtype, const float* dlogits, const float* w, void* dx, int lddx, int N, int vox, int C, int K, void* stream);
 /* dw (K,C) and db (K) f32 are overwritten (same reduction scheme as rsuper_stem_wgrad). */
 int rsuper_head_bwd_weight(int dtype, const void* x, int ldx, const float* dlogits, float* dw, float* db, int N, int vox, int C, int K, void* stream);
+/* Both gradients of the head in one call: dx (bf16 / f32 channels-last) = dlogits^T W, dw / db overwritten.  With bf16 activations, K <= 32 classes and
+ * C <= 32 channels this is ONE pass over dlogits (the weight-gradient kernel also multiplies its staged dlogits tile with W on the matrix cores);
+ * otherwise the two calls above.  Autograd of outc = nn.Conv3d(C, K, 1) (model/dim3/unet.py:47) under loss.backward() (train_ddp.py:349). */
+int rsuper_head_bwd(int dtype, const void* x, int ldx, const float* dlogits, const float* w, void* dx, int lddx, float* dw, float* db,
+                    int N, int vox, int C, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Loss reductions -- training/losses_foundation.py:945-956 (masked BCE), :541-607 (DiceLossMultiClass),

@@ -437,6 +437,17 @@ int rsuper_head_bwd_weight(int dtype, const void* x, int ldx, const float* dlogi
     return rs_launch_head(p, dtype, 2, ST(stream));
 }
 
+int rsuper_head_bwd(int dtype, const void* x, int ldx, const float* dlogits, const float* w, void* dx, int lddx, float* dw, float* db,
+                    int N, int vox, int C, int K, void* stream) {
+    if (!dt_ok(dtype) || !x || !dlogits || !w || !dx || !dw || !db || !ch_ok(C, ldx) || !ch_ok(C, lddx) || K <= 0) return RS_ERR_ARG;
+    if (dtype == RS_BF16 && K <= 32 && C <= 32) {                  // one launch: weight + bias gradient and the data gradient from one pass over dlogits
+        HeadParams p = {x, ldx, w, nullptr, (float*)dlogits, dx, lddx, dw, db, N, vox, C, K};
+        return rs_launch_head(p, dtype, 2, ST(stream));
+    }
+    const int rc = rsuper_head_bwd_data(dtype, dlogits, w, dx, lddx, N, vox, C, K, stream);
+    return rc ? rc : rsuper_head_bwd_weight(dtype, x, ldx, dlogits, dw, db, N, vox, C, K, stream);
+}
+
 int rsuper_plane_partials_fwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
                               double* sums, int flags, int planes, size_t V, void* stream) {
     if (!x || !sums || planes <= 0 || V == 0 || (flags & ~2)) return RS_ERR_ARG;

@@ -917,7 +917,17 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tb = (float*)smem;                                    // [256][33]
     float* ta = tb + 256 * 33;                                   // [32][257] (head only)
+    float* wl = ta + 32 * 257;                                   // [32][33] head weights W[k][c] (fused data gradient only)
     float (*red)[16][64] = (float (*)[16][64])smem;              // [4][16][64], aliases tb after the last chunk
+    // MODE 1 with hp.dx: the data gradient of the head, dx[v][c] = sum_k dlogits[k][v] W[k][c], from the SAME staged dlogits tile (one more exact-f32 MFMA
+    // chain per 32 voxels) -- head_bwd_data_kernel re-read the 184 MB of dlogits and spent 26 x 32 LDS-fed multiply-adds per voxel on the VALU (102 us)
+    const bool with_dx = MODE == 1 && hp.dx != nullptr;
+    if (with_dx) {
+        for (int i = threadIdx.x; i < 32 * 33; i += 256) {
+            const int k = i / 33, c = i - k * 33;
+            wl[i] = (k < hp.K && c < hp.C) ? hp.w[k * hp.C + c] : 0.f;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = lane & 31, kk = lane >> 5;
     const int N = MODE == 0 ? sp.N : hp.N;
@@ -1000,6 +1010,28 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
             if (MODE == 0) { av = tb[vl * 33 + idx]; bv = idx < 27 ? ta[vl * 29 + idx] : 0.f; }
             else { av = ta[idx * 257 + vl]; bv = tb[vl * 33 + idx]; bias_acc += av; }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (with_dx) {
+            const int n = (int)(it / per), v0 = (int)(it % per) * 256;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {                        // this wave's 64 voxels as two 32-row tiles: D[v][c] = sum_k A[v][k] B[k][c]
+                f32x16_t d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int k = 2 * s + kk;
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[k * 257 + wave * 64 + g * 32 + idx], wl[k * 33 + idx], d, 0, 0, 0);
+                }
+                // lane: column c = idx, rows cd_row32(r, lane); channel pairs are packed by the even lanes (one 4-byte store per pair)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float other = __shfl_xor(d[r], 1, 64);
+                    const int v = v0 + wave * 64 + g * 32 + cd_row32(r, lane);
+                    if (!(idx & 1) && v < V && idx < hp.C)
+                        *(uint32_t*)((T*)hp.dx + ((size_t)n * V + v) * hp.lddx + idx) = sizeof(T) == 2 ? f2bf2(d[r], other) : 0u;
+                }
+            }
         }
         __syncthreads();
     }
@@ -1263,13 +1295,14 @@ int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st) {
         else { RS_DISPATCH_C(head_bwd_data_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
     } else {
         if (p.C > 32) return RS_ERR_UNSUPPORTED;
+        if (p.dx && (dtype != RS_BF16 || p.K > 32 || !p.w)) return RS_ERR_UNSUPPORTED;      // fused data gradient: one class pass, bf16 activations
         StemParams sp{};
         const long items = (long)p.N * ((p.vox + 255) / 256);
         dim3 g2((unsigned)(items < SMALL_WS_BLOCKS ? items : SMALL_WS_BLOCKS));
         float* ws = small_ws(1);
         if (!ws) return RS_ERR_LAUNCH;
         for (int k0 = 0; k0 < p.K; k0 += 32) {                  // 32 classes per pass (K = 42 in BASELINE config 5 -> 2 passes)
-            const size_t smem = (size_t)(256 * 33 + 32 * 257) * sizeof(float);
+            const size_t smem = (size_t)(256 * 33 + 32 * 257 + 32 * 33) * sizeof(float);
             if (dtype == RS_F32) {
                 auto kf = small_wgrad_mfma_kernel<float, 1>;
                 (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -58,6 +58,7 @@ _SIGS = {
     'rsuper_head_fwd': (c_int, [c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
     'rsuper_head_bwd_data': (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_head_bwd_weight': (c_int, [c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'rsuper_head_bwd': (c_int, [c_int, P, c_int, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     'rsuper_plane_partials_fwd': (c_int, [P, c_size_t, P, P, P, P, P, c_int, c_int, c_size_t, P]),
     'rsuper_cnorm_rows': (c_int, [c_long]),
     'rsuper_cnorm_small': (c_int, [P, P, P, P, P, c_int, c_long, c_int, c_int, c_float, c_int, P]),

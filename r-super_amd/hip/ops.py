@@ -847,8 +847,7 @@ class HeadFn(torch.autograd.Function):
         dw = grad_dest(w)
         db = grad_dest(b)
         st = _stream()
-        _l.check(_L().rsuper_head_bwd_data(_DT[x.dtype], _ptr(dl), _ptr(w), _ptr(dx), C, N, D * H * W, C, K, st), 'head_bwd_data')
-        _l.check(_L().rsuper_head_bwd_weight(_DT[x.dtype], _ptr(x), C, _ptr(dl), _ptr(dw), _ptr(db), N, D * H * W, C, K, st), 'head_bwd_weight')
+        _l.check(_L().rsuper_head_bwd(_DT[x.dtype], _ptr(x), C, _ptr(dl), _ptr(w), _ptr(dx), C, _ptr(dw), _ptr(db), N, D * H * W, C, K, st), 'head_bwd')
         return dx, dw, db
 
 
