@@ -198,6 +198,11 @@ int rsuper_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, flo
                         int N, int D, int H, int W, int C, void* stream);
 int rsuper_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx,
                         int N, int D, int H, int W, int C, void* stream);
+/* dx = maxpool backward(dy) + add in one pass: x of a down_block is also the skip connection of the matching up_block (model/dim3/unet.py:57-66),
+ * `add` is the gradient that arrived through the skip; autograd would store their sum with one more read-read-write launch.  Even D, H, W only
+ * (RS_ERR_UNSUPPORTED otherwise).  Bit-identical to the two steps (both round the f32 sum of two bf16 values once). */
+int rsuper_maxpool2_bwd_add(int dtype, const void* x, int ldx, const void* dy, int lddy, const void* add, int lda, void* dx, int lddx,
+                            int N, int D, int H, int W, int C, void* stream);
 
 /* Stride-(2,2,2) down-sampling of down_block(pool=False) -- model/dim3/unet_utils.py:38-39 (`block(in_ch, out_ch,
  * stride=down_scale)`; conv_layers.py:29-38 with stride 2, padding 1).  The strided convolution is the stride-1 convolution

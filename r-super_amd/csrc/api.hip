@@ -384,6 +384,13 @@ int rsuper_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int l
     PoolParams p = {x, ldx, (void*)dy, lddy, dx, lddx, nullptr, N, D, H, W, C};
     return rs_launch_pool(p, dtype, 1, 1, ST(stream));
 }
+int rsuper_maxpool2_bwd_add(int dtype, const void* x, int ldx, const void* dy, int lddy, const void* add, int lda, void* dx, int lddx,
+                            int N, int D, int H, int W, int C, void* stream) {
+    if (!dt_ok(dtype) || !x || !dy || !add || !dx || !ch_ok(C, ldx) || !ch_ok(C, lddy) || !ch_ok(C, lda) || !ch_ok(C, lddx)) return RS_ERR_ARG;
+    if ((D & 1) || (H & 1) || (W & 1)) return RS_ERR_UNSUPPORTED;   // the never-pooled trailing planes would need a copy of `add`: the caller adds the two gradients itself
+    PoolParams p = {x, ldx, (void*)dy, lddy, dx, lddx, nullptr, N, D, H, W, C, add, lda};
+    return rs_launch_pool(p, dtype, 1, 1, ST(stream));
+}
 
 int rsuper_subsample2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, float* part, int blocks,
                           int N, int D, int H, int W, int C, void* stream) {

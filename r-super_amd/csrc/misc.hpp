@@ -22,6 +22,7 @@ struct PoolParams {
     void* dx; int lddx;            // backward output
     float* part;                   // forward: partial stats [N][blocks][C][2] or nullptr
     int N, D, H, W, C;             // input dims
+    const void* add; int lda;      // max-pool backward: optional second gradient of x (the skip connection's) added to every voxel
 };
 
 struct UpParams {

@@ -213,6 +213,12 @@ __global__ void maxpool_bwd_kernel(PoolParams p) {
                 o[j] = hit ? dy[j] : 0.f;
                 done[j] = done[j] || hit;
             }
+            if (p.add) {                                         // dx = scatter(dy) + add, rounded once: what autograd's accumulation of the two gradients stores
+                float a[KP];
+                unpack16<T>(*(const uint4*)((const T*)p.add + ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (size_t)p.lda + s * KP), a);
+#pragma unroll
+                for (int j = 0; j < KP; ++j) o[j] += a[j];
+            }
             *(uint4*)((T*)p.dx + ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (size_t)p.lddx + s * KP) = pack16<T>(o);
         }
     }

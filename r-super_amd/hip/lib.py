@@ -49,6 +49,7 @@ _SIGS = {
     'rsuper_in_bwd_finalize': (c_int, [c_int, P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     'rsuper_maxpool2_fwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_maxpool2_bwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'rsuper_maxpool2_bwd_add': (c_int, [c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_subsample2_fwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_subsample2_bwd': (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_upsample_fwd': (c_int, [c_int, P, c_int, P, c_int, P, c_int] + [c_int] * 8 + [P]),

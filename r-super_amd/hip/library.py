@@ -5,6 +5,7 @@ registered as custom HIP ops behind the repo's existing model/ and training/ int
 
     torch.ops.rsuper.basic_block(xa, mra, xb, mrb, w1, w2, ws, pack_bufs, pack_bns, stride) -> (out, mr_out)
     torch.ops.rsuper.maxpool2(x) -> (y, mr)                    torch.ops.rsuper.upsample_trilinear(x, size) -> (y, mr)
+    torch.ops.rsuper.maxpool2_skip(x) -> (y, mr, x)            (x again as the skip connection: both gradients of x meet in one backward launch)
     torch.ops.rsuper.stem_conv(img, w, dtype) -> (y, mr)       torch.ops.rsuper.head_conv(x, w, b) -> logits
     torch.ops.rsuper.conv3(x, w) -> y                          torch.ops.rsuper.channel_norm(x, eps, relu) -> y
     torch.ops.rsuper.depthwise_conv3(x, w) -> y                torch.ops.rsuper.squeeze_excite(x, w1, b1, w2, b2) -> y
@@ -98,6 +99,7 @@ def install():
          '(Tensor xa, Tensor mra, Tensor? xb, Tensor? mrb, Tensor w1, Tensor w2, Tensor? ws, Tensor[]? pack_bufs, int[]? pack_bns, int stride) -> (Tensor, Tensor)',
          _bb_fn_args, _bb_apply_args),
         ('MaxPoolFn', 'maxpool2', '(Tensor x) -> (Tensor, Tensor)', None, None),
+        ('MaxPoolSkipFn', 'maxpool2_skip', '(Tensor(a) x) -> (Tensor, Tensor, Tensor(a))', None, None),
         ('UpsampleFn', 'upsample_trilinear', '(Tensor x, int[] size) -> (Tensor, Tensor)', lambda x, size: (x, tuple(size)), None),
         ('StemFn', 'stem_conv', '(Tensor img, Tensor w, ScalarType dtype) -> (Tensor, Tensor)', None, None),
         ('HeadFn', 'head_conv', '(Tensor x, Tensor w, Tensor b) -> Tensor', None, None),

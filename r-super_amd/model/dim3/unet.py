@@ -103,10 +103,10 @@ class UNet(nn.Module):
         if batch_pack:
             self._pack_all(tuple(x.shape), dt)
         x1, m1 = self.inc(x, dt)
-        x2, m2 = self.down1(x1, m1)
-        x3, m3 = self.down2(x2, m2)
-        x4, m4 = self.down3(x3, m3)
-        x5, m5 = self.down4(x4, m4)
+        x2, m2, x1 = self.down1(x1, m1, True)      # x_k comes back as the skip tensor: both of its gradients meet in the pooling layer's backward
+        x3, m3, x2 = self.down2(x2, m2, True)
+        x4, m4, x3 = self.down3(x3, m3, True)
+        x5, m5, x4 = self.down4(x4, m4, True)
         o, mo = self.up1(x5, m5, x4, m4)
         o, mo = self.up2(o, mo, x3, m3)
         o, mo = self.up3(o, mo, x2, m2)

@@ -1,5 +1,6 @@
 """inconv / down_block / up_block mirroring rsuper_train/model/dim3/unet_utils.py:7-75 (same module tree, so
 state_dict keys are identical: inc.conv1.weight, down1.conv.1.conv1.conv.weight, up4.conv.0.shortcut.conv.weight...)."""
+import torch
 import torch.nn as nn
 
 from .conv_layers import BasicBlock
@@ -9,8 +10,8 @@ from ...hip import ops
 class _Pool(nn.Module):
     """Occupies index 0 of down_block.conv like nn.MaxPool3d does in the reference (unet_utils.py:36)."""
 
-    def forward(self, x):
-        return ops.MaxPoolFn.apply(x)
+    def forward(self, x, with_skip=False):
+        return ops.MaxPoolSkipFn.apply(x) if with_skip else ops.MaxPoolFn.apply(x)
 
 
 class inconv(nn.Module):
@@ -39,14 +40,20 @@ class down_block(nn.Module):
             layers.append(block(out_ch, out_ch, kernel_size=kernel_size, norm=norm))
         self.conv = nn.Sequential(*layers)
 
-    def forward(self, x, mr):
+    def forward(self, x, mr, with_skip=False):
+        """with_skip: also return the input as the tensor to hand to the matching up_block (pooling layers only: its gradient is then added inside
+        the max-pool backward kernel; with a strided first block the input itself is returned)."""
         blocks = list(self.conv)
+        skip = x
         if self.pool:
-            x, mr = blocks[0](x)
+            if with_skip and torch.is_grad_enabled() and x.requires_grad:
+                x, mr, skip = blocks[0](x, True)
+            else:
+                x, mr = blocks[0](x)
             blocks = blocks[1:]
         for blk in blocks:
             x, mr = blk(x, mr)
-        return x, mr
+        return (x, mr, skip) if with_skip else (x, mr)
 
 
 class up_block(nn.Module):
