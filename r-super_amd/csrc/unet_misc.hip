@@ -275,7 +275,9 @@ __global__ void subsample_bwd_kernel(PoolParams p) {
 
 // ------------------------------------------------------------------------------------------------ trilinear, align_corners
 __host__ __device__ __forceinline__ void lin_coord(int o, float scale, int I, int& i0, int& i1, float& l1) {
-    // ATen area_pixel_compute_source_index(align_corners=True): src = scale * dst (float32)
+    // ATen area_pixel_compute_source_index(align_corners=True): src = scale * dst (float32).  No contraction of `scale * o - i0` into one fma: the
+    // host sizes the backward kernel's tap tables with this same function and must see the same zero / non-zero weights as the device
+#pragma clang fp contract(off)
     const float src = scale * (float)o;
     i0 = (int)src;
     if (i0 > I - 1) i0 = I - 1;
@@ -750,8 +752,7 @@ __global__ __launch_bounds__(256, 3) void upsample_bwd4_kernel(UpInParams p, int
             *(uint4*)((T*)p.dx + ((size_t)((n * p.ID + id) * p.IH + ih) * p.IW + iw) * p.lddx + s * CPT) = pack16<T>(acc[i]);
     }
 }
-// largest number of contributing outputs of any input index of one axis (+1 per side where the device's contracted multiply-add may see one more: a
-// candidate whose source coordinate rounds to an exact integer has weight 0 on the host and may have a tiny non-zero weight on the device)
+// largest number of contributing outputs of any input index of one axis (the arithmetic of the kernel: lin_coord is not contracted on either side)
 static int up_max_count(int I, int O) {
     const float sc = O > 1 ? (float)(I - 1) / (float)(O - 1) : 0.f;
     int m = 1;
@@ -759,11 +760,8 @@ static int up_max_count(int I, int O) {
         int lo, hi;
         up_range(i, sc, O, lo, hi);
         int first = -1, last = -2;
-        for (int o = lo; o <= hi; ++o) {
-            const float src = sc * (float)o;
-            const bool exact = src == (float)(int)src && ((int)src == i || (int)src == i - 1 || (int)src == i + 1);
-            if (up_weight(o, i, sc, I) != 0.f || exact) { if (first < 0) first = o; last = o; }
-        }
+        for (int o = lo; o <= hi; ++o)
+            if (up_weight(o, i, sc, I) != 0.f) { if (first < 0) first = o; last = o; }
         if (last - first + 1 > m) m = last - first + 1;
     }
     return m;
@@ -839,6 +837,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
 // exact-f32 v_mfma_f32_32x32x2_f32 chain (14 steps cover the 27 taps + one zero pad).  A = weights (row = channel, held
 // in 14 registers per lane for the whole block), B = gathered input (column = voxel).  A lane ends up with 16 channels
 // of one voxel = four 4-channel groups -> 8-byte (bf16) / 16-byte (f32) stores.  Block = 256 consecutive voxels.
+#ifndef STEM_DIRECT_STORE
+#define STEM_DIRECT_STORE 0
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemParams p) {
     __shared__ float tile[256 * 33];
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemParams p) {
                 q[j] = Elem<T>::rnd(acc[r4 * 4 + j]);
                 tile[vl * 33 + c0 + j] = ok ? q[j] : 0.f;
             }
-            if (ok && c0 < C) {
+            if (STEM_DIRECT_STORE && ok && c0 < C) {
                 if (sizeof(T) == 2) {
                     *(uint2*)(o + c0) = make_uint2(f2bf2(q[0], q[1]), f2bf2(q[2], q[3]));
                 } else {
@@ -892,6 +893,17 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemParams p) {
         }
     }
     __syncthreads();
+    if (!STEM_DIRECT_STORE) {
+        // the block's 256 voxels x C channels leave through the statistics tile as 16-byte vectors, consecutive lanes -> consecutive addresses (the
+        // accumulator layout gives a lane 4 channels of one voxel: 8-byte stores 64 bytes apart, a quarter of every 32-byte sector per instruction)
+        constexpr int KP = Elem<T>::KP;
+        const int cv = C / KP;                                   // vectors per voxel
+        for (int i = threadIdx.x; i < 256 * cv; i += 256) {
+            const int vl = i / cv, c0 = (i - vl * cv) * KP;
+            const int v = blockIdx.x * 256 + vl;
+            if (v < vox) *(uint4*)((T*)p.y + ((size_t)n * vox + v) * p.ldy + c0) = pack16<T>(tile + vl * 33 + c0);
+        }
+    }
     // channel-major reduction: thread (g, c) sums 32 voxels; then 8 partials per channel
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     float a = 0.f, b = 0.f;

@@ -33,4 +33,4 @@ for S, C, Ca in ((96, 64, 32), (48, 128, 64), (24, 256, 128), (12, 320, 256)):
         L.rsuper_upsample_bwd(1, dyb[0].data_ptr(), C, dx.data_ptr(), C, N, I, I, I, S, S, S, C, None)
     t0 = timeit(fin); t1 = timeit(plain)
     mb = N * S ** 3 * C * 2 / 1e6
-    print(f'{I}^3 -> {S}^3 x {C} ch: in_bwd_finalize {t0:7.1f} us ({3 * mb / t0 / 1e3:.2f} TB/s) | upsample_bwd {t1:7.1f} us ({(mb + mb / 8) / t1 / 1e3:.2f} TB/s)')
+    print(f'{I}^3 -> {S}^3 x {C} ch: in_bwd_finalize {t0:7.1f} us ({3 * mb / t0:.2f} TB/s) | upsample_bwd {t1:7.1f} us ({(mb + mb / 8) / t1:.2f} TB/s)')
