@@ -928,7 +928,7 @@ constexpr int SMALL_WS_ROW = 1024 + 32;
 constexpr int SMALL_WS_BLOCKS = 512;
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, HeadParams hp, int k0, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, HeadParams hp, int k0, int c0, float* __restrict__ ws) {
     // Chunks of 256 consecutive voxels are staged block-cooperatively with wide coalesced loads (per-lane 2/4-byte
     // gathers saturated the address unit): tb = channels-last operand [256][33] as f32; ta = head: dlogits planes
     // [32][257], stem: im2col of the image [256][29] built from loads that are contiguous across lanes.
@@ -966,9 +966,9 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
         const int v0 = (int)(it % per) * 256;
         const int v = v0 + tid;
         const T* src = MODE == 0 ? (const T*)sp.y + ((size_t)n * V + (v < V ? v : 0)) * sp.ldy : (const T*)hp.x + ((size_t)n * V + (v < V ? v : 0)) * hp.ldx;
-        const int C = MODE == 0 ? sp.C : hp.C;
+        const int C = MODE == 0 ? sp.C : hp.C;                     // this launch covers channels [c0, c0 + 32)
 #pragma unroll
-        for (int c = 0; c < 32; c += KP) rx[c / KP] = (v < V && c < C) ? *(const uint4*)(src + c) : make_uint4(0, 0, 0, 0);
+        for (int c = 0; c < 32; c += KP) rx[c / KP] = (v < V && c0 + c < C) ? *(const uint4*)(src + c0 + c) : make_uint4(0, 0, 0, 0);
         if (MODE == 1) {
             const int k = tid >> 3, seg = tid & 7;
             const bool kok = k0 + k < hp.K;
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
 
 // wave per element: sums the per-block rows (fixed order -> deterministic) and scatters into dW / db
 template <int MODE>
-__global__ __launch_bounds__(256) void small_wgrad_reduce_kernel(const float* __restrict__ ws, int nrows, StemParams sp, HeadParams hp, int k0) {
+__global__ __launch_bounds__(256) void small_wgrad_reduce_kernel(const float* __restrict__ ws, int nrows, StemParams sp, HeadParams hp, int k0, int c0) {
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= SMALL_WS_ROW) return;
@@ -1085,9 +1085,9 @@ __global__ __launch_bounds__(256) void small_wgrad_reduce_kernel(const float* __
     if (e < 1024) {
         const int rr = e >> 6, ln = e & 63;
         const int i = cd_row32(rr, ln), j = ln & 31;
-        if (MODE == 0) { if (i < sp.C && j < 27) sp.dw[i * 27 + j] = v; }
-        else { if (k0 + i < hp.K && j < hp.C) hp.dw[(k0 + i) * hp.C + j] = v; }
-    } else if (MODE == 1) {
+        if (MODE == 0) { if (c0 + i < sp.C && j < 27) sp.dw[(c0 + i) * 27 + j] = v; }
+        else { if (k0 + i < hp.K && c0 + j < hp.C) hp.dw[(k0 + i) * hp.C + c0 + j] = v; }
+    } else if (MODE == 1 && c0 == 0) {
         const int i = e - 1024;
         if (k0 + i < hp.K) hp.db[k0 + i] = v;
     }
@@ -1286,22 +1286,23 @@ int rs_launch_stem(const StemParams& p, int dtype, int wgrad, hipStream_t st) {
         if (dtype == RS_F32) { RS_DISPATCH_C(stem_fwd_kernel, float, p.C, grid, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(stem_fwd_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
     } else {
-        if (p.C > 32) return RS_ERR_UNSUPPORTED;
         HeadParams hp{};
         const long items = (long)p.N * ((vox + 255) / 256);
         dim3 grid((unsigned)(items < SMALL_WS_BLOCKS ? items : SMALL_WS_BLOCKS));
         float* ws = small_ws(0);
         if (!ws) return RS_ERR_LAUNCH;
         const size_t smem = (size_t)(256 * 33 + 256 * 29) * sizeof(float);
-        if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 0>), grid, dim3(256), smem, st, p, hp, 0, ws);
-        else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 0>), grid, dim3(256), smem, st, p, hp, 0, ws);
-        hipLaunchKernelGGL(small_wgrad_reduce_kernel<0>, dim3((SMALL_WS_ROW + 3) / 4), dim3(256), 0, st, ws, (int)grid.x, p, hp, 0);
+        for (int c0 = 0; c0 < p.C; c0 += 32) {                   // 32 output channels per pass (base_ch 64: two passes)
+            if (dtype == RS_F32) hipLaunchKernelGGL((small_wgrad_mfma_kernel<float, 0>), grid, dim3(256), smem, st, p, hp, 0, c0, ws);
+            else hipLaunchKernelGGL((small_wgrad_mfma_kernel<bf16_t, 0>), grid, dim3(256), smem, st, p, hp, 0, c0, ws);
+            hipLaunchKernelGGL(small_wgrad_reduce_kernel<0>, dim3((SMALL_WS_ROW + 3) / 4), dim3(256), 0, st, ws, (int)grid.x, p, hp, 0, c0);
+        }
     }
     return rs_check_launch();
 }
 
 int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st) {
-    if (p.K > 64) return RS_ERR_UNSUPPORTED;
+    if (p.K > 256) return RS_ERR_UNSUPPORTED;                    // K * C + K floats of weights in LDS
     dim3 grid((p.vox + 255) / 256, p.N);
     if (which == 0) {
         const size_t smem = (size_t)(p.K * p.C + p.K) * sizeof(float);
@@ -1312,26 +1313,26 @@ int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st) {
         if (dtype == RS_F32) { RS_DISPATCH_C(head_bwd_data_kernel, float, p.C, grid, dim3(256), smem, st, p) }
         else { RS_DISPATCH_C(head_bwd_data_kernel, bf16_t, p.C, grid, dim3(256), smem, st, p) }
     } else {
-        if (p.C > 32) return RS_ERR_UNSUPPORTED;
-        if (p.dx && (dtype != RS_BF16 || p.K > 32 || !p.w)) return RS_ERR_UNSUPPORTED;      // fused data gradient: one class pass, bf16 activations
+        if (p.dx && (dtype != RS_BF16 || p.K > 32 || p.C > 32 || !p.w)) return RS_ERR_UNSUPPORTED;      // fused data gradient: one pass, bf16 activations
         StemParams sp{};
         const long items = (long)p.N * ((p.vox + 255) / 256);
         dim3 g2((unsigned)(items < SMALL_WS_BLOCKS ? items : SMALL_WS_BLOCKS));
         float* ws = small_ws(1);
         if (!ws) return RS_ERR_LAUNCH;
-        for (int k0 = 0; k0 < p.K; k0 += 32) {                  // 32 classes per pass (K = 42 in BASELINE config 5 -> 2 passes)
-            const size_t smem = (size_t)(256 * 33 + 32 * 257 + 32 * 33) * sizeof(float);
-            if (dtype == RS_F32) {
-                auto kf = small_wgrad_mfma_kernel<float, 1>;
-                (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                hipLaunchKernelGGL(kf, g2, dim3(256), smem, st, sp, p, k0, ws);
-            } else {
-                auto kf = small_wgrad_mfma_kernel<bf16_t, 1>;
-                (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                hipLaunchKernelGGL(kf, g2, dim3(256), smem, st, sp, p, k0, ws);
+        for (int k0 = 0; k0 < p.K; k0 += 32)                    // 32 classes x 32 channels per pass (K = 42 in BASELINE config 5 -> 2 passes)
+            for (int c0 = 0; c0 < p.C; c0 += 32) {
+                const size_t smem = (size_t)(256 * 33 + 32 * 257 + 32 * 33) * sizeof(float);
+                if (dtype == RS_F32) {
+                    auto kf = small_wgrad_mfma_kernel<float, 1>;
+                    (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                    hipLaunchKernelGGL(kf, g2, dim3(256), smem, st, sp, p, k0, c0, ws);
+                } else {
+                    auto kf = small_wgrad_mfma_kernel<bf16_t, 1>;
+                    (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                    hipLaunchKernelGGL(kf, g2, dim3(256), smem, st, sp, p, k0, c0, ws);
+                }
+                hipLaunchKernelGGL(small_wgrad_reduce_kernel<1>, dim3((SMALL_WS_ROW + 3) / 4), dim3(256), 0, st, ws, (int)g2.x, sp, p, k0, c0);
             }
-            hipLaunchKernelGGL(small_wgrad_reduce_kernel<1>, dim3((SMALL_WS_ROW + 3) / 4), dim3(256), 0, st, ws, (int)g2.x, sp, p, k0);
-        }
     }
     return rs_check_launch();
 }

@@ -30,9 +30,9 @@ class UNet(nn.Module):
             raise NotImplementedError("norm must be 'in' (InstanceNorm3d) on the gfx950 hot path")
         if in_ch != 1 or base_ch % 8:
             raise NotImplementedError('in_ch must be 1 and base_ch a multiple of 8')
-        if base_ch > 32 or num_classes > 64:
-            raise NotImplementedError('the stem / head weight-gradient kernels cover base_ch <= 32 and num_classes <= 64 '
-                                      '(reference configs: base 32, 26-42 classes)')
+        if base_ch not in (8, 16, 32, 64) or num_classes > 256:
+            raise NotImplementedError('the stem / head kernels are instantiated for base_ch 8 / 16 / 32 / 64 and hold the weights of up to 256 classes '
+                                      'in LDS (reference configs: base 32, 26-42 classes)')
         blk = _get_block(block)
         num_block = 2
         ks = [k if isinstance(k, (list, tuple)) else [k] * 3 for k in kernel_size]

@@ -341,6 +341,27 @@ def check_upsample_bwd(N, I, O, C, seed=80):
     return result(f'upsample_bwd[bf16 N{N} {I}->{O} C{C}]', e, 1e-2)
 
 
+def check_unet_wide(mode, base=64, classes=70, S=32):
+    """Widths beyond the shipped configuration (base_ch 64: 640 channels at the bottom, 64-channel stem / head in two 32-channel passes of the small
+    weight-gradient kernel; 70 classes: three 32-class passes) -- the reference UNet takes any width (rsuper_train/model/dim3/unet.py:31-47).
+    Logits against the CPU oracle, every gradient finite; stem / head gradients are pinned by check_stem / check_head at these widths."""
+    from rsuper_amd.model.dim3.unet import UNet
+    net = UNet(1, base, num_classes=classes, compute_dtype=mode)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, 5)
+    net.load_state_dict({k: T(v) for k, v in sd.items()})
+    net = net.to(DEV)
+    img = T(synth.image(1, S, seed=9))
+    y = net(img.to(DEV))['segmentation']
+    y.square().mean().backward()
+    torch.cuda.synchronize()
+    ref = uo.unet_forward({k: T(v) for k, v in sd.items()}, img)
+    e = relerr(y.detach().cpu(), ref)
+    fin = all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+    tol = 1e-3 if mode == 'f32' else 0.3
+    return result(f'unet_wide[{mode} base {base}, {classes} classes, {S}^3]', e if fin else 1e9, tol, f'logits vs oracle {e:.2e}; gradients finite: {fin}')
+
+
 def check_stem(mode, C=8, S=12):
     from rsuper_amd.hip import ops
     dt = DT[mode]
@@ -1185,6 +1206,7 @@ def all_checks(quick=False):
             (check_pool, (mode,)), (check_upsample, (mode,)), (check_upsample, (mode, 16, 6, 12, 70)), (check_upsample, (mode, 8, 8, 32, 71)), (check_upsample, (mode, 8, 2, 4, 72)),
             (check_upsample, (mode, 8, 5, 9, 73)),
             (check_stem, (mode,)), (check_stem, (mode, 32, 16)), (check_head, (mode,)), (check_head, (mode, 32, 42, 12)),
+            (check_stem, (mode, 64, 12)), (check_head, (mode, 64, 70, 10)), (check_head, (mode, 16, 130, 9)), (check_unet_wide, (mode,)),
             (check_basic_block, (mode, 'b8_16', 8, 16, 12, 1)), (check_basic_block, (mode, 'b16_16', 16, 16, 10, 2)),
             (check_basic_block, (mode, 'b24_8', 24, 8, 12, 3)),
             (check_basic_block, (mode, 'b8_16_s2', 8, 16, 12, 4)), (check_basic_block, (mode, 'b16_16_s2', 16, 16, 9, 5)),
