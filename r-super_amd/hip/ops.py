@@ -140,6 +140,43 @@ def pack_weights_batch(dtype, specs):
     return [buf[offs[i]:offs[i + 1]] for i in range(n)]
 
 
+_BLOCK_PACK_CACHE = {}
+
+
+def block_packs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims):
+    """block_pack_specs + pack_weights_batch for one BasicBlock, with the launch descriptor (tile sizes, offsets, ctypes argument arrays) cached per
+    (parameter addresses, geometry): the host builds it once instead of every step -- at the 12^3 / 6^3 levels a block's kernels take 60-70 us and
+    its host code took 100 us (tools/host_profile.py), the queue ran dry there.  Parameters keep their addresses for the life of a module; a new
+    key (another net, a moved parameter) simply adds an entry.  Returns (buffers, bns)."""
+    import ctypes
+    key = (w1.data_ptr(), w2.data_ptr(), 0 if ws is None else ws.data_ptr(), w1.shape[0], Ca, Cb, dtype, tiles_total, with_backward, dims, rs_variant_epoch())
+    ent = _BLOCK_PACK_CACHE.get(key)
+    if ent is None:
+        specs, bns = block_pack_specs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims)
+        dt = _DT[dtype]
+        n = len(specs)
+        sizes = [_L().rsuper_conv3_packed_elems(dt, sp[3], sp[4], sp[5] + sp[6], sp[7]) for sp in specs]
+        offs = [0]
+        for z in sizes:
+            offs.append(offs[-1] + z)
+        desc = (ctypes.c_int * (6 * n))(*[v for sp in specs for v in (sp[0], sp[3], sp[4], sp[5], sp[6], sp[7])])
+        wa = (ctypes.c_void_p * n)(*[sp[1].data_ptr() for sp in specs])
+        wb = (ctypes.c_void_p * n)(*[(sp[2].data_ptr() if sp[2] is not None else None) for sp in specs])
+        oe = (ctypes.c_size_t * n)(*offs[:-1])
+        if len(_BLOCK_PACK_CACHE) > 1024:
+            _BLOCK_PACK_CACHE.clear()
+        ent = _BLOCK_PACK_CACHE[key] = (dt, n, desc, wa, wb, oe, offs, bns)
+    dt, n, desc, wa, wb, oe, offs, bns = ent
+    buf = torch.empty((offs[-1],), device=w1.device, dtype=dtype)
+    _l.check(_L().rsuper_conv3_pack_weights_batch(dt, n, desc, wa, wb, oe, _ptr(buf), _stream()), 'pack_weights_batch')
+    return [buf[offs[i]:offs[i + 1]] for i in range(n)], bns
+
+
+def rs_variant_epoch():
+    """The igemm variant / tile-fill switches change pick_bn's answers: part of the cache key."""
+    return (_L().rsuper_conv3_variant(-1), os.environ.get('RSUPER_BN_FILL', '512'))
+
+
 def block_pack_specs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims=None):
     """The (up to) four fragment buffers a BasicBlock needs: forward conv1(+shortcut), forward conv2, data-gradient
     conv2, data-gradient conv1(+shortcut).  Returns (specs, bns) in that order."""
@@ -535,8 +572,7 @@ class BasicBlockFn(torch.autograd.Function):
             # with gradients wanted, the data-gradient fragments are packed by the same launch (one pack launch per block instead of
             # two; they are read once, much later, so being cold in L2 by then costs nothing measurable)
             both = os.environ.get('RSUPER_PACK_BOTH', '1') == '1' and any(ctx.needs_input_grad)
-            specs, bns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, both, dims)
-            packs = (pack_weights_batch(dt, specs), bns)
+            packs = block_packs(w1, w2, ws, Ca, Cb, dt, tiles * N, both, dims)
         bn1, wp1 = packs[1][0], packs[0][0]
         ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
         part = part_buffer(dt, dims, nc1, bn1, dev)
@@ -670,8 +706,8 @@ class BasicBlockFn(torch.autograd.Function):
         if ctx.packs is not None:
             bpk = (ctx.packs[0][2:], ctx.packs[1][2:])
         else:
-            bspecs, bbns = block_pack_specs(w1, w2, ws, Ca, Cb, dt, tiles * N, True, dims)
-            bpk = (pack_weights_batch(dt, bspecs[2:]), bbns[2:])
+            bufs, bbns = block_packs(w1, w2, ws, Ca, Cb, dt, tiles * N, True, dims)
+            bpk = (bufs[2:], bbns[2:])
         bn, wpd2 = bpk[1][0], bpk[0][0]
         g1 = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
         part = part_buffer(dt, dims, Cout, bn, dev, epi=1)

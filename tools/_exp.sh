@@ -1,8 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python - <<P 2>&1 | grep -v amdgpu
-import sys; sys.path.insert(0,"tests"); sys.path.insert(0,"tests/golden")
-import gpu_checks as gc
-for m in ("f32","bf16"):
-    for fn,a in [(gc.check_stem,(m,64,12)),(gc.check_head,(m,64,70,10)),(gc.check_head,(m,16,130,9)),(gc.check_head,(m,32,42,12)),(gc.check_stem,(m,32,16)),(gc.check_unet_wide,(m,))]:
-        r=fn(*a); print(r["ok"], r["name"], r["err"], r["note"])
-P
+python tools/host_time.py 2>&1 | grep "host enqueue" | head -4
+bash tools/ab.sh 2>&1 | grep -v amdgpu.ids | cut -c1-20
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed" | tail -1
