@@ -185,7 +185,8 @@ def test_packed_batch_gives_same_loss():
 @pytest.mark.parametrize('fill', ['dense', 'segment', 'empty'])
 @pytest.mark.parametrize('d_odd', [5, 9, 21])
 def test_ball_conv_two_stage_equals_direct(d_odd, fill):
-    """The separable two-stage correlation gives the direct kernel's values (f32 summation-order tolerance) and argmax -- on a dense
+    """(Consistency of two kernels of this repo, NOT a parity claim: the reference-pinned checks of the two-stage path are check_ball_large /
+    test_report_loss_fullsize_matches_reference_and_oracle.)  The separable two-stage correlation gives the direct kernel's values (f32 summation-order tolerance) and argmax -- on a dense
     volume, on one that is zero outside an organ-like segment (the second stage then visits the occupied (z, y) rows only) and on an
     all-zero volume (first index wins)."""
     from rsuper_amd.hip import lib
