@@ -308,6 +308,31 @@ def check_pool(mode):
     return result(f'maxpool[{mode}]', e, 1e-6 if mode == 'f32' else 1e-2)
 
 
+def check_pool_skip(mode, shape=(2, 8, 6, 10, 16), seed=64):
+    """MaxPoolSkipFn (pooling layer whose input is also a skip connection: both gradients summed inside the max-pool backward kernel) against the
+    fp32 reference autograd of `F.max_pool3d(x, 2)` + a second use of x, and bit for bit against MaxPoolFn + autograd's own accumulation; even sizes
+    (fused kernel) and odd ones (two steps).  shape = (N, D, H, W, C)."""
+    from rsuper_amd.hip import ops
+    dt = DT[mode]
+    N, D, H, W, C = shape
+    x = rnd(T(synth.rng(seed).standard_normal((N, C, D, H, W)).astype(np.float32)), mode).requires_grad_(True)
+    y_ref = F.max_pool3d(x, 2)
+    go = rnd(T(synth.rng(seed + 1).standard_normal(tuple(y_ref.shape)).astype(np.float32)), mode)
+    gs = rnd(T(synth.rng(seed + 2).standard_normal(tuple(x.shape)).astype(np.float32)), mode)
+    (y_ref * go).sum().backward(retain_graph=True)
+    x.grad += gs                                                     # the skip path's gradient
+    xa = to_cl(x.detach(), dt).requires_grad_(True)
+    y, mr, skip = ops.MaxPoolSkipFn.apply(xa)
+    torch.autograd.backward([y, skip], [to_cl(go, dt), to_cl(gs, dt)])
+    xb = to_cl(x.detach(), dt).requires_grad_(True)
+    y2, _ = ops.MaxPoolFn.apply(xb)
+    torch.autograd.backward([y2, xb * 1.0], [to_cl(go, dt), to_cl(gs, dt)])
+    torch.cuda.synchronize()
+    same = bool(torch.equal(xa.grad, xb.grad)) and bool(torch.equal(y, y2))
+    e = max(relerr(from_cl(y.detach()), y_ref.detach()), relerr(from_cl(xa.grad), rnd(x.grad, mode)))
+    return result(f'maxpool_skip[{mode} {shape}]', e if same else 1.0, 1e-6 if mode == 'f32' else 1e-2, f'identical to MaxPoolFn + accumulation: {same}')
+
+
 def check_upsample(mode, Cin=8, I=3, O=6, seed=63):
     from rsuper_amd.hip import ops
     dt = DT[mode]
@@ -1203,7 +1228,8 @@ def all_checks(quick=False):
             (check_conv_bwd, (mode, 1, (5, 6, 7), 8, 16, 8, True)),
             (check_conv_bwd, (mode, 1, (8, 12, 20), 64, 32, 64, True)),
             (check_conv_bwd, (mode, 1, (6, 6, 6), 80, 0, 80, False)),
-            (check_pool, (mode,)), (check_upsample, (mode,)), (check_upsample, (mode, 16, 6, 12, 70)), (check_upsample, (mode, 8, 8, 32, 71)), (check_upsample, (mode, 8, 2, 4, 72)),
+            (check_pool, (mode,)), (check_pool_skip, (mode,)), (check_pool_skip, (mode, (1, 7, 9, 5, 8), 65)), (check_pool_skip, (mode, (2, 24, 24, 24, 32), 66)),
+            (check_upsample, (mode,)), (check_upsample, (mode, 16, 6, 12, 70)), (check_upsample, (mode, 8, 8, 32, 71)), (check_upsample, (mode, 8, 2, 4, 72)),
             (check_upsample, (mode, 8, 5, 9, 73)),
             (check_stem, (mode,)), (check_stem, (mode, 32, 16)), (check_head, (mode,)), (check_head, (mode, 32, 42, 12)),
             (check_stem, (mode, 64, 12)), (check_head, (mode, 64, 70, 10)), (check_head, (mode, 16, 130, 9)), (check_unet_wide, (mode,)),
