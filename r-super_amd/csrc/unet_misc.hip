@@ -1041,13 +1041,17 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
                     const int k = 2 * s + kk;
                     d = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[k * 257 + wave * 64 + g * 32 + idx], wl[k * 33 + idx], d, 0, 0, 0);
                 }
-                // lane: column c = idx, rows cd_row32(r, lane); channel pairs are packed by the even lanes (one 4-byte store per pair)
+                // through the wave's own rows of tb (no other wave reads them, and a wave's LDS accesses are ordered): accumulator layout (lane = channel,
+                // register = voxel row) -> voxel-major, then 16-byte stores, consecutive lanes -> consecutive addresses
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float other = __shfl_xor(d[r], 1, 64);
-                    const int v = v0 + wave * 64 + g * 32 + cd_row32(r, lane);
-                    if (!(idx & 1) && v < V && idx < hp.C)
-                        *(uint32_t*)((T*)hp.dx + ((size_t)n * V + v) * hp.lddx + idx) = sizeof(T) == 2 ? f2bf2(d[r], other) : 0u;
+                for (int r = 0; r < 16; ++r) tb[(wave * 64 + g * 32 + cd_row32(r, lane)) * 33 + idx] = d[r];
+            }
+            if (sizeof(T) == 2) {
+                const int cv = hp.C / 8;                         // 16-byte vectors per voxel (1 .. 4)
+                for (int i = lane; i < 64 * cv; i += 64) {
+                    const int vl = i / cv, c0 = (i - vl * cv) * 8;
+                    const int v = v0 + wave * 64 + vl;
+                    if (v < V) *(uint4*)((T*)hp.dx + ((size_t)n * V + v) * hp.lddx + c0) = pack16<T>(tb + (wave * 64 + vl) * 33 + c0);
                 }
             }
         }
