@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemParams p) {
     const int idx = lane & 31, kk = lane >> 5;
     const int n = blockIdx.y;
     const int vox = p.D * p.H * p.W;
-    const float* xin = p.x + (size_t)n * vox;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * vox), 0, (uint32_t)vox * 4u, 0x00020000);
     float wreg[14];
 #pragma unroll
     for (int s = 0; s < 14; ++s) {
@@ -861,12 +861,22 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemParams p) {
         const int v = blockIdx.x * 256 + vl;
         const bool ok = v < vox;
         const int x0 = v % p.W, y0 = (v / p.W) % p.H, z0 = v / (p.W * p.H);
+        // the 27 neighbours are v + a constant: one validity bit per (axis, offset) and a buffer load whose out-of-range offsets return zero replace a
+        // coordinate triple + six compares + a 64-bit address per tap (the kernel was bound by that arithmetic, not by its MFMAs)
+        const uint32_t okz = (z0 >= 1 ? 1u : 0u) | 2u | (z0 + 1 < p.D ? 4u : 0u), oky = (y0 >= 1 ? 1u : 0u) | 2u | (y0 + 1 < p.H ? 4u : 0u),
+                       okx = (x0 >= 1 ? 1u : 0u) | 2u | (x0 + 1 < p.W ? 4u : 0u);
+        const uint32_t tapok = ok ? (okz | (oky << 3) | (okx << 6)) : 0u;
         float xa[14];
 #pragma unroll
         for (int s = 0; s < 14; ++s) {
-            const int tap = 2 * s + kk;
-            const int z = z0 + tap / 9 - 1, y = y0 + (tap % 9) / 3 - 1, x = x0 + tap % 3 - 1;
-            xa[s] = (ok && tap < 27 && z >= 0 && z < p.D && y >= 0 && y < p.H && x >= 0 && x < p.W) ? xin[((size_t)z * p.H + y) * p.W + x] : 0.f;
+            const int tap = 2 * s + kk;                           // kk selects one of two compile-time taps per step
+            const int t0 = 2 * s, t1 = 2 * s + 1 < 27 ? 2 * s + 1 : 26;
+            const int off0 = ((t0 / 9 - 1) * p.H + ((t0 % 9) / 3 - 1)) * p.W + (t0 % 3 - 1), off1 = ((t1 / 9 - 1) * p.H + ((t1 % 9) / 3 - 1)) * p.W + (t1 % 3 - 1);
+            const uint32_t need0 = (1u << (t0 / 9)) | (8u << ((t0 % 9) / 3)) | (64u << (t0 % 3)), need1 = (1u << (t1 / 9)) | (8u << ((t1 % 9) / 3)) | (64u << (t1 % 3));
+            const int off = kk ? off1 : off0;
+            const uint32_t need = kk ? need1 : need0;
+            const bool tok = tap < 27 && (tapok & need) == need;
+            xa[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, tok ? (uint32_t)(v + off) * 4u : 0xFFFFFFFFu, 0, 0));
         }
         f32x16_t acc;
 #pragma unroll
@@ -990,11 +1000,15 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
             }
         } else {
             const int x0 = v % sp.W, y0 = (v / sp.W) % sp.H, z0 = v / (sp.W * sp.H);
-            const float* xin = sp.x + (size_t)n * V;
+            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(sp.x + (size_t)n * V), 0, (uint32_t)V * 4u, 0x00020000);
+            const uint32_t okz = (z0 >= 1 ? 1u : 0u) | 2u | (z0 + 1 < sp.D ? 4u : 0u), oky = (y0 >= 1 ? 1u : 0u) | 2u | (y0 + 1 < sp.H ? 4u : 0u),
+                           okx = (x0 >= 1 ? 1u : 0u) | 2u | (x0 + 1 < sp.W ? 4u : 0u);
+            const uint32_t tapok = v < V ? (okz | (oky << 3) | (okx << 6)) : 0u;
 #pragma unroll
-            for (int tap = 0; tap < 27; ++tap) {
-                const int z = z0 + tap / 9 - 1, y = y0 + (tap % 9) / 3 - 1, x = x0 + tap % 3 - 1;
-                ri[tap] = (v < V && z >= 0 && z < sp.D && y >= 0 && y < sp.H && x >= 0 && x < sp.W) ? xin[((size_t)z * sp.H + y) * sp.W + x] : 0.f;
+            for (int tap = 0; tap < 27; ++tap) {                  // neighbour = v + a constant; validity bits instead of a coordinate triple + six compares per tap
+                const int off = ((tap / 9 - 1) * sp.H + ((tap % 9) / 3 - 1)) * sp.W + (tap % 3 - 1);
+                const uint32_t need = (1u << (tap / 9)) | (8u << ((tap % 9) / 3)) | (64u << (tap % 3));
+                ri[tap] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (tapok & need) == need ? (uint32_t)(v + off) * 4u : 0xFFFFFFFFu, 0, 0));
             }
         }
     };
