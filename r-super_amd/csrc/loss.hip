@@ -38,7 +38,36 @@ __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) 
     const uint8_t* w2 = p.w2 ? p.w2 + base : nullptr;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool vec_ok = (p.V & 3) == 0 && (p.xstride & 3) == 0;   // 16-byte alignment of every plane
-    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < (size_t)p.V; i += (size_t)gridDim.x * 256 * 4) {
+    // wide path: 16 voxels per thread and trip (four 16-byte logit loads, one 16-byte load per mask / weight plane) -- the 4-voxel trips below read the
+    // byte planes with 4-byte loads (a quarter of the bytes per request): 84 us for 276 MB at 96^3 x 26 classes
+    size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool wide_ok = vec_ok && (p.V & 15) == 0 && !w1;
+    if (wide_ok) {
+        auto term = [&](float xv, uint32_t tb, uint32_t kb, uint32_t w2b) {
+            const float tt = tb ? 1.f : 0.f, kk = ((kb != 0u) != (p.kinv != 0)) ? 1.f : 0.f;
+            float sg, b;
+            sig_bce(xv, tt, sg, b);
+            b *= kk;
+            s[0] += b; s[1] += sg * kk; s[2] += sg * tt * kk; s[3] += tt * kk; s[5] += b * (w2b ? 0.f : 1.f);
+        };
+        for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16; i < (size_t)p.V; i += (size_t)gridDim.x * 256 * 16) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = *(const float4*)(x + i + 4 * u);
+            const uint4 tq = t ? *(const uint4*)(t + i) : make_uint4(0, 0, 0, 0);
+            const uint4 kq = k ? *(const uint4*)(k + i) : make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+            const uint4 wq = w2 ? *(const uint4*)(w2 + i) : make_uint4(0, 0, 0, 0);
+            const uint32_t tw[4] = {tq.x, tq.y, tq.z, tq.w}, kw[4] = {kq.x, kq.y, kq.z, kq.w}, ww[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xv[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) term(xv[j], (tw[u] >> (8 * j)) & 0xFFu, (kw[u] >> (8 * j)) & 0xFFu, (ww[u] >> (8 * j)) & 0xFFu);
+            }
+        }
+        i0 = (size_t)p.V;                                          // nothing left for the narrow loop
+    }
+    for (size_t i = i0; i < (size_t)p.V; i += (size_t)gridDim.x * 256 * 4) {
         float xv[4]; uint8_t tv[4] = {0, 0, 0, 0}, kv[4] = {1, 1, 1, 1}, w2v[4] = {0, 0, 0, 0}; float w1v[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = vec_ok && i + 4 <= (size_t)p.V;
         if (full) {
