@@ -8,6 +8,7 @@
 //   upsample fwd/bwd      F.interpolate(trilinear, align_corners=True)   (unet_utils.py:69)
 //   stem fwd/wgrad        inconv.conv1: Conv3d(1 -> C, k=3, bias=False)  (unet_utils.py:14)
 //   head fwd/bwd          outc: Conv3d(C -> K, k=1) + bias               (unet.py:47)
+#include <string.h>
 #include "common.hpp"
 #include "kernels.hpp"
 #include "misc.hpp"
@@ -1221,8 +1222,22 @@ static int launch_upsample_bwd4(const void* g, int ldg, void* dx, int lddx, int 
     static const bool off = getenv("RSUPER_UPSAMPLE_BWD4") && atoi(getenv("RSUPER_UPSAMPLE_BWD4")) == 0;
     if (off || (C % 8) || N > 65535) return RS_ERR_UNSUPPORTED;
     if ((size_t)OD * OH * OW * (size_t)ldg * 2 >= 0xFFFFFFFFull) return RS_ERR_UNSUPPORTED;                    // 32-bit byte offsets
-    if (up_pair_window(ID, OD) > UP4_ROWS || up_pair_window(IH, OH) > UP4_ROWS) return RS_ERR_UNSUPPORTED;
-    const int nmax = up_max_count(IW, OW);
+    // the table sizes depend on the shape only: remembered per (ID, IH, IW, OD, OH, OW) (the host loops cost a few microseconds per call otherwise)
+    struct Memo { int k[6]; int ok, nmax; };
+    static thread_local Memo memo[8] = {};
+    static thread_local int memo_next = 0;
+    const int key[6] = {ID, IH, IW, OD, OH, OW};
+    const Memo* hit = nullptr;
+    for (int i = 0; i < 8 && !hit; ++i) if (memo[i].k[0] && !memcmp(memo[i].k, key, sizeof(key))) hit = &memo[i];
+    if (!hit) {
+        Memo& m = memo[memo_next++ & 7];
+        memcpy(m.k, key, sizeof(key));
+        m.ok = up_pair_window(ID, OD) <= UP4_ROWS && up_pair_window(IH, OH) <= UP4_ROWS;
+        m.nmax = up_max_count(IW, OW);
+        hit = &m;
+    }
+    if (!hit->ok) return RS_ERR_UNSUPPORTED;
+    const int nmax = hit->nmax;
     if (nmax > 6) return RS_ERR_UNSUPPORTED;
     UpInParams p = {g, ldg, dx, lddx, N, ID, IH, IW, OD, OH, OW, C};
     const int nbx = (IW * (C / 8) + 255) / 256;
