@@ -126,7 +126,7 @@ int rsuper_conv3_igemm_s2(int dtype, int mode, const void* xa, int lda, int Ca, 
  * reduce kernel -- deterministic, no atomics).  use_tr selects ds_read_b64_tr_b16 operand fetch (bf16). */
 /* Number of voxel-tile splits (= partial slabs in `workspace`) rsuper_conv3_wgrad should be called with for this shape:
  * fills the chip with resident blocks for the kernel configuration the launch will pick.  Returns <= 0 on bad arguments. */
-int rsuper_conv3_wgrad_splits(int dtype, int Ca, int Cb, int Mtot, int N, int D, int H, int W);
+int rsuper_conv3_wgrad_splits(int dtype, int Ca, int Cb, int Ya, int Yb, int N, int D, int H, int W);
 
 int rsuper_conv3_wgrad(int dtype, int use_tr,
                        const void* xa, int lda, int Ca, const float* mra,

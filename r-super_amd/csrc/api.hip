@@ -242,10 +242,12 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     return rs_launch_igemm(p, dtype, epi, ST(stream));
 }
 
-int rsuper_conv3_wgrad_splits(int dtype, int Ca, int Cb, int Mtot, int N, int D, int H, int W) {
-    if (!dt_ok(dtype) || Ca <= 0 || Cb < 0 || Mtot <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return -1;
-    const int nch = (Ca + 31) / 32 + (Cb + 31) / 32;
-    if (const int sv = rs_wgrad_sv_splits(dtype, Mtot, Mtot, nch, N, D, H, W)) return sv;      // small volumes: N x (depth parts per sample)
+int rsuper_conv3_wgrad_splits(int dtype, int Ca, int Cb, int Ya, int Yb, int N, int D, int H, int W) {
+    if (!dt_ok(dtype) || Ca <= 0 || Cb < 0 || Ya <= 0 || Yb < 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return -1;
+    const int nch = (Ca + 31) / 32 + (Cb + 31) / 32, Mtot = Ya + Yb;
+    // the same predicate the launcher evaluates with the real (Ya, Yb): a fused [conv1 | shortcut] whose first source is not a multiple of 32 rows
+    // does not take the small-volume kernel, so its split count must not be sized for it
+    if (const int sv = rs_wgrad_sv_splits(dtype, Mtot, Ya, nch, N, D, H, W)) return sv;        // small volumes: N x (depth parts per sample)
     return rs_wgrad_splits(dtype, Mtot, nch, N * rsuper_conv3_tiles(D, H, W));
 }
 
@@ -260,6 +262,8 @@ static int conv3_wgrad_impl(int reduce, int dtype, int use_tr, const void* xa, i
     {   // same 4 GiB limit for the buffer-addressed x_hat staging
         const unsigned long long vox = (unsigned long long)N * D * H * W, es = dtype == RS_F32 ? 4 : 2;
         if (vox * (unsigned long long)lda * es >= (1ull << 32) || (Cb > 0 && vox * (unsigned long long)ldb * es >= (1ull << 32))) return RS_ERR_UNSUPPORTED;
+        // ... and for dY: the second-generation kernel reads it through buffer resources too (32-bit byte offsets, num_records = voxels x row bytes)
+        if (vox * (unsigned long long)ldya * es >= (1ull << 32) || (Yb > 0 && vox * (unsigned long long)ldyb * es >= (1ull << 32))) return RS_ERR_UNSUPPORTED;
     }
     WgradParams p;
     memset(&p, 0, sizeof(p));

@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) 
     // wide path: 16 voxels per thread and trip (four 16-byte logit loads, one 16-byte load per mask / weight plane) -- the 4-voxel trips below read the
     // byte planes with 4-byte loads (a quarter of the bytes per request): 84 us for 276 MB at 96^3 x 26 classes
     size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    const bool wide_ok = vec_ok && (p.V & 15) == 0 && !w1;
+    // the 16-byte loads need 16-byte aligned bases too (a mask handed over as a view at an odd storage offset keeps the 4-voxel path)
+    const bool wide_ok = vec_ok && (p.V & 15) == 0 && !w1 &&
+                         ((((uintptr_t)p.x | (uintptr_t)p.t | (uintptr_t)p.k | (uintptr_t)p.w2) & 15) == 0);
     if (wide_ok) {
         auto term = [&](float xv, uint32_t tb, uint32_t kb, uint32_t w2b) {
             const float tt = tb ? 1.f : 0.f, kk = ((kb != 0u) != (p.kinv != 0)) ? 1.f : 0.f;

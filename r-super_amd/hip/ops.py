@@ -459,7 +459,7 @@ def wgrad(xa, xb, ya, yb, dwa, dwb, dims, side_reduce=False, defer=False):
     dt = _DT[xa.t.dtype]
     N, D, H, W = dims
     Mtot = ya.C + (yb.C if yb is not None else 0)
-    splits = _L().rsuper_conv3_wgrad_splits(dt, xa.C, xb.C if xb is not None else 0, Mtot, N, D, H, W)
+    splits = _L().rsuper_conv3_wgrad_splits(dt, xa.C, xb.C if xb is not None else 0, ya.C, yb.C if yb is not None else 0, N, D, H, W)
     assert splits >= 1
     yb_args = (None, 0, 0) if yb is None else (_ptr(yb.t, yb.off), yb.ld, yb.C)
     Cin_t = xa.C + (xb.C if xb is not None else 0)
@@ -690,6 +690,16 @@ class BasicBlockFn(torch.autograd.Function):
     def backward(ctx, dout, _unused):
         if ctx.stride == 2:
             return _BB._backward_s2(ctx, dout)
+        try:
+            return _BB._backward_s1(ctx, dout)
+        except BaseException:
+            # an exception between the first wgrad(defer=True) and flush_wgrad_reduces() (e.g. the OutOfMemoryError graph._verify survives) must not
+            # leave entries behind: they pin the split slabs and would be reduced into orphaned buffers by the next backward
+            del _DEFERRED[:]
+            raise
+
+    @staticmethod
+    def _backward_s1(ctx, dout):
         xa, mra, xb, mrb, ys, mr_y1, w1, w2, ws = ctx.saved_tensors
         dout = dout.contiguous()
         N, D, H, W, Ca = xa.shape

@@ -198,6 +198,80 @@ def check_conv_bwd(mode, N, S, Ca, Cb, Cout, fused_sc, seed=0, tr=None):
                   f'g {e_g:.2e} dx {e_dx:.2e} dw {e_w:.2e}')
 
 
+def _xhat_bf16(x, mr):
+    """The kernels' prologue on bf16 inputs, restated: x_hat = bf16(max(fma(x, rstd, -mean * rstd), 0)) with f32 constants (csrc/common.hpp norm_relu16);
+    the fma is evaluated in float64 and rounded once to f32 (differs from a hardware fma only on exact f32 ties of the f64 value)."""
+    sc = mr[:, :, 1].float()
+    nb = (-mr[:, :, 0].float() * sc)                                          # f32 product, as the kernel forms it
+    v = (x.double() * sc.double()[:, :, None, None, None] + nb.double()[:, :, None, None, None]).float()
+    return torch.relu(v).bfloat16().double()
+
+
+def check_conv_exact(kind, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, norm=True, seed=0):
+    """bf16 forward ('fwd') / data gradient ('dgrad') of the igemm kernels against float64 on EXACTLY the bf16 operands the kernel multiplies
+    (the forward / dgrad analogue of check_wgrad_xhat).  Per element the bound is one bf16 rounding of the result
+    (2^-8 |ref|, round-to-nearest-even of the f32 accumulator) plus the f32 accumulation slack of the K = 27 Cin reduction
+    ((K / 8 + 4) roundings of at most 2^-24 sum|a b| each: one per MFMA k-step and lane half); err = max |got - ref| / bound must be <= 1.
+    One dropped tap x channel term is ~ sum|a b| / K, five times the slack, on every output it feeds."""
+    from rsuper_amd.hip import ops
+    dt = torch.bfloat16
+    D, H, W = S
+    Cin = Ca + Cb
+    xa = (_rng_t(seed + 1, (N, Ca, D, H, W)) + 0.3).bfloat16().float()
+    xb = (_rng_t(seed + 2, (N, Cb, D, H, W)) * 1.5 - 0.2).bfloat16().float() if Cb else None
+    w1 = _rng_t(seed + 3, (Cout, Cin, 3, 3, 3), 1.0 / math.sqrt(27 * Cin))
+    ws = _rng_t(seed + 4, (Cout, Cin, 3, 3, 3), 1.0 / math.sqrt(27 * Cin)) if fused_sc else None
+    wd = [w.bfloat16().double() for w in ((w1, ws) if fused_sc else (w1,))]
+    mra = stats_ref(xa)
+    mrb = stats_ref(xb) if xb is not None else None
+    dims = (N, D, H, W)
+    if kind == 'fwd':
+        if norm:
+            xh = _xhat_bf16(xa, mra) if xb is None else torch.cat([_xhat_bf16(xa, mra), _xhat_bf16(xb, mrb)], 1)
+        else:
+            xh = (xa if xb is None else torch.cat([xa, xb], 1)).double()
+        ref = torch.cat([F.conv3d(xh, w, padding=1) for w in wd], 1)
+        mag = torch.cat([F.conv3d(xh.abs(), w.abs(), padding=1) for w in wd], 1)
+        res = _rng_t(seed + 5, (N, ref.shape[1], D, H, W)).bfloat16().float() if residual else None
+        if residual:
+            ref = ref + res.double()
+            mag = mag + res.double().abs()
+        nc = ref.shape[1]
+        bn = ops.pick_bn(nc, dt, dims=dims)
+        wp = ops.pack_weights(dt, 0, w1.to(DEV), ws.to(DEV) if fused_sc else None, Ca, Cb, Cout, Cout if fused_sc else 0, bn)
+        out = torch.full((N, D, H, W, nc), float('nan'), device=DEV, dtype=dt)
+        part = ops.part_buffer(dt, dims, nc, bn, DEV, fill=float('nan'))
+        a = ops.Src(to_cl(xa, dt), mr=mra.to(DEV) if norm else None)
+        b = ops.Src(to_cl(xb, dt), mr=mrb.to(DEV) if norm else None) if xb is not None else None
+        ops.igemm(0, a, b, wp, nc, bn, dims, out, res=ops.Src(to_cl(res, dt)) if residual else None, part=part)
+        K = 27 * Cin
+    else:
+        dys = [_rng_t(seed + 6 + i, (N, Cout, D, H, W)).bfloat16().float() for i in range(len(wd))]
+        ref = sum(F.conv_transpose3d(dy.double(), w, padding=1) for dy, w in zip(dys, wd))
+        mag = sum(F.conv_transpose3d(dy.double().abs(), w.abs(), padding=1) for dy, w in zip(dys, wd))
+        x = xa if xb is None else torch.cat([xa, xb], 1)
+        mr = mra if xb is None else torch.cat([mra, mrb], 1)
+        mask = (x > mr[:, :, 0].float()[:, :, None, None, None]).double()          # sign((x - mean) * rstd) as the epilogue evaluates it in f32
+        ref, mag = ref * mask, mag * mask
+        nc = Cin
+        bn = ops.pick_bn(nc, dt, dims=dims)
+        wp = ops.pack_weights(dt, 1, w1.to(DEV), ws.to(DEV) if fused_sc else None, Cout, Cout if fused_sc else 0, Cin, 0, bn)
+        out = torch.full((N, D, H, W, nc), float('nan'), device=DEV, dtype=dt)
+        part = ops.part_buffer(dt, dims, nc, bn, DEV, fill=float('nan'), epi=1)
+        sa = ops.Src(to_cl(xa, dt), mr=mra.to(DEV))
+        sb = ops.Src(to_cl(xb, dt), mr=mrb.to(DEV)) if xb is not None else None
+        ops.igemm(1, ops.Src(to_cl(dys[0], dt)), ops.Src(to_cl(dys[1], dt)) if fused_sc else None, wp, nc, bn, dims, out, part=part, ea=sa, eb=sb)
+        K = 27 * Cout * len(wd)
+    torch.cuda.synchronize()
+    got = from_cl(out).double()
+    bound = 2.0 ** -8 * ref.abs() + (K / 8 + 4) * 2.0 ** -24 * mag + 1e-30
+    ratio = ((got - ref).abs() / bound)
+    ratio = torch.where(torch.isfinite(ratio), ratio, torch.full_like(ratio, float('inf')))
+    same = (got == ref.float().bfloat16().double()).double().mean().item()   # elements equal to the correctly rounded float64 result
+    return result(f'conv_exact[{kind} N{N} S{S} {Ca}+{Cb}->{Cout} sc{int(fused_sc)} res{int(residual)} norm{int(norm)}]', ratio.max().item(), 1.0,
+                  f'max |got-ref| / (1 bf16 rounding + f32 slack) {ratio.max().item():.3f}; == bf16(float64 result) on {same:.4f} of the elements; bn {bn}')
+
+
 def check_wgrad_xhat(N, S, Ca, Cb, Ya, Yb, seed=0):
     """Weight gradient on PRE-NORMALISED bf16 sources (no statistics: csrc/conv3d_wgrad_dma.hip, operands by LDS-DMA) against the float64
     gradient of F.conv3d on exactly the bf16 operands the kernel sees -- f32 accumulation is the only difference, hence the tight bound."""
@@ -1285,6 +1359,19 @@ def all_checks(quick=False):
                (check_pointwise, (m, 100, 36, 20, True)), (check_pointwise, (m, 33, 4, 4, False)), (check_pointwise, (m, 1000, 72, 260, True))]
     for variant in (0, 1, 4, 6, 7):  # every bf16 igemm kernel on every conv case (6 / 7: the volume-fitted K-split kernel, incl. its split-reduction shape) (the default picks per launch)
         cs += [(with_variant, (variant, fn) + a) for fn, a in list(cs) if fn in (check_conv_fwd, check_conv_bwd) and a[0] == 'bf16']
+    # bf16 forward / data gradient against float64 on the same bf16 operands, one-rounding bound: ragged volumes (every face of the halo),
+    # one / two sources, fused shortcut (128 / 96 / 64 / 16 columns), residual, raw and normalised sources, the low-resolution box shapes; default dispatch
+    # and every forced kernel variant
+    exact = [('fwd', 1, (5, 9, 19), 32, 0, 32), ('fwd', 2, (8, 8, 16), 32, 0, 32, False, True), ('fwd', 1, (8, 12, 20), 64, 32, 64, True),
+             ('fwd', 1, (4, 8, 16), 64, 0, 64, False, False, False), ('fwd', 1, (6, 6, 6), 80, 0, 80, False, True), ('fwd', 1, (5, 6, 7), 8, 16, 8, True),
+             ('fwd', 1, (12, 20, 48), 64, 64, 64, True, False, True, 3), ('fwd', 2, (12, 12, 12), 128, 0, 128, False, True, True, 4),
+             ('fwd', 2, (9, 17, 33), 32, 64, 32, True, False, True, 5),
+             ('dgrad', 1, (5, 9, 19), 32, 0, 32), ('dgrad', 1, (8, 12, 20), 64, 32, 64, True), ('dgrad', 2, (6, 6, 6), 64, 0, 64),
+             ('dgrad', 2, (12, 12, 12), 128, 0, 128, False, False, True, 6), ('dgrad', 1, (5, 6, 7), 8, 16, 8, True), ('dgrad', 2, (9, 17, 33), 32, 64, 32, True, False, True, 7),
+             ('dgrad', 1, (12, 20, 48), 128, 64, 64, True, False, True, 8)]
+    cs += [(check_conv_exact, a) for a in exact]
+    for variant in (0, 1, 4, 6, 7):
+        cs += [(with_variant, (variant, check_conv_exact) + a) for a in exact]
     cs += [(with_variant, (1, check_conv_fwd, 'bf16', 2, (8, 24, 32), 32, 0, 32, False, True)),       # persistent: several tiles per block
            (with_variant, (1, check_conv_fwd, 'bf16', 1, (12, 20, 48), 64, 64, 128, True, False)),    # 128 columns, 4 chunks, 2 sources
            (with_variant, (1, check_conv_bwd, 'bf16', 2, (8, 24, 32), 64, 64, 64, True)),
