@@ -81,6 +81,12 @@ int rsuper_conv3_wgrad2_min_tiles(int t);
  * (pack the weights with bn = 64 then), else 0. */
 int rsuper_conv3_box_bn(int dtype, int N, int D, int H, int W, int n_cols);
 
+/* The wide full-resolution layers (more than 32 columns, enough 4x8x16-voxel tiles for one persistent block per CU: up4.0 / the 96^3 level at
+ * batch 2) run the depth-reuse kernel (conv3d_igemm_kd.hip: an activation fragment feeds the three kd taps, 0.5 / NF LDS fragment reads per MFMA):
+ * returns the block width (64 forward; 64 / 96 / 128 data gradient) rsuper_conv3_igemm(dtype, epi, ..., n_cols, bn, N, D, H, W) takes that kernel
+ * with -- pack the weights and size `part` with that bn -- else 0. */
+int rsuper_conv3_kd_bn(int dtype, int epi, int N, int D, int H, int W, int n_cols);
+
 /* Volumes of at most 6x6x6 voxels (the 6^3 bottleneck level: model/dim3/unet.py:53, four poolings of a 96^3 patch) run one box
  * per sample with the REDUCTION (32-channel chunks) split over blocks: each block writes its raw f32 tile to a workspace and a
  * second kernel adds the splits and applies the epilogue (deterministic: fixed split order).  The caller registers ONE device

@@ -14,6 +14,7 @@
 
 static inline bool dt_ok(int dt) { return dt == RS_F32 || dt == RS_BF16; }
 static inline bool ch_ok(int C, int ld) { return C >= 0 && (C % 8) == 0 && (ld % 8) == 0 && ld >= C; }
+static inline bool bn_ok(int bn) { return bn == 32 || bn == 64 || bn == 96 || bn == 128; }
 static inline int ntiles_for(int n_cols, int bn) { const int per = bn / 32; return ((n_cols + bn - 1) / bn) * per; }
 
 // ---- optimiser: split the tensor list into kernel-argument sized chunks
@@ -55,7 +56,7 @@ int rsuper_device_check(void) {
 }
 
 size_t rsuper_conv3_packed_elems(int dtype, int ka, int kb, int n_cols, int bn) {
-    if (!dt_ok(dtype) || (bn != 32 && bn != 64 && bn != 128)) return 0;
+    if (!dt_ok(dtype) || !bn_ok(bn)) return 0;
     return rs_packed_elems(dtype, ka, kb, ntiles_for(n_cols, bn));
 }
 
@@ -64,7 +65,7 @@ int rsuper_conv3_pack_weights(int dtype, int mode, const float* wa, const float*
     if (!dt_ok(dtype) || !wa || !packed || (mode != 0 && mode != 1) || ka <= 0 || kb < 0 || na <= 0 || nb < 0) return RS_ERR_ARG;
     if ((kb > 0 || nb > 0) && mode == 1 && kb > 0 && !wb) return RS_ERR_ARG;
     if (mode == 0 && nb > 0 && !wb) return RS_ERR_ARG;
-    if (bn != 32 && bn != 64 && bn != 128) return RS_ERR_ARG;
+    if (!bn_ok(bn)) return RS_ERR_ARG;
     PackParams q;
     q.wa = wa; q.wb = wb; q.mode = mode; q.ka = ka; q.kb = kb; q.na = na; q.nb = nb;
     q.ntiles = ntiles_for(na + nb, bn);
@@ -83,7 +84,7 @@ int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, cons
         const size_t base = host_out_elems[i0];
         for (int i = 0; i < b.n; ++i) {
             const int* d = host_desc + (size_t)(i0 + i) * 6;
-            if ((d[0] != 0 && d[0] != 1) || d[1] <= 0 || d[2] < 0 || d[3] <= 0 || d[4] < 0 || (d[5] != 32 && d[5] != 64 && d[5] != 128)) return RS_ERR_ARG;
+            if ((d[0] != 0 && d[0] != 1) || d[1] <= 0 || d[2] < 0 || d[3] <= 0 || d[4] < 0 || !bn_ok(d[5])) return RS_ERR_ARG;
             PackParams& q = b.q[i];
             q.wa = host_wa[i0 + i]; q.wb = host_wb[i0 + i]; q.mode = d[0]; q.ka = d[1]; q.kb = d[2]; q.na = d[3]; q.nb = d[4];
             q.ntiles = ntiles_for(d[3] + d[4], d[5]);
@@ -109,7 +110,7 @@ static int g_variant = 3;
 int rsuper_conv3_wgrad2_min_tiles(int t) { return rs_wgrad2_min_tiles(t); }
 
 int rsuper_conv3_variant(int v) {
-    if (v >= 0 && v <= 7 && v != 5) g_variant = v;                   // 5 was the second-generation producer/consumer kernel (measured equal, removed)
+    if (v >= 0 && v <= 8 && v != 5) g_variant = v;                   // 5 was the second-generation producer/consumer kernel (measured equal, removed)
     return g_variant;
 }
 // variant 2 (auto, default): producer/consumer kernel where it measured faster on MI355X -- data-gradient launches with
@@ -159,6 +160,26 @@ static int box_for(int dtype, int bn, int N, int D, int H, int W, int n_cols) {
     return (cfg && bn == (cfg == 3 ? 32 : 64)) ? cfg : 0;
 }
 
+// Depth-reuse kernel (conv3d_igemm_kd.hip, round 5): bf16 launches with more than 32 columns whose volume gives the persistent blocks enough 4 x 8 x 16-voxel
+// tiles (the full-resolution level at batch 2: 3456 tiles; RSUPER_KD_MIN_TILES).  A pure function of (dtype, epi, shape, columns) so that the block width
+// (rsuper_conv3_kd_bn -> pick_bn), the partial-row count and the launch agree.  Forward launches (normalised sources, staging with arithmetic in registers)
+// take 64-column blocks; data-gradient launches (raw dY) 64 / 96 / 128.  Variant 8 forces it wherever its limits allow (tests).
+static int kd_bn_for(int dtype, int epi, int N, int D, int H, int W, int n_cols) {
+    if (dtype != RS_BF16 || n_cols <= 32) return 0;
+    static const int off = getenv("RSUPER_KD") ? atoi(getenv("RSUPER_KD")) == 0 : 0;
+    static const int min_tiles = getenv("RSUPER_KD_MIN_TILES") ? atoi(getenv("RSUPER_KD_MIN_TILES")) : 2048;
+    if (g_variant != 8 && (g_variant != 3 || off)) return 0;
+    if ((long)N * D * H * W >= (1l << 24) || D > 1023 || H > 1023 || W > 1023) return 0;
+    const long tiles = (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
+    if (g_variant != 8 && tiles < min_tiles) return 0;
+    (void)epi;
+    return 64;                                                     // 96 / 128-column blocks (two column fragments per wave) exceed the register file with register staging
+}
+int rsuper_conv3_kd_bn(int dtype, int epi, int N, int D, int H, int W, int n_cols) {
+    if (!dt_ok(dtype) || (epi != 0 && epi != 1) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || n_cols <= 0) return 0;
+    return kd_bn_for(dtype, epi, N, D, H, W, n_cols);
+}
+
 int rsuper_conv3_set_workspace(void* ptr, size_t bytes) {
     g_ws = ptr; g_ws_bytes = ptr ? bytes : 0;
     return RS_OK;
@@ -171,6 +192,7 @@ int rsuper_conv3_box_bn(int dtype, int N, int D, int H, int W, int n_cols) {
 }
 
 int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn) {
+    if (bn == kd_bn_for(dtype, epi, N, D, H, W, n_cols)) return rs_igemm_kd_part_rows(bn, N, D, H, W, n_cols);
     if (const int cfg = box_for(dtype, bn, N, D, H, W, n_cols)) return rs_box_part_rows(cfg, D, H, W);
     return rs_igemm_part_rows(bn, use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0, rsuper_conv3_tiles(D, H, W), n_cols, N);
 }
@@ -216,7 +238,8 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return RS_ERR_ARG;
     if (res && ((ldr % 8) || ldr < n_cols)) return RS_ERR_ARG;
     if (epi == 1 && (!exa || !emra || eCa + eCb != n_cols || (eCb > 0 && (!exb || !emrb)))) return RS_ERR_ARG;
-    if (dtype == RS_F32 && bn == 128) return RS_ERR_UNSUPPORTED;   // register budget: f32 parity mode uses bn <= 64
+    if (!bn_ok(bn)) return RS_ERR_ARG;
+    if (dtype == RS_F32 && bn >= 96) return RS_ERR_UNSUPPORTED;    // register budget: f32 parity mode uses bn <= 64
     {   // buffer-addressed staging / epilogue: every activation tensor must stay below 4 GiB (32-bit byte offsets)
         const unsigned long long vox = (unsigned long long)N * D * H * W, es = dtype == RS_F32 ? 4 : 2;
         const int lds[6] = {lda, Cb > 0 ? ldb : 0, ldo, res ? ldr : 0, epi == 1 ? elda : 0, (epi == 1 && eCb > 0) ? eldb : 0};
@@ -238,6 +261,8 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
         if (!g_ws || boxc_ws_need(p.nsplit, N, D, H, W, n_cols) > g_ws_bytes) return RS_ERR_ARG;      // never write past the registered workspace
     }
     p.pc = use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0;
+    if (bn == kd_bn_for(dtype, epi, N, D, H, W, n_cols)) { p.pc = 3; p.box = 0; }
+    else if (bn == 96) return RS_ERR_UNSUPPORTED;                  // 96-column blocks exist on the depth-reuse kernel only
     if (p.pc && bn == 32 && (g_variant == 4 || (g_variant == 3 && (Ca + 31) / 32 + (Cb + 31) / 32 == 1))) p.pc = 2;
     return rs_launch_igemm(p, dtype, epi, ST(stream));
 }

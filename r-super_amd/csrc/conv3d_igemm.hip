@@ -883,6 +883,7 @@ int rs_igemm_part_rows(int bn, int pc, int tiles, int n_cols, int N) {
 
 int rs_launch_igemm(const IgemmParams& p, int dtype, int epi, hipStream_t st) {
     if (p.box > 0 && dtype == RS_BF16) return rs_launch_igemm_box(p, p.box, epi, st);
+    if (p.pc == 3) return rs_igemm_kd_supported(p, dtype) ? rs_launch_igemm_kd(p, epi, st) : RS_ERR_UNSUPPORTED;
     if (p.pc == 2 && rs_igemm_ws_supported(p, dtype, epi)) return rs_launch_igemm_ws(p, epi, st);
     if (dtype == RS_BF16 && p.pc) {
         if (p.ntiles % (p.bn / 32)) return RS_ERR_ARG;

@@ -16,13 +16,13 @@ struct IgemmParams {
     ConvSrc a, b;          // GEMM-K sources (b.C == 0 when unused)
     const void* wp;        // packed B fragments (rs_launch_pack)
     int ntiles;            // 32-column tiles in the packed weights (multiple of bn/32)
-    int bn;                // block N tile: 32, 64 or 128
+    int bn;                // block N tile: 32, 64 or 128 (96: depth-reuse kernel only)
     int N, D, H, W;
     int Cout;              // valid GEMM-N columns
     void* out; int ldo;
     const void* res; int ldr;   // EPI 0: optional residual added before store
     float* part;           // per-block partial sums [N][rows][Cout][2] or nullptr (rows = rs_igemm_part_rows)
-    int pc;                // 1: producer/consumer persistent kernel (bf16); 2: weight-stationary kernel (bf16, bn 32)
+    int pc;                // 1: producer/consumer persistent kernel (bf16); 2: weight-stationary kernel (bf16, bn 32); 3: depth-reuse kernel (bf16, bn 64 / 96 / 128)
     ConvSrc ea, eb;        // EPI 1: forward inputs (with mr) whose relu mask / x_n the data-gradient needs
     int box;               // > 0: volume-fitted K-split kernel (conv3d_igemm_box.hip), value = rs_box_config (3: one box per sample, reduction split over blocks)
     float* ws; int nsplit; // box == 3: f32 workspace [nsplit][N * D * H * W][Cout] and the number of chunk ranges
@@ -58,6 +58,10 @@ int rs_igemm_part_rows(int bn, int pc, int tiles, int n_cols, int N);
 // weight-stationary variant (conv3d_igemm_ws.hip): bf16, bn 32 / 64; same partial-row count as the producer/consumer kernel
 bool rs_igemm_ws_supported(const IgemmParams& p, int dtype, int epi);
 int rs_launch_igemm_ws(const IgemmParams& p, int epi, hipStream_t st);
+// depth-reuse kernel for the wide full-resolution layers (conv3d_igemm_kd.hip): bf16, 64 / 96 / 128-column blocks, 4 x 8 x 16-voxel tiles
+bool rs_igemm_kd_supported(const IgemmParams& p, int dtype);
+int rs_igemm_kd_part_rows(int bn, int N, int D, int H, int W, int n_cols);
+int rs_launch_igemm_kd(const IgemmParams& p, int epi, hipStream_t st);
 // volume-fitted in-block K-split kernel for under-filled (low-resolution) launches (conv3d_igemm_box.hip): bf16, bn 64
 int rs_box_config(int N, int D, int H, int W, int n_cols);
 int rs_box_part_rows(int cfg, int D, int H, int W);

@@ -24,6 +24,7 @@ _SIGS = {
     'rsuper_conv3_variant': (c_int, [c_int]),
     'rsuper_conv3_wgrad2_min_tiles': (c_int, [c_int]),
     'rsuper_conv3_box_bn': (c_int, [c_int] * 6),
+    'rsuper_conv3_kd_bn': (c_int, [c_int] * 7),
     'rsuper_conv3_set_workspace': (c_int, [P, c_size_t]),
     'rsuper_conv3_workspace_bytes': (c_size_t, []),
     'rsuper_conv3_wgrad_splits': (c_int, [c_int] * 9),

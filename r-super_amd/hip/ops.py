@@ -55,13 +55,19 @@ def _L():
     return L
 
 
-def pick_bn(n_cols, dtype, tiles_total=None, dims=None):
+def pick_bn(n_cols, dtype, tiles_total=None, dims=None, epi=None):
     """Block N tile of the implicit GEMM (32/64/128 output columns); f32 parity mode is limited to 64.
     tiles_total (spatial tiles x batch): on small volumes prefer the largest tile that still yields >= 512 workgroups
     (24^3 and below would otherwise leave most of the 256 CUs idle; the narrower tiles also run on the persistent kernel).
     dims = (N, D, H, W): launches the library would hand to the volume-fitted K-split kernel (rsuper_conv3_box_bn: low-resolution
-    levels that cannot fill the chip with 4x4x16 tiles) take its 64-column blocks."""
+    levels that cannot fill the chip with 4x4x16 tiles) take its 64-column blocks.
+    epi (0 forward, 1 data gradient; with dims): launches the library hands to the depth-reuse kernel (rsuper_conv3_kd_bn: the wide full-resolution
+    layers) take its 64 / 96 / 128-column blocks."""
     cands = (32, 64) if dtype == torch.float32 else (32, 64, 128)
+    if dims is not None and epi is not None and dtype != torch.float32:
+        bn = _L().rsuper_conv3_kd_bn(_DT[dtype], epi, *dims, n_cols)
+        if bn:
+            return bn
     if dtype != torch.float32 and dims is None and _L().rsuper_conv3_variant(-1) in (6, 7):
         return 64         # forced volume-fitted kernel (tests): 64-column blocks whatever the column count
     if dims is not None and dtype != torch.float32:
@@ -183,11 +189,11 @@ def block_pack_specs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims
     Cout, Cin = w1.shape[0], Ca + Cb
     has_sc = ws is not None
     nc1 = Cout * (2 if has_sc else 1)
-    bn1, bn2 = pick_bn(nc1, dtype, tiles_total, dims), pick_bn(Cout, dtype, tiles_total, dims)
+    bn1, bn2 = pick_bn(nc1, dtype, tiles_total, dims, epi=0), pick_bn(Cout, dtype, tiles_total, dims, epi=0)
     specs = [(0, w1, ws, Ca, Cb, Cout, Cout if has_sc else 0, bn1), (0, w2, None, Cout, 0, Cout, 0, bn2)]
     bns = [bn1, bn2]
     if with_backward:
-        bnd2, bnd1 = pick_bn(Cout, dtype, tiles_total, dims), pick_bn(Cin, dtype, tiles_total, dims)
+        bnd2, bnd1 = pick_bn(Cout, dtype, tiles_total, dims, epi=1), pick_bn(Cin, dtype, tiles_total, dims, epi=1)
         specs += [(1, w2, None, Cout, 0, Cout, 0, bnd2), (1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bnd1)]
         bns += [bnd2, bnd1]
     return specs, bns

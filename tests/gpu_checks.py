@@ -106,7 +106,7 @@ def check_conv_fwd(mode, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, nor
     mra = stats_ref(xa).to(DEV) if norm else None
     mrb = stats_ref(xb).to(DEV) if (norm and xb is not None) else None
     nc = Cout * (2 if fused_sc else 1)
-    bn = ops.pick_bn(nc, dt, dims=(N, D, H, W))
+    bn = ops.pick_bn(nc, dt, dims=(N, D, H, W), epi=0)
     wp = ops.pack_weights(dt, 0, w1.to(DEV), ws.to(DEV) if ws is not None else None, Ca, Cb, Cout, Cout if fused_sc else 0, bn)
     out = torch.empty((N, D, H, W, nc), device=DEV, dtype=dt)
     part = ops.part_buffer(dt, (N, D, H, W), nc, bn, DEV, fill=float('nan'))
@@ -161,7 +161,7 @@ def check_conv_bwd(mode, N, S, Ca, Cb, Cout, fused_sc, seed=0, tr=None):
     sb = ops.Src(to_cl(xb, dt), mr=mrb) if xb is not None else None
     y1 = ops.Src(to_cl(dy1, dt))
     y2 = ops.Src(to_cl(dys, dt)) if fused_sc else None
-    bn = ops.pick_bn(Cin, dt, dims=(N, D, H, W))
+    bn = ops.pick_bn(Cin, dt, dims=(N, D, H, W), epi=1)
     wp = ops.pack_weights(dt, 1, w1.to(DEV), ws.to(DEV) if ws is not None else None, Cout, Cout if fused_sc else 0, Cin, 0, bn)
     g0 = torch.empty((N, D, H, W, Cin), device=DEV, dtype=dt)
     part = ops.part_buffer(dt, (N, D, H, W), Cin, bn, DEV, fill=float('nan'), epi=1)
@@ -237,7 +237,7 @@ def check_conv_exact(kind, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, n
             ref = ref + res.double()
             mag = mag + res.double().abs()
         nc = ref.shape[1]
-        bn = ops.pick_bn(nc, dt, dims=dims)
+        bn = ops.pick_bn(nc, dt, dims=dims, epi=0)
         wp = ops.pack_weights(dt, 0, w1.to(DEV), ws.to(DEV) if fused_sc else None, Ca, Cb, Cout, Cout if fused_sc else 0, bn)
         out = torch.full((N, D, H, W, nc), float('nan'), device=DEV, dtype=dt)
         part = ops.part_buffer(dt, dims, nc, bn, DEV, fill=float('nan'))
@@ -254,7 +254,7 @@ def check_conv_exact(kind, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, n
         mask = (x > mr[:, :, 0].float()[:, :, None, None, None]).double()          # sign((x - mean) * rstd) as the epilogue evaluates it in f32
         ref, mag = ref * mask, mag * mask
         nc = Cin
-        bn = ops.pick_bn(nc, dt, dims=dims)
+        bn = ops.pick_bn(nc, dt, dims=dims, epi=1)
         wp = ops.pack_weights(dt, 1, w1.to(DEV), ws.to(DEV) if fused_sc else None, Cout, Cout if fused_sc else 0, Cin, 0, bn)
         out = torch.full((N, D, H, W, nc), float('nan'), device=DEV, dtype=dt)
         part = ops.part_buffer(dt, dims, nc, bn, DEV, fill=float('nan'), epi=1)
@@ -1221,7 +1221,7 @@ def with_strided(force, fn, *a):
 def with_variant(variant, fn, *a):
     """Run a conv check under a forced igemm kernel variant (0 classic, 1 producer/consumer, 2 = round-1 auto choice,
     4 = weight-stationary kernel on every 32-column launch, 6 / 7 = volume-fitted K-split kernel with the box
-    chosen per volume / the 4x4x4 box); restores the default (3)."""
+    chosen per volume / the 4x4x4 box, 8 = depth-reuse kernel for every launch with more than 32 columns); restores the default (3)."""
     from rsuper_amd.hip import ops
     L = ops._L()
     L.rsuper_conv3_variant(variant)
@@ -1357,7 +1357,7 @@ def all_checks(quick=False):
         cs += [(check_pointwise, (m, 27648, 128, 512, False)), (check_pointwise, (m, 13824, 512, 128, True)), (check_pointwise, (m, 3456, 256, 1024, False)),
                (check_pointwise, (m, 3456, 1024, 256, True)), (check_pointwise, (m, 432, 320, 1280, False)),       # reduction split over the waves
                (check_pointwise, (m, 100, 36, 20, True)), (check_pointwise, (m, 33, 4, 4, False)), (check_pointwise, (m, 1000, 72, 260, True))]
-    for variant in (0, 1, 4, 6, 7):  # every bf16 igemm kernel on every conv case (6 / 7: the volume-fitted K-split kernel, incl. its split-reduction shape) (the default picks per launch)
+    for variant in (0, 1, 4, 6, 7, 8):  # every bf16 igemm kernel on every conv case (8: the depth-reuse kernel wherever its limits allow) (6 / 7: the volume-fitted K-split kernel, incl. its split-reduction shape) (the default picks per launch)
         cs += [(with_variant, (variant, fn) + a) for fn, a in list(cs) if fn in (check_conv_fwd, check_conv_bwd) and a[0] == 'bf16']
     # bf16 forward / data gradient against float64 on the same bf16 operands, one-rounding bound: ragged volumes (every face of the halo),
     # one / two sources, fused shortcut (128 / 96 / 64 / 16 columns), residual, raw and normalised sources, the low-resolution box shapes; default dispatch
@@ -1370,7 +1370,7 @@ def all_checks(quick=False):
              ('dgrad', 2, (12, 12, 12), 128, 0, 128, False, False, True, 6), ('dgrad', 1, (5, 6, 7), 8, 16, 8, True), ('dgrad', 2, (9, 17, 33), 32, 64, 32, True, False, True, 7),
              ('dgrad', 1, (12, 20, 48), 128, 64, 64, True, False, True, 8)]
     cs += [(check_conv_exact, a) for a in exact]
-    for variant in (0, 1, 4, 6, 7):
+    for variant in (0, 1, 4, 6, 7, 8):
         cs += [(with_variant, (variant, check_conv_exact) + a) for a in exact]
     cs += [(with_variant, (1, check_conv_fwd, 'bf16', 2, (8, 24, 32), 32, 0, 32, False, True)),       # persistent: several tiles per block
            (with_variant, (1, check_conv_fwd, 'bf16', 1, (12, 20, 48), 64, 64, 128, True, False)),    # 128 columns, 4 chunks, 2 sources

@@ -47,7 +47,7 @@ for name, S, Ca, Cb, Cout, sc in LAYERS:
     tiles = ops._L().rsuper_conv3_tiles(S, S, S)
     sa, sb = ops.Src(xa, mr=mra), (ops.Src(xb, mr=mrb) if Cb else None)
     # forward
-    bn = ops.pick_bn(nc, dt, tiles * N, dims)
+    bn = ops.pick_bn(nc, dt, tiles * N, dims, epi=0)
     wp = ops.pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if sc else 0, bn)
     out = torch.empty((N, S, S, S, nc), device=dev, dtype=dt)
     part = ops.part_buffer(dt, (N, S, S, S), nc, bn, dev)
@@ -56,7 +56,7 @@ for name, S, Ca, Cb, Cout, sc in LAYERS:
     # dgrad
     dy1 = torch.randn((N, S, S, S, Cout), device=dev).to(dt)
     dy2 = torch.randn((N, S, S, S, Cout), device=dev).to(dt) if sc else None
-    bnd = ops.pick_bn(Cin, dt, tiles * N, dims)
+    bnd = ops.pick_bn(Cin, dt, tiles * N, dims, epi=1)
     wpd = ops.pack_weights(dt, 1, w1, ws, Cout, Cout if sc else 0, Cin, 0, bnd)
     g0 = torch.empty((N, S, S, S, Cin), device=dev, dtype=dt)
     partd = ops.part_buffer(dt, (N, S, S, S), Cin, bnd, dev, epi=1)
