@@ -167,13 +167,25 @@ static int box_for(int dtype, int bn, int N, int D, int H, int W, int n_cols) {
 static int kd_bn_for(int dtype, int epi, int N, int D, int H, int W, int n_cols) {
     if (dtype != RS_BF16 || n_cols <= 32) return 0;
     static const int off = getenv("RSUPER_KD") ? atoi(getenv("RSUPER_KD")) == 0 : 0;
-    static const int min_tiles = getenv("RSUPER_KD_MIN_TILES") ? atoi(getenv("RSUPER_KD_MIN_TILES")) : 2048;
+    static const int min_tiles = getenv("RSUPER_KD_MIN_TILES") ? atoi(getenv("RSUPER_KD_MIN_TILES")) : 400;
+    static const int dgrad = getenv("RSUPER_KD_DGRAD") ? atoi(getenv("RSUPER_KD_DGRAD")) : 0;
+    static const int wide = getenv("RSUPER_KD_WIDE") ? atoi(getenv("RSUPER_KD_WIDE")) : 0;
     if (g_variant != 8 && (g_variant != 3 || off)) return 0;
     if ((long)N * D * H * W >= (1l << 24) || D > 1023 || H > 1023 || W > 1023) return 0;
-    const long tiles = (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
-    if (g_variant != 8 && tiles < min_tiles) return 0;
-    (void)epi;
-    return 64;                                                     // 96 / 128-column blocks (two column fragments per wave) exceed the register file with register staging
+    if (g_variant != 8) {
+        // measured (profiles/r05_conv_layers.txt, same box): forward launches of exactly 33 .. 64 columns at 96^3 / 48^3 gain 10-11 % (up4.0 648 -> 576 us,
+        // 64 -> 64 @48^3 60 -> 54 us); 128-column forwards (two column blocks) and the data gradients do not beat the 128-column classic / producer-consumer
+        // kernels yet -- they stay selectable (RSUPER_KD_DGRAD=1) and run every parity case under variant 8
+        const long tiles = (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
+        if (tiles < min_tiles) return 0;
+        if (epi == 0 && n_cols > 64) return 0;
+        if (epi == 1 && !dgrad) return 0;
+    }
+    // one column fragment per wave (64-column blocks): two fragments per wave (96 / 128-column blocks, raw sources by LDS-DMA) do not fit the register file
+    // without spills yet and measured slower (up4.0 data gradient: 96-column blocks 733 us against 705 us for 2 x 64); RSUPER_KD_WIDE=1 selects them
+    if (epi == 0 || !wide) return 64;
+    const int r = n_cols % 128;
+    return (n_cols > 128 || r == 0) ? 128 : r > 96 ? 128 : r > 64 ? 96 : 64;
 }
 int rsuper_conv3_kd_bn(int dtype, int epi, int N, int D, int H, int W, int n_cols) {
     if (!dt_ok(dtype) || (epi != 0 && epi != 1) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || n_cols <= 0) return 0;

@@ -12,29 +12,39 @@
 //     wave = (h pair hp, column half): ALL FOUR depth planes of its h pair x NF column fragments (4 x NF accumulators);
 //   * an activation fragment (halo plane d', rows 2 hp + kh, shift kw) is the operand of the three taps kd with 0 <= d' - kd < 4: per (kh, kw)
 //     group 6 fragment reads + 3 NF weight fragments feed 12 NF MFMAs -> 0.5 / NF LDS reads + 0.25 weight loads per MFMA;
-//   * K is staged 16 channels (one MFMA k-step) at a time: halo 6 x 10 x 18 rows x 48-byte pitch = 51.8 KB, two buffers, ONE barrier per item;
-//     the eight waves stage the next item themselves from hooks in the MFMA loop (norm + ReLU in registers, ds_write_b128), the loads of the
-//     item after that in flight in registers -- the scheme of conv3d_wgrad2.hip;
+//   * K is staged 16 channels (one MFMA k-step) at a time: halo 6 x 10 x 18 rows x 48-byte pitch = 51.8 KB, two buffers, ONE barrier per item.
+//     Normalised sources (forward): the eight waves stage the next item themselves from hooks in the MFMA loop (norm + ReLU in registers, one
+//     word = 7 vector-ALU operations per hook, ds_write_b128), the loads of the item after that in flight in registers (conv3d_wgrad2.hip's scheme).
+//     Raw sources (data gradient: dY): LDS-DMA, 7 wave instructions per wave and item, no registers, no arithmetic -- which is what leaves room for
+//     two column fragments per wave (96 / 128-column blocks);
 //   * persistent blocks over the tiles of a sample (XCD-aware order), per-block tile descriptors in LDS (no index arithmetic in the loop),
-//     wave-private epilogue through a 4.6 KB LDS scratch, statistics accumulated in registers over the block's tiles (one partial row per
-//     (block, h pair)).
+//     wave-private epilogue through a 4.6 KB LDS scratch whose operands (residual / forward input of the ReLU mask) are requested from inside the
+//     tile's last MFMA loop, statistics reduced per tile into per-wave LDS accumulators (one partial row per (block, h pair)).
 #include "common.hpp"
 #include "kernels.hpp"
 #include <stdlib.h>
-#include <type_traits>
 #include <stdio.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int TD = 4, TH = 8, TW = 16, HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int HROWS = HD * HH * HW;                 // 1080 halo rows
 constexpr int PITCH = 48;                           // 32 B of data (16 bf16 channels) + 16 B: odd multiple of 16 -> conflict-free ds_read_b128
-constexpr int HALO_BYTES = HROWS * PITCH;           // 51840
+constexpr int HB = 51 * 1024;                       // buffer stride (>= 1080 x 48): the LDS-DMA path fills a buffer in 51 pieces of 1 KB
+constexpr int NP = 7;                               // DMA pieces per wave and item (51 over 8 waves)
 constexpr int NT = 512, NW = 8;
-constexpr int NV = 5;                               // 16-byte staging vectors per thread and item (2160 over 512 threads)
+constexpr int NV = 5;                               // 16-byte staging vectors per thread and item, register path (2160 over 512 threads)
 constexpr int SCR_ROW = 36;                         // floats per epilogue scratch row
 constexpr int SCR_BYTES = 32 * SCR_ROW * 4;         // per wave
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// raw sources need no arithmetic on their way into LDS: `buffer_load_dwordx4 ... lds` copies 1 KB per wave instruction from per-lane global offsets into a
+// lane-linear LDS image (lane l -> M0 + 16 l), out-of-range offsets arrive as zeros (semantics pinned by tools/ubench/lds_dma_probe.hip, as in
+// conv3d_wgrad2.hip).  The compiler does not see the instruction: completion is waited for by an explicit counted vmcnt before the item barrier.
+__device__ __forceinline__ void kd_dma16(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, uint32_t soff, uint32_t lds_byte) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(voff), "s"(lds_byte), "s"(rs), "s"(soff) : "memory", "m0");
+}
 
 // row_to_hw (common.hpp) without branches: the if-chain becomes a private-memory lookup table (scratch) otherwise
 __device__ __forceinline__ void row_to_hw_nt(int i, int& hs, int& w) {
@@ -44,21 +54,28 @@ __device__ __forceinline__ void row_to_hw_nt(int i, int& hs, int& w) {
 }
 
 #ifdef KD_PROF
-__device__ unsigned long long g_kd_prof[8 * 4 + 2];                    // block (0, 0, 0): [wave][item-loop cycles, barrier cycles, epilogue cycles, items]
+__device__ unsigned long long g_kd_prof[8 * 4 + 2];                // block (0, 0, 0): [wave][item-loop, barrier, epilogue ticks, items], kernel ticks, 100 MHz ticks
 #endif
 
 // one 16-channel slice of [a | b]: first channel, channels / row bytes / base / bytes of its source, table index of its constants, byte offset of its packed weights (tap 0)
 struct Item { int c, C; uint32_t rowb, nrec; uint64_t base; int tabc; uint32_t wofs; };
+struct Tile { uint32_t base, bad0, bad1, org; };
 
 // NF0 / NF1: 32-column fragments of the waves 0-3 / 4-7 (block = (NF0 + NF1) x 32 columns).  EPI: 0 forward, 1 data gradient, 2 forward + residual.
-// NORM: both sources carry (mean, rstd).
+// NORM: both sources carry (mean, rstd) and are staged through registers; raw sources are staged by LDS-DMA.
 template <int NF0, int NF1, int EPI, bool NORM>
 __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BN32 = NF0 + NF1;
-    // every field is copied into a local once: a select between two fields of the kernel-argument struct can become a load from a computed address,
-    // which moves the struct to scratch and turns everything read from it into per-lane values (waterfall loops around every buffer instruction)
-    // (readfirstlane: the value becomes the result of an intrinsic instead of a load, so `cond ? Cb : Ca` cannot be rewritten into a table lookup)
+#ifndef KD_DMA
+#define KD_DMA 1
+#endif
+    // raw sources: LDS-DMA for the wide blocks (no registers to spare there); 64-column blocks stage through registers like the normalised ones -- with the
+    // DMA pieces in the VMEM queue every wait for a weight fragment issued after them also waits for the pieces (in-order vmcnt): item loop 4.4 k -> 6.8 k ticks
+    constexpr bool DMA = !NORM && (KD_DMA == 2 || (KD_DMA == 1 && BN32 > 2));
+    // Every field is copied into a local once, and selections between the two sources are mask arithmetic further down: inside by-reference lambdas a
+    // `cond ? b : a` of two such variables becomes a select of two ADDRESSES -- the variables then live in scratch, every use is a flat load + vmcnt(0) and
+    // everything derived from it a per-lane value (waterfall loops around the buffer instructions).  Measured: 938 us vs 559 us on up4.0 forward.
     auto U = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto UP = [](const void* q) {
         const uint64_t a = (uint64_t)q;
@@ -73,10 +90,11 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
     const int pD = p.D, pH = p.H, pW = p.W, pN = p.N, Cout = p.Cout, ldo = p.ldo, ldr = p.ldr, ntiles = p.ntiles;
     const void* const wpk = p.wp; void* const outp = p.out; const void* const resp = p.res; float* const partp = p.part;
     const int ctot = Ca + Cb;
-    char* bufs = smem;                                                  // 2 x HALO_BYTES
-    float4* ntab = (float4*)(smem + 2 * HALO_BYTES);                    // [(Ca + Cb) / 2] (sc0, sc1, nb0, nb1)
-    float* emr = (float*)(smem + 2 * HALO_BYTES + ctot * 8);            // [BN32 * 32][mean, rstd] of the epilogue source (EPI 1)
-    char* scr_base = smem + 2 * HALO_BYTES + ctot * 8 + BN32 * 256;
+    char* bufs = smem;                                                  // 2 x HB
+    float4* ntab = (float4*)(smem + 2 * HB);                            // [(Ca + Cb) / 2] (sc0, sc1, nb0, nb1)   (NORM)
+    float* emr = (float*)(smem + 2 * HB + (NORM ? ctot * 8 : 0));       // [BN32 * 32][mean, rstd] of the epilogue source (EPI 1)
+    float* sacc = emr + BN32 * 64;                                      // [wave][2][32][sum, sum2]: statistics of this block's tiles
+    char* scr_base = (char*)(sacc + NW * 128);
     uint4* dtab = (uint4*)(scr_base + NW * SCR_BYTES);                  // tile descriptors of this block
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -90,10 +108,11 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
     const int nkA = (Ca + 15) / 16, nkB = (Cb + 15) / 16, nk = nkA + nkB;
     const int nchA = (Ca + 31) / 32;
     const int nitems = my_tiles * nk;
-    const uint32_t tapstride = (uint32_t)ntiles * 2048u;              // bytes between consecutive taps of one (chunk, k-step) in the packed weights
+    const uint32_t tapstride = (uint32_t)ntiles * 2048u;                // bytes between consecutive taps of one (chunk, k-step) in the packed weights
     const uint32_t nvox_total = (uint32_t)(pN * pD * pH * pW);
     const uint32_t rowbA = (uint32_t)lda * 2u, rowbB = (uint32_t)ldb * 2u;
     const uint32_t nrecA = nvox_total * rowbA, nrecB = Cb ? nvox_total * rowbB : 0u;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the dynamic region
 
     // ---- per-block tables
     if (NORM) {
@@ -111,6 +130,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
             emr[i] = v;
         }
     }
+    for (int i = tid; i < NW * 128; i += NT) sacc[i] = 0.f;
     {
         // entry k = k-th tile of this block in the XCD-aware order of conv3d_igemm.hip (linear workgroup id b runs on XCD b % 8; every XCD gets a
         // contiguous run of tiles): (halo origin voxel, ~valid (hd | hh << 6) | bit 31, ~valid hw, d0 | h0 << 10 | w0 << 20); entries past the last tile
@@ -136,7 +156,6 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
                                  live ? (~ok1 & 0x3FFFFu) : 0x3FFFFu, (uint32_t)(d0 | (h0 << 10) | (w0 << 20)));
         }
     }
-    struct Tile { uint32_t base, bad0, bad1, org; };
     auto fetch_tile = [&](int k) {                                      // wave-uniform: one broadcast LDS read + readfirstlanes
         const uint4 v = dtab[k];
         Tile t;
@@ -144,9 +163,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
         t.bad1 = __builtin_amdgcn_readfirstlane(v.z); t.org = __builtin_amdgcn_readfirstlane(v.w);
         return t;
     };
-    auto item_of = [&](int j) {                                         // j-th 16-channel slice of [a | b]
-        // selections between the two sources are mask arithmetic, not `cond ? b : a`: inside these by-reference lambdas a select of two captured variables
-        // becomes a select of two ADDRESSES, the variables move to scratch and every use pays a flat load + vmcnt(0)
+    auto item_of = [&](int j) {                                         // j-th 16-channel slice of [a | b] (mask arithmetic: see the top)
         Item it;
         const uint32_t mb = j >= nkA ? 0xFFFFFFFFu : 0u;
         const uint64_t mb64 = j >= nkA ? ~0ull : 0ull;
@@ -162,20 +179,22 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
         return it;
     };
 
-    // ---- staging side: thread -> 16-byte slot tid & 1 of halo rows perm(tid >> 1) + 256 i.  Inside every run of 8 rows the order is 0,2,4,6,1,3,5,7: the
-    //      eight lanes of a ds_write_b128 group then cover rows r, r+2, r+4, r+6 = dword offsets 12 r + {0, 24, 48, 72} + 0..7 -> 32 distinct banks
+    // ---- staging through registers (NORM): thread -> 16-byte slot tid & 1 of halo rows perm(tid >> 1) + 256 i.  Inside every run of 8 rows the order is
+    //      0,2,4,6,1,3,5,7: the eight lanes of a ds_write_b128 group then cover rows r, r+2, r+4, r+6 = dword offsets 12 r + {0, 24, 48, 72} + 0..7 -> 32 banks
     const int s_slot = tid & 1, rk = tid >> 1;
     const int row0 = (rk & ~7) | ((rk & 3) << 1) | ((rk >> 2) & 1);
     int xvo[NV];
     uint32_t pm0[NV], pm1[NV];
+    if (!DMA) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int r = row0 + 256 * i;
-        const int hd = r / (HH * HW), rem = r - hd * (HH * HW);
-        const int hh = rem / HW, hw = rem - hh * HW;
-        xvo[i] = (hd * pH + hh) * pW + hw;
-        pm0[i] = r < HROWS ? ((1u << hd) | (1u << (6 + hh))) : 0x80000000u;
-        pm1[i] = r < HROWS ? (1u << hw) : 0u;
+        for (int i = 0; i < NV; ++i) {
+            const int r = row0 + 256 * i;
+            const int hd = r / (HH * HW), rem = r - hd * (HH * HW);
+            const int hh = rem / HW, hw = rem - hh * HW;
+            xvo[i] = (hd * pH + hh) * pW + hw;
+            pm0[i] = r < HROWS ? ((1u << hd) | (1u << (6 + hh))) : 0x80000000u;
+            pm1[i] = r < HROWS ? (1u << hw) : 0u;
+        }
     }
     const int x_st = row0 * PITCH + s_slot * 16;                         // LDS byte of vector 0; vector i at + 12288 i
     uint4 px[NV];
@@ -212,16 +231,56 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
     auto commit_st = [&](char* buf, int i) {                             // ... and the finished vector written into `buf`
         if (row0 + 256 * i < HROWS) *(uint4*)(buf + x_st + i * (256 * PITCH)) = px[i];
     };
-    auto commit_v = [&](char* buf, int i) {
+
+    // ---- staging by LDS-DMA (raw sources): piece q = wave + 8 k of a buffer is its bytes [1024 q, 1024 q + 1024); lane l moves 16-byte unit u = 64 q + l
+    //      = (halo row u / 3, slot u % 3; slot 2 is the pad of the 48-byte pitch and rows >= 1080 do not exist: out-of-range offset, zeros)
+    uint32_t dvo[NP];                                                    // voxel offset of the unit's halo row | slot << 24 | invalid << 25
+    auto dma_geom = [&](int k, int& hd, int& hh, int& hw, int& slot, bool& valid) {
+        const int u = 64 * (wave + 8 * k) + lane;
+        const int r = u / 3;
+        slot = u - 3 * r;
+        hd = r / (HH * HW);
+        const int rem = r - hd * (HH * HW);
+        hh = rem / HW; hw = rem - hh * HW;
+        valid = r < HROWS && slot < 2 && wave + 8 * k < 51;
+    };
+    if (DMA) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) commit_w(i, j);
-        commit_st(buf, i);
+        for (int k = 0; k < NP; ++k) {
+            int hd, hh, hw, slot; bool valid;
+            dma_geom(k, hd, hh, hw, slot, valid);
+            dvo[k] = valid ? ((uint32_t)((hd * pH + hh) * pW + hw) | ((uint32_t)slot << 24)) : (1u << 25);
+        }
+    }
+    auto dma_item = [&](const Tile& t, const Item& it, uint32_t buf_off) {   // stage (tile, item) into the buffer at byte offset buf_off
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)it.base, 0, it.nrec, 0x00020000);
+        uint32_t lbase = lds0 + buf_off + (uint32_t)wave * 1024u;
+        asm volatile("" : "+s"(lbase));                                  // (keeps the 7 piece addresses of both buffers from being hoisted into scalar registers)
+        const bool boundary = ((t.bad0 & 0xFFFFu) | t.bad1) != 0u;       // wave-uniform: a tile that touches a face of the volume (or a dead entry)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (wave + 8 * k >= 51) continue;                            // wave-uniform
+            const uint32_t q = dvo[k];
+            const uint32_t slot = (q >> 24) & 1u;
+            bool ok = (q >> 25) == 0u && it.c + (int)slot * 8 < it.C;
+            if (boundary) {                                              // no VMEM inside the branch; interior tiles (the bulk) skip the coordinate arithmetic
+                int hd, hh, hw, sl; bool valid;
+                dma_geom(k, hd, hh, hw, sl, valid);
+                ok = ok && (((t.bad0 >> hd) | (t.bad0 >> (6 + hh)) | (t.bad1 >> hw)) & 1u) == 0u;
+            }
+            const uint32_t voff = ok ? __umul24(t.base + (q & 0xFFFFFFu), it.rowb) + slot * 16u : 0xFFFFFFF0u;
+            kd_dma16(rs, voff, (uint32_t)(it.c * 2), lbase + (uint32_t)k * 8192u);
+        }
     };
 
     auto run = [&](auto NF_, auto LATE_) {
         constexpr int NF = std::remove_reference_t<decltype(NF_)>::value;
         constexpr bool late = std::remove_reference_t<decltype(LATE_)>::value;
-        constexpr int RB = NF == 1 ? 3 : 2;                              // weight ring, in (kh, kw) groups: 3 divides the 9 groups of an item, 2 needs a move per item
+#ifndef KD_RB
+#define KD_RB 3
+#endif
+        constexpr int RB = NF == 1 ? KD_RB : 2;                                        // weight ring, in (kh, kw) groups: 3 divides the 9 groups of an item, 2 needs a move per item
+        constexpr int EVF = NF == 1 ? 2 : 1;                             // fragments whose epilogue operands are requested ahead (2 vectors each)
         const int ntile0 = blockIdx.y * BN32 + (nhalf ? NF0 : 0);
         // A fragments: lane -> (row of the h pair, w) by row_to_hw, 16-byte half lane >> 5
         int hs, wl;
@@ -230,8 +289,10 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
         // B fragments: buffer loads with a per-lane VGPR offset and wave-uniform SGPR offsets
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, 0x7FFFFFFF, 0x00020000);
         const uint32_t lane16 = (uint32_t)lane * 16u + (uint32_t)ntile0 * 1024u;
+        uint32_t ts_item = tapstride;                                    // re-laundered every item: the 27 tap offsets are loop invariants the compiler would
+                                                                         // otherwise keep in 27 scalar registers across the whole loop (scalar spills)
         auto load_b = [&](uint32_t wofs, int g, int kd, uint4* dst) {    // g = kh * 3 + kw (static), kd static
-            const uint32_t so = wofs + (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(kd * 9 + g) * tapstride));
+            const uint32_t so = wofs + (uint32_t)(kd * 9 + g) * ts_item;
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
                 const auto q = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + nf * 1024, so, 0);
@@ -244,7 +305,25 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
         row_to_hw_nt(er0, rhs[0], rw[0]);
         row_to_hw_nt(er0 + 16, rhs[1], rw[1]);
         float* scr = (float*)(scr_base + wave * SCR_BYTES);
+        float* sw = sacc + wave * 128;
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(outp, 0, nvox_total * (uint32_t)ldo * 2u, 0x00020000);
+        // epilogue operand (residual / forward input of the ReLU mask) of column fragment nf: source, row pitch, this lane's first column -- recomputed
+        // where needed (a few operations) instead of living in registers across the MFMA loop
+        auto ep_desc = [&](int nf, const bf16_t*& x, uint32_t& ld, int& c0, bool& cok) {
+            const int col0 = (ntile0 + nf) * 32 + cg * 8;
+            cok = col0 < Cout;
+            if (EPI == 1) {
+                const bool useb = col0 >= eCa;
+                const uint64_t um64 = useb ? ~0ull : 0ull;
+                const uint32_t um = useb ? 0xFFFFFFFFu : 0u;
+                x = (const bf16_t*)((uint64_t)exa ^ (((uint64_t)exa ^ (uint64_t)exb) & um64));
+                ld = (uint32_t)elda ^ (((uint32_t)elda ^ (uint32_t)eldb) & um);
+                c0 = col0 - (int)((uint32_t)eCa & um);
+            } else {
+                x = (const bf16_t*)resp; ld = (uint32_t)ldr; c0 = col0;
+            }
+        };
+        const bf16_t* const dummy = (const bf16_t*)(EPI == 1 ? exa : (resp ? resp : xa));   // a mapped address for the requests of items that end no tile
 
         f32x16_t acc[TD][NF];
 #pragma unroll
@@ -253,47 +332,51 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
             for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[d][nf][r] = 0.f;
-        float s1[NF][8], s2[NF][8];                                      // running statistics over all tiles of this block
+        constexpr bool RSTAT = NF == 1;                                  // statistics over the block's tiles in registers (NF 1) or reduced per fragment into LDS (NF 2: no registers left)
+        float rs1[8], rs2[8];
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[nf][j] = 0.f; s2[nf][j] = 0.f; }
+        for (int q = 0; q < 8; ++q) { rs1[q] = 0.f; rs2[q] = 0.f; }
+        const bool wave_live = ntile0 * 32 < Cout;                       // a wave whose columns all lie past Cout (96 columns on 64-column blocks) multiplies nothing
 
-        // ---- prologue: item 0 staged synchronously into buffer 0, item 1 in flight in registers
+        // ---- prologue: item 0 staged synchronously into buffer 0; register path: item 1 in flight in registers
         __syncthreads();                                                 // tables
-        int k1 = 0, j1 = 0;                                              // (tile, slice) of the item held in px
+        int k1 = 0, j1 = 0;                                              // (tile, slice) of the NEXT item (register path: the one held in px)
         Tile t1 = fetch_tile(0);
         Item i1 = item_of(0);
-        {
+        if constexpr (DMA) {
+            dma_item(t1, i1, 0u);
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        } else {
 #pragma unroll
             for (int i = 0; i < NV; ++i) issue_v(t1, i1, i);
             load_norm(i1);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) commit_v(bufs, i);
-            if (++j1 == nk) { j1 = 0; ++k1; t1 = fetch_tile(k1); }
-            i1 = item_of(j1);
+            for (int i = 0; i < NV; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) commit_w(i, j);
+                commit_st(bufs, i);
+            }
+        }
+        if (++j1 == nk) { j1 = 0; ++k1; t1 = fetch_tile(k1); }
+        i1 = item_of(j1);
+        if constexpr (!DMA) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) issue_v(t1, i1, i);
         }
         uint4 bq[RB][3][NF];
-        Item icur = item_of(0);
+        uint32_t wofs_cur = item_of(0).wofs;
 #pragma unroll
         for (int g = 0; g < RB - 1; ++g)
 #pragma unroll
-            for (int kd = 0; kd < 3; ++kd) load_b(icur.wofs, g, kd, bq[g][kd]);
+            for (int kd = 0; kd < 3; ++kd) load_b(wofs_cur, g, kd, bq[g][kd]);
         __syncthreads();
 
         int kc = 0, jc = 0;                                              // (tile, slice) of the current item
         Tile tc = fetch_tile(0);
-        // The SIMD arbitrates its two waves by age: without help the older wave (0-3) runs its 108 MFMAs in 5.6 k ticks and waits 3 k at the barrier while the
-        // younger one needs 8.5 k, the last third of it alone on the SIMD with nothing to cover its operand waits (tools/kd_prof.sh).  Static priority for the
-        // younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4) lets both finish together.
 #ifndef KD_PRIO
-#define KD_PRIO 1
+#define KD_PRIO 0
 #endif
-        if (KD_PRIO == 1 && !late) __builtin_amdgcn_s_setprio(1);
-        if (KD_PRIO == 2 && !late) __builtin_amdgcn_s_setprio(3);
-        if (KD_PRIO == 3 && late) __builtin_amdgcn_s_setprio(1);
+        if (KD_PRIO == 1 && !late) __builtin_amdgcn_s_setprio(1);        // measured: priority only swaps which wave of a SIMD runs ahead (tools/kd_prof.sh)
 #ifdef KD_PROF
         unsigned long long pf_loop = 0, pf_bar = 0, pf_epi = 0;
         const unsigned long long pf_c0 = __builtin_readcyclecounter(), pf_r0 = __builtin_amdgcn_s_memrealtime();
@@ -301,27 +384,73 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
         for (int it = 0; it < nitems; ++it) {
 #ifdef KD_PROF
             const unsigned long long q0 = __builtin_readcyclecounter();
+            unsigned long long q1 = q0;
 #endif
-            const char* buf = bufs + (it & 1) * HALO_BYTES;
-            char* nxt = bufs + ((it + 1) & 1) * HALO_BYTES;
-            // item it + 1 sits in px (tile t1, slice i1); item it + 2 is requested by the hooks
+            const char* buf = bufs + (it & 1) * HB;
+            char* nxt = bufs + ((it + 1) & 1) * HB;
+            const bool last = jc == nk - 1;                              // this item completes a tile
+            asm volatile("" : "+s"(ts_item));
+            // register path: item it + 1 sits in px (tile t1, slice i1), item it + 2 is requested by the hooks.  DMA path: item it + 1 is requested now.
             int k2 = k1, j2 = j1 + 1;
             if (j2 == nk) { j2 = 0; ++k2; }
-            const Tile t2 = j2 == 0 ? fetch_tile(k2) : t1;
-            const Item i2 = item_of(j2);
-            load_norm(i1);
-            const Item inext = i1;                                       // weights of the next item: the ring runs across the barrier
+            Tile t2 = t1;
+            Item i2 = i1;
+            const uint32_t wofs_next = i1.wofs;                          // weights of the next item: the ring runs across the barrier
+            if constexpr (DMA) {
+#ifndef KD_SKIP_STAGE
+                dma_item(t1, i1, (uint32_t)((it + 1) & 1) * HB);
+#endif
+            } else {
+                if (j2 == 0) t2 = fetch_tile(k2);
+                i2 = item_of(j2);
+                load_norm(i1);
+            }
             const uint32_t a_base = (uint32_t)(a_lane);
             auto fetch_a = [&](int g, int dp) {                          // static: group g = kh * 3 + kw, halo plane dp
                 const int kh = g / 3, kw = g % 3;
                 return *(const uint4*)(buf + a_base + ((dp * HH + kh) * HW + kw) * PITCH);
             };
-            constexpr int AR = 4, AD = 3;                                // fragment ring / prefetch distance
+            // epilogue operands of fragment f of the tile this item may complete (f = nf * TD + d): requested from inside the MFMA loop -- every item issues
+            // the loads (address select: a branch around VMEM costs a vmcnt(0) at the join), items that end no tile read one cached dummy vector
+            const int d0 = tc.org & 1023, h0 = (tc.org >> 10) & 1023, w0 = (int)(tc.org >> 20);
+            const uint32_t dstride = (uint32_t)(pH * pW);
+            auto out_vox = [&](int ps, int d, uint32_t& vx) {            // voxel of rows er0 + 16 ps of fragment plane d; false: outside the volume
+                const int h = h0 + 2 * hp + rhs[ps], w = w0 + rw[ps];
+                vx = (uint32_t)(((n * pD + d0 + d) * pH + h) * pW + w);
+                return h < pH && w < pW && d0 + d < pD;
+            };
+            uint4 ev[EVF][2];
+            auto epi_load = [&](int f, bool real) {                      // f static
+                const int nf = f / TD, d = f % TD;
+                const bf16_t* ex; uint32_t eld; int ec0; bool cok;
+                ep_desc(nf, ex, eld, ec0, cok);
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    uint32_t vx;
+                    const bool ok = out_vox(ps, d, vx) && real && cok;
+                    const bf16_t* ptr = ok ? ex + (size_t)(vx * eld + (uint32_t)ec0) : dummy;
+                    ev[f % EVF][ps] = *(const uint4*)ptr;
+                }
+            };
+#ifndef KD_AD
+#define KD_AD 5
+#endif
+            constexpr int AD = NF == 1 ? KD_AD : 2, AR = AD + 1;                       // fragment ring / prefetch distance
             uint4 aq[AR];
+            if (!wave_live) {                                            // a dead wave only stages its share (register path) and meets the others at the barrier
+                if constexpr (!DMA) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) commit_w(i, j);
+                        commit_st(nxt, i);
+                        issue_v(t2, i2, i);
+                    }
+                }
+                goto item_done;
+            }
 #pragma unroll
             for (int s = 0; s < AD; ++s) aq[s % AR] = fetch_a(s / HD, s % HD);
-            // staging hooks: the older wave of a SIMD (waves 0-3) multiplies first and stages in the second half of the item, the younger one the other way
-            // round (conv3d_wgrad2.hip: complementary halves)
 #pragma unroll
             for (int g = 0; g < 9; ++g) {
 #pragma unroll
@@ -333,10 +462,15 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
 #ifndef KD_SKIP_B
                     if (dp < 3) {                                        // weights of group g + RB - 1 (possibly of the next item), tap kd = dp
                         const int gn = g + RB - 1;
-                        if (gn < 9) load_b(icur.wofs, gn, dp, bq[gn % RB][dp]);
-                        else load_b(inext.wofs, gn - 9, dp, bq[gn % RB][dp]);
+                        if (gn < 9) load_b(wofs_cur, gn, dp, bq[gn % RB][dp]);
+                        else load_b(wofs_next, gn - 9, dp, bq[gn % RB][dp]);
                     }
 #endif
+                    if (EPI != 0) {
+#pragma unroll
+                        for (int f = 0; f < EVF; ++f)
+                            if (s == 6 + 2 * f) epi_load(f, last);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int kd = 0; kd < 3; ++kd) {
@@ -352,29 +486,21 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
 #endif
                         }
                     }
-                    // hooks: vector i of item it + 1 is normalised + written into the other buffer, then its register takes the load of item it + 2
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) {
-                        const int hs_early = (i * 27) / NV, hs_late = 27 + (i * 27) / NV;
 #ifndef KD_SKIP_STAGE                                                    // ablation switches (tools/kd_ablate.sh): where the time of an item goes
-#ifndef KD_HOOKS
-#define KD_HOOKS 1
-#endif
-                        if (KD_HOOKS == 0) {                             // whole vectors, complementary halves
-                            if (s == (late ? hs_late : hs_early)) { commit_v(nxt, i); issue_v(t2, i2, i); }
-                        } else {                                         // 25 pieces (4 words + store / next load per vector) spread over the 54 steps (1) or over this wave's half (2)
+                    if constexpr (!DMA) {
+                        // hooks: 25 pieces per item (4 words + store / next load per vector) spread over the 54 steps; the two waves of a SIMD one step apart
+#pragma unroll
+                        for (int i = 0; i < NV; ++i)
 #pragma unroll
                             for (int j = 0; j < 5; ++j) {
-                                const int pc = i * 5 + j;
-                                const int at = KD_HOOKS == 1 ? (pc * 54) / 25 + (late ? 1 : 0) : (late ? 27 : 0) + (pc * 27) / 25;
+                                const int at = ((i * 5 + j) * 54) / 25 + (late ? 1 : 0);
                                 if (s == (at < 54 ? at : 53)) {
                                     if (j < 4) commit_w(i, j);
                                     else { commit_st(nxt, i); issue_v(t2, i2, i); }
                                 }
                             }
-                        }
-#endif
                     }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -384,102 +510,100 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
 #pragma unroll
                     for (int nf = 0; nf < NF; ++nf) bq[0][kd][nf] = bq[1][kd][nf];
             }
-
 #ifdef KD_PROF
-            const unsigned long long q1 = __builtin_readcyclecounter();
+            q1 = __builtin_readcyclecounter();
 #endif
 #ifdef KD_SKIP_EPI
-            if (jc == nk - 1 && it == nitems - 1) {
+            if (last && it == nitems - 1) {
 #else
-            if (jc == nk - 1) {
+            if (last) {
 #endif
                 // -------------------------------------------------------------- wave-private epilogue of this tile
-                const int d0 = tc.org & 1023, h0 = (tc.org >> 10) & 1023, w0 = (int)(tc.org >> 20);
                 const int hi = lane >> 5, col_l = lane & 31;
-                uint32_t vox[TD][2];
-                bool okv[TD][2];
 #pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int h = h0 + 2 * hp + rhs[ps], w = w0 + rw[ps];
-#pragma unroll
-                    for (int d = 0; d < TD; ++d) {
-                        okv[d][ps] = d0 + d < pD && h < pH && w < pW;
-                        vox[d][ps] = (uint32_t)(((n * pD + d0 + d) * pH + h) * pW + w);
-                    }
-                }
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) {
+                for (int f = 0; f < NF * TD; ++f) {
+                    const int nf = f / TD, d = f % TD;
                     const int col0 = (ntile0 + nf) * 32 + cg * 8;        // first output column of this lane's vectors
-                    const bool cok = col0 < Cout;
-                    const bool useb = EPI == 1 && col0 >= eCa;
-                    const uint64_t um64 = useb ? ~0ull : 0ull;
-                    const uint32_t um = useb ? 0xFFFFFFFFu : 0u;
-                    const bf16_t* es_x = (const bf16_t*)((uint64_t)exa ^ (((uint64_t)exa ^ (uint64_t)exb) & um64));
-                    const uint32_t es_ld = (uint32_t)elda ^ (((uint32_t)elda ^ (uint32_t)eldb) & um);
-                    const int ecol0 = col0 - (int)((uint32_t)eCa & um);
                     float emu[8], ers[8];
                     if (EPI == 1) {
                         const float4* e4 = (const float4*)(emr + (((nhalf ? NF0 : 0) + nf) * 32 + cg * 8) * 2);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { const float4 v = e4[j]; emu[2 * j] = v.x; ers[2 * j] = v.y; emu[2 * j + 1] = v.z; ers[2 * j + 1] = v.w; }
                     }
-                    uint4 ev[2][2];
-                    auto epi_load = [&](int d, uint4* dst) {
+                    float s1[8], s2[8];
 #pragma unroll
-                        for (int ps = 0; ps < 2; ++ps) {
-                            const bool ok = cok && okv[d][ps];
-                            // branch-free (address select): divergent branches around VMEM make the compiler fall back to vmcnt(0)
-                            const bf16_t* ptr = EPI == 1 ? (ok ? es_x + (size_t)(vox[d][ps] * es_ld + (uint32_t)ecol0) : (const bf16_t*)exa)
-                                                         : (const bf16_t*)resp + (ok ? (size_t)(vox[d][ps] * (uint32_t)ldr + (uint32_t)col0) : (size_t)0);
-                            dst[ps] = *(const uint4*)ptr;
-                        }
-                    };
-                    if (EPI != 0) epi_load(0, ev[0]);
+                    for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+                    // 1) fragment -> scratch, fragment-row major (same wave: its LDS accesses are ordered)
 #pragma unroll
-                    for (int d = 0; d < TD; ++d) {
-                        if (EPI != 0 && d + 1 < TD) epi_load(d + 1, ev[(d + 1) & 1]);
+                    for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * hi) * SCR_ROW + col_l] = acc[d][nf][r];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * hi) * SCR_ROW + col_l] = acc[d][nf][r];
+                    for (int r = 0; r < 16; ++r) acc[d][nf][r] = 0.f;
+                    // 2) scratch -> 16-byte vectors
 #pragma unroll
-                        for (int ps = 0; ps < 2; ++ps) {
-                            const int row = er0 + 16 * ps;
-                            float v[8];
-                            const float4* sp = (const float4*)(scr + row * SCR_ROW + cg * 8);
-                            { const float4 t4 = sp[0]; v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w; }
-                            { const float4 t4 = sp[1]; v[4] = t4.x; v[5] = t4.y; v[6] = t4.z; v[7] = t4.w; }
-                            const bool ok = cok && okv[d][ps];
-                            if (EPI != 1) {
-                                if (EPI == 2) {
-                                    float rr[8];
-                                    unpack16<bf16_t>(ev[d & 1][ps], rr);
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int row = er0 + 16 * ps;
+                        float v[8];
+                        const float4* sp = (const float4*)(scr + row * SCR_ROW + cg * 8);
+                        { const float4 t4 = sp[0]; v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w; }
+                        { const float4 t4 = sp[1]; v[4] = t4.x; v[5] = t4.y; v[6] = t4.z; v[7] = t4.w; }
+                        uint32_t vx;
+                        const bool ok = out_vox(ps, d, vx) && col0 < Cout;
+                        if (EPI != 1) {
+                            if (EPI == 2) {
+                                float rr[8];
+                                unpack16<bf16_t>(ev[f % EVF][ps], rr);
 #pragma unroll
-                                    for (int q = 0; q < 8; ++q) v[q] += rr[q];
-                                }
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) { v[q] = ok ? Elem<bf16_t>::rnd(v[q]) : 0.f; s1[nf][q] += v[q]; s2[nf][q] += v[q] * v[q]; }
-                            } else {
-                                float xx[8];
-                                unpack16<bf16_t>(ev[d & 1][ps], xx);
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) {
-                                    const float xn = (xx[q] - emu[q]) * ers[q];
-                                    v[q] = Elem<bf16_t>::rnd((ok && xn > 0.f) ? v[q] : 0.f);
-                                    s1[nf][q] += v[q]; s2[nf][q] += v[q] * xn;
-                                }
+                                for (int q = 0; q < 8; ++q) v[q] += rr[q];
                             }
-                            const uint4 pk = pack16<bf16_t>(v);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pk), ors,
-                                                                   ok ? (vox[d][ps] * (uint32_t)ldo + (uint32_t)col0) * 2u : 0xFFFFFFF0u, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);           // keep the scheduler from interleaving all passes (register pressure)
-                        }
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[d][nf][r] = 0.f;
+                            for (int q = 0; q < 8; ++q) { v[q] = ok ? Elem<bf16_t>::rnd(v[q]) : 0.f; s1[q] += v[q]; s2[q] += v[q] * v[q]; }
+                        } else {
+                            float xx[8];
+                            unpack16<bf16_t>(ev[f % EVF][ps], xx);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const float xn = (xx[q] - emu[q]) * ers[q];
+                                v[q] = Elem<bf16_t>::rnd((ok && xn > 0.f) ? v[q] : 0.f);
+                                s1[q] += v[q]; s2[q] += v[q] * xn;
+                            }
+                        }
+                        const uint4 pk = pack16<bf16_t>(v);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pk), ors, ok ? (vx * (uint32_t)ldo + (uint32_t)col0) * 2u : 0xFFFFFFF0u, 0, 0);
                     }
+                    if (EPI != 0 && f + EVF < NF * TD) epi_load(f + EVF, true);   // the slot just consumed takes the operands of fragment f + EVF
+                    // 3) statistics of this fragment: lanes with the same column group hold partial sums over their rows -> reduce, accumulate per wave in LDS
+                    if (RSTAT) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { rs1[q] += s1[q]; rs2[q] += s2[q]; }
+                    } else if (partp) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                            for (int o = 4; o < 64; o <<= 1) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
+                        }
+                        if (lane < 4) {
+                            float4* dst = (float4*)(sw + nf * 64 + cg * 16);
+#pragma unroll
+                            for (int q = 0; q < 8; q += 2) {
+                                float4 a = dst[q >> 1];
+                                a.x += s1[q]; a.y += s2[q]; a.z += s1[q + 1]; a.w += s2[q + 1];
+                                dst[q >> 1] = a;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                   // keep the scheduler from interleaving all fragments (register pressure)
                 }
             }
+        item_done:
 #ifdef KD_PROF
             const unsigned long long q2 = __builtin_readcyclecounter();
 #endif
+            if constexpr (DMA) {
+                // this item's DMA pieces were its first VMEM operations: at most the weight fragments requested for the next item may still be in flight
+                // (a tile's last item also issued the epilogue's stores after them: drain)
+                if (last) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" : : "n"((RB - 1) * 3 * NF) : "memory");
+            }
             __syncthreads();                                             // item it consumed, item it + 1 complete in the other buffer
 #ifdef KD_PROF
             const unsigned long long q3 = __builtin_readcyclecounter();
@@ -487,10 +611,13 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
 #endif
             // advance the item cursors
             if (++jc == nk) { jc = 0; ++kc; tc = fetch_tile(kc); }
-            icur = inext;
-            k1 = k2; j1 = j2; t1 = t2; i1 = i2;
+            wofs_cur = wofs_next;
+            if constexpr (DMA) {
+                if (j2 == 0) t1 = fetch_tile(k2);
+                i1 = item_of(j2);
+            } else { t1 = t2; i1 = i2; }
+            k1 = k2; j1 = j2;
         }
-
 #ifdef KD_PROF
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
             g_kd_prof[wave * 4] = pf_loop; g_kd_prof[wave * 4 + 1] = pf_bar; g_kd_prof[wave * 4 + 2] = pf_epi; g_kd_prof[wave * 4 + 3] = (unsigned long long)nitems;
@@ -498,22 +625,31 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
         }
 #endif
         // statistics: ONE partial row per (block, h pair); this wave's columns
-        if (partp) {
+        if (RSTAT && partp) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) { rs1[q] += __shfl_xor(rs1[q], o, 64); rs2[q] += __shfl_xor(rs2[q], o, 64); }
+            }
+            if (lane < 4) {
+                float4* dst = (float4*)(sw + cg * 16);
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) dst[q >> 1] = make_float4(rs1[q], rs2[q], rs1[q + 1], rs2[q + 1]);
+            }
+        }
+        if (partp && lane < 4) {
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(partp, 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-#pragma unroll
-                    for (int o = 4; o < 64; o <<= 1) { s1[nf][q] += __shfl_xor(s1[nf][q], o, 64); s2[nf][q] += __shfl_xor(s2[nf][q], o, 64); }
-                }
                 const int col0 = (ntile0 + nf) * 32 + cg * 8;
-                const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(partp, 0, 0x7FFFFFFF, 0x00020000);
-                const uint32_t poff = (lane < 4 && col0 < Cout) ? (uint32_t)(((((size_t)n * gx + blockIdx.x) * 4 + hp) * Cout + col0) * 8) : 0xFFFFFFF0u;
+                const uint32_t poff = col0 < Cout ? (uint32_t)(((((size_t)n * gx + blockIdx.x) * 4 + hp) * Cout + col0) * 8) : 0xFFFFFFF0u;
+                const float4* src = (const float4*)(sw + nf * 64 + cg * 16);
 #pragma unroll
-                for (int q = 0; q < 8; q += 2) {
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = src[q];
                     u32x4_t pv;
-                    pv[0] = __float_as_uint(s1[nf][q]); pv[1] = __float_as_uint(s2[nf][q]); pv[2] = __float_as_uint(s1[nf][q + 1]); pv[3] = __float_as_uint(s2[nf][q + 1]);
-                    __builtin_amdgcn_raw_buffer_store_b128(pv, prs, poff == 0xFFFFFFF0u ? poff : poff + q * 8, 0, 0);
+                    pv[0] = __float_as_uint(a.x); pv[1] = __float_as_uint(a.y); pv[2] = __float_as_uint(a.z); pv[3] = __float_as_uint(a.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(pv, prs, poff == 0xFFFFFFF0u ? poff : poff + q * 16, 0, 0);
                 }
             }
         }
@@ -534,26 +670,33 @@ int launch_kd(const IgemmParams& p, int epi, hipStream_t st) {
     const int tiles = kd_tiles(p.D, p.H, p.W);
     const int gy = p.ntiles / (NF0 + NF1);
     const int gx = kd_grid_x(tiles, gy, p.N);
-    const size_t smem = 2 * (size_t)HALO_BYTES + (size_t)(p.a.C + p.b.C) * 8 + (NF0 + NF1) * 256 + NW * (size_t)SCR_BYTES + ((tiles + gx - 1) / gx + 4) * 16;
+    const bool norm = p.a.mr != nullptr;
+    const size_t smem = 2 * (size_t)HB + (norm ? (size_t)(p.a.C + p.b.C) * 8 : 0) + (NF0 + NF1) * 256 + NW * 512 + NW * (size_t)SCR_BYTES + ((tiles + gx - 1) / gx + 4) * 16;
     if (smem > 160 * 1024) return RS_ERR_UNSUPPORTED;
     dim3 grid(gx, gy, p.N), block(NT);
-    const bool norm = p.a.mr != nullptr;
 #define KD_LAUNCH(E, NRM)                                                                                              \
     {                                                                                                                  \
         auto k = igemm_kd_kernel<NF0, NF1, E, NRM>;                                                                    \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);              \
         hipLaunchKernelGGL(k, grid, block, smem, st, p);                                                               \
     }
-    if (epi == 1) { if (norm) KD_LAUNCH(1, true) else KD_LAUNCH(1, false) }
-    else if (p.res) { if (norm) KD_LAUNCH(2, true) else KD_LAUNCH(2, false) }
-    else { if (norm) KD_LAUNCH(0, true) else KD_LAUNCH(0, false) }
+    if constexpr (NF0 == 1) {                                            // register staging: one column fragment per wave (two do not fit the register file)
+        if (epi == 1) { if (norm) KD_LAUNCH(1, true) else KD_LAUNCH(1, false) }
+        else if (p.res) { if (norm) KD_LAUNCH(2, true) else KD_LAUNCH(2, false) }
+        else { if (norm) KD_LAUNCH(0, true) else KD_LAUNCH(0, false) }
+    } else {
+        if (norm) return RS_ERR_UNSUPPORTED;
+        if (epi == 1) KD_LAUNCH(1, false)
+        else if (p.res) KD_LAUNCH(2, false)
+        else KD_LAUNCH(0, false)
+    }
 #undef KD_LAUNCH
 #ifdef KD_PROF
     if (getenv("RSUPER_KD_PROF")) {
         unsigned long long h[34];
         (void)hipDeviceSynchronize();
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_kd_prof), sizeof(h));
-        fprintf(stderr, "kd_prof epi%d norm%d (cycles per item; readcyclecounter ticks):", epi, (int)norm);
+        fprintf(stderr, "kd_prof epi%d norm%d bn%d (ticks per item):", epi, (int)norm, p.bn);
         for (int w = 0; w < 8; ++w) fprintf(stderr, " w%d loop %.0f epi %.0f bar %.0f |", w, (double)h[w * 4] / h[w * 4 + 3], (double)h[w * 4 + 2] / h[w * 4 + 3], (double)h[w * 4 + 1] / h[w * 4 + 3]);
         fprintf(stderr, " items %llu; %llu ticks in %.1f us (100 MHz counter) = %.0f MHz\n", h[3], h[32], h[33] / 100.0, h[32] / (h[33] / 100.0));
     }
@@ -563,10 +706,11 @@ int launch_kd(const IgemmParams& p, int epi, hipStream_t st) {
 
 }  // namespace
 
-// bf16, 64 / 96 / 128-column blocks; both sources normalised or both raw; 24-bit voxel arithmetic in the staging addresses
+// bf16, 64 / 96 / 128-column blocks (96 / 128: raw sources only); both sources normalised or both raw; 24-bit voxel arithmetic in the staging addresses
 bool rs_igemm_kd_supported(const IgemmParams& p, int dtype) {
     if (dtype != RS_BF16 || (p.bn != 64 && p.bn != 96 && p.bn != 128) || p.ntiles % (p.bn / 32)) return false;
     if (p.b.C > 0 && (p.a.mr != nullptr) != (p.b.mr != nullptr)) return false;
+    if (p.bn != 64 && p.a.mr != nullptr) return false;
     if ((long)p.N * p.D * p.H * p.W >= (1l << 24) || p.D > 1023 || p.H > 1023 || p.W > 1023) return false;
     if (p.a.ld * 2 >= (1 << 24) || p.b.ld * 2 >= (1 << 24)) return false;
     return true;
