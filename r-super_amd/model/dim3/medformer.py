@@ -98,3 +98,38 @@ class MedFormer(nn.Module):
         feat, _ = out.cl(dt)
         logits = ops.HeadFn.apply(feat, self.outc.weight, self.outc.bias)
         return {'segmentation': [logits, aux] if self.aux_loss else logits}
+
+
+def update_output_layer_onk(model, original_classes, new_classes, copy_pancreas=False):
+    """Output-layer surgery for the public checkpoints (medformer.py:224-319, call site train_ddp.py:574-580 `--update_output_layer`): the 1x1x1
+    heads `model.outc` and -- with deep supervision -- `model.aux_out` are rebuilt for `new_classes`; the row of every class that also exists in
+    `original_classes` is copied from the old head, with `copy_pancreas` (the `--no_mask` runs) the remaining rows take the 'pancreatic_lesion' row,
+    otherwise they keep the fresh nn.Conv3d initialisation.  A head that already has len(new_classes) outputs is left untouched, as in the reference.
+    The new layers are created in the reference's order (outc, then aux_out) so a seeded run draws the same initial rows; they live on the device and
+    in the dtype of the layers they replace.  The classification branch the reference also rewires is a baseline outside R-Super (not constructible
+    here).  Returns the model."""
+    def update_conv(old_conv, full_class_list):
+        new_conv = nn.Conv3d(old_conv.in_channels, len(full_class_list), kernel_size=old_conv.kernel_size, stride=old_conv.stride, padding=old_conv.padding,
+                             dilation=old_conv.dilation, groups=old_conv.groups, bias=old_conv.bias is not None)
+        new_conv = new_conv.to(device=old_conv.weight.device, dtype=old_conv.weight.dtype)
+        with torch.no_grad():
+            for new_idx, new_cls in enumerate(full_class_list):
+                src = None
+                if new_cls in original_classes:
+                    src = original_classes.index(new_cls)
+                elif copy_pancreas:
+                    src = original_classes.index('pancreatic_lesion')          # ValueError when the old list has no such class, as in the reference
+                if src is not None:
+                    new_conv.weight[new_idx] = old_conv.weight[src]
+                    if old_conv.bias is not None:
+                        new_conv.bias[new_idx] = old_conv.bias[src]
+        return new_conv
+
+    original_classes, new_classes = list(original_classes), list(new_classes)
+    if model.outc.out_channels != len(new_classes):
+        model.outc = update_conv(model.outc, new_classes)
+    if hasattr(model, 'aux_out') and model.aux_loss and model.aux_out.out_channels != len(new_classes):
+        model.aux_out = update_conv(model.aux_out, new_classes)
+    if getattr(model, 'classification_branch', None) is not None and not isinstance(model.classification_branch, bool):
+        raise NotImplementedError('classification branch heads are a baseline outside the R-Super path (medformer.py:297-317)')
+    return model

@@ -294,6 +294,10 @@ def get_parser(argv=None, config_root=None):
     parser.add_argument('--classification_branch', action='store_true')
     parser.add_argument('--multi_ch_tumor', action='store_true')
     parser.add_argument('--model_genesis_pretrain', action='store_true')
+    parser.add_argument('--update_output_layer', action='store_true', help='rebuild the output heads for the class list of the dataset, keeping the kernels of the classes in --old_classes (train_ddp.py:437)')
+    parser.add_argument('--old_classes', type=str, default=None, help='yaml file with the class list of the checkpoint (sorted on load, train_ddp.py:438,647-652)')
+    parser.add_argument('--no_mask', action='store_true', help='report-only training; with --update_output_layer new classes start from the pancreatic_lesion kernels (train_ddp.py:454,577)')
+    parser.add_argument('--pretrained', type=str, default=None, help='pretrained model path (train_ddp.py:431)')
     parser.add_argument('--clip_pretrain', action='store_true')
     parser.add_argument('--epochs', type=int, default=None)
     parser.add_argument('--classes_number', type=int, default=None)
@@ -396,11 +400,42 @@ def main_worker(proc_idx, ngpus_per_node, fold_idx, args, result_dict=None, trai
     if torch.cuda.is_available():
         torch.cuda.set_device(proc_idx % torch.cuda.device_count())
     args.classes = len(trainset.classes)
-    net = get_model(args, pretrain=args.pretrain, classes=trainset.classes).to('cuda')
-    ema_net = make_ema(net) if args.ema else None
+    net, ema_net = init_network(args, classes=trainset.classes, old_classes=load_old_classes(args))
     # --hip_graph in a distributed run: the bare module goes to train_epoch, whose GraphedNetwork averages the gradients itself
     model = wrap_ddp(net, proc_idx) if (args.distributed and not getattr(args, 'hip_graph', False)) else net
     return train_net(model, trainset, testset, args, ema_net, fold_idx=fold_idx)
+
+
+def load_old_classes(args):
+    """--old_classes: yaml list of the checkpoint's classes, sorted (train_ddp.py:647-654)."""
+    path = getattr(args, 'old_classes', None)
+    if path is None:
+        return None
+    if isinstance(path, (list, tuple)):
+        return sorted(path)
+    import yaml
+    with open(path) as f:
+        args.old_classes = sorted(yaml.load(f, Loader=yaml.SafeLoader))
+    return args.old_classes
+
+
+def init_network(args, classes=None, old_classes=None):
+    """init_network (train_ddp.py:552-590): the model is built for the OLD class list when the output layer is to be rebuilt and no separate
+    pretrained file is named (the checkpoint has to load first), then `update_output_layer_onk` swaps the heads for `classes`.  The EMA copy is taken
+    after the surgery (the reference rebuilds it separately; its first update, alpha = 0 at step 0, overwrites it with the parameters anyway)."""
+    update = getattr(args, 'update_output_layer', False)
+    if update and old_classes is None:
+        raise ValueError('--update_output_layer needs --old_classes')
+    c = old_classes if (update and getattr(args, 'pretrained', None) is None) else classes
+    net = get_model(args, pretrain=args.pretrain, classes=c)
+    if update:
+        if not hasattr(net, 'aux_loss'):
+            raise NotImplementedError('--update_output_layer rewires MedFormer heads (model/dim3/medformer.py:224)')
+        from .model.dim3.medformer import update_output_layer_onk
+        net = update_output_layer_onk(net, original_classes=old_classes, new_classes=classes, copy_pancreas=getattr(args, 'no_mask', False))
+    net = net.to('cuda')
+    ema_net = make_ema(net) if args.ema else None
+    return net, ema_net
 
 
 def load_label_names(args, root_attr='data_root', required=True):
