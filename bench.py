@@ -157,10 +157,13 @@ class Leg:
         self.last = None
         self.graphed = None
         self.sanity = False
+        self.guard = None           # train_ddp.StepGuard: the reference's per-step guards as device flags, read one step late
 
     def run(self, n):
         from rsuper_amd.train_ddp import train_step
         for _ in range(n):
+            if self.guard is not None:
+                self.guard.check_input(self.batch['image'])
             if self.sanity:        # the reference's per-step guards, as train_epoch runs them (train_ddp.py:311-313; the loss's own at losses_foundation.py:864-869, 1070-1071)
                 img = self.batch['image']
                 assert not torch.isnan(img).any(), 'Input is nan'
@@ -170,6 +173,9 @@ class Leg:
                 self.last = self.graphed(self.batch, self.step)
             else:
                 self.last = train_step(self.model, self.ema, self.opt, self.batch, self.largs, self.classes, self.step)
+            if self.guard is not None:
+                self.guard.end_step()
+                self.guard.poll()          # raises for the step before this one (its flags have landed while this step was being queued)
             self.step += 1
 
     def use_graph(self):
@@ -376,6 +382,7 @@ def main():
     ap.add_argument('--report', action='store_true', help='config 3: report supervision on (ball_dice_both, 50/50 mask/report batch)')
     ap.add_argument('--no-pool', action='store_true', help="variant (not the headline): down_block(pool=False) -- the strided BasicBlock members (SURVEY 8 row g)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--guards', type=int, default=1, help="1: the reference's per-step guards run inside the timed region as device-side flags (default); 0: off")
     ap.add_argument('--no-secondary', action='store_true', help='skip the config-3 / f32 / bf16-vs-f32 legs')
     ap.add_argument('--roofline-steps', type=int, default=10, help='steps of the separate HIP-event pass after the timed region')
     ap.add_argument('--secondary-only', action='store_true', help='(internal) run only the secondary legs and print their JSON')
@@ -399,7 +406,10 @@ def main():
     torch.cuda.set_device(local)
     lib.require_device()
     dev = f'cuda:{local}'
-    lf.SANITY_CHECKS = False             # the reference's per-step .sum()/isnan host syncs are checked once after the timed region
+    # The reference's per-step guards (input isnan / range asserts train_ddp.py:311-313, mask / unknown / volume consistency losses_foundation.py:864-869,
+    # NaN loss :1070-1071) run INSIDE the timed region as device-side flags (train_ddp.StepGuard: raised one step late, the update of a NaN step is
+    # skipped on the device).  --sync-guards 0 turns them off; secondary.sanity_on_ms_per_step is the same step with the reference's synchronous form.
+    lf.SANITY_CHECKS = bool(args.guards)
     classes = synth.PANTS_CLASSES
     B, S = args.batch, args.size
 
@@ -407,7 +417,14 @@ def main():
         print(json.dumps(secondary_legs(args, rank, world, local, classes, B, S)))
         return
     leg = Leg(args, args.dtype, args.report, rank, world, local, args.force_ddp, classes, B, S)
+    if args.guards:
+        from rsuper_amd.train_ddp import StepGuard
+        leg.guard = lf.GUARD = StepGuard(dev)
     dt = leg.timed(args.steps, args.warmup)
+    if leg.guard is not None:
+        leg.guard.poll(final=True)
+        leg.guard = lf.GUARD = None
+    lf.SANITY_CHECKS = False             # the legs below (roofline pass, secondary workloads) run without them, as before
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -445,7 +462,8 @@ def main():
                                    f'(fwd + {"seg+Volume+Ball" if args.report else "masked BCE + Dice"} loss + bwd + clip + AdamW + EMA), '
                                    f'{S}^3 patches, batch {B}/GPU (BASELINE.json configs[{2 if args.report else 1}])' + (' -- VARIANT pool=False (strided down blocks)' if args.no_pool else ''),
                        'global_batch': world * B, 'patch': S, 'parallelism': f'dp{world}', 'final_loss': loss_val,
-                       'sanity_checks_in_timed_region': False},
+                       'sanity_checks_in_timed_region': bool(args.guards),
+                       'sanity_checks_form': 'device-side flags read one step late (train_ddp.StepGuard)' if args.guards else 'off'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': traffic, 'traffic_unit': 'bytes per step over all conv MFMA launches (FETCH_SIZE x2 + WRITE_SIZE)',
                          'traffic_source': traffic_src,

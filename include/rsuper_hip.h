@@ -403,6 +403,16 @@ int rsuper_rank_assign(const long long* ids, unsigned int n, float log2_d, float
 /* flags[p] = any(m[p][:]) for `planes` contiguous byte volumes of V voxels (V % 16 == 0 when planes > 1): the
  * `.sum() > 0` / `.any()` tests of calculate_loss / ball_loss (:1625, :313, :335) at HBM rate. */
 int rsuper_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, void* stream);
+
+/* The per-step input guards of train_epoch (train_ddp.py:311-313: `assert not isnan(img).any()`, `max(img) <= 100`, `min(img) >= -100` -- three
+ * device->host synchronisations per step in the reference) as one pass over the f32 tensor x[n] (16-byte aligned) that only ORs device flags:
+ * flags[0] any NaN, flags[1] any x > hi, flags[2] any x < lo.  The host mirror (train_ddp.StepGuard) reads the flags asynchronously and raises the
+ * reference's assertion no later than one step after the fact. */
+int rsuper_guard_range(const float* x, size_t n, float lo, float hi, int* flags, void* stream);
+/* The batch consistency checks of calculate_loss (losses_foundation.py:864-869) on device flags: per sample b with m_any[b] != 0 (chosen segment mask not all
+ * zero; bytes from rsuper_plane_any), flags[0] |= (u_any[b] == 0) ("unk_voxels should not be all zeros ..."), flags[1] |= (sum_t volumes[b][t] == 0)
+ * ("tumor_volumes_report should not be all zeros ...").  volumes: [B][T] f32. */
+int rsuper_guard_consistency(const uint8_t* m_any, const uint8_t* u_any, const float* volumes, int B, int T, int* flags, void* stream);
 int rsuper_mask_op(uint8_t* a, const uint8_t* b, long V, int op /*0 and, 1 or, 2 andnot*/, void* stream);
 
 /* Bit-packed label ingestion: device-side np.unpackbits(packed, axis=0)[:C] of the label / unk / chosen-

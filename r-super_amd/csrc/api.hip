@@ -695,6 +695,14 @@ int rsuper_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C,
     if (!packed || !out || B <= 0 || P <= 0 || C <= 0 || C > 8 * P || V <= 0) return RS_ERR_ARG;
     return rs_launch_unpack_bits(packed, out, B, P, C, V, ST(stream));
 }
+int rsuper_guard_consistency(const uint8_t* m_any, const uint8_t* u_any, const float* volumes, int B, int T, int* flags, void* stream) {
+    if (!m_any || !u_any || !volumes || !flags || B <= 0 || T <= 0) return RS_ERR_ARG;
+    return rs_launch_guard_consistency(m_any, u_any, volumes, B, T, flags, ST(stream));
+}
+int rsuper_guard_range(const float* x, size_t n, float lo, float hi, int* flags, void* stream) {
+    if (!x || !flags || ((uintptr_t)x & 3) || (n >= 4 && ((uintptr_t)x & 15))) return RS_ERR_ARG;
+    return rs_launch_guard_range(x, n, lo, hi, flags, ST(stream));
+}
 int rsuper_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, void* stream) {
     if (!m || !flags || planes <= 0 || V <= 0 || ((uintptr_t)m & 15) || (V & 15 && planes > 1)) return RS_ERR_ARG;
     return rs_launch_plane_any(m, planes, V, flags, ST(stream));

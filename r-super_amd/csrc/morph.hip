@@ -672,6 +672,53 @@ __global__ void plane_flags_zero_kernel(uint8_t* flags, long planes) {
     if (i < planes) flags[i] = 0;
 }
 
+// The input range guards of train_epoch (train_ddp.py:311-313: isnan / max <= hi / min >= lo, three host synchronisations in the reference) as ONE pass
+// that only sets device flags: flags[0] |= any NaN, flags[1] |= any x > hi, flags[2] |= any x < lo.  The host reads the flags one step later.
+__global__ __launch_bounds__(256) void guard_range_kernel(const float* __restrict__ x, size_t n, float lo, float hi, int* __restrict__ flags) {
+    int bad = 0;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = ((const float4*)x)[i];
+        const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bad |= (f[j] != f[j] ? 1 : 0) | (f[j] > hi ? 2 : 0) | (f[j] < lo ? 4 : 0);
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) { const float f = x[i]; bad |= (f != f ? 1 : 0) | (f > hi ? 2 : 0) | (f < lo ? 4 : 0); }
+    if (__any(bad)) {                                            // wave-uniform: nothing is written on the clean path
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o, 64);
+        if ((threadIdx.x & 63) == 0) {
+            if (bad & 1) atomicOr(flags + 0, 1);
+            if (bad & 2) atomicOr(flags + 1, 1);
+            if (bad & 4) atomicOr(flags + 2, 1);
+        }
+    }
+}
+// losses_foundation.py:864-869 per sample b: a chosen segment mask that is not all zero needs a non-zero unknown-voxel map and a non-zero report volume.
+// m_any / u_any: one byte per sample (rsuper_plane_any), vol: [B][T] f32.  flags[0] |= mask without unknown voxels, flags[1] |= mask without a volume.
+__global__ void guard_consistency_kernel(const uint8_t* m_any, const uint8_t* u_any, const float* vol, int B, int T, int* flags) {
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        if (!m_any[b]) continue;
+        if (!u_any[b]) atomicOr(flags + 0, 1);
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += vol[(size_t)b * T + t];
+        if (s == 0.f) atomicOr(flags + 1, 1);
+    }
+}
+int rs_launch_guard_consistency(const uint8_t* m_any, const uint8_t* u_any, const float* vol, int B, int T, int* flags, hipStream_t st) {
+    hipLaunchKernelGGL(guard_consistency_kernel, dim3(1), dim3(64), 0, st, m_any, u_any, vol, B, T, flags);
+    return rs_check_launch();
+}
+int rs_launch_guard_range(const float* x, size_t n, float lo, float hi, int* flags, hipStream_t st) {
+    if (n == 0) return RS_OK;
+    size_t nb = (n / 4 + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(guard_range_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, n, lo, hi, flags);
+    return rs_check_launch();
+}
+
 int rs_launch_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, hipStream_t st) {
     hipLaunchKernelGGL(plane_flags_zero_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, st, flags, planes);   // a kernel, not a memset node (optim.hip)
     long nb = (V / 16 + 255) / 256;

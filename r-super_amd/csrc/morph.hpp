@@ -13,6 +13,8 @@ int rs_launch_topk_mark(const float* x, const uint8_t* m, long V, uint32_t thr, 
 int rs_launch_topk_select(const float* x, const uint8_t* m, long V, const unsigned int* k, int nk, uint8_t* out, unsigned int* ws, int clip, hipStream_t st);
 int rs_launch_compact(const float* x, const uint8_t* pm, long V, float* vals, uint32_t* idx, unsigned int* n, hipStream_t st);
 int rs_launch_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float dlog2, float scale, float* w, hipStream_t st);
+int rs_launch_guard_consistency(const uint8_t* m_any, const uint8_t* u_any, const float* vol, int B, int T, int* flags, hipStream_t st);
+int rs_launch_guard_range(const float* x, size_t n, float lo, float hi, int* flags, hipStream_t st);
 int rs_launch_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, hipStream_t st);
 int rs_launch_mask_op(uint8_t* a, const uint8_t* b, long V, int op, hipStream_t st);
 int rs_launch_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, hipStream_t st);

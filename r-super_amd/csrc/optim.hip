@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(MTChunk c, AdamParams a,
     float coef = 1.f;
     if (total_sq) {                                              // clip_grad_norm_: max_norm / (norm + 1e-6), clamped to 1
         const float norm = (float)sqrt(*total_sq);
+        // A non-finite gradient norm (NaN loss: the reference raises before backward, losses_foundation.py:1070-1071) skips the whole update: with the
+        // guards read one step late (train_ddp.StepGuard) the weights, moments and EMA must still be the ones of the last good step when the host raises.
+        // (fminf(NaN, 1) = 1 would otherwise apply the NaN gradients.)
+        if (!(norm <= 3.0e38f)) return;
         coef = fminf(a.max_norm / (norm + 1e-6f), 1.f);
     }
     for (size_t i = base + threadIdx.x; i < base + MT_ELEMS && i < n; i += 256) {

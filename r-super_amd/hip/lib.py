@@ -101,6 +101,8 @@ _SIGS = {
     'rsuper_topk_select': (c_int, [P, P, c_long, c_uint, P, P, P]),
     'rsuper_topk_select_multi': (c_int, [P, P, c_long, P, c_int, P, P, c_int, P]),
     'rsuper_plane_any': (c_int, [P, c_long, c_long, P, P]),
+    'rsuper_guard_range': (c_int, [P, c_size_t, c_float, c_float, P, P]),
+    'rsuper_guard_consistency': (c_int, [P, P, P, c_int, c_int, P, P]),
     'rsuper_mask_op': (c_int, [P, P, c_long, c_int, P]),
     'rsuper_unpack_bits': (c_int, [P, P, c_int, c_int, c_int, c_long, P]),
     'rsuper_zero_where': (c_int, [P, P, c_long, P]),

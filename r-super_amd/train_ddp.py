@@ -33,6 +33,70 @@ def make_ema(net):
     return ema
 
 
+class StepGuard:
+    """The reference's per-step guards -- input range asserts (train_ddp.py:311-313), mask / unknown / volume consistency (losses_foundation.py:864-869),
+    NaN loss (:1070-1071) -- without their device->host synchronisations (six per step in the reference; +0.6 ms per step here when done the same way).
+    Every condition ORs a flag on the device; `end_step()` snapshots the flags into pinned memory behind an event and clears them; `poll()` -- called after
+    the NEXT step has been queued, so the wait hides behind it -- raises the reference's exception for the step before.  Weights stay intact meanwhile:
+    a NaN loss gives a non-finite gradient norm, for which the fused optimiser skips the update (csrc/optim.hip).  `poll(final=True)` drains at the end
+    of an epoch."""
+    MESSAGES = ((AssertionError, 'Input is nan'), (AssertionError, 'Input is bigger than 100'), (AssertionError, 'Input is smaller than -100'),
+                (ValueError, 'unk_voxels should not be all zeros if chosen_segment_mask is not all zeros'),
+                (ValueError, 'tumor_volumes_report should not be all zeros if chosen_segment_mask is not all zeros'),
+                (ValueError, 'loss is nan, propagating this can destroy the network weights, STOP!'))
+
+    def __init__(self, device):
+        self.flags = torch.zeros(8, dtype=torch.int32, device=device)
+        self.host = [torch.zeros(8, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.events = [None, None]
+        self.n = 0
+
+    def check_input(self, img):
+        from .hip import lib as _l, ops as _ops
+        x = img if (img.dtype == torch.float32 and img.is_contiguous()) else img.float().contiguous()
+        _l.check(_l.lib().rsuper_guard_range(x.data_ptr(), x.numel(), -100.0, 100.0, self.flags.data_ptr(), _ops._stream()), 'guard_range')
+
+    def consistency(self, m_any, u_any, volumes):
+        """losses_foundation.py:864-869 on the per-sample any-bytes of the segment mask / unknown map and the (B, T) report volumes -> flags 3, 4."""
+        from .hip import lib as _l, ops as _ops
+        v = volumes if (volumes.dtype == torch.float32 and volumes.is_contiguous()) else volumes.float().contiguous()
+        B = int(m_any.numel())
+        _l.check(_l.lib().rsuper_guard_consistency(m_any.data_ptr(), u_any.data_ptr(), v.data_ptr(), B, int(v.numel() // B), self.flags.data_ptr() + 12,
+                                                   _ops._stream()), 'guard_consistency')
+
+    def nan(self, x):
+        """flag 5 |= any NaN in the f32 tensor x (the loss)."""
+        from .hip import lib as _l, ops as _ops
+        x = x.reshape(-1).float().contiguous()
+        _l.check(_l.lib().rsuper_guard_range(x.data_ptr(), x.numel(), float('-inf'), float('inf'), self.flags.data_ptr() + 20, _ops._stream()), 'guard_nan')
+
+    def end_step(self):
+        k = self.n & 1
+        self.host[k].copy_(self.flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        self.flags.zero_()
+        self.n += 1
+
+    def _check(self, k):
+        ev = self.events[k]
+        if ev is None:
+            return
+        ev.synchronize()
+        self.events[k] = None
+        h = self.host[k]
+        for i, (exc, msg) in enumerate(self.MESSAGES):
+            if int(h[i]) != 0:
+                raise exc(msg + ' (raised one step late: device-side guard; the update of a step with a non-finite gradient norm was skipped)')
+
+    def poll(self, final=False):
+        """After end_step() of step s: checks step s - 1 (final: also step s)."""
+        self._check(self.n & 1)              # the older snapshot
+        if final:
+            self._check((self.n + 1) & 1)
+
+
 PREFETCH_SUPERVISION = os.environ.get('RSUPER_PREFETCH_SUPERVISION', '1') == '1'      # =0: the report losses read their host inputs inside calculate_loss (A/B)
 
 
@@ -205,6 +269,20 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
             fwd_net = getattr(optimizer, '_graphed_net', None)
             if fwd_net is None or fwd_net.net is not net:
                 fwd_net = optimizer._graphed_net = GraphedNetwork(net)
+    # the reference's guards as device flags (StepGuard); RSUPER_ASYNC_GUARDS=0: synchronise where the reference does.  Replayed steps keep the host-side
+    # NaN test below (their loss code is not re-run)
+    guard = StepGuard(dev) if (lf.SANITY_CHECKS and stepper is None and dev.type == 'cuda' and os.environ.get('RSUPER_ASYNC_GUARDS', '1') == '1') else None
+    lf.GUARD = guard
+    try:
+        return _train_epoch_loop(trainLoader, net, ema_net, optimizer, epoch, writer, args, matcher, guard, stepper, fwd_net, dev, classes, packed, start)
+    finally:
+        lf.GUARD = None
+
+
+def _train_epoch_loop(trainLoader, net, ema_net, optimizer, epoch, writer, args, matcher, guard, stepper, fwd_net, dev, classes, packed, start):
+    loss_meters = OrderedDict()
+    progress = None
+    iter_num_per_epoch = 0
     for i, inputs in enumerate(trainLoader):
         batch = dict(image=inputs['image'], label=inputs['label'], unk_channels=inputs['unk_channels'],
                      volumes=inputs['volumes'].float(), mask=inputs['mask'], diameters=inputs['diameters'].float())
@@ -216,7 +294,9 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
             batch = {k: v.to(dev, non_blocking=True) for k, v in batch.items()}
         img = batch['image']
         step = i + epoch * len(trainLoader)                      # global steps (:306)
-        if lf.SANITY_CHECKS:
+        if lf.SANITY_CHECKS and guard is not None:               # the same three asserts (:311-313) as device flags, raised by guard.poll()
+            guard.check_input(img)
+        elif lf.SANITY_CHECKS:
             assert not torch.isnan(img).any(), 'Input is nan'
             assert torch.max(img) <= 100, f'Input is bigger than 100: {torch.max(img)}'
             assert torch.min(img) >= -100, f'Input is smaller than -100: {torch.min(img)}'
@@ -226,6 +306,8 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
             # another batch shape: eager module -- unless the graphed network also carries the gradient exchange (then it refuses loudly)
             use = fwd_net if (fwd_net is net or fwd_net.accepts(img) or fwd_net.exchange) else net
             loss_all, _ = train_step(use, ema_net, optimizer, batch, args, classes, step, matcher=matcher)
+        if guard is not None:
+            guard.end_step()
         if len(loss_meters) == 0:
             loss_meters = OrderedDict((k, AverageMeter(k, ':6.4f')) for k in loss_all.keys())
             loss_meters['Elapsed Time'] = AverageMeter('Elapsed Time', ':6.2f')
@@ -239,6 +321,8 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
                                  + (' (hipGraph replay: the weights of this step are already updated -- resume from the last checkpoint)'
                                     if stepper is not None else ''))
             loss_meters[k].update(val, img.shape[0])
+        if guard is not None:
+            guard.poll(final=True)               # the meters above have synchronised on this step already: its flags are there, raise now
         loss_meters['Elapsed Time'].update(time.time() - start, n=1)
         if progress is None:
             progress = ProgressMeter(len(trainLoader) if args.dimension == '2d' else args.iter_per_epoch, list(loss_meters.values()),
@@ -426,6 +510,7 @@ def init_network(args, classes=None, old_classes=None):
     update = getattr(args, 'update_output_layer', False)
     if update and old_classes is None:
         raise ValueError('--update_output_layer needs --old_classes')
+    from .model.utils import get_model
     c = old_classes if (update and getattr(args, 'pretrained', None) is None) else classes
     net = get_model(args, pretrain=args.pretrain, classes=c)
     if update:

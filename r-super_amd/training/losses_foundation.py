@@ -23,6 +23,10 @@ from ..hip import ops
 from ..hip.ops import _ptr, _stream, _L
 
 SANITY_CHECKS = os.environ.get('RSUPER_SANITY', '1') != '0'   # reference-style input checks / NaN guard (host syncs)
+# A train_ddp.StepGuard: the same guards without host synchronisation -- the violated condition is a device flag the training loop reads one step
+# later and raises from with the reference's message (the optimiser skips the update of a step whose gradient norm is not finite, so the weights are
+# those of the last good step when it does).  None: the checks synchronise where the reference does.
+GUARD = None
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -379,7 +383,7 @@ SPECULATIVE_BALL_SEARCH = os.environ.get('RSUPER_BALL_SPEC', '1') == '1'
 GWRP_SORT_ABOVE = int(os.environ.get('RSUPER_GWRP_SORT_ABOVE', '16000'))     # pseudo masks above this size rank by sorting (32 k voxels: 690 -> 228 us; below: one O(n^2) launch wins)
 
 
-def _plane_any(t, lead_dims):
+def _plane_any(t, lead_dims, as_bool=True):
     """any() over the trailing volume of a contiguous uint8 tensor, one flag per leading index: (B, ...) -> bool tensor of
     shape t.shape[:lead_dims] on the device (HIP kernel at HBM rate instead of an ATen byte reduction)."""
     t = t if t.is_contiguous() else t.contiguous()
@@ -389,8 +393,9 @@ def _plane_any(t, lead_dims):
     flags = torch.empty(planes, device=t.device, dtype=torch.uint8)
     if (V % 16 == 0 or planes == 1) and t.data_ptr() % 16 == 0:
         _l.check(_L().rsuper_plane_any(_ptr(t), planes, V, _ptr(flags), _stream()), 'plane_any')
-        return flags.view(shape).bool()
-    return t.flatten(lead_dims).any(lead_dims)
+        return flags.view(shape).bool() if as_bool else flags.view(shape)
+    r = t.flatten(lead_dims).any(lead_dims)
+    return r if as_bool else r.to(torch.uint8)
 
 
 def _count(m):
@@ -658,7 +663,9 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
     D, H, W = label.shape[2:]
     V = D * H * W
 
-    if SANITY_CHECKS and chosen_segment_mask is not None:                # :864-869
+    if SANITY_CHECKS and chosen_segment_mask is not None and GUARD is not None:      # :864-869 without the host round trips
+        GUARD.consistency(_plane_any(mask_u8, 1, as_bool=False), _plane_any(unk_u8, 1, as_bool=False), tumor_volumes_report)
+    elif SANITY_CHECKS and chosen_segment_mask is not None:                # :864-869
         m_any = _plane_any(mask_u8, 1).cpu()
         if bool(m_any.any()):
             u_any = _plane_any(unk_u8, 1).cpu()
@@ -779,7 +786,9 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
     for k in list(loss.keys()):
         overall = loss[k] if overall is None else overall + loss[k]
     loss['overall'] = overall
-    if SANITY_CHECKS and bool(torch.isnan(overall).any()):                 # :1070-1071
+    if SANITY_CHECKS and GUARD is not None:                                # :1070-1071, read one step later (the NaN step's update is skipped on the device)
+        GUARD.nan(overall.detach())
+    elif SANITY_CHECKS and bool(torch.isnan(overall).any()):               # :1070-1071
         raise ValueError('loss is nan, propagating this can destroy the network weights, STOP!')
     assert overall.requires_grad, 'Loss overall should require grad'
     return loss

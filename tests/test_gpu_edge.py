@@ -1274,3 +1274,71 @@ def test_box_split_shape_respects_the_registered_workspace():
     for a in [('bf16', 32, (6, 6, 6), 320, 0, 320, True), ('bf16', 13, (6, 6, 6), 64, 0, 320, True)]:
         r = gc.check_conv_bwd(*a)
         assert r['ok'], r
+
+
+def test_step_guard_raises_one_step_late_and_nan_step_is_skipped():
+    """The reference's per-step guards as device flags (train_ddp.StepGuard; train_ddp.py:311-313, losses_foundation.py:864-869, 1070-1071): a bad input
+    or a NaN loss raises the reference's exception no later than one step after the fact, a clean step raises nothing, and the fused optimiser leaves
+    parameters, moments and EMA untouched for a step whose gradient norm is not finite."""
+    from rsuper_amd.train_ddp import StepGuard
+    from rsuper_amd.training import losses_foundation as lf
+    from rsuper_amd.training.utils import FusedAdamWEMA
+    g = StepGuard(torch.device(DEV))
+    img = torch.randn((2, 1, 16, 16, 16), device=DEV)
+    g.check_input(img); g.end_step(); g.poll()                    # step 0 clean, nothing to report yet
+    bad = img.clone(); bad[1, 0, 3, 4, 5] = 250.0
+    g.check_input(bad); g.end_step(); g.poll()                    # step 1 is bad; poll() only looks at step 0
+    g.check_input(img); g.end_step()
+    with pytest.raises(AssertionError, match='Input is bigger than 100'):
+        g.poll()                                                  # ... one step late
+    g.poll(final=True)                                            # step 2 was clean
+    nanimg = img.clone(); nanimg[0, 0, 0, 0, 1] = float('nan')
+    g.check_input(nanimg); g.end_step()
+    with pytest.raises(AssertionError, match='Input is nan'):
+        g.poll(final=True)
+    low = img.clone(); low[0, 0, 15, 15, 15] = -101.0
+    g.check_input(low); g.end_step()
+    with pytest.raises(AssertionError, match='smaller than -100'):
+        g.poll(final=True)
+    # calculate_loss routes its own guards through lf.GUARD instead of synchronising
+    classes = synth.TINY_CLASSES
+    bt = synth.batch(2, 32, classes, ['mask', 'report'], seed=5, diam_range=(4.0, 8.0), max_tumors=1)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in bt.items()}
+    x = torch.from_numpy(synth.logits(2, len(classes), 32, seed=6)).to(DEV)
+    args = _args(loss='ball_dice_last', report_volume_loss_basic=0.1)
+    old_s, old_g = lf.SANITY_CHECKS, lf.GUARD
+    lf.SANITY_CHECKS, lf.GUARD = True, g
+    try:
+        xr = x.clone().requires_grad_(True)
+        lf.calculate_loss({'segmentation': xr}, t['label'], t['unk_channels'], args, None, t['mask'], t['volumes'], t['diameters'], classes)
+        g.end_step(); g.poll(final=True)                          # consistent batch: clean
+        xn = x.clone(); xn[0, 0, 0, 0, 0] = float('nan')
+        lf.calculate_loss({'segmentation': xn.requires_grad_(True)}, t['label'], t['unk_channels'], args, None, t['mask'], t['volumes'], t['diameters'], classes)
+        g.end_step()
+        with pytest.raises(ValueError, match='loss is nan'):
+            g.poll(final=True)
+        vol0 = torch.zeros_like(t['volumes'])
+        lf.calculate_loss({'segmentation': x.clone().requires_grad_(True)}, t['label'], t['unk_channels'], args, None, t['mask'], vol0, torch.zeros_like(t['diameters']), classes)
+        g.end_step()
+        with pytest.raises(ValueError, match='tumor_volumes_report should not be all zeros'):
+            g.poll(final=True)
+    finally:
+        lf.SANITY_CHECKS, lf.GUARD = old_s, old_g
+    # optimiser: a non-finite gradient norm skips the update
+    p = torch.nn.Parameter(torch.randn(1000, device=DEV))
+    e = p.detach().clone()
+    opt = FusedAdamWEMA([p], lr=1e-2)
+    p.grad = torch.randn_like(p)
+    opt.fused_step(max_norm=1.0, ema_params=[e], ema_alpha=0.5)
+    ref_p, ref_e = p.detach().clone(), e.clone()
+    st = opt._state_for(p)
+    ref_m = {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
+    p.grad = torch.full_like(p, float('nan'))
+    opt.fused_step(max_norm=1.0, ema_params=[e], ema_alpha=0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(p.detach(), ref_p) and torch.equal(e, ref_e)
+    for k, v in ref_m.items():
+        assert torch.equal(st[k], v), k
+    p.grad = torch.randn_like(p)
+    opt.fused_step(max_norm=1.0, ema_params=[e], ema_alpha=0.5)
+    assert not torch.equal(p.detach(), ref_p) and bool(torch.isfinite(p).all())
