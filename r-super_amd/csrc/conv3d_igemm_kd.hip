@@ -374,7 +374,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
         int kc = 0, jc = 0;                                              // (tile, slice) of the current item
         Tile tc = fetch_tile(0);
 #ifndef KD_PRIO
-#define KD_PRIO 0
+#define KD_PRIO 5
 #endif
         if (KD_PRIO == 1 && !late) __builtin_amdgcn_s_setprio(1);        // measured: priority only swaps which wave of a SIMD runs ahead (tools/kd_prof.sh)
 #ifdef KD_PROF
@@ -453,6 +453,19 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
             for (int s = 0; s < AD; ++s) aq[s % AR] = fetch_a(s / HD, s % HD);
 #pragma unroll
             for (int g = 0; g < 9; ++g) {
+                // progress-based priority: the wave of a SIMD that is BEHIND in the item outranks its partner, so the two advance together and cover each
+                // other's operand waits (by age alone the older wave runs ahead and the younger one finishes the last third of the item alone)
+                if (KD_PRIO == 4) {
+                    if (g == 0) __builtin_amdgcn_s_setprio(3);
+                    if (g == 3) __builtin_amdgcn_s_setprio(2);
+                    if (g == 6) __builtin_amdgcn_s_setprio(1);
+                }
+                if (KD_PRIO == 5) {
+                    if (g == 0) __builtin_amdgcn_s_setprio(3);
+                    if (g == 2) __builtin_amdgcn_s_setprio(2);
+                    if (g == 4) __builtin_amdgcn_s_setprio(1);
+                    if (g == 6) __builtin_amdgcn_s_setprio(0);
+                }
 #pragma unroll
                 for (int dp = 0; dp < HD; ++dp) {
                     const int s = g * HD + dp;

@@ -317,6 +317,16 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
             for (int s = 0; s < BD; ++s) bq[s] = fetch_b(s);
 #pragma unroll
             for (int s = 0; s < S.n; ++s) {
+#ifndef WG2_PRIO
+#define WG2_PRIO 0
+#endif
+                // progress-based priority (conv3d_igemm_kd.hip): the wave of a SIMD that is behind in the tile outranks its partner
+                if (WG2_PRIO == 1) {
+                    if (s == 0) __builtin_amdgcn_s_setprio(3);
+                    if (s == S.n / 4) __builtin_amdgcn_s_setprio(2);
+                    if (s == S.n / 2) __builtin_amdgcn_s_setprio(1);
+                    if (s == (3 * S.n) / 4) __builtin_amdgcn_s_setprio(0);
+                }
                 if (s + BD < S.n) bq[(s + BD) % BR] = fetch_b(s + BD);
                 // dY plane d is used on halo planes d + KDMIN .. d + 2.  Fully resident (AP = NDL): request it at the first step of halo plane d + KDMIN - 1.
                 // Ring of three (AP = 3 < NDL): the slot of plane d + 1 is the one of plane d - 2, whose last use in groups 0-2 is the pair (kd 2, kh 0) at

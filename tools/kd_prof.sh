@@ -6,6 +6,6 @@ if [ $# -eq 0 ]; then set -- ""; fi
 for F in "$@"; do
   rm -f _build/conv3d_igemm_kd.o; make KD_EXTRA="-DKD_PROF $F" > /dev/null 2>&1
   echo "== flags: $F"
-  (cd ../.. && RSUPER_KD_PROF=1 BC_ONLY=$L timeout 300 python tools/bench_conv.py 2>&1 | grep -v "^#" | grep -v amdgpu.ids | awk '/kd_prof epi0/{if(a++<1)print; next} /kd_prof epi1/{if(b++<1)print; next} {print}')
+  (cd ../.. && RSUPER_KD_PROF=1 BC_ONLY=$L timeout 300 python tools/bench_conv.py 2>&1 | grep -v "^#" | grep -v amdgpu.ids | grep -v "^$" | tail -14 | cut -c1-400)
 done
 rm -f _build/conv3d_igemm_kd.o; make > /dev/null 2>&1
