@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
 #pragma unroll
             for (int s = 0; s < S.n; ++s) {
 #ifndef WG2_PRIO
-#define WG2_PRIO 0
+#define WG2_PRIO 1
 #endif
                 // progress-based priority (conv3d_igemm_kd.hip): the wave of a SIMD that is behind in the tile outranks its partner
                 if (WG2_PRIO == 1) {
