@@ -27,11 +27,11 @@ sa, sb = ops.Src(xa, mr=mra), (ops.Src(xb, mr=mrb) if Cb else None)
 dy1 = torch.randn((N, S, S, S, Cout), device=dev).to(dt)
 dy2 = torch.randn((N, S, S, S, Cout), device=dev).to(dt) if sc else None
 if which == 'fwd':
-    bn = ops.pick_bn(nc, dt, tiles * N, dims); wp = ops.pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if sc else 0, bn)
+    bn = ops.pick_bn(nc, dt, tiles * N, dims, epi=0); wp = ops.pack_weights(dt, 0, w1, ws, Ca, Cb, Cout, Cout if sc else 0, bn)
     out = torch.empty((N, S, S, S, nc), device=dev, dtype=dt); part = ops.part_buffer(dt, dims, nc, bn, dev)
     fn = lambda: ops.igemm(0, sa, sb, wp, nc, bn, dims, out, part=part)
 elif which == 'dgrad':
-    bn = ops.pick_bn(Cin, dt, tiles * N, dims); wp = ops.pack_weights(dt, 1, w1, ws, Cout, Cout if sc else 0, Cin, 0, bn)
+    bn = ops.pick_bn(Cin, dt, tiles * N, dims, epi=1); wp = ops.pack_weights(dt, 1, w1, ws, Cout, Cout if sc else 0, Cin, 0, bn)
     g0 = torch.empty((N, S, S, S, Cin), device=dev, dtype=dt); part = ops.part_buffer(dt, dims, Cin, bn, dev, epi=1)
     fn = lambda: ops.igemm(1, ops.Src(dy1), ops.Src(dy2) if sc else None, wp, Cin, bn, dims, g0, part=part, ea=sa, eb=sb)
 else:
