@@ -343,7 +343,16 @@ __global__ __launch_bounds__(NT_THREADS, 1) void igemm_ws_kernel(IgemmParams p) 
             if (f + ADIST < NFRAG && !(ABL & 8)) aq[(f + ADIST) % AR] = *(const uint4*)(cur + a_base + frag_off(f + ADIST));
             // the two waves of a SIMD take turns at the issue arbiter (otherwise the older one runs ahead and the block waits
             // for the younger one at the barrier)
-            if (f % PRIO_PERIOD == 0) { if (((f / PRIO_PERIOD) & 1) ^ kh_) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#ifndef WS_PRIO_MODE
+#define WS_PRIO_MODE 1
+#endif
+            if (WS_PRIO_MODE == 0) { if (f % PRIO_PERIOD == 0) { if (((f / PRIO_PERIOD) & 1) ^ kh_) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
+            else {                                   // progress-based (conv3d_igemm_kd.hip): the wave that is behind in the item outranks its partner
+                if (f == 0) __builtin_amdgcn_s_setprio(3);
+                if (f == NFRAG / 4) __builtin_amdgcn_s_setprio(2);
+                if (f == NFRAG / 2) __builtin_amdgcn_s_setprio(1);
+                if (f == (3 * NFRAG) / 4) __builtin_amdgcn_s_setprio(0);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {

@@ -286,6 +286,15 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int row = u / TPW, i = u % TPW;
+#ifndef WG_PRIO
+#define WG_PRIO 0
+#endif
+                if (WG_PRIO == 1) {                              // progress-based priority (conv3d_igemm_kd.hip): the wave that is behind in the tile outranks its partner
+                    if (u == 0) __builtin_amdgcn_s_setprio(3);
+                    if (u == NU / 4) __builtin_amdgcn_s_setprio(2);
+                    if (u == NU / 2) __builtin_amdgcn_s_setprio(1);
+                    if (u == (3 * NU) / 4) __builtin_amdgcn_s_setprio(0);
+                }
                 if (u + BD < NU) bq[(u + BD) % BR] = fetch_b((u + BD) / TPW, (u + BD) % TPW);
                 if (i == 0 && row + 1 < TD * TH) aq[(row + 1) & 1] = fetch_a(row + 1);
                 __builtin_amdgcn_sched_barrier(0);
