@@ -333,9 +333,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[d][nf][r] = 0.f;
         constexpr bool RSTAT = NF == 1;                                  // statistics over the block's tiles in registers (NF 1) or reduced per fragment into LDS (NF 2: no registers left)
-        float rs1[8], rs2[8];
+        f32x2_t rs1[4], rs2[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { rs1[q] = 0.f; rs2[q] = 0.f; }
+        for (int q = 0; q < 4; ++q) { rs1[q] = f32x2_t{0.f, 0.f}; rs2[q] = f32x2_t{0.f, 0.f}; }
         const bool wave_live = ntile0 * 32 < Cout;                       // a wave whose columns all lie past Cout (96 columns on 64-column blocks) multiplies nothing
 
         // ---- prologue: item 0 staged synchronously into buffer 0; register path: item 1 in flight in registers
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
 #ifndef KD_AD
 #define KD_AD 5
 #endif
-            constexpr int AD = NF == 1 ? KD_AD : 2, AR = AD + 1;                       // fragment ring / prefetch distance
+            constexpr int AD = NF == 1 ? ((EPI != 0 && NORM) ? KD_AD - 2 : KD_AD) : 2, AR = AD + 1;   // (residual / mask operands in flight: fewer fragments ahead, no spill)                       // fragment ring / prefetch distance
             uint4 aq[AR];
             if (!wave_live) {                                            // a dead wave only stages its share (register path) and meets the others at the barrier
                 if constexpr (!DMA) {
@@ -543,64 +543,71 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { const float4 v = e4[j]; emu[2 * j] = v.x; ers[2 * j] = v.y; emu[2 * j + 1] = v.z; ers[2 * j + 1] = v.w; }
                     }
-                    float s1[8], s2[8];
+                    // statistics as packed pairs (v_pk_add_f32 / v_pk_fma_f32): NF 1 accumulates straight into the block's running sums
+                    f32x2_t s1[4], s2[4];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+                    for (int q = 0; q < 4; ++q) { s1[q] = RSTAT ? rs1[q] : f32x2_t{0.f, 0.f}; s2[q] = RSTAT ? rs2[q] : f32x2_t{0.f, 0.f}; }
                     // 1) fragment -> scratch, fragment-row major (same wave: its LDS accesses are ordered)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * hi) * SCR_ROW + col_l] = acc[d][nf][r];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[d][nf][r] = 0.f;
-                    // 2) scratch -> 16-byte vectors
+                    // 2) scratch -> 16-byte vectors; two elements per operation where the ISA has packed f32 forms, ONE bf16 conversion per pair (its halves,
+                    //    re-expanded, are the rounded values the statistics need)
 #pragma unroll
                     for (int ps = 0; ps < 2; ++ps) {
                         const int row = er0 + 16 * ps;
-                        float v[8];
                         const float4* sp = (const float4*)(scr + row * SCR_ROW + cg * 8);
-                        { const float4 t4 = sp[0]; v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w; }
-                        { const float4 t4 = sp[1]; v[4] = t4.x; v[5] = t4.y; v[6] = t4.z; v[7] = t4.w; }
+                        const float4 ta = sp[0], tb = sp[1];
+                        const f32x2_t v2[4] = {{ta.x, ta.y}, {ta.z, ta.w}, {tb.x, tb.y}, {tb.z, tb.w}};
                         uint32_t vx;
                         const bool ok = out_vox(ps, d, vx) && col0 < Cout;
-                        if (EPI != 1) {
-                            if (EPI == 2) {
-                                float rr[8];
-                                unpack16<bf16_t>(ev[f % EVF][ps], rr);
+                        const uint4 e4 = ev[f % EVF][ps];
+                        const uint32_t ew[4] = {e4.x, e4.y, e4.z, e4.w};
+                        uint32_t ow[4];
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) v[q] += rr[q];
+                        for (int q = 0; q < 4; ++q) {
+                            f32x2_t v = v2[q];
+                            f32x2_t xn = {0.f, 0.f};
+                            if (EPI != 0) {
+                                const f32x2_t xx = {__uint_as_float(ew[q] << 16), __uint_as_float(ew[q] & 0xffff0000u)};
+                                if (EPI == 2) v = v + xx;
+                                else {
+                                    const f32x2_t nm = {-emu[2 * q], -emu[2 * q + 1]}, rs = {ers[2 * q], ers[2 * q + 1]};
+                                    xn = (xx + nm) * rs;                 // == (x - mean) * rstd, the expression every data-gradient epilogue evaluates
+                                }
                             }
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) { v[q] = ok ? Elem<bf16_t>::rnd(v[q]) : 0.f; s1[q] += v[q]; s2[q] += v[q] * v[q]; }
-                        } else {
-                            float xx[8];
-                            unpack16<bf16_t>(ev[f % EVF][ps], xx);
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const float xn = (xx[q] - emu[q]) * ers[q];
-                                v[q] = Elem<bf16_t>::rnd((ok && xn > 0.f) ? v[q] : 0.f);
-                                s1[q] += v[q]; s2[q] += v[q] * xn;
-                            }
+                            const float a0 = (ok && (EPI != 1 || xn[0] > 0.f)) ? v[0] : 0.f, a1 = (ok && (EPI != 1 || xn[1] > 0.f)) ? v[1] : 0.f;
+                            const uint32_t w = f2bf2(a0, a1);
+                            ow[q] = w;
+                            const f32x2_t r = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+                            s1[q] = s1[q] + r;
+                            s2[q] = __builtin_elementwise_fma(r, EPI == 1 ? xn : r, s2[q]);
                         }
-                        const uint4 pk = pack16<bf16_t>(v);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pk), ors, ok ? (vx * (uint32_t)ldo + (uint32_t)col0) * 2u : 0xFFFFFFF0u, 0, 0);
+                        const u32x4_t pk = {ow[0], ow[1], ow[2], ow[3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, ors, ok ? (vx * (uint32_t)ldo + (uint32_t)col0) * 2u : 0xFFFFFFF0u, 0, 0);
                     }
                     if (EPI != 0 && f + EVF < NF * TD) epi_load(f + EVF, true);   // the slot just consumed takes the operands of fragment f + EVF
                     // 3) statistics of this fragment: lanes with the same column group hold partial sums over their rows -> reduce, accumulate per wave in LDS
                     if (RSTAT) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) { rs1[q] += s1[q]; rs2[q] += s2[q]; }
+                        for (int q = 0; q < 4; ++q) { rs1[q] = s1[q]; rs2[q] = s2[q]; }
                     } else if (partp) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
+                        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                            for (int o = 4; o < 64; o <<= 1) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
+                            for (int o = 4; o < 64; o <<= 1) {
+                                s1[q][0] += __shfl_xor(s1[q][0], o, 64); s1[q][1] += __shfl_xor(s1[q][1], o, 64);
+                                s2[q][0] += __shfl_xor(s2[q][0], o, 64); s2[q][1] += __shfl_xor(s2[q][1], o, 64);
+                            }
                         }
                         if (lane < 4) {
                             float4* dst = (float4*)(sw + nf * 64 + cg * 16);
 #pragma unroll
-                            for (int q = 0; q < 8; q += 2) {
-                                float4 a = dst[q >> 1];
-                                a.x += s1[q]; a.y += s2[q]; a.z += s1[q + 1]; a.w += s2[q + 1];
-                                dst[q >> 1] = a;
+                            for (int q = 0; q < 4; ++q) {
+                                float4 a = dst[q];
+                                a.x += s1[q][0]; a.y += s2[q][0]; a.z += s1[q][1]; a.w += s2[q][1];
+                                dst[q] = a;
                             }
                         }
                     }
@@ -640,14 +647,17 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
         // statistics: ONE partial row per (block, h pair); this wave's columns
         if (RSTAT && partp) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int o = 4; o < 64; o <<= 1) { rs1[q] += __shfl_xor(rs1[q], o, 64); rs2[q] += __shfl_xor(rs2[q], o, 64); }
+                for (int o = 4; o < 64; o <<= 1) {
+                    rs1[q][0] += __shfl_xor(rs1[q][0], o, 64); rs1[q][1] += __shfl_xor(rs1[q][1], o, 64);
+                    rs2[q][0] += __shfl_xor(rs2[q][0], o, 64); rs2[q][1] += __shfl_xor(rs2[q][1], o, 64);
+                }
             }
             if (lane < 4) {
                 float4* dst = (float4*)(sw + cg * 16);
 #pragma unroll
-                for (int q = 0; q < 8; q += 2) dst[q >> 1] = make_float4(rs1[q], rs2[q], rs1[q + 1], rs2[q + 1]);
+                for (int q = 0; q < 4; ++q) dst[q] = make_float4(rs1[q][0], rs2[q][0], rs1[q][1], rs2[q][1]);
             }
         }
         if (partp && lane < 4) {
