@@ -46,7 +46,9 @@ size_t rsuper_conv3_packed_elems(int dtype, int ka, int kb, int n_cols, int bn);
  * mode 0 (forward):  K = forward input channels split as ka|kb (concat sources, model/dim3/unet_utils.py:71),
  *                    columns [0,na) from wa and [na,na+nb) from wb (conv1 + shortcut fused, conv_layers.py:79,84).
  * mode 1 (data grad): K = forward output channels (ka rows of wa, kb rows of wb), columns = forward Cin = na;
- *                    taps flipped. */
+ *                    taps flipped.  nb = 0: all na columns; nb = (first column << 16) | columns (first column a multiple of 32):
+ *                    only that column range, as a buffer of its own (rsuper_conv3_packed_elems with n_cols = columns) -- the data gradient of a
+ *                    two-source block as one launch per source (round 5: 96 columns = 32 + 64 run 11 % faster as two launches). */
 int rsuper_conv3_pack_weights(int dtype, int mode, const float* wa, const float* wb, int ka, int kb, int na, int nb,
                               int bn, void* packed, void* stream);
 

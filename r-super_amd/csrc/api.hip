@@ -16,6 +16,9 @@ static inline bool dt_ok(int dt) { return dt == RS_F32 || dt == RS_BF16; }
 static inline bool ch_ok(int C, int ld) { return C >= 0 && (C % 8) == 0 && (ld % 8) == 0 && ld >= C; }
 static inline bool bn_ok(int bn) { return bn == 32 || bn == 64 || bn == 96 || bn == 128; }
 static inline int ntiles_for(int n_cols, int bn) { const int per = bn / 32; return ((n_cols + bn - 1) / bn) * per; }
+// GEMM-N columns of a packing request: mode 0 na + nb; mode 1 (data gradient) na, or the sub-range nb = first column << 16 | columns
+static inline int pack_cols(int mode, int na, int nb) { return mode == 1 ? (nb ? (nb & 0xFFFF) : na) : na + nb; }
+static inline bool pack_range_ok(int mode, int na, int nb) { return mode != 1 || nb == 0 || ((nb >> 16) % 32 == 0 && (nb & 0xFFFF) > 0 && (nb >> 16) + (nb & 0xFFFF) <= na); }
 
 // ---- optimiser: split the tensor list into kernel-argument sized chunks
 template <typename F>
@@ -68,7 +71,8 @@ int rsuper_conv3_pack_weights(int dtype, int mode, const float* wa, const float*
     if (!bn_ok(bn)) return RS_ERR_ARG;
     PackParams q;
     q.wa = wa; q.wb = wb; q.mode = mode; q.ka = ka; q.kb = kb; q.na = na; q.nb = nb;
-    q.ntiles = ntiles_for(na + nb, bn);
+    if (!pack_range_ok(mode, na, nb)) return RS_ERR_ARG;
+    q.ntiles = ntiles_for(pack_cols(mode, na, nb), bn);
     return rs_launch_pack(q, dtype, packed, ST(stream));
 }
 
@@ -87,16 +91,17 @@ int rsuper_conv3_pack_weights_batch(int dtype, int n, const int* host_desc, cons
             if ((d[0] != 0 && d[0] != 1) || d[1] <= 0 || d[2] < 0 || d[3] <= 0 || d[4] < 0 || !bn_ok(d[5])) return RS_ERR_ARG;
             PackParams& q = b.q[i];
             q.wa = host_wa[i0 + i]; q.wb = host_wb[i0 + i]; q.mode = d[0]; q.ka = d[1]; q.kb = d[2]; q.na = d[3]; q.nb = d[4];
-            q.ntiles = ntiles_for(d[3] + d[4], d[5]);
+            if (!pack_range_ok(d[0], d[3], d[4])) return RS_ERR_ARG;
+            q.ntiles = ntiles_for(pack_cols(d[0], d[3], d[4]), d[5]);
             if (!q.wa || ((host_out_elems[i0 + i] - base) % KP)) return RS_ERR_ARG;
             b.vec_start[i] = (host_out_elems[i0 + i] - base) / KP;
         }
         // entries are contiguous: the end of the last one closes the table
         const int* dl = host_desc + (size_t)(i0 + b.n - 1) * 6;
-        b.vec_start[b.n] = b.vec_start[b.n - 1] + rs_packed_elems(dtype, dl[1], dl[2], ntiles_for(dl[3] + dl[4], dl[5])) / KP;
+        b.vec_start[b.n] = b.vec_start[b.n - 1] + rs_packed_elems(dtype, dl[1], dl[2], ntiles_for(pack_cols(dl[0], dl[3], dl[4]), dl[5])) / KP;
         for (int i = 0; i + 1 < b.n; ++i) {   // contiguity check
             const int* d = host_desc + (size_t)(i0 + i) * 6;
-            if (b.vec_start[i] + rs_packed_elems(dtype, d[1], d[2], ntiles_for(d[3] + d[4], d[5])) / KP != b.vec_start[i + 1]) return RS_ERR_ARG;
+            if (b.vec_start[i] + rs_packed_elems(dtype, d[1], d[2], ntiles_for(pack_cols(d[0], d[3], d[4]), d[5])) / KP != b.vec_start[i + 1]) return RS_ERR_ARG;
         }
         const int rc = rs_launch_pack_batch(b, dtype, (char*)packed + base * (dtype == RS_F32 ? 4 : 2), ST(stream));
         if (rc) return rc;

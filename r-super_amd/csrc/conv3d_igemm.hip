@@ -845,7 +845,9 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(PackBatch b, T* out) {
         }
     } else {
         const __amdgpu_buffer_rsrc_t rw = isB ? rb : ra;
-        const int len = min(max(na - n0, 0), 32) * 27;
+        // column sub-range (data gradient only): nb = first column << 16 | columns; na stays the row stride (forward Cin)
+        const int noff = nb >> 16, ncols = nb ? (nb & 0xFFFF) : na;
+        const int len = min(max(ncols - n0, 0), 32) * 27;
         for (int it = 0; it < PER; it += UB) {
             uint32_t v[UB];
             int at[UB];
@@ -854,7 +856,7 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(PackBatch b, T* out) {
                 const int e = tid + (it + u) * 256;
                 const int kl = e / (32 * 27), o = e - kl * (32 * 27), k = kbase + kl;
                 at[u] = kl * RS1 + o;
-                v[u] = __builtin_amdgcn_raw_buffer_load_b32(rw, (o < len && k < klim) ? (uint32_t)((k * na + n0) * 27 + o) * 4u : OOB, 0, 0);
+                v[u] = __builtin_amdgcn_raw_buffer_load_b32(rw, (o < len && k < klim) ? (uint32_t)((k * na + noff + n0) * 27 + o) * 4u : OOB, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) sm[at[u]] = __builtin_bit_cast(float, v[u]);

@@ -32,7 +32,7 @@ struct PackParams {
     const float* wa; const float* wb;
     int mode;              // 0 forward, 1 dgrad
     int ka, kb;            // GEMM-K channels per source
-    int na, nb;            // GEMM-N columns from wa / wb (mode 0); na = forward Cin (mode 1)
+    int na, nb;            // GEMM-N columns from wa / wb (mode 0); mode 1: na = forward Cin (= row stride), nb = 0 (all columns) or first column << 16 | columns
     int ntiles;
 };
 

@@ -128,12 +128,17 @@ def pack_weights(dtype, mode, wa, wb, ka, kb, na, nb, bn):
     return out
 
 
+def _spec_cols(sp):
+    """GEMM-N columns of a packing spec (mode, wa, wb, ka, kb, na, nb, bn): mode 1 with nb != 0 is the column sub-range nb = first << 16 | columns."""
+    return (sp[6] & 0xFFFF) if (sp[0] == 1 and sp[6]) else sp[5] + sp[6]
+
+
 def pack_weights_batch(dtype, specs):
     """One launch for many layers.  specs: list of (mode, wa, wb, ka, kb, na, nb, bn).  Returns a list of packed views."""
     import ctypes
     dt = _DT[dtype]
     n = len(specs)
-    sizes = [_L().rsuper_conv3_packed_elems(dt, sp[3], sp[4], sp[5] + sp[6], sp[7]) for sp in specs]
+    sizes = [_L().rsuper_conv3_packed_elems(dt, sp[3], sp[4], _spec_cols(sp), sp[7]) for sp in specs]
     offs = [0]
     for z in sizes:
         offs.append(offs[-1] + z)
@@ -161,7 +166,7 @@ def block_packs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims):
         specs, bns = block_pack_specs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims)
         dt = _DT[dtype]
         n = len(specs)
-        sizes = [_L().rsuper_conv3_packed_elems(dt, sp[3], sp[4], sp[5] + sp[6], sp[7]) for sp in specs]
+        sizes = [_L().rsuper_conv3_packed_elems(dt, sp[3], sp[4], _spec_cols(sp), sp[7]) for sp in specs]
         offs = [0]
         for z in sizes:
             offs.append(offs[-1] + z)
@@ -180,7 +185,7 @@ def block_packs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims):
 
 def rs_variant_epoch():
     """The igemm variant / tile-fill switches change pick_bn's answers: part of the cache key."""
-    return (_L().rsuper_conv3_variant(-1), os.environ.get('RSUPER_BN_FILL', '512'))
+    return (_L().rsuper_conv3_variant(-1), os.environ.get('RSUPER_BN_FILL', '512'), os.environ.get('RSUPER_SPLIT_DGRAD', '1'))
 
 
 def block_pack_specs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims=None):
@@ -194,9 +199,26 @@ def block_pack_specs(w1, w2, ws, Ca, Cb, dtype, tiles_total, with_backward, dims
     bns = [bn1, bn2]
     if with_backward:
         bnd2, bnd1 = pick_bn(Cout, dtype, tiles_total, dims, epi=1), pick_bn(Cin, dtype, tiles_total, dims, epi=1)
-        specs += [(1, w2, None, Cout, 0, Cout, 0, bnd2), (1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bnd1)]
-        bns += [bnd2, bnd1]
+        specs += [(1, w2, None, Cout, 0, Cout, 0, bnd2)]
+        bns += [bnd2]
+        if split_dgrad_sources(Ca, Cb, dtype, tiles_total, bnd1):
+            # one data-gradient launch per forward source (column ranges [0, Ca) and [Ca, Ca + Cb) of the same GEMM): entries 3 and 4
+            bna, bnb = pick_bn(Ca, dtype, tiles_total, dims, epi=1), pick_bn(Cb, dtype, tiles_total, dims, epi=1)
+            specs += [(1, w1, ws, Cout, Cout if has_sc else 0, Cin, Ca, bna), (1, w1, ws, Cout, Cout if has_sc else 0, Cin, (Ca << 16) | Cb, bnb)]
+            bns += [bna, bnb]
+        else:
+            specs += [(1, w1, ws, Cout, Cout if has_sc else 0, Cin, 0, bnd1)]
+            bns += [bnd1]
     return specs, bns
+
+
+def split_dgrad_sources(Ca, Cb, dtype, tiles_total, bn_joint):
+    """The data gradient of a two-source block (up_block: [skip | up-sampled]) as TWO launches, one per source, when the joint column count only fits
+    32-column blocks (96 = 32 + 64 at up4.0: three 32-column blocks re-stage dY three times, 735 us; a 32-column and a 64-column launch 224 + 424 us on the
+    same box, profiles/r05_split_dgrad.txt).  RSUPER_SPLIT_DGRAD=0 keeps the single launch."""
+    if os.environ.get('RSUPER_SPLIT_DGRAD', '1') == '0' or dtype == torch.float32 or not Cb:
+        return False
+    return bn_joint == 32 and Ca % 32 == 0 and Cb % 64 == 0 and tiles_total is not None and tiles_total >= 2048
 
 
 class Src:
@@ -592,7 +614,7 @@ class BasicBlockFn(torch.autograd.Function):
         igemm(0, Src(ys, C=Cout, mr=mr_y1), None, wp2, Cout, bn2, dims, out, res=res, part=part2)
         mr_out = stats_finalize(part2, cnt)
         ctx.save_for_backward(xa, mra, xb, mrb, ys, mr_y1, w1, w2, ws)
-        ctx.packs = packs if (packs is not None and len(packs[0]) == 4) else None
+        ctx.packs = packs if (packs is not None and len(packs[0]) >= 4) else None
         ctx.mark_non_differentiable(mr_out)
         ctx.set_materialize_grads(False)        # no zero-fill kernel for the statistics output's (never used) gradient
         return out, mr_out
@@ -741,11 +763,18 @@ class BasicBlockFn(torch.autograd.Function):
         # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
         sa = Src(xa, mr=mra)
         sb = None if xb is None else Src(xb, mr=mrb)
-        bn, wpd1 = bpk[1][1], bpk[0][1]
         g0 = torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
-        part0 = part_buffer(dt, dims, Cin, bn, dev, epi=1)
-        igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
-        gm0 = stats_finalize(part0, cnt, mode=1, split=0 if xb is None else Ca)
+        if len(bpk[0]) == 3:                  # one launch per forward source (block_pack_specs / split_dgrad_sources)
+            gm0 = []
+            for (c0, cn, src, wp_, bn) in ((0, Ca, sa, bpk[0][1], bpk[1][1]), (Ca, Cb, sb, bpk[0][2], bpk[1][2])):
+                part0 = part_buffer(dt, dims, cn, bn, dev, epi=1)
+                igemm(1, Src(dy1), sdo if has_sc else None, wp_, cn, bn, dims, g0[..., c0:], out_ld=Cin, part=part0, ea=src)
+                gm0.append(stats_finalize(part0, cnt, mode=1))
+        else:
+            bn, wpd1 = bpk[1][1], bpk[0][1]
+            part0 = part_buffer(dt, dims, Cin, bn, dev, epi=1)
+            igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
+            gm0 = stats_finalize(part0, cnt, mode=1, split=0 if xb is None else Ca)
         dw1 = grad_dest(w1)
         dws = grad_dest(ws) if has_sc else None
         with _Side(ov, (xa, mra, xb, mrb, dy1, dout, dw1, dws)):

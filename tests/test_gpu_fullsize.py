@@ -462,3 +462,51 @@ def test_config2_fullsize_f32_logits_and_gradients_match_oracle():
         with open(os.path.join(out, 'config2_f32_grads.txt'), 'w') as f:
             f.write(f'logits: HIP f32 vs fp32 oracle {e_logits:.3e}; fp32 oracle vs float64 {e_o:.3e}\n{table}\n')
     assert not fails, '\n'.join(fails)
+
+
+def test_two_source_block_data_gradient_split_per_source_matches_single_launch():
+    """up4.0 (32 + 64 input channels, 96^3, B = 2): the data gradient of conv1 | shortcut as one launch per forward source (column ranges [0, 32) and
+    [32, 96) of the same GEMM, weights packed per range: ops.split_dgrad_sources) against the single 96-column launch -- same masked gradients (at most one
+    bf16 rounding apart where the summation order of the two tilings differs), same parameter gradients, same InstanceNorm-backward result."""
+    import os
+    from rsuper_amd.hip import ops
+    from rsuper_amd.model.dim3.conv_layers import BasicBlock
+    g = torch.Generator(device=DEV).manual_seed(21)
+    Ca, Cb, Co, s = 32, 64, 32, 96
+    xa = torch.randn((B, s, s, s, Ca), device=DEV, generator=g).bfloat16()
+    xb = torch.randn((B, s, s, s, Cb), device=DEV, generator=g).bfloat16()
+    go = torch.randn((B, s, s, s, Co), device=DEV, generator=g).bfloat16()
+
+    def stats(x):
+        xf = x.float()
+        m = xf.mean(dim=(1, 2, 3))
+        return torch.stack([m, 1.0 / torch.sqrt(xf.var(dim=(1, 2, 3), unbiased=False) + 1e-4)], -1).contiguous()
+    mra, mrb = stats(xa), stats(xb)
+    torch.manual_seed(5)
+    blk = BasicBlock(Ca + Cb, Co).to(DEV)
+    res = {}
+    old = os.environ.get('RSUPER_SPLIT_DGRAD')
+    try:
+        for mode in ('0', '1'):
+            os.environ['RSUPER_SPLIT_DGRAD'] = mode
+            a, b = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+            for p in blk.parameters():
+                p.grad = None
+            out, _ = ops.BasicBlockFn.apply(a, mra, b, mrb, blk.conv1.conv.weight, blk.conv2.conv.weight, blk.shortcut.conv.weight, None, 1)
+            out.backward(go)
+            torch.cuda.synchronize()
+            res[mode] = (a.grad.float(), b.grad.float(), [p.grad.clone() for p in blk.parameters()])
+    finally:
+        if old is None:
+            os.environ.pop('RSUPER_SPLIT_DGRAD', None)
+        else:
+            os.environ['RSUPER_SPLIT_DGRAD'] = old
+    assert ops.split_dgrad_sources(Ca, Cb, torch.bfloat16, B * ops._L().rsuper_conv3_tiles(s, s, s), 32)
+    for k in (0, 1):
+        x0, x1 = res['0'][k], res['1'][k]
+        scale = x0.abs().max().item()
+        assert bool(torch.isfinite(x1).all())
+        assert ((x0 - x1).abs().max().item() <= 2.0 ** -6 * scale), (k, (x0 - x1).abs().max().item(), scale)
+        assert (x0 - x1).norm().item() <= 2e-3 * x0.norm().item()
+    for p0, p1 in zip(res['0'][2], res['1'][2]):
+        assert (p0 - p1).abs().max().item() <= 1e-3 * p0.abs().max().item()

@@ -18,6 +18,8 @@ LAYERS = [('inc 32->32', 96, 32, 0, 32, False), ('up4.0 96->32+sc', 96, 32, 64, 
           ('64->64', 48, 64, 0, 64, False), ('up3.0 192->64+sc', 48, 64, 128, 64, True), ('128->128', 24, 128, 0, 128, False),
           ('up2.0 384->128+sc', 24, 128, 256, 128, True), ('256->256', 12, 256, 0, 256, False), ('320->320', 6, 320, 0, 320, False)]
 
+if os.environ.get('BC_EXTRA'):                           # extra rows: the two column ranges of up4.0's data gradient as launches of their own (K = 64 -> 64 / 32 columns)
+    LAYERS = [('up4.0 dgrad cols 32..95', 96, 64, 0, 32, True), ('up4.0 dgrad cols 0..31', 96, 32, 0, 32, True)]
 if os.environ.get('BC_ONLY_S2'):                       # only the strided rows below
     LAYERS = []
 if os.environ.get('BC_ONLY'):                          # only the stride-1 layers whose name contains one of the comma-separated substrings
