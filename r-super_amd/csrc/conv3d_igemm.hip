@@ -405,7 +405,6 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
     if (producer) {
         // ------------------------------------------------------------------ producer waves
         const int ptid = tid - 256;
-        if (PC_PRIO == 2) __builtin_amdgcn_s_setprio(2);                // ... or the other way round
         const int slot = ptid & 3;
         const uint32_t nvox_total = (uint32_t)(p.N * p.D * p.H * p.W);
         int vi[NVEC];
@@ -509,10 +508,6 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
         }
     } else {
         // ------------------------------------------------------------------ consumer waves
-#ifndef PC_PRIO
-#define PC_PRIO 0
-#endif
-        if (PC_PRIO == 1) __builtin_amdgcn_s_setprio(2);                // the matrix wave outranks the producer wave of its SIMD
         const int wm = wave / WN, wn = wave % WN;
         int hs, wl;
         row_to_hw(lane & 31, hs, wl);
