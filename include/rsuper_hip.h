@@ -255,6 +255,14 @@ int rsuper_plane_partials_fwd(const float* x, size_t xstride, const uint8_t* t, 
                               double* sums, int flags, int planes, size_t V, void* stream);
 int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
                               const float* g, float* dx, int flags, int planes, size_t V, void* stream);
+/* The same two passes reading the target planes in the dataset's bit-packed form (`np.packbits(label, axis=0)`,
+ * dataset_abdomenatlas_UFO.py:955,970,975 -- class c of sample b is bit 7 - (c & 7) of byte plane b * tP + (c >> 3); tpk = [planes / tC][tP][V], replaces t)
+ * and skipping the planes of the dilated unknown map that cannot hold a 1 (kflags[planes] = rsuper_plane_any of the UNdilated map; only with flags bit 1):
+ * 1/8 of the label bytes and, for the usual batch, none of the unknown-map bytes cross HBM. */
+int rsuper_plane_partials_fwd2(const float* x, size_t xstride, const uint8_t* t, const uint8_t* tpk, int tP, int tC, const uint8_t* k, const uint8_t* kflags,
+                               const float* w1, const uint8_t* w2, double* sums, int flags, int planes, size_t V, void* stream);
+int rsuper_plane_partials_bwd2(const float* x, size_t xstride, const uint8_t* t, const uint8_t* tpk, int tP, int tC, const uint8_t* k, const uint8_t* kflags,
+                               const float* w1, const uint8_t* w2, const float* g, float* dx, int flags, int planes, size_t V, void* stream);
 /* Segmentation term from the sums of the (B*C) label planes: loss[0] = scale * ( sum(S*cw)/(B*C*V) + DiceLossMultiClass ),
  * :945-956 with the adaptive-Tversky Dice of :541-607 (alpha_c = clamp(sum_b FP / (sum_b FP + sum_b FN + 1e-5), 0.2, 0.8),
  * dice = TP / (TP + alpha FP + (1-alpha) FN + 1e-5), mean over (b, c) of (1 - dice) * cw).  sums f32 [B*C][6] as produced

@@ -504,13 +504,27 @@ int rsuper_head_bwd(int dtype, const void* x, int ldx, const float* dlogits, con
 int rsuper_plane_partials_fwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
                               double* sums, int flags, int planes, size_t V, void* stream) {
     if (!x || !sums || planes <= 0 || V == 0 || (flags & ~2)) return RS_ERR_ARG;
-    PlaneParams p = {x, xstride, t, k, w1, w2, sums, nullptr, nullptr, 0, V, k ? (flags >> 1) & 1 : 0};
+    PlaneParams p = {x, xstride, t, k, w1, w2, sums, nullptr, nullptr, 0, V, k ? (flags >> 1) & 1 : 0, nullptr, 0, 0, nullptr};
+    return rs_launch_plane_partials(p, planes, 0, ST(stream));
+}
+int rsuper_plane_partials_fwd2(const float* x, size_t xstride, const uint8_t* t, const uint8_t* tpk, int tP, int tC, const uint8_t* k, const uint8_t* kflags,
+                               const float* w1, const uint8_t* w2, double* sums, int flags, int planes, size_t V, void* stream) {
+    if (!x || !sums || planes <= 0 || V == 0 || (flags & ~2) || (t && tpk)) return RS_ERR_ARG;
+    if (tpk && (tC <= 0 || tP * 8 < tC || planes % tC)) return RS_ERR_ARG;
+    PlaneParams p = {x, xstride, t, k, w1, w2, sums, nullptr, nullptr, 0, V, k ? (flags >> 1) & 1 : 0, tpk, tP, tC, kflags};
     return rs_launch_plane_partials(p, planes, 0, ST(stream));
 }
 int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
                               const float* g, float* dx, int flags, int planes, size_t V, void* stream) {
     if (!x || !g || !dx || planes <= 0 || V == 0 || (flags & ~3)) return RS_ERR_ARG;
-    PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, flags & 1, V, k ? (flags >> 1) & 1 : 0};
+    PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, flags & 1, V, k ? (flags >> 1) & 1 : 0, nullptr, 0, 0, nullptr};
+    return rs_launch_plane_partials(p, planes, 1, ST(stream));
+}
+int rsuper_plane_partials_bwd2(const float* x, size_t xstride, const uint8_t* t, const uint8_t* tpk, int tP, int tC, const uint8_t* k, const uint8_t* kflags,
+                               const float* w1, const uint8_t* w2, const float* g, float* dx, int flags, int planes, size_t V, void* stream) {
+    if (!x || !g || !dx || planes <= 0 || V == 0 || (flags & ~3) || (t && tpk)) return RS_ERR_ARG;
+    if (tpk && (tC <= 0 || tP * 8 < tC || planes % tC)) return RS_ERR_ARG;
+    PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, flags & 1, V, k ? (flags >> 1) & 1 : 0, tpk, tP, tC, kflags};
     return rs_launch_plane_partials(p, planes, 1, ST(stream));
 }
 int rsuper_cnorm_rows(long vox) { return rs_cnorm_rows(vox); }

@@ -32,8 +32,14 @@ __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) 
     const int plane = blockIdx.y;
     const size_t base = (size_t)plane * p.V;
     const float* x = p.x + (size_t)plane * p.xstride;
-    const uint8_t* t = p.t ? p.t + base : nullptr;
-    const uint8_t* k = p.k ? p.k + base : nullptr;
+    // target: one byte per voxel (p.t) or the dataset's bit-packed form (p.tpk: np.packbits along the class axis, dataset_abdomenatlas_UFO.py:955 --
+    // class c of sample b is bit 7 - (c & 7) of byte plane b * tP + (c >> 3)); either way "byte & tm8 != 0"
+    const uint8_t* t = p.tpk ? p.tpk + ((size_t)(plane / p.tC) * p.tP + (size_t)((plane % p.tC) >> 3)) * p.V : (p.t ? p.t + base : nullptr);
+    const uint32_t tm8 = p.tpk ? (0x80u >> ((plane % p.tC) & 7)) : 0xFFu;
+    // unknown-voxel plane without a single unknown voxel (kflags from rsuper_plane_any of the UNdilated map): weight 1 everywhere, nothing to read
+    const bool kskip = p.kinv && p.kflags && !p.kflags[plane];
+    const uint8_t* k = (p.k && !kskip) ? p.k + base : nullptr;
+    const int kinv = k ? p.kinv : 0;
     const float* w1 = p.w1 ? p.w1 + base : nullptr;
     const uint8_t* w2 = p.w2 ? p.w2 + base : nullptr;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -43,10 +49,10 @@ __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) 
     size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     // the 16-byte loads need 16-byte aligned bases too (a mask handed over as a view at an odd storage offset keeps the 4-voxel path)
     const bool wide_ok = vec_ok && (p.V & 15) == 0 && !w1 &&
-                         ((((uintptr_t)p.x | (uintptr_t)p.t | (uintptr_t)p.k | (uintptr_t)p.w2) & 15) == 0);
+                         ((((uintptr_t)p.x | (uintptr_t)p.t | (uintptr_t)p.tpk | (uintptr_t)p.k | (uintptr_t)p.w2) & 15) == 0);
     if (wide_ok) {
         auto term = [&](float xv, uint32_t tb, uint32_t kb, uint32_t w2b) {
-            const float tt = tb ? 1.f : 0.f, kk = ((kb != 0u) != (p.kinv != 0)) ? 1.f : 0.f;
+            const float tt = (tb & tm8) ? 1.f : 0.f, kk = ((kb != 0u) != (kinv != 0)) ? 1.f : 0.f;
             float sg, b;
             sig_bce(xv, tt, sg, b);
             b *= kk;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) 
                 if (w2) w2v[j] = w2[i + j];
                 if (w1) w1v[j] = w1[i + j];
             }
-            const float tt = tv[j] ? 1.f : 0.f, kk = ((kv[j] != 0) != (p.kinv != 0)) ? 1.f : 0.f;
+            const float tt = (tv[j] & tm8) ? 1.f : 0.f, kk = ((kv[j] != 0) != (kinv != 0)) ? 1.f : 0.f;
             float sg, b;
             sig_bce(xv[j], tt, sg, b);
             b *= kk;
@@ -121,12 +127,14 @@ __global__ __launch_bounds__(256) void plane_partials_bwd_kernel(PlaneParams p) 
     const size_t base = (size_t)plane * p.V;
     const float* x = p.x + (size_t)plane * p.xstride;
     float* dx = p.dx + (size_t)plane * p.xstride;
-    const uint8_t* t = p.t ? p.t + base : nullptr;
-    const uint8_t* k = p.k ? p.k + base : nullptr;
+    const uint8_t* t = p.tpk ? p.tpk + ((size_t)(plane / p.tC) * p.tP + (size_t)((plane % p.tC) >> 3)) * p.V : (p.t ? p.t + base : nullptr);
+    const uint32_t tm8 = p.tpk ? (0x80u >> ((plane % p.tC) & 7)) : 0xFFu;
+    const bool kskip = p.kinv && p.kflags && !p.kflags[plane];
+    const uint8_t* k = (p.k && !kskip) ? p.k + base : nullptr;
     const float* w1 = p.w1 ? p.w1 + base : nullptr;
     const uint8_t* w2 = p.w2 ? p.w2 + base : nullptr;
     const float gS = p.g[plane * 6], gA = p.g[plane * 6 + 1], gB = p.g[plane * 6 + 2], gF1 = p.g[plane * 6 + 4], gF2 = p.g[plane * 6 + 5];
-    const bool kinv = p.kinv != 0;
+    const bool kinv = k && p.kinv != 0;
     auto one = [&](size_t i, float xv, bool tb, bool kb, float w1v, bool w2b, float old) {
         const float tt = tb ? 1.f : 0.f;
         const float e = __expf(-fabsf(xv));
@@ -147,16 +155,16 @@ __global__ __launch_bounds__(256) void plane_partials_bwd_kernel(PlaneParams p) 
             if (w1) w1q = *(const float4*)(w1 + i);
             if (p.accumulate) oq = *(const float4*)(dx + i);
             float4 o;
-            o.x = one(i, xq.x, tq.x, k ? ((kq.x != 0) != kinv) : true, w1q.x, w2q.x, oq.x);
-            o.y = one(i, xq.y, tq.y, k ? ((kq.y != 0) != kinv) : true, w1q.y, w2q.y, oq.y);
-            o.z = one(i, xq.z, tq.z, k ? ((kq.z != 0) != kinv) : true, w1q.z, w2q.z, oq.z);
-            o.w = one(i, xq.w, tq.w, k ? ((kq.w != 0) != kinv) : true, w1q.w, w2q.w, oq.w);
+            o.x = one(i, xq.x, (tq.x & tm8) != 0, k ? ((kq.x != 0) != kinv) : true, w1q.x, w2q.x, oq.x);
+            o.y = one(i, xq.y, (tq.y & tm8) != 0, k ? ((kq.y != 0) != kinv) : true, w1q.y, w2q.y, oq.y);
+            o.z = one(i, xq.z, (tq.z & tm8) != 0, k ? ((kq.z != 0) != kinv) : true, w1q.z, w2q.z, oq.z);
+            o.w = one(i, xq.w, (tq.w & tm8) != 0, k ? ((kq.w != 0) != kinv) : true, w1q.w, w2q.w, oq.w);
             *(float4*)(dx + i) = o;
         }
         return;
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)p.V; i += (size_t)gridDim.x * 256)
-        dx[i] = one(i, x[i], t && t[i], k ? ((k[i] != 0) != kinv) : true, w1 ? w1[i] : 0.f, w2 && w2[i], p.accumulate ? dx[i] : 0.f);
+        dx[i] = one(i, x[i], t && (t[i] & tm8), k ? ((k[i] != 0) != kinv) : true, w1 ? w1[i] : 0.f, w2 && w2[i], p.accumulate ? dx[i] : 0.f);
 }
 
 // One block.  Thread c owns class c: column sums over the batch give the adaptive Tversky alpha (clamped to [0.2, 0.8];

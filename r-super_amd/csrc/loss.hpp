@@ -16,6 +16,8 @@ struct PlaneParams {
     int accumulate;                   // backward: dx += instead of dx =
     size_t V;
     int kinv;
+    const uint8_t* tpk; int tP, tC;   // bit-packed target [samples][tP][V] for planes = samples x tC classes (replaces t), or nullptr
+    const uint8_t* kflags;            // with kinv: [planes] any-flags of the UNdilated unknown map; 0 = the plane of k is all zero and is not read (nullptr: read every plane)
 };
 
 // Segmentation loss from the per-plane sums (losses_foundation.py:945-956 + DiceLossMultiClass :541-607) and its Jacobian.

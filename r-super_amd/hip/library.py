@@ -11,7 +11,7 @@ registered as custom HIP ops behind the repo's existing model/ and training/ int
     torch.ops.rsuper.depthwise_conv3(x, w) -> y                torch.ops.rsuper.squeeze_excite(x, w1, b1, w2, b2) -> y
     torch.ops.rsuper.bidir_attention(fqv, mqv, heads, scale) -> (f_out, m_out)      torch.ops.rsuper.cl_planar(x, K) -> planes
 loss ops (training/losses_foundation.py; reference call sites rsuper_train/training/losses_foundation.py:945-956, 541-607, 22-99, 1387-1532):
-    torch.ops.rsuper.plane_partials(logits, x_off, xstride, planes, kinv, t, k, w1, w2) -> (sums of term 0, sums of the other terms)
+    torch.ops.rsuper.plane_partials(logits, x_off, xstride, planes, kinv, t, k, w1, w2, kflags, tpk, tpk_classes) -> (sums of term 0, sums of the other terms)
     torch.ops.rsuper.seg_from_sums(sums, cw, B, C, V, scale) -> loss
     torch.ops.rsuper.dilate_volume(vol, kernel_size) -> vol      torch.ops.rsuper.ball_search(x, diameter, sigma) -> key   (no derivative: masks / indices)
 
@@ -125,15 +125,18 @@ def install_loss_ops(lf):
     if getattr(lf, '_LIBRARY_INSTALLED', False):
         return
 
-    def pp_to_fn(logits, x_off, xstride, planes, kinv, t, k, w1, w2):
-        return logits, [lf._Term(x_off[i], xstride[i], planes[i], t[i], k[i], w1[i], w2[i], kinv[i]) for i in range(len(planes))]
+    def pp_to_fn(logits, x_off, xstride, planes, kinv, t, k, w1, w2, kflags, tpk, tpk_classes):
+        from ..training.dataset.packed import PackedBits
+        return logits, [lf._Term(x_off[i], xstride[i], planes[i], t[i], k[i], w1[i], w2[i], kinv[i], kflags[i],
+                                 None if tpk[i] is None else PackedBits(tpk[i], tpk_classes[i])) for i in range(len(planes))]
 
     def pp_adapt(logits, terms):
         return (logits, [tm.x_off for tm in terms], [tm.xstride for tm in terms], [tm.planes for tm in terms], [tm.kinv for tm in terms],
-                [tm.t for tm in terms], [tm.k for tm in terms], [tm.w1 for tm in terms], [tm.w2 for tm in terms])
+                [tm.t for tm in terms], [tm.k for tm in terms], [tm.w1 for tm in terms], [tm.w2 for tm in terms], [tm.kflags for tm in terms],
+                [None if tm.tpk is None else tm.tpk.packed for tm in terms], [0 if tm.tpk is None else tm.tpk.C for tm in terms])
 
     pp = _register('plane_partials', '(Tensor logits, int[] x_off, int[] xstride, int[] planes, bool[] kinv, Tensor?[] t, Tensor?[] k, '
-                   'Tensor?[] w1, Tensor?[] w2) -> (Tensor, Tensor)', lf._PartialsFn, pp_to_fn)
+                   'Tensor?[] w1, Tensor?[] w2, Tensor?[] kflags, Tensor?[] tpk, int[] tpk_classes) -> (Tensor, Tensor)', lf._PartialsFn, pp_to_fn)
     sf = _register('seg_from_sums', '(Tensor sums, Tensor? cw, int B, int C, int V, float scale) -> Tensor', lf._SegFromSums)
     dv = _register_plain('dilate_volume', '(Tensor vol, int kernel_size) -> Tensor', _ops.dilate_volume)
     bs = _register_plain('ball_search', '(Tensor x, int diameter, float sigma) -> Tensor', _ops.ball_search)

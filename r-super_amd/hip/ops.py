@@ -1270,6 +1270,11 @@ def ball_search(x, diameter, sigma):
 
 def dilate_volume(vol_u8, kernel_size):
     """dilate_volume (training/losses_foundation.py:22-46) on a uint8 0/1 tensor (..., D, H, W)."""
+    return dilate_volume_flags(vol_u8, kernel_size)[0]
+
+
+def dilate_volume_flags(vol_u8, kernel_size):
+    """dilate_volume plus the per-volume any-flags of the INPUT (uint8, 0 = that volume and hence its dilation is all zero; None when not computed)."""
     v = vol_u8.contiguous()
     assert v.dtype == torch.uint8 and v.dim() >= 3
     D, H, W = v.shape[-3:]
@@ -1285,7 +1290,7 @@ def dilate_volume(vol_u8, kernel_size):
         _l.check(_L().rsuper_plane_any(_ptr(v), nvol, D * H * W, _ptr(flags), _stream()), 'plane_any')
     _l.check(_L().rsuper_dilate_volume_sparse(_ptr(v), _ptr(out), _ptr(tmp), _ptr(flags), nvol, D, H, W, kernel_size, _stream()),
              'dilate_volume')
-    return out
+    return out, flags
 
 
 # ------------------------------------------------------------------------------------------------ pointwise GEMM

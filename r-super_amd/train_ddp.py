@@ -289,7 +289,8 @@ def _train_epoch_loop(trainLoader, net, ema_net, optimizer, epoch, writer, args,
         if 'weights' in inputs:
             batch['weights'] = inputs['weights'].float()
         if packed:      # bit-packed label volumes cross PCIe as stored and are inflated on the device (dataset/packed.py)
-            batch = ingest_packed_batch(batch, len(classes), dev)
+            # segmentation-only supervision: the label never leaves its packed form (the loss kernels read the bits)
+            batch = ingest_packed_batch(batch, len(classes), dev, keep_label_packed=float(getattr(args, 'report_volume_loss_basic', 0.0)) == 0)
         else:
             batch = {k: v.to(dev, non_blocking=True) for k, v in batch.items()}
         img = batch['image']

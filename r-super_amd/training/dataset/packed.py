@@ -37,14 +37,44 @@ def unpack_bits_device(packed, num_classes, stream=None):
     return out
 
 
-def ingest_packed_batch(sample, num_classes, device='cuda'):
+class PackedBits:
+    """A label volume kept in the dataset's bit-packed form on the device: `packed` (B, P, D, H, W) uint8 as `np.packbits(axis = class)` wrote it, `C` classes.
+    `calculate_loss` reads it directly in the segmentation term (csrc/loss.hip: the loss kernels extract bit 7 - (c & 7) of byte plane c >> 3; SURVEY 8f-2
+    "loss kernels should read the packed u8 directly"); everything else gets the uint8 0/1 form from `unpack()` (cached)."""
+
+    def __init__(self, packed, num_classes):
+        assert packed.dim() == 5 and packed.dtype == torch.uint8 and packed.is_cuda
+        P = packed.shape[1]
+        assert P * 8 >= num_classes and P * 8 < num_classes + 10, 'packed channel count does not match num_classes (:1032-1033)'
+        self.packed, self.C = packed.contiguous(), int(num_classes)
+        self._u8 = None
+
+    @property
+    def shape(self):
+        return torch.Size((self.packed.shape[0], self.C) + tuple(self.packed.shape[2:]))
+
+    @property
+    def device(self):
+        return self.packed.device
+
+    def unpack(self):
+        if self._u8 is None:
+            self._u8 = unpack_bits_device(self.packed, self.C)
+        return self._u8
+
+
+def ingest_packed_batch(sample, num_classes, device='cuda', keep_label_packed=False):
     """sample: dict with 'image' (B,1,D,H,W) f32 and bit-packed uint8 'label', 'unk_channels', 'mask' (B,P,D,H,W), plus
     'volumes', 'diameters' [, 'weights'] as the dataset yields them.  Returns the device batch `train_step` takes, with the
-    three volumes as uint8 0/1 (B,C,D,H,W)."""
+    three volumes as uint8 0/1 (B,C,D,H,W).  keep_label_packed (segmentation-only supervision): 'label' stays a `PackedBits` -- the loss kernels read the
+    bits (1/8 of the label bytes cross HBM, no inflated copy is written)."""
     out = {}
     for k, v in sample.items():
         t = torch.as_tensor(v)
-        if k in ('label', 'unk_channels', 'mask'):
+        if k == 'label' and keep_label_packed:
+            p = t.to(device, non_blocking=True)
+            out[k] = PackedBits(p.unsqueeze(0) if p.dim() == 4 else p, num_classes)
+        elif k in ('label', 'unk_channels', 'mask'):
             out[k] = unpack_bits_device(t.to(device, non_blocking=True), num_classes)
         else:
             out[k] = t.to(device, non_blocking=True)

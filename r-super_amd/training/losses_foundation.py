@@ -100,11 +100,20 @@ def dice_based_volume_loss(x, y, tolerance=0.1, E=500, cross_entropy=False):
 # ------------------------------------------------------------------------------------------------ fused partial sums
 class _Term:
     """One family of planes of the logits tensor: plane p lives at element offset x_off + p * xstride."""
-    __slots__ = ('x_off', 'xstride', 'planes', 't', 'k', 'w1', 'w2', 'kinv')
+    __slots__ = ('x_off', 'xstride', 'planes', 't', 'k', 'w1', 'w2', 'kinv', 'kflags', 'tpk')
 
-    def __init__(self, x_off, xstride, planes, t=None, k=None, w1=None, w2=None, kinv=False):
+    def __init__(self, x_off, xstride, planes, t=None, k=None, w1=None, w2=None, kinv=False, kflags=None, tpk=None):
         self.x_off, self.xstride, self.planes, self.t, self.k, self.w1, self.w2 = x_off, xstride, planes, t, k, w1, w2
         self.kinv = bool(kinv)       # k is the dilated UNKNOWN mask: voxel weight = 1 - k (no `1 - dilate(unk)` tensor)
+        self.kflags = kflags         # with kinv: uint8 [planes], 0 = the plane of k is all zero (not read)
+        self.tpk = tpk               # dataset.packed.PackedBits: the target in bit-packed form (replaces t)
+
+    def targs(self):
+        """(t, tpk, tP, tC, k, kflags) pointers / sizes for rsuper_plane_partials_fwd2 / _bwd2."""
+        kf = _ptr(self.kflags) if (self.kinv and self.kflags is not None) else None
+        if self.tpk is not None:
+            return (None, _ptr(self.tpk.packed), int(self.tpk.packed.shape[1]), int(self.tpk.C), _ptr(self.k), kf)
+        return (_ptr(self.t), None, 0, 0, _ptr(self.k), kf)
 
 
 class _PartialsFn(torch.autograd.Function):
@@ -121,8 +130,8 @@ class _PartialsFn(torch.autograd.Function):
         acc = torch.zeros((total, 6), device=logits.device, dtype=torch.float64)
         row = 0
         for tm in terms:
-            _l.check(_L().rsuper_plane_partials_fwd(_ptr(logits, tm.x_off), tm.xstride, _ptr(tm.t), _ptr(tm.k), _ptr(tm.w1), _ptr(tm.w2),
-                                                    _ptr(acc, row * 6), 2 if tm.kinv else 0, tm.planes, V, _stream()), 'plane_partials_fwd')
+            _l.check(_L().rsuper_plane_partials_fwd2(_ptr(logits, tm.x_off), tm.xstride, *tm.targs(), _ptr(tm.w1), _ptr(tm.w2),
+                                                     _ptr(acc, row * 6), 2 if tm.kinv else 0, tm.planes, V, _stream()), 'plane_partials_fwd')
             row += tm.planes
         out = acc.to(torch.float32)
         ctx.terms = terms
@@ -147,9 +156,9 @@ class _PartialsFn(torch.autograd.Function):
                     dl.zero_()
                 continue
             g = g.contiguous().float()
-            _l.check(_L().rsuper_plane_partials_bwd(_ptr(logits, tm.x_off), tm.xstride, _ptr(tm.t), _ptr(tm.k), _ptr(tm.w1), _ptr(tm.w2),
-                                                    _ptr(g), _ptr(dl, tm.x_off), (0 if i == 0 else 1) | (2 if tm.kinv else 0), tm.planes, V,
-                                                    _stream()),
+            _l.check(_L().rsuper_plane_partials_bwd2(_ptr(logits, tm.x_off), tm.xstride, *tm.targs(), _ptr(tm.w1), _ptr(tm.w2),
+                                                     _ptr(g), _ptr(dl, tm.x_off), (0 if i == 0 else 1) | (2 if tm.kinv else 0), tm.planes, V,
+                                                     _stream()),
                       'plane_partials_bwd')
         return dl, None
 
@@ -644,7 +653,15 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         raise NotImplementedError('model_genesis / clip_only / classification_branch / multi_ch_tumor are baselines outside '
                                   'the accelerated R-Super path (SURVEY.md section 2.1)')
     _l.require_device()
-    if any(len(v) > 1 for v in lesion_channel_lists(classes).values()):
+    from .dataset.packed import PackedBits
+    merged = any(len(v) > 1 for v in lesion_channel_lists(classes).values())
+    label_pk = None
+    if isinstance(label, PackedBits):      # bit-packed label: read as such by the segmentation term; report supervision needs the uint8 planes
+        if float(args.report_volume_loss_basic) > 0 or merged:
+            label = label.unpack()
+        else:
+            label_pk = label
+    if merged:
         return _calculate_loss_merged(model_output, label, unk_voxels, args, matcher, chosen_segment_mask, tumor_volumes_report,
                                       tumor_diameters, classes, input_tensor, class_weights)
     result = model_output['segmentation']
@@ -657,9 +674,10 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         label_u8, unk_u8, mask_u8 = pre['u8'][3:]                        # the tensors prepare_report_supervision keyed its results on
     else:
         pre = None
-        label_u8 = _u8(label)
-        unk_u8 = _u8(unk_voxels) if unk_voxels is not None else torch.zeros_like(label_u8)
-        mask_u8 = _u8(chosen_segment_mask) if chosen_segment_mask is not None else torch.zeros_like(label_u8)
+        label_u8 = _u8(label) if label_pk is None else None
+        zeros = lambda: torch.zeros(tuple(label.shape), device=label.device, dtype=torch.uint8)
+        unk_u8 = _u8(unk_voxels) if unk_voxels is not None else zeros()
+        mask_u8 = _u8(chosen_segment_mask) if chosen_segment_mask is not None else zeros()
     D, H, W = label.shape[2:]
     V = D * H * W
 
@@ -683,7 +701,8 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         cw = class_weights.to(label.device).float()
         assert cw.shape == (B, C), f'Class weights should be (B, C), got {tuple(cw.shape)}'
 
-    unk5 = ops.dilate_volume(unk_u8, 5) if unk_voxels is not None else None      # :899 / get_known_voxels :150; known = 1 - unk5
+    # :899 / get_known_voxels :150; known = 1 - unk5.  unk_any[b * C + c] = 0: that plane of the map has no unknown voxel at all (nor has its dilation)
+    unk5, unk_any = ops.dilate_volume_flags(unk_u8, 5) if unk_voxels is not None else (None, None)
     groups = lesion_groups(classes)
     chs = list(groups.values())
     L = len(chs)
@@ -702,7 +721,7 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
             if deep:
                 use_ball = use_ball and not (j != 0 and 'last' in args.loss)        # :924
             use_vol = (not use_ball) or ('both' in args.loss)
-        terms = [_Term(0, V, B * C, t=label_u8, k=unk5, kinv=True)]
+        terms = [_Term(0, V, B * C, t=label_u8, k=unk5, kinv=True, kflags=unk_any, tpk=label_pk)]
         if use_vol and L > 0:
             if mseg31 is None:
                 mseg31 = pre['mseg31'] if pre is not None and 'mseg31' in pre else \

@@ -179,6 +179,23 @@ def test_packed_batch_gives_same_loss():
                                   'volumes': bt['volumes'], 'diameters': bt['diameters']}, len(classes), DEV)
     a, b = run(plain), run(packed)
     assert a.keys() == b.keys() and all(a[k] == b[k] for k in a), (a, b)
+    # segmentation-only supervision: the label stays bit-packed and the loss kernels read the bits (csrc/loss.hip rsuper_plane_partials_fwd2 / _bwd2);
+    # planes of the unknown map without a set voxel are skipped by flag.  Loss values AND the gradient of the logits must be bit-identical to the uint8 path.
+    from rsuper_amd.training.dataset import PackedBits
+    la0 = argparse.Namespace(**{**vars(la), 'report_volume_loss_basic': 0.0})
+    kept = ingest_packed_batch({'label': pack_bits(bt['label']), 'unk_channels': pack_bits(bt['unk_channels']), 'mask': pack_bits(bt['mask']),
+                                'volumes': bt['volumes'], 'diameters': bt['diameters']}, len(classes), DEV, keep_label_packed=True)
+    assert isinstance(kept['label'], PackedBits) and kept['label']._u8 is None
+
+    def run_g(batch):
+        x = logits.clone().requires_grad_(True)
+        r = lf.calculate_loss({'segmentation': x}, batch['label'], batch['unk_channels'], la0, None, batch['mask'], batch['volumes'], batch['diameters'], classes)
+        r['overall'].backward()
+        return {k: float(v) for k, v in r.items()}, x.grad
+    (ra, ga), (rb, gb) = run_g(plain), run_g(kept)
+    assert ra == rb, (ra, rb)
+    assert torch.equal(ga, gb)
+    assert kept['label']._u8 is None, 'the packed label must not have been inflated on the segmentation-only path'
 
 
 @pytest.mark.gpu
