@@ -272,6 +272,116 @@ __global__ __launch_bounds__(256) void ball_gather_argmax_kernel(const float* __
     }
 }
 
+// The same gather with a wave per (z, y) row (W <= 64 * NX; lane l owns x = l, l + 64, ...): the walk over the occupancy bits, the half-width table
+// and the row addresses is identical for every x of a row, so it runs once per row on the scalar unit (s_load of the bit words, s_ff1 over the set
+// bits) and the lanes only issue the coalesced F_L loads of non-empty rows; a row whose whole (z, y) neighbourhood is empty costs 2R+1 scalar
+// iterations and no vector memory traffic.  Per-voxel summation order is that of the kernel above (dz outer, rows ascending): same bits.
+template <int NX>
+__global__ __launch_bounds__(256) void ball_gather_rows_kernel(const float* __restrict__ ws, const uint32_t* __restrict__ bits, int HW, int D, int H, int W,
+                                                               int d_odd, float inv2s2, unsigned long long* best, float* conv_out) {
+    __shared__ float g1[64];
+    __shared__ signed char Lt[64 * 64];
+    __shared__ int ymax[64];                                     // per |dz|: the largest |dy| with a row inside the ball (L >= 0 is monotone in |dy|)
+    __shared__ unsigned long long wbest[4];
+    const int R = d_odd >> 1;
+    for (int i = threadIdx.x; i < 64; i += 256) g1[i] = i <= R ? expf(-(float)(i * i) * inv2s2) : 0.f;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) Lt[i] = (i >> 6) <= R && (i & 63) <= R ? (signed char)row_halfwidth(d_odd, i >> 6, i & 63) : (signed char)-1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64; i += 256) {
+        int m = -1;
+        for (int a = 0; a <= R && i <= R; ++a) m = Lt[i * 64 + a] >= 0 ? a : m;
+        ymax[i] = m;
+    }
+    __syncthreads();
+    const long V = (long)D * H * W;
+    const int lane = threadIdx.x & 63, nrows = D * H;
+    const float gv = g1[lane];                                   // lane a holds g(a): the per-row factor comes from v_readlane, not from memory
+    const int ymv = ymax[lane];
+    // the workspace as a buffer resource (the host checks (R + 1) * V * 4 < 2^31): a row's load is ONE instruction with the row's byte offset in an
+    // SGPR -- the scalar unit is one per CU, and ~45 scalar instructions per gathered row (64-bit address products) were this kernel's whole cost
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, (int)((long)(R + 1) * V * 4), 0x00020000);
+    const uint32_t W4 = (uint32_t)W * 4u, HW4 = (uint32_t)H * W4, V4 = (uint32_t)V * 4u;
+    unsigned long long mine = 0ull;
+    for (int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); row < nrows; row += gridDim.x * 4) {
+        const int zz = row / H, yy = row - zz * H;
+        float acc[NX];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) acc[q] = 0.f;
+        for (int dz = -R; dz <= R; ++dz) {
+            const int z = zz + dz;
+            if (z < 0 || z >= D) continue;
+            const int az = dz < 0 ? -dz : dz;
+            const int rng = __builtin_amdgcn_readlane(ymv, az);
+            if (rng < 0) continue;
+            const int ylo = max(yy - rng, 0), yhi = min(yy + rng, H - 1);
+            const uint32_t Lv = (uint32_t)max((int)Lt[az * 64 + lane], 0) * V4;      // lane a holds the byte offset of plane F_L(|dz|, a)
+            const uint32_t zb = (uint32_t)z * HW4;
+            float part[NX];
+#pragma unroll
+            for (int q = 0; q < NX; ++q) part[q] = 0.f;
+            bool any = false;
+            for (int w = ylo >> 5; w <= (yhi >> 5); ++w) {
+                uint32_t m = bits[(long)z * HW + w];
+                const int base = w << 5;
+                if (base < ylo) m &= 0xFFFFFFFFu << (ylo - base);
+                if (base + 31 > yhi) m &= 0xFFFFFFFFu >> (base + 31 - yhi);
+                any |= m != 0u;
+                // four rows per round, their loads in flight together (one row at a time is a chain of dependent HBM/L2 latencies: the kernel's whole cost).
+                // A round past the last set bit re-reads row yy of the plane with factor 0: part + 0 * v = part exactly (v is finite).
+                while (m) {
+                    float g[4], v[4][NX];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool live = m != 0u;
+                        const int y = live ? base + __builtin_ctz(m) : yy;
+                        m &= m - 1u;                              // 0 stays 0
+                        const int ay = y < yy ? yy - y : y - yy;
+                        const uint32_t so = (uint32_t)__builtin_amdgcn_readlane((int)Lv, ay) + zb + (uint32_t)y * W4;
+                        const float gy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), ay));
+                        g[k] = live ? gy : 0.f;
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) {
+                            const int xx = lane + 64 * q;          // a lane past the row end reads the start of the next row (finite, unused)
+                            v[k][q] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)xx * 4u, so, 0));
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) part[q] += g[k] * v[k][q];
+                }
+            }
+            if (any) {                  // an untouched part is +0: adding g * 0 leaves acc as it is (acc is never -0)
+                const float gz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), az));
+#pragma unroll
+                for (int q = 0; q < NX; ++q) acc[q] += gz * part[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int xx = lane + 64 * q;
+            if (xx < W) {
+                const long i = (long)row * W + xx;
+                if (conv_out) conv_out[i] = acc[q];
+                const unsigned long long key = ((unsigned long long)__float_as_uint(acc[q]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+                mine = key > mine ? key : mine;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(mine, o, 64);
+        mine = other > mine ? other : mine;
+    }
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = wbest[0];
+        for (int i = 1; i < 4; ++i) b = wbest[i] > b ? wbest[i] : b;
+        atomicMax(best, b);
+    }
+}
+
 // binary ball of (odd) diameter d_odd centred at (cz,cy,cx); count of set voxels accumulated into *count
 __global__ void insert_ball_kernel(uint8_t* out, int D, int H, int W, int cz, int cy, int cx, int d_odd, int half, unsigned int* count) {
     const long V = (long)D * H * W;
@@ -474,25 +584,38 @@ __device__ __forceinline__ unsigned long long rank_key(float v, uint32_t id) {
     return ((unsigned long long)ord << 32) | (unsigned long long)(~id);
 }
 
+// Block = 64 candidates (two per thread of a 32-lane group) x 8 partitions of every 256-key tile: n / 64 blocks instead of n / 512, so a pseudo mask of a
+// few thousand voxels (the usual case) spreads over the whole chip instead of a dozen CUs (8 k voxels: 183 -> ~25 us).  Keys are unique (the index is
+// part of the key) and padding keys are 0 < every real key, so the count is the exact rank whatever the partitioning.
 __global__ __launch_bounds__(256) void rank_weight_kernel(const float* vals, const uint32_t* idx, unsigned int n, float dlog2, float scale, float* w) {
     __shared__ unsigned long long sk[256];
-    const unsigned int i0 = blockIdx.x * 512 + threadIdx.x, i1 = i0 + 256;
+    __shared__ unsigned int sr[8][64];
+    const unsigned int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const unsigned int i0 = blockIdx.x * 64 + c, i1 = i0 + 32;
     const uint32_t id0 = i0 < n ? idx[i0] : 0u, id1 = i1 < n ? idx[i1] : 0u;
-    const unsigned long long k0 = i0 < n ? rank_key(vals[i0], id0) : 0ull, k1 = i1 < n ? rank_key(vals[i1], id1) : 0ull;
+    const unsigned long long k0 = i0 < n ? rank_key(vals[i0], id0) : ~0ull, k1 = i1 < n ? rank_key(vals[i1], id1) : ~0ull;
     unsigned int r0 = 0, r1 = 0;
     for (unsigned int j0 = 0; j0 < n; j0 += 256) {
         __syncthreads();
         sk[threadIdx.x] = j0 + threadIdx.x < n ? rank_key(vals[j0 + threadIdx.x], idx[j0 + threadIdx.x]) : 0ull;
         __syncthreads();
-        const unsigned int lim = min(256u, n - j0);
-        for (unsigned int j = 0; j < lim; ++j) {
-            const unsigned long long kj = sk[j];
+#pragma unroll 8
+        for (unsigned int j = 0; j < 32; ++j) {
+            const unsigned long long kj = sk[part * 32 + j];
             r0 += kj > k0;
             r1 += kj > k1;
         }
     }
-    if (i0 < n) w[id0] = exp2f((float)r0 * dlog2) * scale;       // d^rank * N / sum_{r<N} d^r
-    if (i1 < n) w[id1] = exp2f((float)r1 * dlog2) * scale;
+    sr[part][c] = r0;
+    sr[part][c + 32] = r1;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned int r = 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) r += sr[p][threadIdx.x];
+        const unsigned int i = blockIdx.x * 64 + threadIdx.x;
+        if (i < n) w[idx[i]] = exp2f((float)r * dlog2) * scale;       // d^rank * N / sum_{r<N} d^r
+    }
 }
 
 // The same weights from a rank ORDER (ids[r] = voxel of rank r, from a sort): identical arithmetic, O(n) -- the pairwise count above is O(n^2) and takes
@@ -550,8 +673,18 @@ int rs_launch_ball_conv_argmax(const float* x, int D, int H, int W, int d_odd, f
         uint32_t* bits = (uint32_t*)(ws + (size_t)((d_odd >> 1) + 1) * V);          // row-occupancy bits behind the row sums
         hipLaunchKernelGGL(ball_row_bits_kernel, dim3(D), dim3(256), 0, st, x, H, W, HW, bits);
         hipLaunchKernelGGL(ball_rowsum_kernel, dim3(blocks), dim3(256), 0, st, x, D, H, W, d_odd >> 1, 1.f / (2.f * std * std), ws);
-        hipLaunchKernelGGL(ball_gather_argmax_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, (const uint32_t*)bits, HW, D, H, W, d_odd,
-                           1.f / (2.f * std * std), best, conv_out);
+        const int rb = (D * H + 3) / 4;
+#define RS_ROWS(NX) hipLaunchKernelGGL(ball_gather_rows_kernel<NX>, dim3(rb), dim3(256), 0, st, (const float*)ws, (const uint32_t*)bits, HW, D, H, W, d_odd, \
+                                       1.f / (2.f * std * std), best, conv_out)
+        const bool small = (long)((d_odd >> 1) + 1) * V * 4 < (1l << 31);
+        if (small && W <= 64) RS_ROWS(1);
+        else if (small && W <= 128) RS_ROWS(2);
+        else if (small && W <= 192) RS_ROWS(3);
+        else if (small && W <= 256) RS_ROWS(4);
+        else
+            hipLaunchKernelGGL(ball_gather_argmax_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, (const uint32_t*)bits, HW, D, H, W, d_odd,
+                               1.f / (2.f * std * std), best, conv_out);
+#undef RS_ROWS
         return rs_check_launch();
     }
     hipLaunchKernelGGL(ball_conv_argmax_kernel, dim3(blocks), dim3(256), 0, st, x, D, H, W, d_odd, 1.f / (2.f * std * std), best, conv_out);
@@ -602,7 +735,7 @@ int rs_launch_compact(const float* x, const uint8_t* pm, long V, float* vals, ui
 
 int rs_launch_rank_weights(const float* vals, const uint32_t* idx, unsigned int n, float dlog2, float scale, float* w, hipStream_t st) {
     if (!n) return RS_OK;
-    hipLaunchKernelGGL(rank_weight_kernel, dim3((n + 511) / 512), dim3(256), 0, st, vals, idx, n, dlog2, scale, w);
+    hipLaunchKernelGGL(rank_weight_kernel, dim3((n + 63) / 64), dim3(256), 0, st, vals, idx, n, dlog2, scale, w);
     return rs_check_launch();
 }
 
