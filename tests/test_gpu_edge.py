@@ -1359,3 +1359,14 @@ def test_step_guard_raises_one_step_late_and_nan_step_is_skipped():
     p.grad = torch.randn_like(p)
     opt.fused_step(max_norm=1.0, ema_params=[e], ema_alpha=0.5)
     assert not torch.equal(p.detach(), ref_p) and bool(torch.isfinite(p).all())
+
+
+@pytest.mark.gpu
+def test_persistent_strided_forward_matches_parity_class_kernel():
+    """csrc/conv3d_igemm_s2k.hip (the bf16 default of the strided [conv1 | shortcut] forward) against csrc/conv3d_igemm_s2.hip on the same operands --
+    full size, odd sizes, ragged channel counts: outputs within bf16 roundings of each other (different fp32 summation orders), per-column
+    statistics to 1e-3, and no further from the float64 evaluation of the same bf16 operands than the parity-class kernel is (tools/check_s2k.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_s2k.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('OK'), r.stdout[-2000:] + r.stderr[-2000:]
