@@ -123,7 +123,7 @@ int rsuper_conv3_igemm(int dtype, int epi,
  *   mode 2 (dgrad)  : xa | xb = dy sources on the half grid (no statistics); out (N, FD, FH, FW, ldo) = the gradient w.r.t. relu(norm(x)),
  *                     masked by [x_n > 0] of the forward input exa (N, FD, FH, FW, elda) with statistics emra; part: N x
  *                     rsuper_conv3_s2_part_rows(dtype, 2, ...) rows of the InstanceNorm-backward sums.  packed = rsuper_conv3_pack_weights(mode - 1, ..., bn = 64). */
-int rsuper_conv3_s2_part_rows(int dtype, int mode, int Ca, int n_cols, int N, int FD, int FH, int FW);
+int rsuper_conv3_s2_part_rows(int dtype, int mode, int Ca, int Cb, int n_cols, int N, int FD, int FH, int FW);
 int rsuper_conv3_igemm_s2(int dtype, int mode, const void* xa, int lda, int Ca, const float* mra,
                           const void* xb, int ldb, int Cb, const void* packed, int n_cols, int N, int FD, int FH, int FW,
                           void* out, int ldo, float* part, const void* exa, int elda, const float* emra, void* stream);

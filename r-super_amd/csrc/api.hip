@@ -219,22 +219,32 @@ static bool s2k_on() {                                                       // 
     const char* e = getenv("RSUPER_S2K");
     return !(e && atoi(e) == 0);
 }
-static IgemmParams s2_shape(int n_cols, int Ca, int N, int FD, int FH, int FW) {
+static bool s2d_on() {                                                       // RSUPER_S2D=0: the parity-class data gradient
+    const char* e = getenv("RSUPER_S2D");
+    return !(e && atoi(e) == 0);
+}
+static IgemmParams s2_shape(int n_cols, int Ca, int Cb, int N, int FD, int FH, int FW) {
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.ntiles = ntiles_for(n_cols, 64); p.bn = 64;
     p.N = N; p.D = (FD + 1) / 2; p.H = (FH + 1) / 2; p.W = (FW + 1) / 2; p.Cout = n_cols;
-    p.a.C = Ca;
+    p.a.C = Ca; p.b.C = Cb;
     return p;
 }
-int rsuper_conv3_s2_part_rows(int dtype, int mode, int Ca, int n_cols, int N, int FD, int FH, int FW) {
+int rsuper_conv3_s2_part_rows(int dtype, int mode, int Ca, int Cb, int n_cols, int N, int FD, int FH, int FW) {
     if ((mode != 1 && mode != 2) || FD <= 0 || FH <= 0 || FW <= 0 || N <= 0 || n_cols <= 0) return 0;
     const int OD = (FD + 1) / 2, OH = (FH + 1) / 2, OW = (FW + 1) / 2, td = mode == 2 ? 2 : 4;
     if (mode == 1 && s2k_on()) {
-        IgemmParams p = s2_shape(n_cols, Ca, N, FD, FH, FW);
+        IgemmParams p = s2_shape(n_cols, Ca, Cb, N, FD, FH, FW);
         static const float one = 1.f;
         p.a.mr = &one;                                                       // "normalised source" for the support query
         if (rs_igemm_s2k_supported(p, dtype, FD, FH, FW)) return rs_igemm_s2k_part_rows(p.ntiles, n_cols, N, OD, OH, OW);
+    }
+    if (mode == 2 && s2d_on()) {
+        IgemmParams p = s2_shape(n_cols, Ca, Cb, N, FD, FH, FW);
+        static const float one = 1.f;
+        p.ea.mr = &one; p.ea.x = &one;
+        if (rs_igemm_s2d_supported(p, dtype, FD, FH, FW)) return rs_igemm_s2d_part_rows(n_cols, N, OD, OH, OW);
     }
     return ((OD + td - 1) / td) * ((OH + 3) / 4) * ((OW + 15) / 16);
 }
@@ -262,6 +272,7 @@ int rsuper_conv3_igemm_s2(int dtype, int mode, const void* xa, int lda, int Ca, 
     p.out = out; p.ldo = ldo; p.part = part;
     p.ea = {exa, elda, n_cols, emra};
     if (mode == 1 && s2k_on() && rs_igemm_s2k_supported(p, dtype, FD, FH, FW)) return rs_launch_igemm_s2k(p, FD, FH, FW, ST(stream));
+    if (mode == 2 && s2d_on() && rs_igemm_s2d_supported(p, dtype, FD, FH, FW)) return rs_launch_igemm_s2d(p, FD, FH, FW, ST(stream));
     return rs_launch_igemm_s2(p, dtype, mode, FD, FH, FW, ST(stream));
 }
 

@@ -73,6 +73,10 @@ int rs_launch_igemm_s2(const IgemmParams& p, int dtype, int mode, int FD, int FH
 bool rs_igemm_s2k_supported(const IgemmParams& p, int dtype, int FD, int FH, int FW);
 int rs_igemm_s2k_part_rows(int ntiles, int n_cols, int N, int D, int H, int W);
 int rs_launch_igemm_s2k(const IgemmParams& p, int FD, int FH, int FW, hipStream_t st);
+// persistent strided data gradient (conv3d_igemm_s2d.hip): bf16, raw dy sources; InstanceNorm-backward rows = rs_igemm_s2d_part_rows per sample
+bool rs_igemm_s2d_supported(const IgemmParams& p, int dtype, int FD, int FH, int FW);
+int rs_igemm_s2d_part_rows(int n_cols, int N, int D, int H, int W);
+int rs_launch_igemm_s2d(const IgemmParams& p, int FD, int FH, int FW, hipStream_t st);
 size_t rs_packed_elems(int dtype, int ka, int kb, int ntiles);
 int rs_launch_pack(const PackParams& q, int dtype, void* out, hipStream_t st);
 // softmax(q k^T * scale) v of a short token sequence (token_attn.hip); d_qkv == nullptr: forward (o, p written), else backward (p, d_o read)

@@ -29,7 +29,7 @@ _SIGS = {
     'rsuper_conv3_workspace_bytes': (c_size_t, []),
     'rsuper_conv3_wgrad_splits': (c_int, [c_int] * 9),
     'rsuper_conv3_part_rows': (c_int, [c_int] * 8),
-    'rsuper_conv3_s2_part_rows': (c_int, [c_int] * 8),
+    'rsuper_conv3_s2_part_rows': (c_int, [c_int] * 9),
     'rsuper_conv3_igemm_s2': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, P, P]),
     'rsuper_conv3_igemm': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                    P, c_int, P, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, P]),

@@ -644,7 +644,7 @@ class BasicBlockFn(torch.autograd.Function):
             OD, OH, OW = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
             wp1 = pack_weights(dt, 0, w1, ws, Ca, 0, Cout, Cout, 64)
             ys = torch.empty((N, OD, OH, OW, nc1), device=dev, dtype=dt)
-            part1 = torch.empty((N, _L().rsuper_conv3_s2_part_rows(_DT[dt], 1, Ca, nc1, N, D, H, W), nc1, 2), device=dev, dtype=torch.float32)
+            part1 = torch.empty((N, _L().rsuper_conv3_s2_part_rows(_DT[dt], 1, Ca, 0, nc1, N, D, H, W), nc1, 2), device=dev, dtype=torch.float32)
             igemm_s2(1, sa, None, wp1, nc1, dims, ys, part1)
             mr_y1 = stats_finalize(part1, OD * OH * OW, split=Cout)[0]
         dims2 = (N, OD, OH, OW)
@@ -703,7 +703,7 @@ class BasicBlockFn(torch.autograd.Function):
         else:
             # the transposed convolution by output parity classes, straight from [dy1 | dOut] on the half grid (no zero-stuffed operand)
             wpd1 = pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, 64)
-            part0 = torch.empty((N, _L().rsuper_conv3_s2_part_rows(_DT[dt], 2, 2 * Cout, Ca, N, D, H, W), Ca, 2), device=dev, dtype=torch.float32)
+            part0 = torch.empty((N, _L().rsuper_conv3_s2_part_rows(_DT[dt], 2, Cout, Cout, Ca, N, D, H, W), Ca, 2), device=dev, dtype=torch.float32)
             igemm_s2(2, Src(dy1), sdo, wpd1, Ca, dims, g0, part0, ea=sa)
         gm0 = stats_finalize(part0, D * H * W, mode=1)
         dw1, dws = grad_dest(w1), grad_dest(ws)

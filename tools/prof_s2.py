@@ -16,7 +16,7 @@ sa = ops.Src(xa, mr=mra)
 if which == 'fwd':
     wp = ops.pack_weights(dt, 0, w1, ws, Ca, 0, Cout, Cout, 64)
     ys = torch.empty((N, O, O, O, nc), device=dev, dtype=dt)
-    part = torch.empty((N, ops._L().rsuper_conv3_s2_part_rows(ops._DT[dt], 1, Ca, nc, N, S, S, S), nc, 2), device=dev, dtype=torch.float32)
+    part = torch.empty((N, ops._L().rsuper_conv3_s2_part_rows(ops._DT[dt], 1, Ca, 0, nc, N, S, S, S), nc, 2), device=dev, dtype=torch.float32)
     fn = lambda: ops.igemm_s2(1, sa, None, wp, nc, dims, ys, part)
 elif which == 'wgrad':
     dy1 = torch.randn((N, O, O, O, Cout), device=dev).to(dt); dy2 = torch.randn((N, O, O, O, Cout), device=dev).to(dt)
@@ -26,7 +26,7 @@ else:
     dy1 = torch.randn((N, O, O, O, Cout), device=dev).to(dt); dy2 = torch.randn((N, O, O, O, Cout), device=dev).to(dt)
     wpd = ops.pack_weights(dt, 1, w1, ws, Cout, Cout, Ca, 0, 64)
     g0 = torch.empty((N, S, S, S, Ca), device=dev, dtype=dt)
-    partd = torch.empty((N, ops._L().rsuper_conv3_s2_part_rows(ops._DT[dt], 2, nc, Ca, N, S, S, S), Ca, 2), device=dev, dtype=torch.float32)
+    partd = torch.empty((N, ops._L().rsuper_conv3_s2_part_rows(ops._DT[dt], 2, Cout, Cout, Ca, N, S, S, S), Ca, 2), device=dev, dtype=torch.float32)
     fn = lambda: ops.igemm_s2(2, ops.Src(dy1), ops.Src(dy2), wpd, Ca, dims, g0, partd, ea=sa)
 for _ in range(3):
     fn()
