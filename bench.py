@@ -243,6 +243,17 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         sec['config3_workload'] = 'same UNet + Volume + Ball report losses (ball_dice_both, weight 0.1, 50/50 mask/report batch), BASELINE configs[2]'
         l3.close()
 
+    def nopool():
+        # UNet(..., pool=False): the strided BasicBlock down blocks (conv3d_igemm_s2k / _s2d / wgrad_s2) instead of max-pool + stride-1 blocks
+        import copy
+        a2 = copy.copy(args)
+        a2.no_pool = True
+        ln = Leg(a2, args.dtype, False, rank, world, local, False, classes, B, S)
+        sec['nopool_ms_per_step'] = ln.timed(n2, w2) / n2 * 1e3
+        sec['nopool_final_loss'] = ln.loss()
+        sec['nopool_workload'] = 'headline workload with down_block(pool=False): strided [conv1 | shortcut] convolutions (unet_utils.py:38-39) instead of max-pooling'
+        ln.close()
+
     def sanity_on():
         # the headline step with the reference's per-step guards active (input NaN / range asserts, the mask / volume consistency checks and the
         # NaN guard on the loss): each is a device -> host read that drains the launch queue; the headline keeps them outside the timed region
@@ -358,6 +369,7 @@ def secondary_legs(args, rank, world, local, classes, B, S):
     if not args.report:
         guarded('sanity_on', sanity_on)
         guarded('config3', config3)
+        guarded('nopool', nopool)
         guarded('graph', graph)
         if args.base == 32:
             guarded('medformer_graph', medformer_graph)

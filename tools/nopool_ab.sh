@@ -1,8 +1,8 @@
 #!/bin/bash
-# bench.py --no-pool (variant: strided down blocks): new strided kernels vs RSUPER_S2_WGRAD=0 vs RSUPER_S2_KERNEL=0
+# bench.py --no-pool (variant: strided down blocks): persistent strided kernels (round 5) vs the parity-class kernels (RSUPER_S2K=0 / RSUPER_S2D=0) vs the full-resolution evaluation (RSUPER_S2_KERNEL=0)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; out=gpurun_out/nopool_ab.txt; : > $out
-for e in "" "RSUPER_S2_WGRAD=0" "RSUPER_S2_KERNEL=0"; do
+for e in "" "RSUPER_S2K=0 RSUPER_S2D=0" "RSUPER_S2K=0" "RSUPER_S2D=0" "RSUPER_S2_KERNEL=0"; do
   echo "== bench.py --no-pool --steps 20 --warmup 5 --no-secondary --no-cpu-baseline   $e" >> $out
   env $e timeout 600 python bench.py --no-pool --steps 20 --warmup 5 --no-secondary --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json

@@ -16,7 +16,7 @@ def read_pass(d):
                 continue
             if 'reduce' in k or 'pack' in k:
                 continue
-            m = re.search(r'(igemm_kd_kernel|igemm_box_kernel|igemm_s2_kernel|pw_gemm_kernel|pw_wgrad_kernel|igemm_pc_kernel|igemm_kernel|wgrad_pc_kernel|wgrad_kernel|igemm_ws_kernel|wgrad\w*_kernel)<([^>]*)>', k)
+            m = re.search(r'(igemm_kd_kernel|igemm_s2k_kernel|igemm_s2d_kernel|igemm_box_kernel|igemm_s2_kernel|pw_gemm_kernel|pw_wgrad_kernel|igemm_pc_kernel|igemm_kernel|wgrad_pc_kernel|wgrad_kernel|igemm_ws_kernel|wgrad\w*_kernel)<([^>]*)>', k)
             name = (m.group(1) + '<' + m.group(2) + '>') if m else k[:60]
             e = out.setdefault(name, {})
             e.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
