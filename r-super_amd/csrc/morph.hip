@@ -792,11 +792,17 @@ __global__ __launch_bounds__(256) void plane_any_kernel(const uint8_t* __restric
     const uint8_t* pl = m + (size_t)blockIdx.y * V;
     const long nvec = V / 16;
     unsigned int any = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {             // four independent 16-byte loads in flight per thread (one at a time ran at 1.4 TB/s)
+        const uint4 a = ((const uint4*)pl)[i], b = ((const uint4*)pl)[i + stride], c = ((const uint4*)pl)[i + 2 * stride], d = ((const uint4*)pl)[i + 3 * stride];
+        any |= (a.x | a.y | a.z | a.w) | (b.x | b.y | b.z | b.w) | (c.x | c.y | c.z | c.w) | (d.x | d.y | d.z | d.w);
+    }
+    for (; i < nvec; i += stride) {
         const uint4 q = ((const uint4*)pl)[i];
         any |= q.x | q.y | q.z | q.w;
     }
-    if (blockIdx.x == 0) for (long i = nvec * 16 + threadIdx.x; i < V; i += 256) any |= pl[i];
+    if (blockIdx.x == 0) for (long j = nvec * 16 + threadIdx.x; j < V; j += 256) any |= pl[j];
     if (__any(any != 0) && (threadIdx.x & 63) == 0) flags[blockIdx.y] = 1;
 }
 
