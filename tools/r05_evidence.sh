@@ -6,7 +6,7 @@ rm -f gpurun_out/r05_pmc_igemm.md
 timeout 300 python tools/bench_conv.py bf16 > gpurun_out/r05_conv_layers.txt 2>/dev/null
 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_r05 -o r -- python bench.py --steps 10 --warmup 3 --roofline-steps 0 --no-secondary --no-cpu-baseline > /dev/null 2>&1
 python tools/kernel_stats.py $(ls /tmp/kt_r05/*kernel_trace.csv | head -1) 13 > gpurun_out/r05_bench_kernel_stats.txt
-python tools/kernel_seq.py $(ls /tmp/kt_r05/*kernel_trace.csv | head -1) > gpurun_out/r05_bench_kernel_seq.txt 2>/dev/null
+python tools/kernel_seq.py $(ls /tmp/kt_r05/*kernel_trace.csv | head -1) 13 > gpurun_out/r05_bench_kernel_seq.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_r05s -o r -- python bench.py --steps 10 --warmup 3 --roofline-steps 0 --no-secondary --no-cpu-baseline > /dev/null 2>&1
 cp $(ls /tmp/kt_r05s/*kernel_stats.csv | head -1) gpurun_out/r05_bench_rocprofv3_kernel_stats.csv 2>/dev/null
 rm -rf gpurun_out/pmc_step_fetch gpurun_out/pmc_step_write
