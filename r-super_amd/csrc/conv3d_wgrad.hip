@@ -62,21 +62,21 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % MT, wt = wave / MT;
+    const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH, tiles_d = (p.D + TD - 1) / TD;
+    const int tiles = tiles_w * tiles_h * tiles_d * p.N;
+    const WgBlockMap bm = wg_block_map(tiles, p.splits);         // (chunk, row group, split) of this block and the split's tiles (wgrad_frag.hpp)
     const int nchA = (p.xa.C + 31) / 32;
-    const bool isB = (int)blockIdx.x >= nchA;
+    const bool isB = bm.bx >= nchA;
     const ConvSrc& xs = isB ? p.xb : p.xa;
-    const int c0 = (isB ? blockIdx.x - nchA : blockIdx.x) * 32;
+    const int c0 = (isB ? bm.bx - nchA : bm.bx) * 32;
     const int cin_total = p.xa.C + p.xb.C;
     const int cin_base = (isB ? p.xa.C : 0) + c0;
     const int Mtot = p.ya.C + p.yb.C;
     const int mgroups = (Mtot + MT * 32 - 1) / (MT * 32);
-    const int mg = blockIdx.y % mgroups;
-    const int kdg = NTAPS == 27 ? 0 : blockIdx.y / mgroups;      // kd handled by this block (9-tap config)
+    const int mg = bm.by % mgroups;
+    const int kdg = NTAPS == 27 ? 0 : bm.by / mgroups;           // kd handled by this block (9-tap config)
     const int m0 = mg * MT * 32;
     const bool norm = xs.mr != nullptr;
-
-    const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH, tiles_d = (p.D + TD - 1) / TD;
-    const int tiles = tiles_w * tiles_h * tiles_d * p.N;
 
     f32x16_t acc[TPW];
 #pragma unroll
@@ -217,21 +217,8 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
     };
 
     int cur_n = -1;
-    // XCD-aware tile order: linear workgroup id b runs on XCD b % 8 (private L2 each), and for a fixed (chunk, row group) the splits z, z + 8, ...
-    // share an XCD.  Class z & 7 owns a contiguous range of tiles and its blocks sweep it together, so the halo rows neighbouring tiles share are
-    // fetched into that L2 once (the grid-stride order put the 8 w / h neighbours of a tile on 8 different XCDs).  Any placement gives the same sums
-    // per slab set; only the assignment of tiles to slabs changes.
-    int tile0, tile_end, tstride;
-    {
-        const int z = blockIdx.z, S = p.splits;
-        if (S >= 8 && tiles >= 64) {
-            const int cls = z & 7, q = S >> 3, rm = S & 7;
-            const int cum0 = cls * q + (cls < rm ? cls : rm), ncl = q + (cls < rm ? 1 : 0);
-            tile0 = (int)((long)tiles * cum0 / S) + (z >> 3);
-            tile_end = (int)((long)tiles * (cum0 + ncl) / S);
-            tstride = ncl;
-        } else { tile0 = z; tile_end = tiles; tstride = S; }
-    }
+    // XCD-aware tile order (wg_block_map): the splits on one XCD own a contiguous range of tiles and sweep it together
+    const int tile0 = bm.tile0, tile_end = bm.tile_end, tstride = bm.tstride;
     if (tile0 < tile_end) issue(tile0);
 #ifdef RS_WG_PROF
     unsigned long long pf[5] = {0, 0, 0, 0, 0};
@@ -335,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
 #endif
     // ---- write this split's partial dW slab: ws[split][tap][m][cin]  (coalesced along cin)
     const int ci = c0 + (lane & 31);
-    float* slab = p.ws + (size_t)blockIdx.z * 27 * Mtot * cin_total;
+    float* slab = p.ws + (size_t)bm.bz * 27 * Mtot * cin_total;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int tl = wt + i * WT;

@@ -84,18 +84,18 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wsel = wave & 1, g = wave >> 1;
     const int dsel = MT == 1 ? wsel * 2 : 0;                     // first tile plane of this wave
+    const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH, tiles_d = (p.D + TD - 1) / TD;
+    const int tiles_per_sample = tiles_w * tiles_h * tiles_d;
+    const WgBlockMap bm = wg_block_map(tiles_per_sample * p.N, p.splits);   // (chunk, row group, split) of this block and the split's tiles (wgrad_frag.hpp)
     const int nchA = (p.xa.C + 31) / 32;
-    const bool isB = (int)blockIdx.x >= nchA;
+    const bool isB = bm.bx >= nchA;
     const ConvSrc& xs = isB ? p.xb : p.xa;
-    const int c0 = (isB ? blockIdx.x - nchA : blockIdx.x) * 32;
+    const int c0 = (isB ? bm.bx - nchA : bm.bx) * 32;
     const int cin_total = p.xa.C + p.xb.C;
     const int cin_base = (isB ? p.xa.C : 0) + c0;
     const int Mtot = p.ya.C + p.yb.C;
-    const int m0 = blockIdx.y * MT * 32;
+    const int m0 = bm.by * MT * 32;
     constexpr bool norm = NORM;                                  // sources carry (mean, rstd): InstanceNorm + ReLU while staging
-
-    const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH, tiles_d = (p.D + TD - 1) / TD;
-    const int tiles_per_sample = tiles_w * tiles_h * tiles_d;
     const int tiles = tiles_per_sample * p.N;
 
     // fragment bases (lane part folded in), relative to a tile buffer
@@ -138,18 +138,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the dynamic region
     const uint32_t ywbit = 1u << (8 + prow);                     // this lane's w position in the tile's validity mask
 
-    // XCD-aware tile order (see conv3d_wgrad.hip): class z & 7 owns a contiguous range of tiles and its blocks sweep it together
-    int tile0, tile_end, tstride;
-    {
-        const int z = blockIdx.z, S = p.splits;
-        if (S >= 8 && tiles >= 64) {
-            const int cls = z & 7, q = S >> 3, rm = S & 7;
-            const int cum0 = cls * q + (cls < rm ? cls : rm), ncl = q + (cls < rm ? 1 : 0);
-            tile0 = (int)((long)tiles * cum0 / S) + (z >> 3);
-            tile_end = (int)((long)tiles * (cum0 + ncl) / S);
-            tstride = ncl;
-        } else { tile0 = z; tile_end = tiles; tstride = S; }
-    }
+    // XCD-aware tile order (wg_block_map): the splits on one XCD own a contiguous range of tiles and sweep it together
+    const int tile0 = bm.tile0, tile_end = bm.tile_end, tstride = bm.tstride;
 
     // Tile descriptors of this block's tiles, built ONCE (the per-tile index arithmetic -- five integer divisions and the range masks -- cost ~1.2 k
     // cycles at the top of every tile with all matrix pipes idle: 108 of 613 us on up4.0): entry k = k-th tile of the block, entries past the
@@ -398,7 +388,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
         // ---- this split's partial dW slab: ws[split][tap][m][cin]  (coalesced along cin)
         if (MT == 2 || wsel == 0) {
             const int ci = c0 + (lane & 31);
-            float* slab = p.ws + (size_t)blockIdx.z * 27 * Mtot * cin_total;
+            float* slab = p.ws + (size_t)bm.bz * 27 * Mtot * cin_total;
             const int mrow0 = m0 + (MT == 2 ? wsel * 32 : 0);
 #pragma unroll
             for (int i = 0; i < (G < 3 ? 7 : 6); ++i) {
