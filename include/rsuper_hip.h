@@ -91,9 +91,10 @@ int rsuper_conv3_kd_bn(int dtype, int epi, int N, int D, int H, int W, int n_col
 
 /* Volumes of at most 6x6x6 voxels (the 6^3 bottleneck level: model/dim3/unet.py:53, four poolings of a 96^3 patch) run one box
  * per sample with the REDUCTION (32-channel chunks) split over blocks: each block writes its raw f32 tile to a workspace and a
- * second kernel adds the splits and applies the epilogue (deterministic: fixed split order).  The caller registers ONE device
- * buffer of at least rsuper_conv3_workspace_bytes() for that; launches on one stream may share it.  Without a registered
- * workspace those volumes take the 4x4x4-box shape.  rsuper_conv3_box_bn returns 32 for them. */
+ * second kernel adds the splits and applies the epilogue (deterministic: fixed split order).  The caller registers one device
+ * buffer of at least rsuper_conv3_workspace_bytes() PER DEVICE (the registration and every launch refer to the calling thread's
+ * current HIP device); launches on one stream share it, launches on two streams of one device must not overlap such
+ * convolutions.  Without a registered workspace those volumes take the 4x4x4-box shape.  rsuper_conv3_box_bn returns 32 for them. */
 int rsuper_conv3_set_workspace(void* ptr, size_t bytes);
 size_t rsuper_conv3_workspace_bytes(void);
 

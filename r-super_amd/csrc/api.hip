@@ -136,8 +136,18 @@ static bool use_pc(int dtype, int epi, int bn, int tiles_total) {
 // 64-column blocks; shape 3 (volumes of at most 6x6x6: one box per sample, the reduction split over blocks through the registered
 // workspace, second pass box_splitk_epilogue_kernel) takes 32-column blocks.  Variants 6 / 7 force the kernel for every bf16 launch
 // (6: shape chosen per volume, 7: the 4x4x4 box) -- test paths.
-static void* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
+// one registered workspace PER DEVICE (indexed by the current HIP device of the calling thread: a host that drives several GPUs from one process
+// registers one on each); launches on two streams of the same device share it and must not overlap 6^3-level convolutions
+static const int RS_MAX_DEVICES = 64;
+static void* g_ws_dev[RS_MAX_DEVICES] = {nullptr};
+static size_t g_ws_bytes_dev[RS_MAX_DEVICES] = {0};
+static int ws_dev() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= RS_MAX_DEVICES) return 0;
+    return d;
+}
+#define g_ws (g_ws_dev[ws_dev()])
+#define g_ws_bytes (g_ws_bytes_dev[ws_dev()])
 static const size_t BOXC_WS_BYTES = (size_t)256 * 216 * 32 * 4;    // nsplit x N x 216 x n_cols floats while N x ceil(n_cols / 32) <= 256 (rs_box_nsplit)
 // Bytes the split shape writes into the workspace: nsplit x N x voxels x n_cols floats.  rs_box_nsplit deals at most 256 / (N x groups) splits (at least
 // one), so beyond N x groups = 256 the requirement grows with N x n_cols without bound -- the shape is only taken while it fits what the caller registered.
