@@ -115,6 +115,20 @@ template <> __device__ __forceinline__ void mma32<float>(f32x16_t& acc, const ui
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+// Tile index inside a sample -> tile coordinates.  Bricks of 2 x 2 x 4 tiles (w, h, d; smaller where the tile grid does not divide) are numbered
+// consecutively: the blocks of an XCD that work side by side on consecutive tile indices (XCD-aware orders of the igemm / weight-gradient kernels) then
+// hold ONE compact brick -- its interior halo rows are fetched into that L2 once -- instead of a 16-tile strip along w whose d neighbours come round
+// only after the strip's rows have left the cache (the d halo is 2 of every 6 staged planes).  A bijection for every tile grid; placement only.
+__device__ __forceinline__ void rs_tile_coords(int t, int tiles_w, int tiles_h, int tiles_d, int& tw, int& th, int& td) {
+    const int lw = (tiles_w & 1) ? 0 : 1, lh = (tiles_h & 1) ? 0 : 1, ld = (tiles_d & 3) == 0 ? 2 : ((tiles_d & 1) ? 0 : 1);   // log2 of the brick extents
+    const int i = t & ((1 << (lw + lh + ld)) - 1), b = t >> (lw + lh + ld);
+    const int nbw = tiles_w >> lw, nbh = tiles_h >> lh;
+    const int bx = b % nbw, r = b / nbw, by = r % nbh, bz = r / nbh;
+    tw = (bx << lw) | (i & ((1 << lw) - 1));
+    th = (by << lh) | ((i >> lw) & ((1 << lh) - 1));
+    td = (bz << ld) | (i >> (lw + lh));
+}
+
 // C/D fragment row of accumulator register `reg` for a 32x32 MFMA (column = lane & 31).
 __device__ __forceinline__ int cd_row32(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 

@@ -64,9 +64,8 @@ __global__ __launch_bounds__(256, (MF * NF <= 4 && sizeof(T) == 2) ? 3 : 2) void
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
     const int tile_id = t;
-    const int tw = t % tiles_w; t /= tiles_w;
-    const int th = t % tiles_h; t /= tiles_h;
-    const int td = t;
+    int tw, th, td;
+    rs_tile_coords(t, tiles_w, tiles_h, (p.D + TD - 1) / TD, tw, th, td);
     const int n = blockIdx.z;
     const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
     const int nchA = (p.a.C + KC - 1) / KC, nchB = (p.b.C + KC - 1) / KC;
@@ -397,9 +396,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
             const int q = tiles >> 3, r = tiles & 7, xcd = t & 7, kk = t >> 3;
             t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
         }
-        const int tw = t % tiles_w; t /= tiles_w;
-        const int th = t % tiles_h; t /= tiles_h;
-        d0 = t * TD; h0 = th * TH; w0 = tw * TW;
+        int tw, th, td;
+        rs_tile_coords(t, tiles_w, tiles_h, (p.D + TD - 1) / TD, tw, th, td);
+        d0 = td * TD; h0 = th * TH; w0 = tw * TW;
     };
 
     if (producer) {

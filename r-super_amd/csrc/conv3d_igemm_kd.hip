@@ -143,9 +143,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
                 const int q = tiles >> 3, r = tiles & 7, xcd = t & 7, kk = t >> 3;
                 t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
             }
-            const int tw = t % tiles_w; t /= tiles_w;
-            const int th = t % tiles_h; t /= tiles_h;
-            const int d0 = t * TD, h0 = th * TH, w0 = tw * TW;
+            int tw, th, td;
+            rs_tile_coords(t, tiles_w, tiles_h, tiles_d, tw, th, td);
+            const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
             auto range = [](int o, int len, int nh) {                   // bits i in [0, nh) with 0 <= o + i < len
                 const int lo = o >= 0 ? 0 : -o;
                 int hi_ = len - 1 - o; if (hi_ > nh - 1) hi_ = nh - 1;

@@ -117,9 +117,9 @@ __global__ __launch_bounds__(NT_THREADS, 1) void igemm_ws_kernel(IgemmParams p) 
                 const int q = tiles >> 3, r = tiles & 7, xcd = t & 7, kk = t >> 3;
                 t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
             }
-            const int tw = t % tiles_w; t /= tiles_w;
-            const int th = t % tiles_h; t /= tiles_h;
-            const int d0 = t * TD, h0 = th * TH, w0 = tw * TW;
+            int tw, th, td;
+            rs_tile_coords(t, tiles_w, tiles_h, (p.D + TD - 1) / TD, tw, th, td);
+            const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
             auto range = [](int o, int len, int nh) {
                 const int lo = o >= 1 ? 0 : 1 - o;
                 int hi_ = len - o; if (hi_ > nh - 1) hi_ = nh - 1;

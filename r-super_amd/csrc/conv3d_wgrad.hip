@@ -127,11 +127,11 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && MT == 2) ? 2 : 1) void 
     for (int j = 0; j < KP; ++j) { sc_[j] = 1.f; nb_[j] = 0.f; }
 
     auto tile_coords = [&](int tile, int& n, int& d0, int& h0, int& w0) {
-        int t = tile;
-        const int tw = t % tiles_w; t /= tiles_w;
-        const int th = t % tiles_h; t /= tiles_h;
-        const int td = t % tiles_d; t /= tiles_d;
-        n = t; d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+        const int per = tiles_w * tiles_h * tiles_d;
+        n = tile / per;
+        int tw, th, td;
+        rs_tile_coords(tile - n * per, tiles_w, tiles_h, tiles_d, tw, th, td);
+        d0 = td * TD; h0 = th * TH; w0 = tw * TW;
     };
     // Per-thread constants of the staging vectors: voxel delta of every vector relative to the tile's halo / tile
     // origin (the (hd, hh, hw) decomposition of its row never changes), so an interior tile costs one add per vector.

@@ -149,11 +149,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgradParams p) {
     const int ntile = tile0 < tile_end ? (tile_end - 1 - tile0) / tstride + 1 : 0;
     for (int k = tid; k < ntile + 3; k += NT) {
         const bool live = k < ntile;
-        int q = live ? tile0 + k * tstride : 0;
-        const int tw = q % tiles_w; q /= tiles_w;
-        const int th = q % tiles_h; q /= tiles_h;
-        const int td = q % tiles_d; q /= tiles_d;
-        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW, n = q;
+        const int q = live ? tile0 + k * tstride : 0;
+        const int n = q / tiles_per_sample;
+        int tw, th, td;
+        rs_tile_coords(q - n * tiles_per_sample, tiles_w, tiles_h, tiles_d, tw, th, td);
+        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
         auto range = [](int o, int len, int nh) {                // bits i in [0, nh) with 0 <= o + i < len
             const int lo = o >= 0 ? 0 : -o;
             int hi_ = len - 1 - o; if (hi_ > nh - 1) hi_ = nh - 1;
