@@ -373,13 +373,24 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
-    const int n = blockIdx.z;
+    // Several column groups (gridDim.y > 1: the 192-column data gradient of up3.0 on 64-column blocks): the groups of one (tile set, sample) read the same
+    // halo rows, but their linear workgroup ids differ by gridDim.x -- 42 there -- and land on different XCDs (private L2 each): every group pulled the
+    // rows over the fabric again (617 MB fetched for 141 MB of operands).  The blocks are renumbered so that consecutive ids share an XCD (as wg_block_map
+    // does for the weight gradient) and decoded column-group-fastest: the groups of a tile set run on ONE XCD.  Placement only.
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bn_ = (int)blockIdx.z;
+    if (gridDim.y > 1) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, NB = gx * gy * gridDim.z, L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned q = NB >> 3, r = NB & 7, xc = L & 7;
+        const unsigned V = xc * q + (xc < r ? xc : r) + (L >> 3);
+        by = (int)(V % gy); bx = (int)((V / gy) % gx); bn_ = (int)(V / (gy * gx));
+    }
+    const int n = bn_;
     const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH, tiles_d = (p.D + TD - 1) / TD;
     const int tiles = tiles_w * tiles_h * tiles_d;
     const int nchA = (p.a.C + KC - 1) / KC, nchB = (p.b.C + KC - 1) / KC;
     const int nch = nchA + nchB;
     const bool normA = p.a.mr != nullptr, normB = p.b.mr != nullptr;
-    const int my_tiles = ((int)blockIdx.x < tiles) ? (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int my_tiles = (bx < tiles) ? (tiles - 1 - bx) / (int)gridDim.x + 1 : 0;
     const int nitems = my_tiles * nch;
 
     if (normA) for (int i = tid; i < 2 * p.a.C; i += 512) mr_lds[i] = p.a.mr[(size_t)n * 2 * p.a.C + i];
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
     // every XCD (private L2) a contiguous run of tiles and the halo rows shared by neighbouring tiles are fetched once
     const bool xcd_remap = (gridDim.x & 7) == 0 && tiles >= 64;
     auto tile_origin = [&](int k, int& d0, int& h0, int& w0) {
-        int t = (int)blockIdx.x + k * (int)gridDim.x;
+        int t = bx + k * (int)gridDim.x;
         if (xcd_remap) {
             const int q = tiles >> 3, r = tiles & 7, xcd = t & 7, kk = t >> 3;
             t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
         const int a_base0 = (((wm * MF / 2) * HH + hs) * HW + wl) * PITCH + (lane >> 5) * 16;
         auto a_const = [](int mf) { return (((mf >> 1) * HH + (mf & 1) * 2) * HW) * PITCH; };
         const uint4* wp = (const uint4*)p.wp;
-        const int ntile0 = blockIdx.y * BN32 + wn * NF;
+        const int ntile0 = by * BN32 + wn * NF;
         const size_t wstep = (size_t)p.ntiles * 64;
         float* scr = (float*)(scr_base + wave * PcCfg<MF, NF>::SCR_BYTES);
         constexpr int SROW = PcCfg<MF, NF>::SCR_ROW;
@@ -704,7 +715,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pc_kernel(IgemmParams p) {
                 for (int o = CGW; o < 64; o <<= 1) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
             }
             const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, 0x7FFFFFFF, 0x00020000);
-            const uint32_t poff = (lane < CGW && cok) ? (uint32_t)(((((size_t)n * gridDim.x + blockIdx.x) * WM + wm) * p.Cout + col0) * 8) : 0xFFFFFFFFu;
+            const uint32_t poff = (lane < CGW && cok) ? (uint32_t)(((((size_t)n * gridDim.x + bx) * WM + wm) * p.Cout + col0) * 8) : 0xFFFFFFFFu;
 #pragma unroll
             for (int q = 0; q < KP; q += 2) {
                 u32x4_t pv;
