@@ -746,15 +746,16 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         loss_r = {}
         # ---- report terms from their sums (volume loss :250-349, ball loss :1537-1864): one launch, nothing leaves the device
         if rest.shape[0] > 0:
-            roww = [1.0] * rest.shape[0]
-            cw_h = None if cw is None else cw.detach().float().cpu().numpy()      # (B, C) class weights: a batch input, not on the device's critical path
+            # class weight of every row = cw[sample, channel] of the term the row belongs to: the (sample, channel) pairs are host knowledge, the gather runs on
+            # the device (no device -> host read of the weights: that was a pipeline drain on every head of every step when class weights are given)
+            R = rest.shape[0]
+            row_b, row_c = [0] * R, [0] * R
             ti = 0
             flags = rvol = None
             if use_vol and L > 0:
-                if cw_h is not None:
-                    for li, c in enumerate(chs):
-                        for b in range(B):
-                            roww[li * B + b] = float(cw_h[b, c])
+                for li, c in enumerate(chs):
+                    for b in range(B):
+                        row_b[li * B + b], row_c[li * B + b] = b, c
                 ti += L * B
                 if pre is not None and 'flags' in pre:
                     flags, rvol = pre['flags'], pre['rvol']               # computed before the forward pass (prepare_report_supervision)
@@ -765,17 +766,19 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
                 for p in plans:
                     if p.kind == 'none':                                  # :1625-1661
                         plan_l += [0, ti]
-                        if cw_h is not None:
-                            for li, c in enumerate(chs):
-                                roww[ti + li] = float(cw_h[p.b, c])
+                        for li, c in enumerate(chs):
+                            row_b[ti + li], row_c[ti + li] = p.b, c
                         ti += L
                     else:
                         plan_l += [1, ti]
-                        if cw_h is not None:
-                            roww[ti] = float(cw_h[p.b, p.c])
+                        row_b[ti], row_c[ti] = p.b, p.c
                         ti += 1
-            assert ti == rest.shape[0]
-            roww_d = torch.tensor(roww, dtype=torch.float32).to(rest.device, non_blocking=True)
+            assert ti == R
+            if cw is None:
+                roww_d = torch.ones(R, dtype=torch.float32, device=rest.device)
+            else:
+                bc = torch.tensor([row_b, row_c], dtype=torch.int64).to(rest.device, non_blocking=True)
+                roww_d = cw.detach().float()[bc[0], bc[1]].contiguous()
             plan_d = torch.tensor(plan_l, dtype=torch.int32).to(rest.device, non_blocking=True) if plan_l else None
             lb, ld, lv = _ReportFromSums.apply(rest, roww_d, plan_d, None if flags is None else flags.contiguous().float(),
                                                None if rvol is None else rvol.contiguous().float().view(-1), B, max(L, 1), V, use_vol and L > 0,
