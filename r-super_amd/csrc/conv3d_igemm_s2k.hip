@@ -65,8 +65,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_s2k_kernel(IgemmParams p, int FD,
     const void* const wpk = p.wp; void* const outp = p.out; float* const partp = p.part;
     char* bufs = smem;                                                  // 2 x HB
     float4* ntab = (float4*)(smem + 2 * HB);                            // [Ca / 2] (sc0, sc1, nb0, nb1)
-    float* sacc = (float*)(smem + 2 * HB + Ca * 8);                     // [wave][32][sum, sum2]
-    char* scr_base = (char*)(sacc + NW * 64);
+    char* scr_base = smem + 2 * HB + Ca * 8;
     uint4* dtab = (uint4*)(scr_base + NW * SCR_BYTES);                  // tile descriptors of this block
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,7 +88,6 @@ __global__ __launch_bounds__(NT, 2) void igemm_s2k_kernel(IgemmParams p, int FD,
         const float* m = mra + ((size_t)n * Ca + 2 * i) * 2;
         ntab[i] = make_float4(m[1], m[3], -m[0] * m[1], -m[2] * m[3]);
     }
-    for (int i = tid; i < NW * 64; i += NT) sacc[i] = 0.f;
     {
         // entry k = k-th tile of this block, XCD-aware order (linear workgroup id b runs on XCD b % 8; every XCD gets a contiguous run of tiles):
         // (voxel of the staged origin (2 d0 - 1, 2 h0 - 1, 2 w0 - 1), ~valid lines << 4 | ~valid column 32 << 13 | bit 31, ~valid columns 0..31, d0 | h0 << 10 | w0 << 20);
@@ -207,7 +205,6 @@ __global__ __launch_bounds__(NT, 2) void igemm_s2k_kernel(IgemmParams p, int FD,
     row_to_hw_nt(er0, rhs[0], rw_[0]);
     row_to_hw_nt(er0 + 16, rhs[1], rw_[1]);
     float* scr = (float*)(scr_base + wave * SCR_BYTES);
-    float* sw = sacc + wave * 64;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(outp, 0, nvox_out * (uint32_t)ldo * 2u, 0x00020000);
 
     f32x16_t acc[TD];
@@ -378,7 +375,6 @@ __global__ __launch_bounds__(NT, 2) void igemm_s2k_kernel(IgemmParams p, int FD,
             }
         }
     }
-    (void)sw;
     };
     if (wave >= 4) run(std::true_type{});
     else run(std::false_type{});
@@ -403,7 +399,7 @@ int launch_s2k(const IgemmParams& p, int FD, int FH, int FW, hipStream_t st) {
     const int tiles = s2k_tiles(NCF, p.D, p.H, p.W);
     const int gy = (p.ntiles + NCF - 1) / NCF;
     const int gx = s2k_grid_x(tiles, gy, p.N);
-    const size_t smem = 2 * (size_t)G::HB + (size_t)p.a.C * 8 + NW * 256 + NW * (size_t)SCR_BYTES + ((tiles + gx - 1) / gx + 4) * 16;
+    const size_t smem = 2 * (size_t)G::HB + (size_t)p.a.C * 8 + NW * (size_t)SCR_BYTES + ((tiles + gx - 1) / gx + 4) * 16;
     if (smem > 160 * 1024) return RS_ERR_UNSUPPORTED;
     auto k = igemm_s2k_kernel<NCF>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -424,7 +420,7 @@ bool rs_igemm_s2k_supported(const IgemmParams& p, int dtype, int FD, int FH, int
     const int gy = (p.ntiles + ncf - 1) / ncf;
     const int gx = s2k_grid_x(tiles, gy, p.N);
     const size_t hb = ncf == 4 ? Geo<4>::HB : Geo<8>::HB;
-    return 2 * hb + (size_t)p.a.C * 8 + NW * 256 + NW * (size_t)SCR_BYTES + ((tiles + gx - 1) / gx + 4) * 16 <= 160 * 1024;
+    return 2 * hb + (size_t)p.a.C * 8 + NW * (size_t)SCR_BYTES + ((tiles + gx - 1) / gx + 4) * 16 <= 160 * 1024;
 }
 
 int rs_igemm_s2k_part_rows(int ntiles, int n_cols, int N, int D, int H, int W) {
