@@ -55,7 +55,7 @@ for N, S, Ca, Cout in [(2, 96, 32, 64), (1, 47, 64, 128), (2, 48, 64, 128), (2, 
     dy = float((ya - yb).abs().max()) / scale
     dp = float((pa - pb).abs().max() / pb.abs().max())
     gf = 2.0 * N * ((S + 1) // 2) ** 3 * 2 * Cout * Ca * 27 / 1e9
-    line = f'N {N} S {S:3d} {Ca:3d} -> 2 x {Cout:3d}: rows {ra:4d} / {rb:4d}  new {ta:7.1f} us ({gf / ta * 1e-3:6.1f} TF)  old {tb:7.1f} us ({gf / tb * 1e-3:6.1f} TF)  out max diff {dy:.2e} of max  stats diff {dp:.2e}'
+    line = f'N {N} S {S:3d} {Ca:3d} -> 2 x {Cout:3d}: rows {ra:4d} / {rb:4d}  new {ta:7.1f} us ({gf / ta * 1e3:6.1f} TF)  old {tb:7.1f} us ({gf / tb * 1e3:6.1f} TF)  out max diff {dy:.2e} of max  stats diff {dp:.2e}'
     if ref is not None:
         ea = float((ya.double() - ref).abs().max()) / scale
         eb = float((yb.double() - ref).abs().max()) / scale
@@ -104,7 +104,7 @@ for N, S, Cin, Cout in [(2, 96, 32, 64), (1, 47, 64, 128), (2, 48, 64, 128), (2,
     dy = float((ya - yb).abs().max()) / scale
     dp = float((pa - pb).abs().max() / pb.abs().max())
     gf = 2.0 * N * ((S + 1) // 2) ** 3 * 2 * Cout * Cin * 27 / 1e9
-    line = f'dgrad N {N} S {S:3d} 2 x {Cout:3d} -> {Cin:3d}: rows {ra:4d} / {rb:4d}  new {ta:7.1f} us ({gf / ta * 1e-3:6.1f} TF)  old {tb:7.1f} us ({gf / tb * 1e-3:6.1f} TF)  out max diff {dy:.2e} of max  sums diff {dp:.2e}'
+    line = f'dgrad N {N} S {S:3d} 2 x {Cout:3d} -> {Cin:3d}: rows {ra:4d} / {rb:4d}  new {ta:7.1f} us ({gf / ta * 1e3:6.1f} TF)  old {tb:7.1f} us ({gf / tb * 1e3:6.1f} TF)  out max diff {dy:.2e} of max  sums diff {dp:.2e}'
     if ref is not None:
         ea = float((ya.double() - ref).abs().max()) / scale
         eb = float((yb.double() - ref).abs().max()) / scale
