@@ -546,9 +546,17 @@ int rs_wgrad_config(int dtype, int Mtot, int tiles_total) {
     return (dtype == RS_BF16 && tiles_total >= 128) ? 2 : 1;
 }
 
+// 64-row weight gradients with too few tiles for 64-row blocks of the second-generation kernel (the 64 -> 64 layers at 48^3: 864 tiles / 128 splits) run it
+// as two 32-row blocks per chunk: half the splits, 13.5 tiles per block -- 64 -> 64 @48^3 72.5 -> 67.7 us (tools/bench_conv.py, same box).  RSUPER_WG2_MT1=0: off (A/B).
+bool rs_wgrad2_mt1(int dtype, int Mtot, int tiles_total) {
+    static const int on = getenv("RSUPER_WG2_MT1") ? atoi(getenv("RSUPER_WG2_MT1")) : 1;
+    return on && dtype == RS_BF16 && Mtot == 64 && tiles_total >= 512 && tiles_total < 2048;
+}
+
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total) {
     const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);
-    const int gy = cfg == 0 ? 1 : (cfg == 1 ? 3 : 1) * ((Mtot + 63) / 64);
+    int gy = cfg == 0 ? 1 : (cfg == 1 ? 3 : 1) * ((Mtot + 63) / 64);
+    if (rs_wgrad2_mt1(dtype, Mtot, tiles_total)) gy = 2;          // 64 rows as two 32-row blocks on the second-generation kernel (twice the tiles per block)
     const int target = cfg == 1 ? 512 : 256;                     // resident blocks on 256 CUs
     int s = target / (nch * gy > 0 ? nch * gy : 1);
     if (s > tiles_total) s = tiles_total;

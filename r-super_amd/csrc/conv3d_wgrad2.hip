@@ -451,6 +451,8 @@ int rs_launch_wgrad2(const WgradParams& p, hipStream_t st) {
 #ifndef WG2_BD
 #define WG2_BD 2
 #endif
-    if (p.xa.mr) return Mtot <= 32 ? launch2<1, WG2_BD, true>(p, st) : launch2<2, WG2_BD, true>(p, st);
-    return Mtot <= 32 ? launch2<1, WG2_BD, false>(p, st) : launch2<2, WG2_BD, false>(p, st);
+    const int tiles = p.N * ((p.D + TD - 1) / TD) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    const bool mt1 = Mtot <= 32 || rs_wgrad2_mt1(RS_BF16, Mtot, tiles);
+    if (p.xa.mr) return mt1 ? launch2<1, WG2_BD, true>(p, st) : launch2<2, WG2_BD, true>(p, st);
+    return mt1 ? launch2<1, WG2_BD, false>(p, st) : launch2<2, WG2_BD, false>(p, st);
 }

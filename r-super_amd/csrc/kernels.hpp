@@ -92,6 +92,7 @@ struct ReduceBatch {
     unsigned blocks;
 };
 int rs_launch_wgrad_reduce_batch(ReduceBatch& b, hipStream_t st);
+bool rs_wgrad2_mt1(int dtype, int Mtot, int tiles_total);
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total);
 // small-volume weight gradient (conv3d_wgrad_sv.hip): a depth slab of one sample whole in LDS, flat-voxel reduction; splits = 0: does not apply
 int rs_wgrad_sv_splits(int dtype, int Mtot, int Ya, int nch, int N, int D, int H, int W);

@@ -1337,7 +1337,9 @@ def all_checks(quick=False):
     # small volumes as the UNet has them (12^3 with 2 depth parts, 6^3 whole, ragged, two x / dY sources, channel tails): csrc/conv3d_wgrad_sv.hip by default
     cs += [(check_conv_bwd, ('bf16', 2, (12, 12, 12), 64, 0, 64, False)), (check_conv_bwd, ('bf16', 2, (12, 12, 12), 32, 64, 32, True)),
            (check_conv_bwd, ('bf16', 1, (11, 9, 13), 40, 0, 24, True)), (check_wgrad_sliced_dy, (2, (12, 12, 12), 64, 64, 6)),
-           (check_wgrad_xhat, (2, (12, 12, 12), 96, 32, 64, 32, 12)), (check_wgrad_xhat, (4, (6, 6, 6), 64, 0, 96, 0, 13))]
+           (check_wgrad_xhat, (2, (12, 12, 12), 96, 32, 64, 32, 12)), (check_wgrad_xhat, (4, (6, 6, 6), 64, 0, 96, 0, 13)),
+           # 64 rows at 576 tiles: the second-generation kernel as two 32-row blocks per chunk (rs_wgrad2_mt1), one and two dY sources
+           (check_wgrad_xhat, (2, (32, 48, 48), 64, 0, 64, 0, 14)), (check_wgrad_sliced_dy, (2, (32, 48, 48), 32, 32, 7))]
     cs += [(with_wgrad2, (check_conv_bwd, 'bf16', 2, (16, 16, 64), 32, 32, 64, True)), (with_wgrad2, (check_conv_bwd, 'bf16', 1, (16, 32, 64), 64, 0, 64, False)),
            (with_wgrad2, (check_conv_bwd, 'bf16', 2, (24, 24, 48), 32, 0, 32, False)),
            (check_wgrad_sliced_dy, (1, (23, 23, 23), 64, 128)), (with_wgrad2, (check_wgrad_sliced_dy, 1, (23, 23, 23), 64, 128)),
