@@ -86,8 +86,11 @@ int rsuper_conv3_box_bn(int dtype, int N, int D, int H, int W, int n_cols);
 /* The wide full-resolution layers (more than 32 columns, enough 4x8x16-voxel tiles for one persistent block per CU: up4.0 / the 96^3 level at
  * batch 2) run the depth-reuse kernel (conv3d_igemm_kd.hip: an activation fragment feeds the three kd taps, 0.5 / NF LDS fragment reads per MFMA):
  * returns the block width (64 forward; 64 / 96 / 128 data gradient) rsuper_conv3_igemm(dtype, epi, ..., n_cols, bn, N, D, H, W) takes that kernel
- * with -- pack the weights and size `part` with that bn -- else 0. */
-int rsuper_conv3_kd_bn(int dtype, int epi, int N, int D, int H, int W, int n_cols);
+ * with -- pack the weights and size `part` with that bn -- else 0.
+ * src_flags bit 0: the launch has two sources of which exactly ONE carries (mean, rstd) (mra == NULL xor mrb == NULL): the depth-reuse kernel stages
+ * both sources the same way and does not take such a launch -- the query returns 0 and rsuper_conv3_igemm keeps the kernel that bn gets elsewhere.
+ * rsuper_conv3_igemm derives the bit from its own arguments; pass the same value to this query and to rsuper_conv3_part_rows. */
+int rsuper_conv3_kd_bn(int dtype, int epi, int N, int D, int H, int W, int n_cols, int src_flags);
 
 /* Volumes of at most 6x6x6 voxels (the 6^3 bottleneck level: model/dim3/unet.py:53, four poolings of a 96^3 patch) run one box
  * per sample with the REDUCTION (32-channel chunks) split over blocks: each block writes its raw f32 tile to a workspace and a
@@ -99,8 +102,9 @@ int rsuper_conv3_set_workspace(void* ptr, size_t bytes);
 size_t rsuper_conv3_workspace_bytes(void);
 
 /* Rows per sample of the `part` buffer rsuper_conv3_igemm(dtype, epi, ..., n_cols, bn, N, D, H, W) writes under the
- * current variant (classic: one row per tile; producer/consumer: one row per (persistent block, consumer wave row)). */
-int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn);
+ * current variant (classic: one row per tile; producer/consumer: one row per (persistent block, consumer wave row)).
+ * src_flags: as for rsuper_conv3_kd_bn (bit 0: one normalised + one raw source). */
+int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn, int src_flags);
 
 /* Implicit-GEMM convolution.  epi 0: forward  y = conv(prologue(x)) [+ res]; part <- per-tile (sum, sumsq) of y.
  *                             epi 1: data gradient g = conv(dy, flipped w) * [x_hat > 0]; part <- (sum g, sum g*x_n),

@@ -179,8 +179,9 @@ static int box_for(int dtype, int bn, int N, int D, int H, int W, int n_cols) {
 // tiles (the full-resolution level at batch 2: 3456 tiles; RSUPER_KD_MIN_TILES).  A pure function of (dtype, epi, shape, columns) so that the block width
 // (rsuper_conv3_kd_bn -> pick_bn), the partial-row count and the launch agree.  Forward launches (normalised sources, staging with arithmetic in registers)
 // take 64-column blocks; data-gradient launches (raw dY) 64 / 96 / 128.  Variant 8 forces it wherever its limits allow (tests).
-static int kd_bn_for(int dtype, int epi, int N, int D, int H, int W, int n_cols) {
+static int kd_bn_for(int dtype, int epi, int N, int D, int H, int W, int n_cols, int src_flags) {
     if (dtype != RS_BF16 || n_cols <= 32) return 0;
+    if (src_flags & 1) return 0;        // one normalised and one raw source: the depth-reuse kernel stages both sources the same way (rs_igemm_kd_supported)
     static const int off = getenv("RSUPER_KD") ? atoi(getenv("RSUPER_KD")) == 0 : 0;
     static const int min_tiles = getenv("RSUPER_KD_MIN_TILES") ? atoi(getenv("RSUPER_KD_MIN_TILES")) : 400;
     static const int dgrad = getenv("RSUPER_KD_DGRAD") ? atoi(getenv("RSUPER_KD_DGRAD")) : 0;
@@ -202,9 +203,9 @@ static int kd_bn_for(int dtype, int epi, int N, int D, int H, int W, int n_cols)
     const int r = n_cols % 128;
     return (n_cols > 128 || r == 0) ? 128 : r > 96 ? 128 : r > 64 ? 96 : 64;
 }
-int rsuper_conv3_kd_bn(int dtype, int epi, int N, int D, int H, int W, int n_cols) {
+int rsuper_conv3_kd_bn(int dtype, int epi, int N, int D, int H, int W, int n_cols, int src_flags) {
     if (!dt_ok(dtype) || (epi != 0 && epi != 1) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || n_cols <= 0) return 0;
-    return kd_bn_for(dtype, epi, N, D, H, W, n_cols);
+    return kd_bn_for(dtype, epi, N, D, H, W, n_cols, src_flags);
 }
 
 int rsuper_conv3_set_workspace(void* ptr, size_t bytes) {
@@ -218,8 +219,8 @@ int rsuper_conv3_box_bn(int dtype, int N, int D, int H, int W, int n_cols) {
     return cfg == 3 ? 32 : cfg ? 64 : 0;
 }
 
-int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn) {
-    if (bn == kd_bn_for(dtype, epi, N, D, H, W, n_cols)) return rs_igemm_kd_part_rows(bn, N, D, H, W, n_cols);
+int rsuper_conv3_part_rows(int dtype, int epi, int N, int D, int H, int W, int n_cols, int bn, int src_flags) {
+    if (bn == kd_bn_for(dtype, epi, N, D, H, W, n_cols, src_flags)) return rs_igemm_kd_part_rows(bn, N, D, H, W, n_cols);
     if (const int cfg = box_for(dtype, bn, N, D, H, W, n_cols)) return rs_box_part_rows(cfg, D, H, W);
     return rs_igemm_part_rows(bn, use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0, rsuper_conv3_tiles(D, H, W), n_cols, N);
 }
@@ -320,7 +321,10 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
         if (!g_ws || boxc_ws_need(p.nsplit, N, D, H, W, n_cols) > g_ws_bytes) return RS_ERR_ARG;      // never write past the registered workspace
     }
     p.pc = use_pc(dtype, epi, bn, N * rsuper_conv3_tiles(D, H, W)) ? 1 : 0;
-    if (bn == kd_bn_for(dtype, epi, N, D, H, W, n_cols)) { p.pc = 3; p.box = 0; }
+    // the depth-reuse kernel is selected from the shape AND the sources of this launch: a launch it cannot take (one normalised + one raw
+    // source) keeps the kernel the same bn gets everywhere else, and rsuper_conv3_part_rows(..., src_flags = 1) sizes `part` for that kernel
+    const int src_flags = (Cb > 0 && (mra != nullptr) != (mrb != nullptr)) ? 1 : 0;
+    if (bn == kd_bn_for(dtype, epi, N, D, H, W, n_cols, src_flags)) { p.pc = 3; p.box = 0; }
     else if (bn == 96) return RS_ERR_UNSUPPORTED;                  // 96-column blocks exist on the depth-reuse kernel only
     if (p.pc && bn == 32 && (g_variant == 4 || (g_variant == 3 && (Ca + 31) / 32 + (Cb + 31) / 32 == 1))) p.pc = 2;
     return rs_launch_igemm(p, dtype, epi, ST(stream));

@@ -381,7 +381,7 @@ bool rs_igemm_s2d_supported(const IgemmParams& p, int dtype, int FD, int FH, int
     if (dtype != RS_BF16 || p.a.mr || p.b.mr || !p.ea.mr || !p.ea.x) return false;
     if ((p.a.C % 16) || (p.b.C % 16) || p.a.C < 16) return false;
     if (p.D > 1020 || p.H > 1020 || p.W > 4000) return false;
-    if ((unsigned long long)p.N * p.D * p.H * p.W >= (1ull << 24)) return false;     // __umul24 of the voxel index
+    if ((unsigned long long)p.N * FD * FH * FW >= (1ull << 24)) return false;     // __umul24 of the voxel index: the data gradient writes and masks on the FULL grid
     const int tiles = s2d_tiles(p.D, p.H, p.W), gy = (p.Cout + 31) / 32;
     return s2d_smem(tiles, s2d_grid_x(tiles, gy, p.N)) <= 160 * 1024 && gy <= p.ntiles;
 }

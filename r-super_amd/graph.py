@@ -32,6 +32,7 @@ import torch.nn as nn
 from .hip import ops
 from .train_ddp import train_step
 from .training import losses_foundation as lf
+from .training.dataset.packed import PackedBits
 from .training.utils import FusedAdamWEMA, ema_alpha_for_step
 
 
@@ -126,6 +127,13 @@ class GraphedTrainStep:
         else:
             for k, v in batch.items():
                 dst = self.static[k]
+                if isinstance(dst, PackedBits) != isinstance(v, PackedBits):
+                    raise ValueError(f'batch entry {k!r} changed form (bit-packed vs uint8) after the capture')
+                if isinstance(v, PackedBits):        # the bit-packed label of segmentation-only batches (dataset/packed.py): the graph reads dst.packed
+                    if dst.C != v.C:
+                        raise ValueError(f'batch entry {k!r} changed its class count: {v.C} vs captured {dst.C}')
+                    dst._u8 = None                   # an inflated copy made outside the graph (self-verification) belongs to the previous batch
+                    dst, v = dst.packed, v.packed
                 if dst.shape != v.shape or dst.dtype != v.dtype:
                     raise ValueError(f'batch entry {k!r} changed shape / dtype: {tuple(v.shape)} {v.dtype} vs captured {tuple(dst.shape)} {dst.dtype}')
                 dst.copy_(v, non_blocking=True)
@@ -207,7 +215,7 @@ class GraphedTrainStep:
 
     def _capture(self, batch, step):
         dev = next(self.net.parameters()).device
-        self.static = {k: v.to(dev).clone() for k, v in batch.items()}
+        self.static = {k: (PackedBits(v.packed.to(dev).clone(), v.C) if isinstance(v, PackedBits) else v.to(dev).clone()) for k, v in batch.items()}
         self.dyn = torch.zeros(4, device=dev, dtype=torch.float32)
         self.dyn.copy_(torch.tensor(self._scalars(step), dtype=torch.float32))
         sanity = lf.SANITY_CHECKS

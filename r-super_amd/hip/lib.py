@@ -24,11 +24,11 @@ _SIGS = {
     'rsuper_conv3_variant': (c_int, [c_int]),
     'rsuper_conv3_wgrad2_min_tiles': (c_int, [c_int]),
     'rsuper_conv3_box_bn': (c_int, [c_int] * 6),
-    'rsuper_conv3_kd_bn': (c_int, [c_int] * 7),
+    'rsuper_conv3_kd_bn': (c_int, [c_int] * 8),
     'rsuper_conv3_set_workspace': (c_int, [P, c_size_t]),
     'rsuper_conv3_workspace_bytes': (c_size_t, []),
     'rsuper_conv3_wgrad_splits': (c_int, [c_int] * 9),
-    'rsuper_conv3_part_rows': (c_int, [c_int] * 8),
+    'rsuper_conv3_part_rows': (c_int, [c_int] * 9),
     'rsuper_conv3_s2_part_rows': (c_int, [c_int] * 9),
     'rsuper_conv3_igemm_s2': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, P, P]),
     'rsuper_conv3_igemm': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,

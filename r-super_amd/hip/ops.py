@@ -55,17 +55,18 @@ def _L():
     return L
 
 
-def pick_bn(n_cols, dtype, tiles_total=None, dims=None, epi=None):
+def pick_bn(n_cols, dtype, tiles_total=None, dims=None, epi=None, mixed=False):
     """Block N tile of the implicit GEMM (32/64/128 output columns); f32 parity mode is limited to 64.
     tiles_total (spatial tiles x batch): on small volumes prefer the largest tile that still yields >= 512 workgroups
     (24^3 and below would otherwise leave most of the 256 CUs idle; the narrower tiles also run on the persistent kernel).
     dims = (N, D, H, W): launches the library would hand to the volume-fitted K-split kernel (rsuper_conv3_box_bn: low-resolution
     levels that cannot fill the chip with 4x4x16 tiles) take its 64-column blocks.
     epi (0 forward, 1 data gradient; with dims): launches the library hands to the depth-reuse kernel (rsuper_conv3_kd_bn: the wide full-resolution
-    layers) take its 64 / 96 / 128-column blocks."""
+    layers) take its 64 / 96 / 128-column blocks.  mixed: the launch has one normalised and one raw source (the depth-reuse kernel does not take those;
+    pass the same flag to part_buffer)."""
     cands = (32, 64) if dtype == torch.float32 else (32, 64, 128)
     if dims is not None and epi is not None and dtype != torch.float32:
-        bn = _L().rsuper_conv3_kd_bn(_DT[dtype], epi, *dims, n_cols)
+        bn = _L().rsuper_conv3_kd_bn(_DT[dtype], epi, *dims, n_cols, 1 if mixed else 0)
         if bn:
             return bn
     if dtype != torch.float32 and dims is None and _L().rsuper_conv3_variant(-1) in (6, 7):
@@ -100,10 +101,10 @@ def _chk_act(x):
     assert x.dim() == 5 and x.is_contiguous() and x.dtype in _DT and x.shape[-1] % 8 == 0, (x.shape, x.dtype, x.is_contiguous())
 
 
-def part_buffer(dtype, dims, n_cols, bn, device, fill=None, epi=0):
+def part_buffer(dtype, dims, n_cols, bn, device, fill=None, epi=0, mixed=False):
     """Per-block partial-sum buffer (N, rows, n_cols, 2) in the shape rsuper_conv3_igemm(epi, ...) writes for this dtype/bn."""
     N, D, H, W = dims
-    rows = _L().rsuper_conv3_part_rows(_DT[dtype], epi, N, D, H, W, n_cols, bn)
+    rows = _L().rsuper_conv3_part_rows(_DT[dtype], epi, N, D, H, W, n_cols, bn, 1 if mixed else 0)
     if fill is None:
         return torch.empty((N, rows, n_cols, 2), device=device, dtype=torch.float32)
     return torch.full((N, rows, n_cols, 2), fill, device=device, dtype=torch.float32)

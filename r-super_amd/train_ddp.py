@@ -271,7 +271,10 @@ def train_epoch(trainLoader, net, ema_net, optimizer, epoch, writer, scaler, arg
                 fwd_net = optimizer._graphed_net = GraphedNetwork(net)
     # the reference's guards as device flags (StepGuard); RSUPER_ASYNC_GUARDS=0: synchronise where the reference does.  Replayed steps keep the host-side
     # NaN test below (their loss code is not re-run)
-    guard = StepGuard(dev) if (lf.SANITY_CHECKS and stepper is None and dev.type == 'cuda' and os.environ.get('RSUPER_ASYNC_GUARDS', '1') == '1') else None
+    # Only with the fused optimiser: its kernel skips the update of a step whose gradient norm is not finite (csrc/optim.hip), which is what makes reading the
+    # flags one step late safe.  Any other optimiser keeps the reference's synchronous checks (the NaN loss raises BEFORE backward, losses_foundation.py:1070).
+    guard = StepGuard(dev) if (lf.SANITY_CHECKS and stepper is None and dev.type == 'cuda' and isinstance(optimizer, FusedAdamWEMA)
+                               and os.environ.get('RSUPER_ASYNC_GUARDS', '1') == '1') else None
     lf.GUARD = guard
     try:
         return _train_epoch_loop(trainLoader, net, ema_net, optimizer, epoch, writer, args, matcher, guard, stepper, fwd_net, dev, classes, packed, start)
@@ -512,9 +515,18 @@ def init_network(args, classes=None, old_classes=None):
     if update and old_classes is None:
         raise ValueError('--update_output_layer needs --old_classes')
     from .model.utils import get_model
-    c = old_classes if (update and getattr(args, 'pretrained', None) is None) else classes
+    src = getattr(args, 'pretrained', None)
+    if update and not src and getattr(args, 'resume', False):
+        update = False       # a resumed run: `latest` was saved after the surgery and already holds the new-class heads (train_net loads it)
+    c = old_classes if update else classes
     net = get_model(args, pretrain=args.pretrain, classes=c)
     if update:
+        # the old-class weights have to be IN the network before its heads are rebuilt (the reference's get_model(pretrain=True) loads args.pretrained before
+        # update_output_layer_onk, medformer.py:224-319): --pretrained FILE is loaded here.  Without it the surgery would copy rows of a freshly initialised
+        # head -- refuse that instead of doing it silently.
+        if not src:
+            raise ValueError('--update_output_layer rebuilds the heads of a TRAINED old-class network: name its checkpoint with --pretrained FILE')
+        load_checkpoint(src, net)
         if not hasattr(net, 'aux_loss'):
             raise NotImplementedError('--update_output_layer rewires MedFormer heads (model/dim3/medformer.py:224)')
         from .model.dim3.medformer import update_output_layer_onk

@@ -23,8 +23,11 @@ class SyntheticUFODataset(data.Dataset):
     indices report-only samples (lesion label 0, unknown / segment mask = the organ, 1-3 tumours with diameters and volumes),
     the 50/50 source balance of the reference loader (:192-202)."""
 
-    def __init__(self, classes, size=96, length=64, seed=0):
+    def __init__(self, classes, size=96, length=64, seed=0, packed=False):
         self.classes, self.S, self.length, self.seed = list(classes), int(size), int(length), int(seed)
+        # packed: label / unk_channels / mask leave as np.packbits(axis = class), the form AugmentedCropDataset(packed=True) yields (train_epoch then
+        # inflates them on the device or hands the packed label to the loss kernels, dataset/packed.py)
+        self.packed = bool(packed)
         self.img_list = list(range(self.length))
         self.lesion = [i for i, c in enumerate(self.classes) if 'lesion' in c]
         self.organ = {}
@@ -63,6 +66,8 @@ class SyntheticUFODataset(data.Dataset):
                     d = float(g.uniform(5.0, 40.0))
                     diameters[t] = (d, 0.8 * d, 0.7 * d)
                     volumes[t] = (4.0 / 3.0) * math.pi * (d / 2.0) ** 3
+        if self.packed:
+            label, unk, mask = (np.packbits(v.astype(np.bool_), axis=0) for v in (label, unk, mask))
         return {'image': torch.from_numpy(img), 'label': torch.from_numpy(label), 'unk_channels': torch.from_numpy(unk),
                 'volumes': torch.from_numpy(volumes), 'mask': torch.from_numpy(mask), 'diameters': torch.from_numpy(diameters),
                 'name': f'synthetic_{idx:05d}'}

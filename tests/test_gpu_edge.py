@@ -1116,6 +1116,32 @@ def test_train_epoch_with_hip_graph_matches_eager(tmp_path, report):
 
 
 @pytest.mark.gpu
+def test_train_epoch_with_hip_graph_on_a_packed_dataset_matches_eager(tmp_path):
+    """--hip_graph on a dataset that yields bit-packed volumes (AugmentedCropDataset(packed=True), here the synthetic stand-in): with segmentation-only
+    supervision train_epoch keeps the label a PackedBits, and the captured step must hold it in a static packed buffer (the capture used to call
+    .to / .clone on it).  Same meters and final weights as the eager driver on the same packed dataset, and as the eager driver on the unpacked one."""
+    import os
+    from rsuper_amd.train_ddp import get_parser, main_worker
+    from rsuper_amd.training.dataset import SyntheticUFODataset
+    classes = ['kidney_left', 'kidney_right', 'liver', 'pancreas', 'pancreatic_lesion']
+    out = {}
+    for tag, extra, packed in (('plain', [], False), ('eager', [], True), ('graph', ['--hip_graph'], True)):
+        ds = SyntheticUFODataset(classes, size=32, length=16, seed=3, packed=packed)
+        args = get_parser(['--epochs', '2', '--batch_size', '2', '--cp_path', str(tmp_path) + '/', '--unique_name', tag, '--loss', 'ball_dice_last',
+                           '--report_volume_loss_basic', '0'] + extra)
+        args.base_chan, args.iter_per_epoch, args.print_freq, args.compute_dtype = 8, 4, 100, 'bf16'
+        torch.manual_seed(0)
+        hist = main_worker(0, 1, 0, args, trainset=ds)
+        ck = torch.load(os.path.join(str(tmp_path), 'abdomenatlas_ufo', tag, 'fold_0_latest.pth'), map_location='cpu', weights_only=False)
+        sd = ck['model_state_dict']
+        out[tag] = (hist, sd.state_dict() if hasattr(sd, 'state_dict') else sd)
+    drop = lambda h: [{k: v for k, v in e.items() if k != 'Elapsed Time'} for e in h]
+    for tag in ('eager', 'graph'):
+        assert drop(out['plain'][0]) == drop(out[tag][0]), (tag, out['plain'][0], out[tag][0])
+        assert all(torch.equal(out['plain'][1][k], out[tag][1][k]) for k in out['plain'][1]), tag
+
+
+@pytest.mark.gpu
 def test_dispatcher_ops_forward_only_and_autograd_paths_agree():
     """rsuper::maxpool2 / rsuper::head_conv through the dispatcher: the AutogradCUDA kernel (forward + autograd node) and the CUDA kernel
     alone (inference_mode skips the autograd key) give identical results, and gradients flow through the registered op."""
