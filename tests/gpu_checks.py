@@ -125,6 +125,34 @@ def check_conv_fwd(mode, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, nor
                   max(e1, e2 * (0.1 if mode == 'bf16' else 1.0)), tol, f'out {e1:.2e} stats {e2:.2e}')
 
 
+def check_conv_mixed_sources(N, S, Ca, Cb, Cout, seed=0):
+    """bf16 forward with ONE normalised source (a) and ONE raw source (b) at a shape the default dispatch hands to the depth-reuse kernel when both sources are
+    of one kind (>= 400 tiles of 4x8x16, 33..64 columns): that kernel stages both sources the same way and does not take such a launch -- query
+    (pick_bn / part_buffer with mixed=True, i.e. src_flags bit 0) and launch must agree on the ordinary kernel instead of failing (api.hip)."""
+    from rsuper_amd.hip import ops
+    dt = torch.bfloat16
+    D, H, W = S
+    dims = (N, D, H, W)
+    xa = rnd(_rng_t(seed + 1, (N, Ca, D, H, W)) + 0.3, 'bf16')
+    xb = rnd(torch.relu(_rng_t(seed + 2, (N, Cb, D, H, W)) * 1.5 - 0.2), 'bf16')
+    w1 = _rng_t(seed + 3, (Cout, Ca + Cb, 3, 3, 3), 1.0 / math.sqrt(27 * (Ca + Cb)))
+    xh = torch.cat([F.relu(uo.instance_norm(xa)).bfloat16().float(), xb], 1)
+    ref = F.conv3d(xh, rnd(w1, 'bf16'), padding=1)
+    from rsuper_amd.hip import lib as _lib
+    assert _lib.lib().rsuper_conv3_kd_bn(ops._DT[dt], 0, N, D, H, W, Cout, 0) == 64, 'pick a shape the depth-reuse kernel takes with uniform sources'
+    bn = ops.pick_bn(Cout, dt, dims=dims, epi=0, mixed=True)
+    wp = ops.pack_weights(dt, 0, w1.to(DEV), None, Ca, Cb, Cout, 0, bn)
+    out = torch.full((N, D, H, W, Cout), float('nan'), device=DEV, dtype=dt)
+    part = ops.part_buffer(dt, dims, Cout, bn, DEV, fill=float('nan'), mixed=True)
+    ops.igemm(0, ops.Src(to_cl(xa, dt), mr=stats_ref(xa).to(DEV)), ops.Src(to_cl(xb, dt)), wp, Cout, bn, dims, out, part=part)
+    mr = ops.stats_finalize(part, D * H * W)
+    torch.cuda.synchronize()
+    e1 = relerr(from_cl(out), ref)
+    mr_ref = stats_ref(rnd(ref, 'bf16'))
+    e2 = relerr(mr.cpu()[..., 0], mr_ref[..., 0]) + relerr(mr.cpu()[..., 1], mr_ref[..., 1])
+    return result(f'conv_mixed_sources[bf16 N{N} S{S} {Ca}n+{Cb}raw->{Cout}]', max(e1, e2), TOL['bf16'], f'out {e1:.2e} stats {e2:.2e} bn {bn}')
+
+
 def _block_ref(mode, xa, xb, w1, ws, dy1, dys):
     """Reference for the fused conv1(+shortcut) data/weight gradients on x_hat = relu(IN(x))."""
     x = (xa if xb is None else torch.cat([xa, xb], 1)).clone().requires_grad_(True)
@@ -262,14 +290,31 @@ def check_conv_exact(kind, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, n
         sb = ops.Src(to_cl(xb, dt), mr=mrb.to(DEV)) if xb is not None else None
         ops.igemm(1, ops.Src(to_cl(dys[0], dt)), ops.Src(to_cl(dys[1], dt)) if fused_sc else None, wp, nc, bn, dims, out, part=part, ea=sa, eb=sb)
         K = 27 * Cout * len(wd)
+    fin = ops.stats_finalize(part, D * H * W, mode=0 if kind == 'fwd' else 1)
     torch.cuda.synchronize()
     got = from_cl(out).double()
     bound = 2.0 ** -8 * ref.abs() + (K / 8 + 4) * 2.0 ** -24 * mag + 1e-30
     ratio = ((got - ref).abs() / bound)
     ratio = torch.where(torch.isfinite(ratio), ratio, torch.full_like(ratio, float('inf')))
     same = (got == ref.float().bfloat16().double()).double().mean().item()   # elements equal to the correctly rounded float64 result
-    return result(f'conv_exact[{kind} N{N} S{S} {Ca}+{Cb}->{Cout} sc{int(fused_sc)} res{int(residual)} norm{int(norm)}]', ratio.max().item(), 1.0,
-                  f'max |got-ref| / (1 bf16 rounding + f32 slack) {ratio.max().item():.3f}; == bf16(float64 result) on {same:.4f} of the elements; bn {bn}')
+    # The rows the launch emits for the NEXT kernel (what the one-rounding check did not cover): the statistics the consumer normalises
+    # with (forward: mean, rstd) / the InstanceNorm-backward sums (data gradient: mean g, mean g x_n), against float64 sums over the tensor the launch
+    # WROTE (the bf16 values a consumer reads).  A kernel may sum its f32 accumulators before rounding: that moves a mean by ~ 2^-9 rms / sqrt(voxels),
+    # two orders below the bound used here (1e-4 of the column's rms / of rstd); one dropped or doubled partial row of a few hundred is >= 1e-3.
+    fin = fin.cpu().double()
+    cnt = D * H * W
+    if kind == 'fwd':
+        mean = got.mean(dim=(2, 3, 4)); var = (got * got).mean(dim=(2, 3, 4)) - mean * mean
+        rms = (got * got).mean(dim=(2, 3, 4)).sqrt().clamp_min(1e-30)
+        e_s = max(((fin[..., 0] - mean).abs() / rms).max().item(), (fin[..., 1] * torch.sqrt(var.clamp_min(0) + 1e-4) - 1.0).abs().max().item())
+    else:
+        xn = (x.double() - mr[:, :, 0].double()[:, :, None, None, None]) * mr[:, :, 1].double()[:, :, None, None, None]
+        rms = (got * got).mean(dim=(2, 3, 4)).sqrt().clamp_min(1e-30)
+        e_s = max(((fin[..., 0] - got.mean(dim=(2, 3, 4))).abs() / rms).max().item(), ((fin[..., 1] - (got * xn).mean(dim=(2, 3, 4))).abs() / rms).max().item())
+    e_s = e_s if math.isfinite(e_s) else float('inf')
+    return result(f'conv_exact[{kind} N{N} S{S} {Ca}+{Cb}->{Cout} sc{int(fused_sc)} res{int(residual)} norm{int(norm)}]', max(ratio.max().item(), e_s / 1e-4), 1.0,
+                  f'max |got-ref| / (1 bf16 rounding + f32 slack) {ratio.max().item():.3f}; == bf16(float64 result) on {same:.4f} of the elements; '
+                  f'emitted rows vs float64 sums of the written tensor {e_s:.1e} (bound 1e-4); bn {bn}')
 
 
 def check_wgrad_xhat(N, S, Ca, Cb, Ya, Yb, seed=0):
@@ -1372,6 +1417,11 @@ def all_checks(quick=False):
              ('dgrad', 2, (12, 12, 12), 128, 0, 128, False, False, True, 6), ('dgrad', 1, (5, 6, 7), 8, 16, 8, True), ('dgrad', 2, (9, 17, 33), 32, 64, 32, True, False, True, 7),
              ('dgrad', 1, (12, 20, 48), 128, 64, 64, True, False, True, 8)]
     cs += [(check_conv_exact, a) for a in exact]
+    cs += [(check_conv_mixed_sources, (2, (32, 64, 64), 32, 32, 64))]
+    # the shapes the depth-reuse kernel takes under the DEFAULT dispatch (>= 400 tiles of 4x8x16: 432 / 512 tiles on 256 persistent blocks, so a block's
+    # statistics registers run over several tiles): 64 -> 64 @48^3 with residual, an up-block head 64 + 32 -> 32 + shortcut
+    cs += [(check_conv_exact, ('fwd', 2, (48, 48, 48), 64, 0, 64, False, True, True, 9)), (check_conv_exact, ('fwd', 2, (32, 64, 64), 64, 32, 32, True, False, True, 10)),
+           (check_conv_exact, ('dgrad', 2, (32, 64, 64), 64, 32, 32, True, False, True, 11))]
     for variant in (0, 1, 4, 6, 7, 8):
         cs += [(with_variant, (variant, check_conv_exact) + a) for a in exact]
     cs += [(with_variant, (1, check_conv_fwd, 'bf16', 2, (8, 24, 32), 32, 0, 32, False, True)),       # persistent: several tiles per block

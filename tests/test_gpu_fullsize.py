@@ -326,12 +326,13 @@ def test_graphed_step_full_size_56_steps_identical_to_eager():
     assert r.returncode == 0 and 'identical over 56 steps' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
-@pytest.mark.parametrize('which,cos_min,l2_max', [('unet', 0.95, 0.20), ('medformer', 0.82, 0.25)])
+@pytest.mark.parametrize('which,cos_min,l2_max', [('unet', 0.965, 0.16), ('medformer', 0.82, 0.25)])
 def test_bf16_gradients_of_the_real_loss_align_with_f32(which, cos_min, l2_max):
     """The benchmarked arithmetic (bf16 conv stages) against the parity arithmetic (exact-f32 MFMA) on the REAL objective at full size (B = 2,
     96^3, 26 classes, segmentation loss, identical initial weights and batch): the loss agrees to 1e-3, the logits to `l2_max` relative L2 and
     the parameter gradients point the same way -- cosine of all gradients together (measured: UNet 0.973, MedFormer 0.884; per-tensor medians
-    0.948 / 0.881).  A statement about the whole bf16 network that random-output-gradient probes on tiny, ill-conditioned nets cannot make
+    0.948 / 0.881; UNet identical to four digits in rounds 4, 5 and 6: profiles/r06_grad_bf16_vs_f32_head_vs_r04.txt -- THE deterministic, chaos-free
+    statement about the bf16 kernels; the UNet bounds sit 0.8 % / 9 % from the measured values).  A statement about the whole bf16 network that random-output-gradient probes on tiny, ill-conditioned nets cannot make
     (there both modes are 0.6-1.0 apart in relative L2: tools/medformer_bf16_vs_f32.py)."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -342,6 +343,44 @@ def test_bf16_gradients_of_the_real_loss_align_with_f32(which, cos_min, l2_max):
     lf32, lbf, l2, gl2, cos = (float(v) for v in m.groups())
     assert abs(lf32 - lbf) <= 1e-3 * abs(lf32), line
     assert l2 <= l2_max and cos >= cos_min, line
+
+
+def _drift_runs(mode, seeds, steps, extra=()):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'drift.py'), '--mode', mode, '--steps', str(steps), '--seeds', ','.join(map(str, seeds))] + list(extra),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    return [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_bf16_training_tracks_f32_over_an_ensemble_of_seeds():
+    """VERDICT r05 item 1 (the 35-step bf16-vs-f32 loss gap of bench.py's secondary leg went 0.0024 -> 0.0457 between rounds 4 and 5).  Measured in round 6
+    (profiles/r06_drift_bisect.txt, r06_drift_ensemble.txt, r06_grad_bf16_vs_f32_head_vs_r04.txt): that gap is a property of the TRAJECTORY, not of a kernel --
+    pure summation-order commits move it by +-0.03, a 1e-6 relative perturbation of the initial weights moves the f32 trajectory itself by 0.004 .. 0.028 at
+    step 35, and over six (initial weights, batch) seeds the round-4 tree and this tree have the same distribution (mean -0.006 / +0.0002, sd 0.033 / 0.030 at
+    step 35; both signs).  So the regression statement is made over the ensemble: the MEAN signed gap at step 35 over six seeds is zero within its standard
+    error (0.03 / sqrt(6) = 0.012; bound 0.04), no single run strays further than 0.12, and every run of either mode decreases the loss by >= 45 %."""
+    seeds = [0, 1, 2, 3, 4, 5]
+    f32 = {r['seed']: r['loss'] for r in _drift_runs('f32', seeds, 35)}
+    b16 = {r['seed']: r['loss'] for r in _drift_runs('bf16', seeds, 35)}
+    d = [b16[s][-1] - f32[s][-1] for s in seeds]
+    mean = sum(d) / len(d)
+    assert abs(mean) <= 0.04, (mean, d)
+    assert max(abs(v) for v in d) <= 0.12, d
+    for s in seeds:
+        assert b16[s][-1] < 0.55 * b16[s][0] and f32[s][-1] < 0.55 * f32[s][0], (s, b16[s][0], b16[s][-1], f32[s][0], f32[s][-1])
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_training_is_bit_reproducible_across_processes(mode):
+    """two SEPARATE processes give bit-identical loss curves at full size (B = 2, 96^3, 26 classes; 12 optimiser steps each,
+    f32 and bf16).  (The differing 70-step f32 losses of the round-5 evidence runs came from different commits: the same tree printed 0.35382044315338135
+    in three processes on two boxes in round 6, profiles/r06_drift_bisect.txt.)  Every reduction on the path has a fixed order; the one float atomic
+    (csrc/loss.hip plane sums, f64) feeds an f32 rounding whose input would have to sit within 1e-16 relative of a tie to notice the order."""
+    a = _drift_runs(mode, [0], 12)[0]['loss']
+    b = _drift_runs(mode, [0], 12)[0]['loss']
+    assert a == b, (a, b)
 
 
 @pytest.mark.parametrize('tag', synth.FULLSIZE_REPORT_CASES)
