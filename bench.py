@@ -146,10 +146,15 @@ class Leg:
         self.opt = FusedAdamWEMA(self.net.parameters(), lr=6e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.05)
         kinds = (['mask', 'report'] * B)[:B] if report else ['mask'] * B
         bt = synth.batch(B, S, classes, kinds, seed=7 + rank + seed, diam_range=(5.0, 40.0), max_tumors=3)
+        if getattr(args, 'unpacked_labels', False):      # A/B: the three volumes as uint8 planes (rounds 1-5)
+            vols = dict(label=torch.from_numpy(bt['label']).to(dev), unk_channels=torch.from_numpy(bt['unk_channels']).to(dev), mask=torch.from_numpy(bt['mask']).to(dev))
+        else:
+            # the dataset's own storage form (np.packbits over the class axis, dataset_abdomenatlas_UFO.py:955,970,975) resident in HBM: what
+            # train_epoch hands calculate_loss (dataset/packed.py ingest_packed_batch(keep_packed=True)); the loss kernels read the bits
+            from rsuper_amd.training.dataset import pack_bits, PackedBits
+            vols = {k: PackedBits(torch.from_numpy(pack_bits(bt[k])).to(dev), len(classes)) for k in ('label', 'unk_channels', 'mask')}
         self.batch = dict(image=torch.from_numpy(synth.image(B, S, seed=1234 + rank + seed)).to(dev),
-                          label=torch.from_numpy(bt['label']).to(dev), unk_channels=torch.from_numpy(bt['unk_channels']).to(dev),
-                          mask=torch.from_numpy(bt['mask']).to(dev), volumes=torch.from_numpy(bt['volumes']).to(dev),
-                          diameters=torch.from_numpy(bt['diameters']).to(dev))
+                          volumes=torch.from_numpy(bt['volumes']).to(dev), diameters=torch.from_numpy(bt['diameters']).to(dev), **vols)
         self.largs = loss_args(report)
         self.classes = classes
         self.step = 0
@@ -420,6 +425,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--guards', type=int, default=1, help="1: the reference's per-step guards run inside the timed region as device-side flags (default); 0: off")
     ap.add_argument('--no-secondary', action='store_true', help='skip the config-3 / f32 / bf16-vs-f32 legs')
+    ap.add_argument('--unpacked-labels', action='store_true', help='A/B: label / unknown / segment volumes as uint8 planes instead of the bit-packed storage form')
     ap.add_argument('--roofline-steps', type=int, default=10, help='steps of the separate HIP-event pass after the timed region')
     ap.add_argument('--secondary-only', action='store_true', help='(internal) run only the secondary legs and print their JSON')
     ap.add_argument('--force-ddp', action='store_true', help='wrap in the data-parallel reducer even with one rank (exercises the RCCL path)')
@@ -498,6 +504,7 @@ def main():
                                    f'(fwd + {"seg+Volume+Ball" if args.report else "masked BCE + Dice"} loss + bwd + clip + AdamW + EMA), '
                                    f'{S}^3 patches, batch {B}/GPU (BASELINE.json configs[{2 if args.report else 1}])' + (' -- VARIANT pool=False (strided down blocks)' if args.no_pool else ''),
                        'global_batch': world * B, 'patch': S, 'parallelism': f'dp{world}', 'final_loss': loss_val,
+                       'label_volumes': 'uint8 planes' if args.unpacked_labels else 'bit-packed (np.packbits over classes, the dataset storage form), read packed by the loss kernels',
                        'sanity_checks_in_timed_region': bool(args.guards),
                        'sanity_checks_form': 'device-side flags read one step late (train_ddp.StepGuard)' if args.guards else 'off'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,

@@ -434,6 +434,15 @@ int rsuper_mask_op(uint8_t* a, const uint8_t* b, long V, int op /*0 and, 1 or, 2
  * segment volumes the dataset stores with np.packbits(axis=0) -- training/dataset/dim3/dataset_abdomenatlas_UFO.py:955,
  * 970,975 (pack), :1031-1034 (unpack).  packed: [B][P = ceil(C/8)][V] bytes (MSB = lowest class), out: [B][C][V] 0/1. */
 int rsuper_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, void* stream);
+/* The report losses read only a few planes of a bit-packed volume ("loss kernels should read the packed u8 directly"; losses_foundation.py:286-297,
+ * 1571-1605 index the lesion channels of label / unknown / segment mask): plane (b, c) of out[B][C][V] is written iff flags[b * C + c] != 0 or force[c] != 0
+ * (flags: [B * C] device bytes or NULL, force: [C] device bytes or NULL; both NULL = rsuper_unpack_bits); the other planes are left untouched, byte planes
+ * without a wanted class are not read. */
+int rsuper_unpack_bits_sel(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, const uint8_t* flags, const uint8_t* force, void* stream);
+/* flags[b * C + c] = any(class c of sample b) from the packed bytes (OR over byte plane (b, c >> 3), bit 7 - (c & 7)): rsuper_plane_any on the inflated volume
+ * at 1/8 of the bytes.  packed 16-byte aligned, V % 16 == 0.  Use: the kflags of rsuper_plane_partials_*2 / the flags of rsuper_dilate_volume_sparse for the
+ * unknown-voxel map (get_known_voxels, losses_foundation.py:150-165), the mask / unknown consistency guard (:864-869). */
+int rsuper_plane_any_bits(const uint8_t* packed, int B, int P, int C, long V, uint8_t* flags, void* stream);
 int rsuper_zero_where(float* x, const uint8_t* m, long V, void* stream);
 int rsuper_count(const uint8_t* m, long V, unsigned int* count, void* stream);
 

@@ -760,6 +760,14 @@ int rsuper_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C,
     if (!packed || !out || B <= 0 || P <= 0 || C <= 0 || C > 8 * P || V <= 0) return RS_ERR_ARG;
     return rs_launch_unpack_bits(packed, out, B, P, C, V, ST(stream));
 }
+int rsuper_unpack_bits_sel(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, const uint8_t* flags, const uint8_t* force, void* stream) {
+    if (!packed || !out || B <= 0 || P <= 0 || C <= 0 || C > 8 * P || V <= 0) return RS_ERR_ARG;
+    return rs_launch_unpack_bits_sel(packed, out, B, P, C, V, flags, force, ST(stream));
+}
+int rsuper_plane_any_bits(const uint8_t* packed, int B, int P, int C, long V, uint8_t* flags, void* stream) {
+    if (!packed || !flags || B <= 0 || P <= 0 || C <= 0 || C > 8 * P || V <= 0 || ((uintptr_t)packed & 15) || (V & 15)) return RS_ERR_ARG;
+    return rs_launch_plane_any_bits(packed, B, P, C, V, flags, ST(stream));
+}
 int rsuper_guard_consistency(const uint8_t* m_any, const uint8_t* u_any, const float* volumes, int B, int T, int* flags, void* stream) {
     if (!m_any || !u_any || !volumes || !flags || B <= 0 || T <= 0) return RS_ERR_ARG;
     return rs_launch_guard_consistency(m_any, u_any, volumes, B, T, flags, ST(stream));

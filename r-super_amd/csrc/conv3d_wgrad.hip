@@ -550,13 +550,15 @@ int rs_wgrad_config(int dtype, int Mtot, int tiles_total) {
 // as two 32-row blocks per chunk: half the splits, 13.5 tiles per block -- 64 -> 64 @48^3 72.5 -> 67.7 us (tools/bench_conv.py, same box).  RSUPER_WG2_MT1=0: off (A/B).
 bool rs_wgrad2_mt1(int dtype, int Mtot, int tiles_total) {
     static const int on = getenv("RSUPER_WG2_MT1") ? atoi(getenv("RSUPER_WG2_MT1")) : 1;
-    return on && dtype == RS_BF16 && Mtot == 64 && tiles_total >= 512 && tiles_total < 2048;
+    static const int maxm = getenv("RSUPER_WG2_MT1_MAXM") ? atoi(getenv("RSUPER_WG2_MT1_MAXM")) : 64;                // experiment knobs (tools/wg_mt1_exp.sh)
+    static const int mint = getenv("RSUPER_WG2_MT1_MIN_TILES") ? atoi(getenv("RSUPER_WG2_MT1_MIN_TILES")) : 512;
+    return on && dtype == RS_BF16 && Mtot >= 64 && Mtot <= maxm && (Mtot % 32) == 0 && tiles_total >= mint && tiles_total < 2048;
 }
 
 int rs_wgrad_splits(int dtype, int Mtot, int nch, int tiles_total) {
     const int cfg = rs_wgrad_config(dtype, Mtot, tiles_total);
     int gy = cfg == 0 ? 1 : (cfg == 1 ? 3 : 1) * ((Mtot + 63) / 64);
-    if (rs_wgrad2_mt1(dtype, Mtot, tiles_total)) gy = 2;          // 64 rows as two 32-row blocks on the second-generation kernel (twice the tiles per block)
+    if (rs_wgrad2_mt1(dtype, Mtot, tiles_total)) gy = Mtot / 32;  // 32-row blocks on the second-generation kernel (twice the tiles per block, half the slab bytes)
     const int target = cfg == 1 ? 512 : 256;                     // resident blocks on 256 CUs
     int s = target / (nch * gy > 0 ? nch * gy : 1);
     if (s > tiles_total) s = tiles_total;

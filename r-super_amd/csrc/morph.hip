@@ -786,6 +786,89 @@ int rs_launch_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int
     return rs_check_launch();
 }
 
+__global__ void plane_flags_zero_kernel(uint8_t* flags, long planes);
+
+// The same inflation for SOME class planes only: plane (b, c) is written iff flags[b * C + c] != 0 or force[c] != 0 (either table may be null; both null = every
+// plane).  A byte plane none of whose eight classes is wanted is not read.  What the report losses need of a bit-packed volume: the lesion channels (force) and,
+// of the unknown map, the planes that hold a voxel at all (flags from plane_any_bits_kernel) -- the other planes of `out` are never written and never read.
+__global__ __launch_bounds__(256) void unpack_bits_sel_kernel(const uint8_t* __restrict__ packed, uint8_t* __restrict__ out, int P, int C, long V,
+                                                              const uint8_t* __restrict__ flags, const uint8_t* __restrict__ force) {
+    const long nvec = (V + 15) / 16;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int pl = blockIdx.y % P, b = blockIdx.y / P;
+    unsigned want = 0;                                           // wave-uniform (depends on the block's plane only)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = pl * 8 + k;
+        if (c < C && ((flags && flags[(size_t)b * C + c]) || (force && force[c]) || (!flags && !force))) want |= 1u << k;
+    }
+    if (!want || t >= nvec) return;
+    const uint8_t* src = packed + ((size_t)b * P + pl) * V;
+    const long v0 = t * 16;
+    const bool full = v0 + 16 <= V && (V & 15) == 0;
+    uint8_t in[16];
+    if (full) *(uint4*)in = *(const uint4*)(src + v0);
+    else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) in[j] = v0 + j < V ? src[v0 + j] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (!((want >> k) & 1u)) continue;
+        const int c = pl * 8 + k;
+        uint8_t o[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = (in[j] >> (7 - k)) & 1;
+        uint8_t* dst = out + ((size_t)b * C + c) * V + v0;
+        if (full) *(uint4*)dst = *(const uint4*)o;
+        else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (v0 + j < V) dst[j] = o[j];
+        }
+    }
+}
+int rs_launch_unpack_bits_sel(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, const uint8_t* flags, const uint8_t* force, hipStream_t st) {
+    const long nvec = (V + 15) / 16;
+    hipLaunchKernelGGL(unpack_bits_sel_kernel, dim3((unsigned)((nvec + 255) / 256), (unsigned)(B * P)), dim3(256), 0, st, packed, out, P, C, V, flags, force);
+    return rs_check_launch();
+}
+
+// flags[b * C + c] = any voxel of class c of sample b set, straight from the packed bytes: the OR over byte plane (b, p) holds the eight class flags of that plane
+// (bit 7 - k = class 8 p + k).  1/8 of the bytes rsuper_plane_any reads on the inflated volume.  flags must be zeroed first (plane_flags_zero_kernel).
+__global__ __launch_bounds__(256) void plane_any_bits_kernel(const uint8_t* __restrict__ packed, int P, int C, long V, uint8_t* __restrict__ flags) {
+    const int pl = blockIdx.y % P, b = blockIdx.y / P;
+    const uint8_t* src = packed + (size_t)blockIdx.y * V;
+    const long nvec = V / 16;
+    unsigned int any = 0;
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        const uint4 a = ((const uint4*)src)[i], b4 = ((const uint4*)src)[i + stride], c = ((const uint4*)src)[i + 2 * stride], d = ((const uint4*)src)[i + 3 * stride];
+        any |= (a.x | a.y | a.z | a.w) | (b4.x | b4.y | b4.z | b4.w) | (c.x | c.y | c.z | c.w) | (d.x | d.y | d.z | d.w);
+    }
+    for (; i < nvec; i += stride) {
+        const uint4 q = ((const uint4*)src)[i];
+        any |= q.x | q.y | q.z | q.w;
+    }
+    if (blockIdx.x == 0) for (long j = nvec * 16 + threadIdx.x; j < V; j += 256) any |= src[j];
+    any |= any >> 16; any |= any >> 8; any &= 0xFFu;             // fold the four byte lanes of the word
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o, 64);
+    if (any && (threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (((any >> (7 - k)) & 1u) && pl * 8 + k < C) flags[(size_t)b * C + pl * 8 + k] = 1;
+    }
+}
+int rs_launch_plane_any_bits(const uint8_t* packed, int B, int P, int C, long V, uint8_t* flags, hipStream_t st) {
+    hipLaunchKernelGGL(plane_flags_zero_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, st, flags, (long)B * C);
+    long nb = (V / 16 + 255) / 256;
+    if (nb > 32) nb = 32;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(plane_any_bits_kernel, dim3((unsigned)nb, (unsigned)(B * P)), dim3(256), 0, st, packed, P, C, V, flags);
+    return rs_check_launch();
+}
+
 // any(plane) for `planes` byte volumes of V voxels each: flags[p] = 1 if the plane has a non-zero byte.  Replaces the ATen
 // `.flatten(1).any(1)` reductions of the loss' host control flow (150 us each on a 46 MB uint8 tensor) at HBM rate.
 __global__ __launch_bounds__(256) void plane_any_kernel(const uint8_t* __restrict__ m, long V, uint8_t* __restrict__ flags) {

@@ -18,6 +18,8 @@ int rs_launch_guard_range(const float* x, size_t n, float lo, float hi, int* fla
 int rs_launch_plane_any(const uint8_t* m, long planes, long V, uint8_t* flags, hipStream_t st);
 int rs_launch_mask_op(uint8_t* a, const uint8_t* b, long V, int op, hipStream_t st);
 int rs_launch_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, hipStream_t st);
+int rs_launch_unpack_bits_sel(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, const uint8_t* flags, const uint8_t* force, hipStream_t st);
+int rs_launch_plane_any_bits(const uint8_t* packed, int B, int P, int C, long V, uint8_t* flags, hipStream_t st);
 int rs_launch_zero_where(float* x, const uint8_t* m, long V, hipStream_t st);
 int rs_launch_count(const uint8_t* m, long V, unsigned int* count, hipStream_t st);
 int rs_launch_rank_assign(const long long* ids, unsigned int n, float dlog2, float scale, float* w, hipStream_t st);

@@ -132,7 +132,7 @@ class GraphedTrainStep:
                 if isinstance(v, PackedBits):        # the bit-packed label of segmentation-only batches (dataset/packed.py): the graph reads dst.packed
                     if dst.C != v.C:
                         raise ValueError(f'batch entry {k!r} changed its class count: {v.C} vs captured {dst.C}')
-                    dst._u8 = None                   # an inflated copy made outside the graph (self-verification) belongs to the previous batch
+                    dst.reset()                      # planes / flags inflated outside the graph (self-verification) belong to the previous batch
                     dst, v = dst.packed, v.packed
                 if dst.shape != v.shape or dst.dtype != v.dtype:
                     raise ValueError(f'batch entry {k!r} changed shape / dtype: {tuple(v.shape)} {v.dtype} vs captured {tuple(dst.shape)} {dst.dtype}')

@@ -1274,8 +1274,10 @@ def dilate_volume(vol_u8, kernel_size):
     return dilate_volume_flags(vol_u8, kernel_size)[0]
 
 
-def dilate_volume_flags(vol_u8, kernel_size):
-    """dilate_volume plus the per-volume any-flags of the INPUT (uint8, 0 = that volume and hence its dilation is all zero; None when not computed)."""
+def dilate_volume_flags(vol_u8, kernel_size, flags=None):
+    """dilate_volume plus the per-volume any-flags of the INPUT (uint8, 0 = that volume and hence its dilation is all zero; None when not computed).
+    flags given (e.g. PackedBits.class_flags(): taken from the packed bytes): used as they are -- volumes flagged 0 are not read at all, so they need not
+    even have been written (PackedBits.planes(..., with_flagged=True))."""
     v = vol_u8.contiguous()
     assert v.dtype == torch.uint8 and v.dim() >= 3
     D, H, W = v.shape[-3:]
@@ -1283,8 +1285,9 @@ def dilate_volume_flags(vol_u8, kernel_size):
     out = torch.empty_like(v)
     ks = kernel_size + 1 if kernel_size % 2 == 0 else kernel_size
     tmp = torch.empty_like(v) if ks > 7 else None
-    flags = None
-    if nvol > 1 and (D * H * W) % 16 == 0 and v.data_ptr() % 16 == 0:
+    if flags is not None:
+        assert flags.numel() == nvol and flags.dtype == torch.uint8
+    elif nvol > 1 and (D * H * W) % 16 == 0 and v.data_ptr() % 16 == 0:
         # one HBM-rate pass marks the volumes that are entirely zero (most label planes have no unknown / segment voxels);
         # the dilation passes write zeros for those without reading them
         flags = torch.empty(nvol, device=v.device, dtype=torch.uint8)

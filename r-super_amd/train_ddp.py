@@ -292,8 +292,9 @@ def _train_epoch_loop(trainLoader, net, ema_net, optimizer, epoch, writer, args,
         if 'weights' in inputs:
             batch['weights'] = inputs['weights'].float()
         if packed:      # bit-packed label volumes cross PCIe as stored and are inflated on the device (dataset/packed.py)
-            # segmentation-only supervision: the label never leaves its packed form (the loss kernels read the bits)
-            batch = ingest_packed_batch(batch, len(classes), dev, keep_label_packed=float(getattr(args, 'report_volume_loss_basic', 0.0)) == 0)
+            # the three volumes never leave their packed form: the loss kernels read the label bits, the report losses inflate the lesion planes they index
+            # and take the unknown map's plane flags from the packed bytes (calculate_loss) -- with and without report supervision
+            batch = ingest_packed_batch(batch, len(classes), dev, keep_packed=True)
         else:
             batch = {k: v.to(dev, non_blocking=True) for k, v in batch.items()}
         img = batch['image']

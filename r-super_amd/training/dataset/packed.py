@@ -37,6 +37,9 @@ def unpack_bits_device(packed, num_classes, stream=None):
     return out
 
 
+_FORCE = {}      # (C, channels, device) -> (C,) uint8 device table of the channels PackedBits.planes always inflates
+
+
 class PackedBits:
     """A label volume kept in the dataset's bit-packed form on the device: `packed` (B, P, D, H, W) uint8 as `np.packbits(axis = class)` wrote it, `C` classes.
     `calculate_loss` reads it directly in the segmentation term (csrc/loss.hip: the loss kernels extract bit 7 - (c & 7) of byte plane c >> 3; SURVEY 8f-2
@@ -47,7 +50,7 @@ class PackedBits:
         P = packed.shape[1]
         assert P * 8 >= num_classes and P * 8 < num_classes + 10, 'packed channel count does not match num_classes (:1032-1033)'
         self.packed, self.C = packed.contiguous(), int(num_classes)
-        self._u8 = None
+        self._u8, self._flags, self._planes = None, None, {}
 
     @property
     def shape(self):
@@ -57,21 +60,79 @@ class PackedBits:
     def device(self):
         return self.packed.device
 
+    @property
+    def is_cuda(self):
+        return self.packed.is_cuda
+
     def unpack(self):
         if self._u8 is None:
             self._u8 = unpack_bits_device(self.packed, self.C)
         return self._u8
 
+    # ---- what the report losses read of a volume without inflating it (csrc/morph.hip unpack_bits_sel / plane_any_bits) --------------------------------
+    def _force(self, chs):
+        key = tuple(int(c) for c in chs)
+        f = _FORCE.get((self.C, key, self.packed.device))
+        if f is None:
+            h = torch.zeros(self.C, dtype=torch.uint8)
+            h[list(key)] = 1
+            f = _FORCE[(self.C, key, self.packed.device)] = h.to(self.packed.device)
+        return f
 
-def ingest_packed_batch(sample, num_classes, device='cuda', keep_label_packed=False):
+    def class_flags(self):
+        """(B * C,) uint8 device flags: class c of sample b has a voxel (np.unpackbits(...)[c].any() from the packed bytes, 1/8 of the traffic)."""
+        if self._flags is None:
+            B, P = self.packed.shape[:2]
+            V = self.packed[0, 0].numel()
+            self._flags = torch.empty(B * self.C, device=self.packed.device, dtype=torch.uint8)
+            _l.check(_l.lib().rsuper_plane_any_bits(self.packed.data_ptr(), B, P, self.C, V, self._flags.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                     'plane_any_bits')
+        return self._flags
+
+    def planes(self, chs, with_flagged=False):
+        """uint8 (B, C, D, H, W) in which ONLY the planes of the channels `chs` (and, with_flagged, every plane that holds a voxel at all: class_flags) are
+        written -- the rest of the tensor is never read by its users (the report losses index the lesion channels; the dilated unknown map is consumed
+        through its flags).  Cached per (chs, with_flagged)."""
+        key = (tuple(int(c) for c in chs), bool(with_flagged))
+        t = self._planes.get(key)
+        if t is None:
+            B, P = self.packed.shape[:2]
+            V = self.packed[0, 0].numel()
+            t = torch.empty(tuple(self.shape), device=self.packed.device, dtype=torch.uint8)
+            fl = self.class_flags() if with_flagged else None
+            _l.check(_l.lib().rsuper_unpack_bits_sel(self.packed.data_ptr(), t.data_ptr(), B, P, self.C, V, fl.data_ptr() if fl is not None else None,
+                                                     self._force(chs).data_ptr(), torch.cuda.current_stream().cuda_stream), 'unpack_bits_sel')
+            self._planes[key] = t
+        return t
+
+    def sample_any(self, as_bool=True):
+        """(B,) any voxel of any class per sample (the `.any()` tests of calculate_loss :864-869) from the packed bytes."""
+        B = self.packed.shape[0]
+        n = self.packed[0].numel()
+        f = torch.empty(B, device=self.packed.device, dtype=torch.uint8)
+        if n % 16 == 0 and self.packed.data_ptr() % 16 == 0:
+            _l.check(_l.lib().rsuper_plane_any(self.packed.data_ptr(), B, n, f.data_ptr(), torch.cuda.current_stream().cuda_stream), 'plane_any')
+        else:
+            f = self.packed.flatten(1).any(1).to(torch.uint8)
+        return f.bool() if as_bool else f
+
+    def reset(self):
+        """Forget everything derived from `packed` (a hipGraph step copies the next batch into the same buffer)."""
+        self._u8, self._flags = None, None
+        self._planes.clear()
+
+
+def ingest_packed_batch(sample, num_classes, device='cuda', keep_label_packed=False, keep_packed=False):
     """sample: dict with 'image' (B,1,D,H,W) f32 and bit-packed uint8 'label', 'unk_channels', 'mask' (B,P,D,H,W), plus
     'volumes', 'diameters' [, 'weights'] as the dataset yields them.  Returns the device batch `train_step` takes, with the
-    three volumes as uint8 0/1 (B,C,D,H,W).  keep_label_packed (segmentation-only supervision): 'label' stays a `PackedBits` -- the loss kernels read the
-    bits (1/8 of the label bytes cross HBM, no inflated copy is written)."""
+    three volumes as uint8 0/1 (B,C,D,H,W).  keep_label_packed: 'label' stays a `PackedBits` -- the loss kernels read the
+    bits (1/8 of the label bytes cross HBM, no inflated copy is written).  keep_packed: all three volumes stay `PackedBits` (round 6): `calculate_loss`
+    reads the label bits in the segmentation term, inflates only the lesion planes the report losses index (`PackedBits.planes`) and takes the unknown
+    map's plane flags from the packed bytes -- with or without report supervision."""
     out = {}
     for k, v in sample.items():
         t = torch.as_tensor(v)
-        if k == 'label' and keep_label_packed:
+        if k in ('label', 'unk_channels', 'mask') and (keep_packed or (k == 'label' and keep_label_packed)):
             p = t.to(device, non_blocking=True)
             out[k] = PackedBits(p.unsqueeze(0) if p.dim() == 4 else p, num_classes)
         elif k in ('label', 'unk_channels', 'mask'):

@@ -36,6 +36,23 @@ def _u8(t):
     return (t != 0).to(torch.uint8).contiguous()
 
 
+def _is_packed(v):
+    from .dataset.packed import PackedBits
+    return isinstance(v, PackedBits)
+
+
+def _lesion_planes(v, chs):
+    """uint8 (B, C, D, H, W) view of a label / unknown / segment volume for the REPORT losses, which index the lesion channels `chs` only (:286-297,
+    :1571-1605): a tensor is taken as it is; of a bit-packed volume (dataset.packed.PackedBits) only those planes are inflated -- the other
+    planes of the returned tensor are never written and must not be read."""
+    return v.planes(chs) if _is_packed(v) else _u8(v)
+
+
+def _sample_any(v, as_bool=True):
+    """(B,) any() per sample of a uint8 tensor or a bit-packed volume."""
+    return v.sample_any(as_bool) if _is_packed(v) else _plane_any(v, 1, as_bool=as_bool)
+
+
 def lesion_channel_lists(classes):
     """get_lesion_channels (:204-221): lesion/cyst/pdac/pnet channels grouped per organ, in class order; every group is
     the list of channels the reference max-merges (:218-219)."""
@@ -479,6 +496,14 @@ def _volume_flags(label_u8, mseg31, tumor_volumes_report, chs):
     return flags, tumor_volumes_report.float().sum(-1, keepdim=True)
 
 
+def _unknown_planes(unk_voxels, chs):
+    """(uint8 planes, per-plane any-flags or None) of the unknown-voxel map: a tensor as it is (flags computed by the dilation); of a bit-packed map the
+    planes that hold a voxel at all plus the lesion planes, with the flags read from the packed bytes."""
+    if _is_packed(unk_voxels):
+        return unk_voxels.planes(chs, with_flagged=True), unk_voxels.class_flags()
+    return _u8(unk_voxels), None
+
+
 def prepare_report_supervision(label, unk_voxels, chosen_segment_mask, tumor_volumes_report, tumor_diameters, classes, args):
     """Call BEFORE the forward pass of a training step (train_ddp.train_step does): the batch-only inputs of the ball loss -- two dilations and
     three small host reads -- are queued ahead of the network, so that calculate_loss(pre=...) does not start with a blocking copy.  Without
@@ -495,9 +520,9 @@ def prepare_report_supervision(label, unk_voxels, chosen_segment_mask, tumor_vol
     chs = list(lesion_groups(classes).values())
     if not chs:
         return None
-    label_u8 = _u8(label)
-    unk_u8 = _u8(unk_voxels) if unk_voxels is not None else torch.zeros_like(label_u8)
-    mask_u8 = _u8(chosen_segment_mask)
+    label_u8 = _lesion_planes(label, chs)
+    unk_u8 = _unknown_planes(unk_voxels, chs)[0] if unk_voxels is not None else torch.zeros(tuple(label.shape), device=label.device, dtype=torch.uint8)
+    mask_u8 = _lesion_planes(chosen_segment_mask, chs)
     with torch.no_grad():
         pre = _ball_inputs(label_u8, unk_u8, mask_u8, tumor_volumes_report, tumor_diameters, chs, True)
         if 'both' in args.loss:                                             # the volume loss runs too: its dilated masks and (B, 2L + 1) flags
@@ -653,14 +678,14 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         raise NotImplementedError('model_genesis / clip_only / classification_branch / multi_ch_tumor are baselines outside '
                                   'the accelerated R-Super path (SURVEY.md section 2.1)')
     _l.require_device()
-    from .dataset.packed import PackedBits
     merged = any(len(v) > 1 for v in lesion_channel_lists(classes).values())
     label_pk = None
-    if isinstance(label, PackedBits):      # bit-packed label: read as such by the segmentation term; report supervision needs the uint8 planes
-        if float(args.report_volume_loss_basic) > 0 or merged:
-            label = label.unpack()
-        else:
-            label_pk = label
+    if merged:      # lesion groups spanning several channels merge whole tensors first (_calculate_loss_merged): inflate
+        label, unk_voxels, chosen_segment_mask = (v.unpack() if _is_packed(v) else v for v in (label, unk_voxels, chosen_segment_mask))
+    elif _is_packed(label):
+        # bit-packed label: the segmentation term reads the bits (rsuper_plane_partials_fwd2 / _bwd2); the report terms index the lesion channels only, of which
+        # _lesion_planes inflates the planes -- with or without report supervision nothing else of the volume is ever inflated
+        label_pk = label
     if merged:
         return _calculate_loss_merged(model_output, label, unk_voxels, args, matcher, chosen_segment_mask, tumor_volumes_report,
                                       tumor_diameters, classes, input_tensor, class_weights)
@@ -674,19 +699,25 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         label_u8, unk_u8, mask_u8 = pre['u8'][3:]                        # the tensors prepare_report_supervision keyed its results on
     else:
         pre = None
-        label_u8 = _u8(label) if label_pk is None else None
+        chs_ = list(lesion_groups(classes).values())
+        report_on = float(args.report_volume_loss_basic) > 0
+        label_u8 = _u8(label) if label_pk is None else (_lesion_planes(label, chs_) if report_on else None)
         zeros = lambda: torch.zeros(tuple(label.shape), device=label.device, dtype=torch.uint8)
-        unk_u8 = _u8(unk_voxels) if unk_voxels is not None else zeros()
-        mask_u8 = _u8(chosen_segment_mask) if chosen_segment_mask is not None else zeros()
+        unk_u8 = _unknown_planes(unk_voxels, chs_)[0] if unk_voxels is not None else zeros()
+        mask_u8 = (_lesion_planes(chosen_segment_mask, chs_) if (report_on or not _is_packed(chosen_segment_mask)) else None) \
+            if chosen_segment_mask is not None else zeros()
     D, H, W = label.shape[2:]
     V = D * H * W
 
+    # (the per-sample any() of a bit-packed volume comes from its packed bytes: the uint8 views above hold the lesion planes only)
+    m_src = chosen_segment_mask if _is_packed(chosen_segment_mask) else mask_u8
+    u_src = unk_voxels if _is_packed(unk_voxels) else unk_u8
     if SANITY_CHECKS and chosen_segment_mask is not None and GUARD is not None:      # :864-869 without the host round trips
-        GUARD.consistency(_plane_any(mask_u8, 1, as_bool=False), _plane_any(unk_u8, 1, as_bool=False), tumor_volumes_report)
+        GUARD.consistency(_sample_any(m_src, as_bool=False), _sample_any(u_src, as_bool=False), tumor_volumes_report)
     elif SANITY_CHECKS and chosen_segment_mask is not None:                # :864-869
-        m_any = _plane_any(mask_u8, 1).cpu()
+        m_any = _sample_any(m_src).cpu()
         if bool(m_any.any()):
-            u_any = _plane_any(unk_u8, 1).cpu()
+            u_any = _sample_any(u_src).cpu()
             v_any = (tumor_volumes_report.sum(1) != 0).cpu()
             for b in range(B):
                 if m_any[b] and not u_any[b]:
@@ -702,7 +733,8 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
         assert cw.shape == (B, C), f'Class weights should be (B, C), got {tuple(cw.shape)}'
 
     # :899 / get_known_voxels :150; known = 1 - unk5.  unk_any[b * C + c] = 0: that plane of the map has no unknown voxel at all (nor has its dilation)
-    unk5, unk_any = ops.dilate_volume_flags(unk_u8, 5) if unk_voxels is not None else (None, None)
+    unk5, unk_any = ops.dilate_volume_flags(unk_u8, 5, flags=unk_voxels.class_flags() if _is_packed(unk_voxels) else None) \
+        if unk_voxels is not None else (None, None)
     groups = lesion_groups(classes)
     chs = list(groups.values())
     L = len(chs)
@@ -721,7 +753,7 @@ def calculate_loss(model_output, label, unk_voxels, args, matcher, chosen_segmen
             if deep:
                 use_ball = use_ball and not (j != 0 and 'last' in args.loss)        # :924
             use_vol = (not use_ball) or ('both' in args.loss)
-        terms = [_Term(0, V, B * C, t=label_u8, k=unk5, kinv=True, kflags=unk_any, tpk=label_pk)]
+        terms = [_Term(0, V, B * C, t=None if label_pk is not None else label_u8, k=unk5, kinv=True, kflags=unk_any, tpk=label_pk)]
         if use_vol and L > 0:
             if mseg31 is None:
                 mseg31 = pre['mseg31'] if pre is not None and 'mseg31' in pre else \

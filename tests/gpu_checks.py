@@ -317,6 +317,73 @@ def check_conv_exact(kind, N, S, Ca, Cb, Cout, fused_sc=False, residual=False, n
                   f'emitted rows vs float64 sums of the written tensor {e_s:.1e} (bound 1e-4); bn {bn}')
 
 
+def check_conv_exact_s2(kind, N, S, Ca, Cout, seed=0, kernel='1'):
+    """The stride-2 [conv1 | shortcut] GEMM of BasicBlock(stride=2) (unet_utils.py:38-39) -- persistent strided forward `s2k` / data gradient `s2d` (kernel='1',
+    the default) or the parity-class kernel (kernel='0') -- held to the ABSOLUTE bound check_conv_exact uses (round 5 only compared the two
+    kernels with each other): float64 F.conv3d(stride=2) / conv_transpose3d(stride=2) on exactly the bf16 operands, one bf16 rounding of the result + f32
+    accumulation slack per element, and the emitted statistics / InstanceNorm-backward rows against float64 sums of the written tensor at 1e-4."""
+    from rsuper_amd.hip import ops
+    dt = torch.bfloat16
+    D, H, W = S
+    OD, OH, OW = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    dims = (N, D, H, W)
+    xa = (_rng_t(seed + 1, (N, Ca, D, H, W)) * 1.5 + 0.3).bfloat16().float()
+    mra = stats_ref(xa)
+    w1 = _rng_t(seed + 3, (Cout, Ca, 3, 3, 3), 1.0 / math.sqrt(27 * Ca))
+    ws = _rng_t(seed + 4, (Cout, Ca, 3, 3, 3), 1.0 / math.sqrt(27 * Ca))
+    wcat = torch.cat([w1, ws], 0).bfloat16().double()
+    old = {k: os.environ.get(k) for k in ('RSUPER_S2K', 'RSUPER_S2D')}
+    os.environ['RSUPER_S2K'] = os.environ['RSUPER_S2D'] = kernel
+    try:
+        sa = ops.Src(to_cl(xa, dt), mr=mra.to(DEV))
+        if kind == 'fwd':
+            xh = _xhat_bf16(xa, mra)
+            ref = F.conv3d(xh, wcat, stride=2, padding=1)
+            mag = F.conv3d(xh.abs(), wcat.abs(), stride=2, padding=1)
+            nc, cnt, K = 2 * Cout, OD * OH * OW, 27 * Ca
+            wp = ops.pack_weights(dt, 0, w1.to(DEV), ws.to(DEV), Ca, 0, Cout, Cout, 64)
+            out = torch.full((N, OD, OH, OW, nc), float('nan'), device=DEV, dtype=dt)
+            part = torch.full((N, ops._L().rsuper_conv3_s2_part_rows(ops._DT[dt], 1, Ca, 0, nc, N, D, H, W), nc, 2), float('nan'), device=DEV, dtype=torch.float32)
+            ops.igemm_s2(1, sa, None, wp, nc, dims, out, part)
+            fin = ops.stats_finalize(part, cnt)
+        else:
+            dy = _rng_t(seed + 6, (N, 2 * Cout, OD, OH, OW)).bfloat16().float()
+            opad = (1 - D % 2, 1 - H % 2, 1 - W % 2)
+            ref = F.conv_transpose3d(dy.double(), wcat, stride=2, padding=1, output_padding=opad)
+            mag = F.conv_transpose3d(dy.double().abs(), wcat.abs(), stride=2, padding=1, output_padding=opad)
+            mask = (xa > mra[:, :, 0].float()[:, :, None, None, None]).double()
+            ref, mag = ref * mask, mag * mask
+            nc, cnt, K = Ca, D * H * W, 27 * 2 * Cout
+            wp = ops.pack_weights(dt, 1, w1.to(DEV), ws.to(DEV), Cout, Cout, Ca, 0, 64)
+            out = torch.full((N, D, H, W, Ca), float('nan'), device=DEV, dtype=dt)
+            part = torch.full((N, ops._L().rsuper_conv3_s2_part_rows(ops._DT[dt], 2, Cout, Cout, Ca, N, D, H, W), Ca, 2), float('nan'), device=DEV, dtype=torch.float32)
+            dcl = to_cl(dy, dt)
+            ops.igemm_s2(2, ops.Src(dcl, C=Cout), ops.Src(dcl, C=Cout, off=Cout), wp, Ca, dims, out, part, ea=sa)
+            fin = ops.stats_finalize(part, cnt, mode=1)
+        torch.cuda.synchronize()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    got = from_cl(out).double()
+    bound = 2.0 ** -8 * ref.abs() + (K / 8 + 4) * 2.0 ** -24 * mag + 1e-30
+    ratio = (got - ref).abs() / bound
+    ratio = torch.where(torch.isfinite(ratio), ratio, torch.full_like(ratio, float('inf')))
+    fin = fin.cpu().double()
+    rms = (got * got).mean(dim=(2, 3, 4)).sqrt().clamp_min(1e-30)
+    if kind == 'fwd':
+        mean = got.mean(dim=(2, 3, 4)); var = (got * got).mean(dim=(2, 3, 4)) - mean * mean
+        e_s = max(((fin[..., 0] - mean).abs() / rms).max().item(), (fin[..., 1] * torch.sqrt(var.clamp_min(0) + 1e-4) - 1.0).abs().max().item())
+    else:
+        xn = (xa.double() - mra[:, :, 0].double()[:, :, None, None, None]) * mra[:, :, 1].double()[:, :, None, None, None]
+        e_s = max(((fin[..., 0] - got.mean(dim=(2, 3, 4))).abs() / rms).max().item(), ((fin[..., 1] - (got * xn).mean(dim=(2, 3, 4))).abs() / rms).max().item())
+    e_s = e_s if math.isfinite(e_s) else float('inf')
+    return result(f'conv_exact_s2[{kind} kernel{kernel} N{N} S{S} {Ca}->2x{Cout}]', max(ratio.max().item(), e_s / 1e-4), 1.0,
+                  f'max |got-ref| / (1 bf16 rounding + f32 slack) {ratio.max().item():.3f}; emitted rows vs float64 sums of the written tensor {e_s:.1e} (bound 1e-4)')
+
+
 def check_wgrad_xhat(N, S, Ca, Cb, Ya, Yb, seed=0):
     """Weight gradient on PRE-NORMALISED bf16 sources (no statistics: csrc/conv3d_wgrad_dma.hip, operands by LDS-DMA) against the float64
     gradient of F.conv3d on exactly the bf16 operands the kernel sees -- f32 accumulation is the only difference, hence the tight bound."""
@@ -1418,6 +1485,10 @@ def all_checks(quick=False):
              ('dgrad', 1, (12, 20, 48), 128, 64, 64, True, False, True, 8)]
     cs += [(check_conv_exact, a) for a in exact]
     cs += [(check_conv_mixed_sources, (2, (32, 64, 64), 32, 32, 64))]
+    # stride 2 (row g): odd sizes 47 / 13, ragged, even, several bricks per persistent block, channel tails; both kernel generations
+    for kern in ('1', '0'):
+        cs += [(check_conv_exact_s2, (kind, N, S, Ca, Co, sd, kern)) for kind in ('fwd', 'dgrad') for N, S, Ca, Co, sd in
+               [(1, (47, 47, 47), 16, 32, 1), (1, (13, 13, 13), 16, 32, 2), (2, (24, 24, 24), 32, 64, 3), (1, (9, 20, 35), 48, 24, 4), (2, (48, 48, 48), 32, 64, 5)]]
     # the shapes the depth-reuse kernel takes under the DEFAULT dispatch (>= 400 tiles of 4x8x16: 432 / 512 tiles on 256 persistent blocks, so a block's
     # statistics registers run over several tiles): 64 -> 64 @48^3 with residual, an up-block head 64 + 32 -> 32 + shortcut
     cs += [(check_conv_exact, ('fwd', 2, (48, 48, 48), 64, 0, 64, False, True, True, 9)), (check_conv_exact, ('fwd', 2, (32, 64, 64), 64, 32, 32, True, False, True, 10)),

@@ -199,6 +199,85 @@ def test_packed_batch_gives_same_loss():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('C,shape', [(5, (8, 8, 16)), (26, (16, 16, 16)), (42, (4, 12, 20)), (9, (3, 5, 7))])
+def test_packed_plane_selection_and_flags_match_numpy(C, shape):
+    """rsuper_unpack_bits_sel / rsuper_plane_any_bits (PackedBits.planes / class_flags / sample_any) against numpy on the unpacked volume, bit-exact:
+    selected planes hold np.unpackbits(...)[c], planes neither selected nor flagged keep their previous bytes, flags == per-(sample, class) any()."""
+    from rsuper_amd.training.dataset import pack_bits, PackedBits
+    rng = np.random.default_rng(C)
+    x = rng.random((3, C) + shape) < 0.02
+    x[:, 1] = False                                  # an empty class everywhere
+    x[1] = False                                     # an empty sample
+    x[2, C - 1] = True
+    packed = torch.from_numpy(pack_bits(x)).to(DEV)
+    V = int(np.prod(shape))
+    if V % 16 == 0:
+        pb = PackedBits(packed, C)
+        fl = pb.class_flags().cpu().numpy().reshape(3, C)
+        assert np.array_equal(fl.astype(bool), x.reshape(3, C, -1).any(-1))
+        assert np.array_equal(pb.sample_any().cpu().numpy(), x.reshape(3, -1).any(-1))
+    from rsuper_amd.hip import lib
+    L = lib.lib()
+    chs = [0, C - 1] if C > 8 else [C - 2]
+    force = torch.zeros(C, dtype=torch.uint8); force[chs] = 1
+    force = force.to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    for use_flags in ((False, True) if V % 16 == 0 else (False,)):
+        out = torch.full((3, C) + shape, 7, device=DEV, dtype=torch.uint8)
+        flags = PackedBits(packed, C).class_flags() if use_flags else None
+        assert L.rsuper_unpack_bits_sel(packed.data_ptr(), out.data_ptr(), 3, packed.shape[1], C, V, flags.data_ptr() if use_flags else None, force.data_ptr(), st) == 0
+        got = out.cpu().numpy()
+        written = np.zeros((3, C), bool)
+        written[:, chs] = True
+        if use_flags:
+            written |= x.reshape(3, C, -1).any(-1)
+        for b in range(3):
+            for c in range(C):
+                if written[b, c]:
+                    assert np.array_equal(got[b, c].astype(bool), x[b, c]) and got[b, c].max() <= 1, (b, c)
+                else:
+                    assert (got[b, c] == 7).all(), (b, c)
+    # both tables null == rsuper_unpack_bits
+    out = torch.full((3, C) + shape, 7, device=DEV, dtype=torch.uint8)
+    assert L.rsuper_unpack_bits_sel(packed.data_ptr(), out.data_ptr(), 3, packed.shape[1], C, V, None, None, st) == 0
+    assert np.array_equal(out.cpu().numpy().astype(bool), x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('loss', ['ball_dice_last', 'ball_dice_both', 'dice_volume'])
+def test_fully_packed_batch_gives_same_report_loss_and_gradient(loss):
+    """SURVEY 8f-2 on the path R-Super trains: label, unknown map AND segment mask stay bit-packed under report supervision -- the
+    segmentation term reads the label bits, the report terms get the lesion planes only (PackedBits.planes), the unknown map's plane flags come from the packed
+    bytes.  Every loss key and the gradient of the logits are bit-identical to the uint8 batch (which the golden fixtures pin), no volume is inflated whole."""
+    from rsuper_amd.training import losses_foundation as lf
+    from rsuper_amd.training.dataset import PackedBits, pack_bits, ingest_packed_batch
+    classes = synth.TINY_CLASSES
+    B, S = 2, 32
+    bt = synth.batch(B, S, classes, ['mask', 'report'], seed=11)
+    logits = torch.from_numpy(synth.logits(B, len(classes), S, seed=5)).to(DEV)
+    la = argparse.Namespace(loss=loss, aux_weight=[0.5, 0.5], seg_loss=1.0, report_volume_loss_basic=0.1, volume_loss_tolerance=0.2,
+                            ball_bce_weight=1.0, ball_dice_weight=1.0, ball_volume_margin=0.2, multi_ch_tumor=False, stardard_ce_ball=False,
+                            classification_branch=False)
+    plain = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in bt.items() if k in ('label', 'unk_channels', 'mask', 'volumes', 'diameters')}
+    kept = ingest_packed_batch({'label': pack_bits(bt['label']), 'unk_channels': pack_bits(bt['unk_channels']), 'mask': pack_bits(bt['mask']),
+                                'volumes': bt['volumes'], 'diameters': bt['diameters']}, len(classes), DEV, keep_packed=True)
+    assert all(isinstance(kept[k], PackedBits) for k in ('label', 'unk_channels', 'mask'))
+
+    def run_g(batch, prefetch):
+        x = logits.clone().requires_grad_(True)
+        pre = lf.prepare_report_supervision(batch['label'], batch['unk_channels'], batch['mask'], batch['volumes'], batch['diameters'], classes, la) if prefetch else None
+        r = lf.calculate_loss({'segmentation': x}, batch['label'], batch['unk_channels'], la, None, batch['mask'], batch['volumes'], batch['diameters'], classes, pre=pre)
+        r['overall'].backward()
+        return {k: float(v) for k, v in r.items()}, x.grad
+    ra, ga = run_g(plain, False)
+    for prefetch in (False, True):
+        rb, gb = run_g(kept, prefetch)
+        assert ra == rb, (prefetch, ra, rb)
+        assert torch.equal(ga, gb), prefetch
+    assert all(kept[k]._u8 is None for k in ('label', 'unk_channels', 'mask')), 'no packed volume may have been inflated whole'
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('fill', ['dense', 'segment', 'empty'])
 @pytest.mark.parametrize('d_odd', [5, 9, 21])
 def test_ball_conv_two_stage_equals_direct(d_odd, fill):

@@ -14,9 +14,14 @@ import synth  # noqa: E402
 
 DEV = 'cuda'
 S, B = 96, 2
-# test_config2_fullsize_f32...: HIP-vs-float64 error allowed per gradient tensor, in units of the fp32 oracle's own distance from float64:
-# relative L2 over the sample (the statistic that is stable) and the single worst element (dominated by individual ReLU-mask flips)
-GRAD_L2_FACTOR, GRAD_MAX_FACTOR, GRAD_FLOOR = 2.0, 12.0, 5e-5
+# test_config2_fullsize_f32...: HIP-vs-float64 error allowed per gradient tensor, in units of the fp32 oracle's own distance from float64: relative L2 over the
+# sample (the stable statistic), the 99.9th percentile of the element errors (the 4th largest of 4096 samples), and the single worst element.  The worst element
+# gets ONE flipped ReLU mask on top of the factor: d(relu) is discontinuous, so a pre-activation that fp32 rounding puts on the other side of zero than float64
+# changes dY at that voxel by a whole term -- of a weight-gradient element that is a sum over the N x D x H x W voxels of its level, i.e. ~ 1 / sqrt(voxels) of the
+# largest entry (6^3 level: 432 terms -> 4.8e-2; measured in round 5 / 6: down4.conv.2.conv1 4.3e-2 and 2.9e-2 on 2 of 4096 sampled elements, the third largest
+# 9.0e-3 and the 99.9th percentile 1.5x the oracle's -- round 5 covered this with a factor of 12 on the maximum; profiles/r06_config2_f32_grads.txt).
+GRAD_L2_FACTOR, GRAD_MAX_FACTOR, GRAD_Q_FACTOR, GRAD_FLOOR = 2.0, 3.0, 3.0, 5e-5
+LEVEL_SIZE = {'inc': 96, 'up4': 96, 'outc': 96, 'down1': 48, 'up3': 48, 'down2': 24, 'up2': 24, 'down3': 12, 'up1': 12, 'down4': 6}
 
 
 @pytest.fixture(scope='module', autouse=True)
@@ -482,19 +487,28 @@ def test_config2_fullsize_f32_logits_and_gradients_match_oracle():
     assert e_logits <= 1e-4, f'logits: max |HIP f32 - oracle| / max |oracle| = {e_logits:.3e}'
     y64, g64 = run_oracle(torch.float64)
     e_o = (y32.double() - y64).abs().max().item() / scale          # how far the fp32 oracle itself is from float64, for the record
-    rows, fails = [], []
+    rows, fails, diag = [], [], {}
     for k, ref in g64.items():
         gs = max(np.abs(ref).max(), 1e-30)
         e_h = np.abs(g_hip[k].astype(np.float64) - ref).max() / gs
         e_r = np.abs(g32[k] - ref).max() / gs
         l2_h = np.linalg.norm(g_hip[k].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
         l2_r = np.linalg.norm(g32[k] - ref) / max(np.linalg.norm(ref), 1e-30)
-        b_l2, b_max = max(GRAD_L2_FACTOR * l2_r, GRAD_FLOOR), max(GRAD_MAX_FACTOR * e_r, GRAD_FLOOR)
-        rows.append((max(l2_h / b_l2, e_h / b_max), k, e_h, e_r, l2_h, l2_r))
+        one_flip = 1.0 / math.sqrt(B * (S * LEVEL_SIZE[k.split('.')[0]] // 96) ** 3)
+        b_l2, b_max = max(GRAD_L2_FACTOR * l2_r, GRAD_FLOOR), max(GRAD_MAX_FACTOR * e_r + one_flip, GRAD_FLOOR)
+        eh_all, er_all = np.sort(np.abs(g_hip[k].astype(np.float64) - ref).ravel() / gs), np.sort(np.abs(g32[k] - ref).ravel() / gs)
+        q = max(len(eh_all) - 1 - len(eh_all) // 1000, 0)              # the 99.9th percentile: 4th largest of a 4096-element sample
+        diag[k] = (eh_all[q], er_all[q], int((eh_all > 3.0 * e_r).sum()), len(eh_all), eh_all[-3:][::-1], er_all[-3:][::-1])
+        b_q = max(GRAD_Q_FACTOR * diag[k][1], GRAD_FLOOR)
+        rows.append((max(l2_h / b_l2, e_h / b_max, diag[k][0] / b_q), k, e_h, e_r, l2_h, l2_r))
+        if diag[k][0] > b_q:
+            fails.append(f'{k}: 99.9th percentile of the element errors {diag[k][0]:.3e} (fp32 oracle {diag[k][1]:.3e}, bound {b_q:.3e})')
         if l2_h > b_l2 or e_h > b_max:
             fails.append(f'{k}: HIP f32 gradient vs float64: rel L2 {l2_h:.3e} (fp32 oracle {l2_r:.3e}, bound {b_l2:.3e}), max {e_h:.3e} (fp32 oracle {e_r:.3e}, bound {b_max:.3e})')
     rows.sort(reverse=True)
-    table = '\n'.join(f'{k:34s} hip {e_h:.2e} oracle32 {e_r:.2e}  (rel L2: hip {l2_h:.2e} oracle32 {l2_r:.2e})' for _, k, e_h, e_r, l2_h, l2_r in rows)
+    table = '\n'.join(f'{k:34s} hip {e_h:.2e} oracle32 {e_r:.2e}  (rel L2: hip {l2_h:.2e} oracle32 {l2_r:.2e}; 99.9th pct: hip {diag[k][0]:.2e} oracle32 {diag[k][1]:.2e}; '
+                      f'{diag[k][2]} of {diag[k][3]} sampled elements beyond 3x the oracle32 maximum; three largest: hip ' + ' '.join(f'{v:.1e}' for v in diag[k][4])
+                      + ' oracle32 ' + ' '.join(f'{v:.1e}' for v in diag[k][5]) + ')' for _, k, e_h, e_r, l2_h, l2_r in rows)
     print(f'config-2 f32: logits {e_logits:.2e} (fp32 oracle vs float64 {e_o:.2e}); gradient samples, max error / max |float64 gradient| per tensor:\n{table}')
     out = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(out):
