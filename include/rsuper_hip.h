@@ -434,6 +434,14 @@ int rsuper_mask_op(uint8_t* a, const uint8_t* b, long V, int op /*0 and, 1 or, 2
  * segment volumes the dataset stores with np.packbits(axis=0) -- training/dataset/dim3/dataset_abdomenatlas_UFO.py:955,
  * 970,975 (pack), :1031-1034 (unpack).  packed: [B][P = ceil(C/8)][V] bytes (MSB = lowest class), out: [B][C][V] 0/1. */
 int rsuper_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, void* stream);
+/* Timing events for SURVEY 8(d)'s per-launch measurement (bench.py's roofline pass: HIP events around every conv MFMA launch, on the launch stream): events
+ * created with hipEventDisableSystemFence -- a default event performs a system-scope release (cache write-back + invalidate) when recorded, which is charged to the
+ * bracket and leaves the next kernel a cold L2; the HIP header recommends the flag for events that only measure time.  elapsed_ms waits for `b`. */
+int rsuper_timer_event_create(void** ev);
+int rsuper_timer_event_record(void* ev, void* stream);
+int rsuper_timer_event_elapsed_ms(void* a, void* b, float* ms);
+int rsuper_timer_event_destroy(void* ev);
+
 /* The report losses read only a few planes of a bit-packed volume ("loss kernels should read the packed u8 directly"; losses_foundation.py:286-297,
  * 1571-1605 index the lesion channels of label / unknown / segment mask): plane (b, c) of out[B][C][V] is written iff flags[b * C + c] != 0 or force[c] != 0
  * (flags: [B * C] device bytes or NULL, force: [C] device bytes or NULL; both NULL = rsuper_unpack_bits); the other planes are left untouched, byte planes

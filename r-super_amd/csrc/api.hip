@@ -760,6 +760,30 @@ int rsuper_unpack_bits(const uint8_t* packed, uint8_t* out, int B, int P, int C,
     if (!packed || !out || B <= 0 || P <= 0 || C <= 0 || C > 8 * P || V <= 0) return RS_ERR_ARG;
     return rs_launch_unpack_bits(packed, out, B, P, C, V, ST(stream));
 }
+// ---- timing events of the roofline pass (bench.py, ops.KernelTimer).  hipEventDisableSystemFence: an event of the default kind performs a system-scope release when
+// it is recorded -- cache write-back + invalidate between every pair of launches it brackets, which both costs time inside the bracket and makes the NEXT kernel start
+// on a cold L2 (packed weight fragments, halo rows shared with the previous launch).  hip_runtime_api.h: "can be used for events that are only being used to measure
+// timing ... can improve the accuracy of timing measurements by avoiding the cost of cache writeback and invalidation".
+int rsuper_timer_event_create(void** ev) {
+    if (!ev) return RS_ERR_ARG;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return RS_ERR_LAUNCH;
+    *ev = (void*)e;
+    return RS_OK;
+}
+int rsuper_timer_event_record(void* ev, void* stream) {
+    if (!ev) return RS_ERR_ARG;
+    return hipEventRecord((hipEvent_t)ev, ST(stream)) == hipSuccess ? RS_OK : RS_ERR_LAUNCH;
+}
+int rsuper_timer_event_elapsed_ms(void* a, void* b, float* ms) {
+    if (!a || !b || !ms) return RS_ERR_ARG;
+    if (hipEventSynchronize((hipEvent_t)b) != hipSuccess) return RS_ERR_LAUNCH;
+    return hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b) == hipSuccess ? RS_OK : RS_ERR_LAUNCH;
+}
+int rsuper_timer_event_destroy(void* ev) {
+    if (!ev) return RS_ERR_ARG;
+    return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? RS_OK : RS_ERR_LAUNCH;
+}
 int rsuper_unpack_bits_sel(const uint8_t* packed, uint8_t* out, int B, int P, int C, long V, const uint8_t* flags, const uint8_t* force, void* stream) {
     if (!packed || !out || B <= 0 || P <= 0 || C <= 0 || C > 8 * P || V <= 0) return RS_ERR_ARG;
     return rs_launch_unpack_bits_sel(packed, out, B, P, C, V, flags, force, ST(stream));

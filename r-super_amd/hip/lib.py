@@ -107,6 +107,10 @@ _SIGS = {
     'rsuper_guard_consistency': (c_int, [P, P, P, c_int, c_int, P, P]),
     'rsuper_mask_op': (c_int, [P, P, c_long, c_int, P]),
     'rsuper_unpack_bits': (c_int, [P, P, c_int, c_int, c_int, c_long, P]),
+    'rsuper_timer_event_create': (c_int, [P]),
+    'rsuper_timer_event_record': (c_int, [P, P]),
+    'rsuper_timer_event_elapsed_ms': (c_int, [P, P, P]),
+    'rsuper_timer_event_destroy': (c_int, [P]),
     'rsuper_unpack_bits_sel': (c_int, [P, P, c_int, c_int, c_int, c_long, P, P, P]),
     'rsuper_plane_any_bits': (c_int, [P, c_int, c_int, c_int, c_long, P, P]),
     'rsuper_zero_where': (c_int, [P, P, c_long, P]),

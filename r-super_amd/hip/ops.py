@@ -244,29 +244,55 @@ class KernelTimer:
     wall time: `busy_ms` is the length of the UNION of all launch intervals on the device timeline (time during which at
     least one timed kernel was running) -- the denominator of an honest aggregate FLOP rate."""
 
-    def __init__(self):
+    def __init__(self, fenced=None):
+        # fenced=False (default): events created with hipEventDisableSystemFence through the C ABI (rsuper_timer_event_*): a default event -- what
+        # torch.cuda.Event(enable_timing=True) creates -- performs a system-scope release (cache write-back + invalidate) every time it is recorded, i.e. twice per
+        # bracketed launch: that is charged to the bracket and makes every timed kernel start on a cold L2 (the packed weight fragments and the halo rows its
+        # predecessor left there).  hip_runtime_api.h recommends the flag for events that only measure time.  RSUPER_TIMER_FENCED=1 / fenced=True: torch events (A/B).
+        self.fenced = (os.environ.get('RSUPER_TIMER_FENCED', '0') == '1') if fenced is None else bool(fenced)
         self.records = []
-        self.base = torch.cuda.Event(enable_timing=True)
-        self.base.record()
+        self._pool = []
+        self.step = 0
+        self.base = self._event()
+        self._record(self.base)
+
+    def next_step(self):
+        """Launches recorded from here on belong to the next step (summary() then also reports per-step figures)."""
+        self.step += 1
+
+    def _event(self):
+        if self.fenced:
+            return torch.cuda.Event(enable_timing=True)
+        import ctypes
+        h = ctypes.c_void_p()
+        _l.check(_L().rsuper_timer_event_create(ctypes.byref(h)), 'timer_event_create')
+        self._pool.append(h)
+        return h
+
+    def _record(self, ev):
+        if self.fenced:
+            ev.record()
+        else:
+            _l.check(_L().rsuper_timer_event_record(ev, _stream()), 'timer_event_record')
+
+    def _elapsed(self, a, b):
+        if self.fenced:
+            return a.elapsed_time(b)
+        import ctypes
+        ms = ctypes.c_float()
+        _l.check(_L().rsuper_timer_event_elapsed_ms(a, b, ctypes.byref(ms)), 'timer_event_elapsed')
+        return float(ms.value)
 
     def launch(self, kind, flops, fn):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
+        s, e = self._event(), self._event()
+        self._record(s)
         fn()
-        e.record()
-        self.records.append((kind, flops, s, e))
+        self._record(e)
+        self.records.append((kind, flops, s, e, self.step))
 
-    def summary(self):
-        torch.cuda.synchronize()
-        out = {}
-        spans = []
-        for kind, flops, s, e in self.records:
-            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
-            d['launches'] += 1
-            d['flops'] += flops
-            d['ms'] += s.elapsed_time(e)
-            spans.append((self.base.elapsed_time(s), self.base.elapsed_time(e)))
-        spans.sort()
+    @staticmethod
+    def _union(spans):
+        spans = sorted(spans)
         busy, cur_s, cur_e = 0.0, None, None
         for a, b in spans:
             if cur_e is None or a > cur_e:
@@ -277,7 +303,27 @@ class KernelTimer:
                 cur_e = max(cur_e, b)
         if cur_e is not None:
             busy += cur_e - cur_s
-        self.busy_ms = busy
+        return busy
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        spans, per_step = [], {}
+        for kind, flops, s, e, step in self.records:
+            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0, max_ms=0.0))
+            d['launches'] += 1
+            d['flops'] += flops
+            el = self._elapsed(s, e)
+            d['ms'] += el
+            d['max_ms'] = max(d['max_ms'], el)
+            sp = (self._elapsed(self.base, s), self._elapsed(self.base, e))
+            spans.append(sp)
+            per_step.setdefault(step, []).append(sp)
+        self.busy_ms = self._union(spans)
+        self.step_busy_ms = [self._union(v) for _, v in sorted(per_step.items())]     # union of the launch intervals of every step
+        for h in self._pool:
+            _L().rsuper_timer_event_destroy(h)
+        self._pool = []
         return out
 
 
