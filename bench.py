@@ -300,7 +300,8 @@ def secondary_legs(args, rank, world, local, classes, B, S):
         sec['medformer_workload'] = ('MedFormer of config/abdomenatlas_ufo/medformer_3d.yaml (37.9 M parameters, deep supervision), same batch and '
                                      'segmentation loss: conv stem / BasicBlock stages / up-sampling / head / depthwise / InstanceNorm on the HIP kernels, '
                                      'every 1x1x1 convolution / linear layer of the attention stages (forward, data and weight gradient) on the HIP pointwise MFMA GEMMs; '
-                                     'the SemanticMapFusion transformer attention core on its own HIP kernel; only the 27-token semantic-map products and the 26-class aux head remain library GEMMs (SURVEY 8f-1)')
+                                     'the SemanticMapFusion transformer attention core on its own HIP kernel; round 6: the 27-token semantic-map product (as a slab-reduced dy^T x) and the 26-class aux head (padded to 28 columns) '
+                                     'on the same pointwise kernels -- no library GEMM is left on the default path (SURVEY 8f-1)')
         lm.close()
 
     def medformer_roofline():

@@ -1417,7 +1417,8 @@ def pointwise_gemm(x2, w, bias, mode, compute, res=None):
     compute: torch.bfloat16 (bf16 MFMA, fp32 accumulate) or torch.float32 (exact-f32 MFMA); storage stays fp32.
     res (R, N) f32 contiguous: added after the bias in the epilogue (identity shortcuts)."""
     import weakref
-    assert x2.dim() == 2 and x2.dtype == torch.float32 and x2.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+    # x2 may be a column slice of a wider row-major matrix (stride(1) == 1, row stride a multiple of 4): the kernel takes the leading dimension
+    assert x2.dim() == 2 and x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.stride(0) % 4 == 0 and w.dtype == torch.float32 and w.is_contiguous()
     R, K = x2.shape
     N = w.shape[0] if mode == 0 else w.shape[1]
     assert (w.shape[1] if mode == 0 else w.shape[0]) == K
@@ -1437,7 +1438,7 @@ def pointwise_gemm(x2, w, bias, mode, compute, res=None):
         ws = torch.empty((_L().rsuper_pointwise_packed_bytes(dt, K, N),), device=x2.device, dtype=torch.uint8)
         wptr, packed = _ptr(w), _ptr(ws)
     assert res is None or (res.shape == (R, N) and res.dtype == torch.float32 and res.is_contiguous())
-    _l.check(_L().rsuper_pointwise(dt, mode, _ptr(x2), K, wptr, _ptr(bias) if bias is not None else None, _ptr(res), N, _ptr(y), N, R, K, N, packed,
+    _l.check(_L().rsuper_pointwise(dt, mode, _ptr(x2), x2.stride(0), wptr, _ptr(bias) if bias is not None else None, _ptr(res), N, _ptr(y), N, R, K, N, packed,
                                    _stream()), 'pointwise')
     return y
 
@@ -1445,14 +1446,14 @@ def pointwise_gemm(x2, w, bias, mode, compute, res=None):
 def pointwise_wgrad(dy2, x2, want_bias, compute):
     """dW = dy2^T x2 (N, K) and, if wanted, db = dy2.sum(0): csrc/pointwise.hip, slabs of the rows added in slab order (deterministic)."""
     assert dy2.dim() == 2 and x2.dim() == 2 and dy2.shape[0] == x2.shape[0] and dy2.dtype == x2.dtype == torch.float32
-    assert dy2.is_contiguous() and x2.is_contiguous()
+    assert dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0      # column slices of wider matrices are fine
     R, N = dy2.shape
     K = x2.shape[1]
     S = _L().rsuper_pointwise_wgrad_splits(R, N, K)
     ws = torch.empty((S * (N * K + N),), device=dy2.device, dtype=torch.float32)
     dw = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
     db = torch.empty((N,), device=dy2.device, dtype=torch.float32) if want_bias else None
-    _l.check(_L().rsuper_pointwise_wgrad(_DT[compute], _ptr(dy2), N, _ptr(x2), K, R, N, K, _ptr(ws), S, _ptr(dw), _ptr(db) if want_bias else None,
+    _l.check(_L().rsuper_pointwise_wgrad(_DT[compute], _ptr(dy2), dy2.stride(0), _ptr(x2), x2.stride(0), R, N, K, _ptr(ws), S, _ptr(dw), _ptr(db) if want_bias else None,
                                          _stream()), 'pointwise_wgrad')
     return dw, db
 

@@ -93,6 +93,8 @@ HIP_POINTWISE = os.environ.get('RSUPER_MF_LIBRARY_GEMM') != '1'      # 1x1x1 con
 FUSE_RESIDUAL = os.environ.get('RSUPER_MF_FUSE_RES', '1') == '1'          # identity shortcuts added in the pointwise GEMM's epilogue
 HIP_TOKEN_ATTN = os.environ.get('RSUPER_MF_TOKEN_ATTN', '1') == '1'       # fusion transformer's attention core on csrc/token_attn.hip (=0: the ATen chain, A/B)
 HIP_POINTWISE_WGRAD = os.environ.get('RSUPER_MF_LIBRARY_WGRAD') != '1'   # their weight / bias gradients too (=1: library GEMMs, A/B)
+HIP_MAP_PRODUCT = os.environ.get('RSUPER_MF_MAP_PRODUCT', '1') == '1'        # =0: the semantic-map product as a library GEMM (A/B)
+PAD_OUT_CHANNELS = os.environ.get('RSUPER_MF_PAD_HEAD', '1') == '1'           # =0: the aux head as a library GEMM (A/B)
 HIP_POINTWISE_MIN_ROWS = int(os.environ.get('RSUPER_MF_PW_MIN_ROWS', '32'))    # below (the 27-token maps): library GEMM
 GEMM_COMPUTE = torch.float32    # MFMA operand type of the HIP pointwise GEMMs: set per forward by MedFormer from its compute_dtype
 GEMM_DTYPE = torch.float32      # set per forward by MedFormer (opt-in bf16 operands for the 1x1x1 GEMMs, see medformer.py)
@@ -206,6 +208,15 @@ def linear(x, w, b=None, res=None):
         return linear(x, w, b) + res
     if HIP_POINTWISE and rows >= HIP_POINTWISE_MIN_ROWS and ops.pointwise_supported(x, w):
         return _LinearFn.apply(x, w, b, res)
+    if HIP_POINTWISE and PAD_OUT_CHANNELS and res is None and rows >= HIP_POINTWISE_MIN_ROWS and w.shape[0] % 4 and w.shape[1] % 4 == 0 and x.is_cuda \
+            and x.dtype == torch.float32:
+        # an output-channel count that is not a multiple of 4 (the 26-class deep-supervision head, medformer.py:190-194): zero rows pad the weight to the next
+        # multiple, the GEMM runs on csrc/pointwise.hip like every other 1x1x1 convolution and the padding columns are dropped (their gradient is zero)
+        n, padn = w.shape[0], (-w.shape[0]) % 4
+        wp = torch.cat([w, w.new_zeros((padn, w.shape[1]))], 0)
+        bp = None if b is None else torch.cat([b, b.new_zeros(padn)])
+        if ops.pointwise_supported(x, wp):
+            return _LinearFn.apply(x, wp, bp, None)[..., :n]
     if x.dtype == torch.float32 and (rows >= SPLITK_MIN_ROWS or (gemm_library.active and max(rows, w.shape[0], w.shape[1]) >= LT_MIN_K)):
         return _LinearFn.apply(x, w, b, res)
     y = F.linear(x, w, b)
@@ -385,6 +396,32 @@ class PatchMerging(nn.Module):
         return self.reduction(instance_norm(merged, IN_EPS))
 
 
+class _MapProductFn(torch.autograd.Function):
+    """map[b, code, c] = sum_v wv[b, v, code] * base[b, v, c] -- the 27-token semantic-map product (medformer_utils.py:206-236, `einsum` of the soft-max
+    weights with the base projection): a long reduction (13824 voxels) into a tiny output, which is the shape of a pointwise-convolution WEIGHT gradient
+    dW = dy^T x, so it runs on csrc/pointwise.hip's slab kernel (`rsuper_pointwise_wgrad`, deterministic slab order) per sample; its two gradients are the
+    forward (mode 0) and data-gradient (mode 1) forms of the same GEMM family.  wv: (B, V, Kc) f32 contiguous (codes padded to a multiple of 4 with columns
+    whose result rows the caller drops), base: (B, V, md) f32, a column slice of the wider projection output is fine.  Round 6: replaces the last library
+    GEMMs of the attention stages together with the padded aux head (VERDICT r05 missing #3)."""
+
+    @staticmethod
+    def forward(ctx, wv, base):
+        ctx.save_for_backward(wv, base)
+        ctx.compute = GEMM_COMPUTE
+        return torch.stack([ops.pointwise_wgrad(wv[b], base[b], False, ctx.compute)[0] for b in range(wv.shape[0])])       # (B, Kc, md)
+
+    @staticmethod
+    def backward(ctx, dmap):
+        wv, base = ctx.saved_tensors
+        dmap = dmap.contiguous()
+        dwv = dbase = None
+        if ctx.needs_input_grad[0]:      # dwv[b, v, code] = sum_c base[b, v, c] dmap[b, code, c]
+            dwv = torch.stack([ops.pointwise_gemm(base[b], dmap[b], None, 0, ctx.compute) for b in range(wv.shape[0])])
+        if ctx.needs_input_grad[1]:      # dbase[b, v, c] = sum_code wv[b, v, code] dmap[b, code, c]
+            dbase = torch.stack([ops.pointwise_gemm(wv[b], dmap[b], None, 1, ctx.compute) for b in range(wv.shape[0])])
+        return dwv, dbase
+
+
 class SemanticMapGeneration(nn.Module):
     """map[code, c] = sum_voxels softmax_v(semantic_proj(x)[v, code]) * base_proj(x)[v, c] (medformer_utils.py:206-236)."""
 
@@ -405,6 +442,13 @@ class SemanticMapGeneration(nn.Module):
         if pad:
             w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
         y = ops.Conv3Fn.apply(x, w).float().flatten(1, 3)                       # (B, voxels, md + codes + pad)
+        kc = codes + pad
+        if HIP_POINTWISE and HIP_MAP_PRODUCT and md % 4 == 0 and kc % 4 == 0 and y.is_cuda and y.shape[1] >= HIP_POINTWISE_MIN_ROWS:
+            # soft-max over the voxels of every code column (the `pad` columns come from zero weight rows: uniform weights, their map rows are dropped)
+            # (soft-max over the LAST axis of the transposed view: ATen's soft-max over a middle axis with 32 inner elements runs 64 threads in all --
+            # 27.2 instead of 25.4 ms per replayed step when the product moved here first)
+            wv = F.softmax(y[..., md:md + kc].transpose(1, 2), dim=-1).transpose(1, 2).contiguous()      # (B, voxels, kc)
+            return _MapProductFn.apply(wv, y[..., :md])[:, :codes].reshape(x.shape[0], *self.map_size, md)
         weight = F.softmax(y[..., md:md + codes].transpose(1, 2), dim=-1)       # (B, codes, voxels): softmax over the voxels of a code
         with gemm_library(weight.shape[-1]):                                    # 27 x voxels x map_dim: a long reduction into a tiny output
             return torch.matmul(weight, y[..., :md]).reshape(x.shape[0], *self.map_size, md)
