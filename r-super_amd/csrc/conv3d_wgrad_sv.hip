@@ -235,6 +235,11 @@ int rs_wgrad_sv_splits(int dtype, int Mtot, int Ya, int nch, int N, int D, int H
     if (off || dtype != RS_BF16 || w2 == 0 || w2 >= (1 << 20)) return 0;      // 0 / "never": the tests force the tile-streaming kernels
     const long tiles = (long)N * ((D + 3) / 4) * ((H + 3) / 4) * ((W + 15) / 16);
     if (tiles > 64 || (Ya < Mtot && (Ya % 32))) return 0;
+    // above 6^3 the kernel pays only while the whole launch is small: the wide fused [conv1 | shortcut] of up1.0 (512 rows x 18 input chunks at 12^3 = 288 output
+    // tiles x N x depth parts blocks, each re-staging its slab) measured 180 us here against 120 us on the tile-streaming kernel; 256 -> 256 / 128 -> 2 x 256 at
+    // 12^3 are equal on both, the 6^3 level is 20-25 % faster here (tools/r06_wgsv_exp.sh, profiles/r06_wgsv_exp.txt)
+    static const long max_tiles12 = getenv("RSUPER_WGRAD_SV_MAX") ? atol(getenv("RSUPER_WGRAD_SV_MAX")) : 4096;
+    if ((long)D * H * W > 216 && (long)Mtot * nch > max_tiles12) return 0;
     const SvGeom g = sv_geometry(N, D, H, W, nch, Mtot);
     return g.P > 0 ? N * g.P : 0;
 }

@@ -1195,10 +1195,12 @@ def test_train_epoch_with_hip_graph_matches_eager(tmp_path, report):
 
 
 @pytest.mark.gpu
-def test_train_epoch_with_hip_graph_on_a_packed_dataset_matches_eager(tmp_path):
+@pytest.mark.parametrize('report', ['0', '0.1'])
+def test_train_epoch_with_hip_graph_on_a_packed_dataset_matches_eager(tmp_path, report):
     """--hip_graph on a dataset that yields bit-packed volumes (AugmentedCropDataset(packed=True), here the synthetic stand-in): with segmentation-only
     supervision train_epoch keeps the label a PackedBits, and the captured step must hold it in a static packed buffer (the capture used to call
-    .to / .clone on it).  Same meters and final weights as the eager driver on the same packed dataset, and as the eager driver on the unpacked one."""
+    .to / .clone on it); with report supervision (round 6: all three volumes stay packed) the network is replayed from two graphs around the eager loss, which
+    reads the packed volumes.  Same meters and final weights as the eager driver on the same packed dataset, and as the eager driver on the unpacked one."""
     import os
     from rsuper_amd.train_ddp import get_parser, main_worker
     from rsuper_amd.training.dataset import SyntheticUFODataset
@@ -1207,7 +1209,7 @@ def test_train_epoch_with_hip_graph_on_a_packed_dataset_matches_eager(tmp_path):
     for tag, extra, packed in (('plain', [], False), ('eager', [], True), ('graph', ['--hip_graph'], True)):
         ds = SyntheticUFODataset(classes, size=32, length=16, seed=3, packed=packed)
         args = get_parser(['--epochs', '2', '--batch_size', '2', '--cp_path', str(tmp_path) + '/', '--unique_name', tag, '--loss', 'ball_dice_last',
-                           '--report_volume_loss_basic', '0'] + extra)
+                           '--report_volume_loss_basic', report] + extra)
         args.base_chan, args.iter_per_epoch, args.print_freq, args.compute_dtype = 8, 4, 100, 'bf16'
         torch.manual_seed(0)
         hist = main_worker(0, 1, 0, args, trainset=ds)

@@ -20,6 +20,8 @@ LAYERS = [('inc 32->32', 96, 32, 0, 32, False), ('up4.0 96->32+sc', 96, 32, 64, 
 
 if os.environ.get('BC_EXTRA'):                           # extra rows: the two column ranges of up4.0's data gradient as launches of their own (K = 64 -> 64 / 32 columns)
     LAYERS = [('up4.0 dgrad cols 32..95', 96, 64, 0, 32, True), ('up4.0 dgrad cols 0..31', 96, 32, 0, 32, True)]
+if os.environ.get('BC_LAYERS'):                        # custom rows: "name:S:Ca:Cb:Cout:sc;..." (sc = 0 / 1)
+    LAYERS = [(f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]), f[5] == '1') for f in (r.split(':') for r in os.environ['BC_LAYERS'].split(';'))]
 if os.environ.get('BC_ONLY_S2'):                       # only the strided rows below
     LAYERS = []
 if os.environ.get('BC_ONLY'):                          # only the stride-1 layers whose name contains one of the comma-separated substrings
@@ -72,7 +74,7 @@ for name, S, Ca, Cb, Cout, sc in LAYERS:
 # ---- the strided member (down_block(pool=False)): [conv1 | shortcut] of BasicBlock(Cin, Cout, stride=2) on the parity-class kernel against the
 #      rounds-1/2 evaluation (the stride-1 GEMM at full resolution + rsuper_subsample2 / zero-stuffed dy).  FLOPs = the strided convolution's own.
 print('# stride-2 [conv1 | shortcut]: parity-class kernel (conv3d_igemm_s2.hip) vs stride-1 evaluation at full resolution', flush=True)
-for name, S, Ca, Cout in ([] if os.environ.get('BC_ONLY') else [('down1.0 s2 32->64+sc', 96, 32, 64), ('down2.0 s2 64->128+sc', 48, 64, 128), ('down3.0 s2 128->256+sc', 24, 128, 256)]):
+for name, S, Ca, Cout in ([] if (os.environ.get('BC_ONLY') or os.environ.get('BC_LAYERS')) else [('down1.0 s2 32->64+sc', 96, 32, 64), ('down2.0 s2 64->128+sc', 48, 64, 128), ('down3.0 s2 128->256+sc', 24, 128, 256)]):
     dims = (N, S, S, S); O = (S + 1) // 2
     xa = torch.randn((N, S, S, S, Ca), device=dev).to(dt)
     mra = torch.stack([torch.zeros(N, Ca, device=dev), torch.ones(N, Ca, device=dev)], -1).contiguous()
