@@ -159,6 +159,13 @@ int rsuper_conv3_wgrad_reduce(const float* workspace, int splits, int Cin, int Y
  * (loss.backward(), train_ddp.py:349 -- every nn.Conv3d weight gradient); nothing but the optimiser / the gradient exchange reads dW. */
 int rsuper_conv3_wgrad_reduce_batch(int n, const void* const* workspaces, const int* splits, const int* Cin, const int* Ya, const int* Yb,
                                     void* const* dwa, void* const* dwb, void* stream);
+/* The same launch also finalises up to two statistics buffers (rsuper_stats_finalize's arithmetic, bit-identical): in a BasicBlock's backward the data gradient of
+ * conv1 leaves its InstanceNorm-backward partial rows and the block's two weight gradients their slabs -- one launch turns both into what the InstanceNorm-backward
+ * tail and the optimiser read (autograd of conv_layers.py:86-94; a dependent ~5 us launch less per block and input source).  n in [1, 48], nstats in [0, 2];
+ * arrays of length nstats: parts[i] = [sN][snblk][sC][2] f32, souts[i] = [sN][sC][2] f32 (two tables when ssplit > 0), scnt = voxels per sample, smode 0 / 1. */
+int rsuper_conv3_wgrad_reduce_batch_stats(int n, const void* const* workspaces, const int* splits, const int* Cin, const int* Ya, const int* Yb,
+                                           void* const* dwa, void* const* dwb, int nstats, const void* const* parts, const int* sN, const int* snblk,
+                                           const int* sC, const double* scnt, const int* smode, const int* ssplit, void* const* souts, float eps, void* stream);
 
 /* Weight gradient of the STRIDED member (Conv3d(k=3, stride=2, pad=1): BasicBlock(stride=2) conv1 + shortcut of down_block(pool=False),
  * unet_utils.py:18-33, conv_layers.py:60-94):  dW[co][ci][t] = sum_o dy[o][co] * x_hat[2o + t - 1][ci].

@@ -403,6 +403,28 @@ int rsuper_conv3_wgrad_reduce_batch(int n, const void* const* workspaces, const 
     return RS_OK;
 }
 
+int rsuper_conv3_wgrad_reduce_batch_stats(int n, const void* const* workspaces, const int* splits, const int* Cin, const int* Ya, const int* Yb,
+                                           void* const* dwa, void* const* dwb, int nstats, const void* const* parts, const int* sN, const int* snblk,
+                                           const int* sC, const double* scnt, const int* smode, const int* ssplit, void* const* souts, float eps, void* stream) {
+    if (nstats < 0 || nstats > RS_REDUCE_STATS_MAX || n < 1 || n > RS_REDUCE_BATCH_MAX) return RS_ERR_ARG;
+    if (!workspaces || !splits || !Cin || !Ya || !Yb || !dwa || !dwb) return RS_ERR_ARG;
+    if (nstats > 0 && (!parts || !sN || !snblk || !sC || !scnt || !smode || !ssplit || !souts)) return RS_ERR_ARG;
+    ReduceBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (!workspaces[i] || splits[i] <= 0 || Cin[i] <= 0 || (Cin[i] % 8) || Ya[i] <= 0 || Yb[i] < 0 || !dwa[i] || (Yb[i] > 0 && !dwb[i])) return RS_ERR_ARG;
+        b.e[i] = {(const float*)workspaces[i], (float*)dwa[i], (float*)dwb[i], splits[i], Ya[i] + Yb[i], Ya[i], Cin[i], 0u};
+    }
+    b.nstats = nstats;
+    for (int i = 0; i < nstats; ++i) {
+        if (!parts[i] || !souts[i] || sN[i] <= 0 || snblk[i] <= 0 || sC[i] <= 0 || scnt[i] <= 0.0 || (smode[i] != 0 && smode[i] != 1) || ssplit[i] < 0 || ssplit[i] >= sC[i])
+            return RS_ERR_ARG;
+        b.sj[i] = {(const float*)parts[i], (float*)souts[i], sN[i], snblk[i], sC[i], smode[i], ssplit[i], eps, scnt[i], 0u};
+    }
+    return rs_launch_wgrad_reduce_batch(b, ST(stream));
+}
+
 int rsuper_conv3_wgrad_s2_splits(int dtype, int Ca, int Mtot, int N, int FD, int FH, int FW) {
     if (!dt_ok(dtype) || Ca <= 0 || Mtot <= 0 || N <= 0 || FD <= 0 || FH <= 0 || FW <= 0) return -1;
     return rs_wgrad_s2_splits(dtype, Ca, Mtot, N, FD, FH, FW);

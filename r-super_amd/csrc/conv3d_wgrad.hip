@@ -418,9 +418,63 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
 // Both reductions above for a LIST of weight gradients in one launch: block -> (entry, block index inside the entry); entries with at least 16
 // slabs take the element-parallel form (8 split groups), the others the row form.  Sums are formed in exactly the order of the single-entry
 // kernels of the same form (bit-identical results for < 16 and for 16 .. 127 slabs; >= 128 slabs sum in 8 instead of 32 groups).
+// stats_finalize_kernel (unet_misc.hip) for 256 threads, bit-identical: the 1024-thread kernel sums in 32 row groups (group g: rows g, g + 32, ... in trips of
+// four) and adds the groups in order; here thread (cl, q) carries the four logical groups q, q + 8, q + 16, q + 24 through the same trips and the same final order.
+__device__ __forceinline__ void reduce_batch_stats_role(const ReduceBatch::Stats& j, unsigned l, double (*red)[2]) {
+    const int cgs = (j.C + 31) / 32;
+    const int n = (int)(l / cgs), cg = (int)(l % cgs);
+    const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int c = cg * 32 + cl;
+    const int nblk = j.nblk, C = j.C;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int g = q + 8 * u;
+        double s0 = 0.0, s1 = 0.0;
+        if (c < C) {
+            const float* base = j.part + ((size_t)n * nblk * C + c) * 2;
+            int b = g;
+            for (; b + 96 < nblk; b += 128) {
+                const float2 v0 = *(const float2*)(base + (size_t)b * C * 2), v1 = *(const float2*)(base + (size_t)(b + 32) * C * 2);
+                const float2 v2 = *(const float2*)(base + (size_t)(b + 64) * C * 2), v3 = *(const float2*)(base + (size_t)(b + 96) * C * 2);
+                s0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+                s1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+            }
+            for (; b < nblk; b += 32) {
+                const float2 v = *(const float2*)(base + (size_t)b * C * 2);
+                s0 += (double)v.x; s1 += (double)v.y;
+            }
+        }
+        red[g * 32 + cl][0] = s0; red[g * 32 + cl][1] = s1;
+    }
+    __syncthreads();
+    if (q == 0 && c < C) {
+        double s0 = red[cl][0], s1 = red[cl][1];
+        for (int k = 1; k < 32; ++k) { s0 += red[k * 32 + cl][0]; s1 += red[k * 32 + cl][1]; }
+        float* o = j.split <= 0 ? j.out + ((size_t)n * C + c) * 2
+                   : c < j.split ? j.out + ((size_t)n * j.split + c) * 2
+                                 : j.out + (size_t)j.N * j.split * 2 + ((size_t)n * (C - j.split) + (c - j.split)) * 2;
+        if (j.mode == 0) {
+            const double mean = s0 / j.cnt;
+            double var = s1 / j.cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            o[0] = (float)mean;
+            o[1] = (float)(1.0 / sqrt(var + (double)j.eps));
+        } else {
+            o[0] = (float)(s0 / j.cnt); o[1] = (float)(s1 / j.cnt);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(ReduceBatch b) {
     __shared__ float4 part[8][32];
     __shared__ float tile[64 * 27 + 64];
+    if (blockIdx.x >= b.blocks) {                                // a statistics job (ReduceBatch::sj)
+        __shared__ double sred[1024][2];
+        int ji = 0;
+        for (int i = 1; i < b.nstats; ++i) ji = blockIdx.x >= b.sj[i].blk_start ? i : ji;
+        reduce_batch_stats_role(b.sj[ji], blockIdx.x - b.sj[ji].blk_start, sred);
+        return;
+    }
     int ei = 0;
     for (int i = 1; i < b.n; ++i) ei = blockIdx.x >= b.e[i].blk_start ? i : ei;      // entries are few: linear scan in scalar registers
     const ReduceBatch::Entry& en = b.e[ei];
@@ -575,6 +629,10 @@ int rs_launch_wgrad_reduce_batch(ReduceBatch& b, hipStream_t st) {
         blocks += e.splits >= 16 ? (unsigned)((elems + 127) / 128) : (unsigned)(e.Mtot * ((e.Cin + 63) / 64));
     }
     b.blocks = blocks;
+    for (int i = 0; i < b.nstats; ++i) {
+        b.sj[i].blk_start = blocks;
+        blocks += (unsigned)(((b.sj[i].C + 31) / 32) * b.sj[i].N);
+    }
     hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
     return rs_check_launch();
 }

@@ -86,10 +86,16 @@ int rs_launch_wgrad(const WgradParams& p, int dtype, int use_tr, hipStream_t st,
 int rs_launch_wgrad_reduce(const WgradParams& p, hipStream_t st);
 // slab reductions of several weight gradients in ONE launch (the per-layer reduce is a ~10 us launch at the dependent-launch floor, 34 per step)
 #define RS_REDUCE_BATCH_MAX 48
+#define RS_REDUCE_STATS_MAX 2
 struct ReduceBatch {
     int n;
     struct Entry { const float* ws; float* dwa; float* dwb; int splits, Mtot, Ya, Cin; unsigned blk_start; } e[RS_REDUCE_BATCH_MAX];
     unsigned blocks;
+    // statistics finalisations riding in the same launch (round 6): blocks [blocks, blocks + sum of the jobs' blocks) evaluate rs_launch_stats_finalize's
+    // arithmetic for job j -- the data-gradient launch of a BasicBlock's conv1 leaves its InstanceNorm-backward rows, the block's weight gradients their slabs,
+    // and ONE launch turns both into what in_bwd_finalize / the optimiser read (a dependent 5 us launch less per block and source)
+    int nstats;
+    struct Stats { const float* part; float* out; int N, nblk, C, mode, split; float eps; double cnt; unsigned blk_start; } sj[RS_REDUCE_STATS_MAX];
 };
 int rs_launch_wgrad_reduce_batch(ReduceBatch& b, hipStream_t st);
 bool rs_wgrad2_mt1(int dtype, int Mtot, int tiles_total);

@@ -39,6 +39,7 @@ _SIGS = {
                                            P, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_conv3_wgrad_reduce': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     'rsuper_conv3_wgrad_reduce_batch': (c_int, [c_int, P, P, P, P, P, P, P, P]),
+    'rsuper_conv3_wgrad_reduce_batch_stats': (c_int, [c_int, P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, c_float, P]),
     'rsuper_conv3_wgrad_s2_splits': (c_int, [c_int] * 7),
     'rsuper_conv3_wgrad_s2': (c_int, [c_int, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_pointwise_packed_bytes': (c_size_t, [c_int, c_int, c_int]),

@@ -503,24 +503,54 @@ _DEFERRED = []
 DEFER_WGRAD_REDUCE = os.environ.get('RSUPER_WGRAD_DEFER', '1') == '1'
 
 
-def flush_wgrad_reduces():
-    """Sum the slabs of every weight gradient whose reduction was deferred (one launch on the current stream).  Idempotent."""
-    if not _DEFERRED:
-        return
+FUSE_STATS_REDUCE = os.environ.get('RSUPER_FUSE_STATS_REDUCE', '1') == '1'      # =0: every statistics finalisation as its own launch (A/B)
+
+
+def flush_wgrad_reduces(stats=None):
+    """Sum the slabs of every weight gradient whose reduction was deferred (one launch on the current stream).  Idempotent.
+    stats: up to two (part, cnt, mode, split) statistics buffers finalised by the SAME launch (rsuper_conv3_wgrad_reduce_batch_stats: the arithmetic of
+    stats_finalize, bit-identical); returns the list of their results in stats_finalize's form.  Without deferred reductions to ride on they are finalised
+    by their own launches."""
     import ctypes
+    if stats and (not _DEFERRED or not FUSE_STATS_REDUCE or len(stats) > 2 or len(_DEFERRED) > 48):
+        res = [stats_finalize(p_, cnt, mode=mode, split=split) for p_, cnt, mode, split in stats]
+        flush_wgrad_reduces()
+        return res
+    if not _DEFERRED:
+        return [] if stats else None
     ents = list(_DEFERRED)
     del _DEFERRED[:]
     n = len(ents)
     PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
     args = (n, PA(*[_ptr(e[0]) for e in ents]), IA(*[e[1] for e in ents]), IA(*[e[2] for e in ents]), IA(*[e[3] for e in ents]),
             IA(*[e[4] for e in ents]), PA(*[_ptr(e[5]) for e in ents]), PA(*[_ptr(e[6]) for e in ents]))
+    res = None
+    if stats:
+        m = len(stats)
+        outs = [torch.empty((p_.shape[0], p_.shape[2], 2), device=p_.device, dtype=torch.float32) for p_, _, _, _ in stats]
+        PB, IB, DB = ctypes.c_void_p * m, ctypes.c_int * m, ctypes.c_double * m
+        sargs = (m, PB(*[_ptr(p_) for p_, _, _, _ in stats]), IB(*[p_.shape[0] for p_, _, _, _ in stats]), IB(*[p_.shape[1] for p_, _, _, _ in stats]),
+                 IB(*[p_.shape[2] for p_, _, _, _ in stats]), DB(*[float(c) for _, c, _, _ in stats]), IB(*[mo for _, _, mo, _ in stats]),
+                 IB(*[sp for _, _, _, sp in stats]), PB(*[_ptr(o) for o in outs]), EPS)
+        res = []
+        for (p_, _, _, sp), o in zip(stats, outs):
+            N, C = p_.shape[0], p_.shape[2]
+            if sp:
+                flat = o.view(-1)
+                res.append((flat[:N * sp * 2].view(N, sp, 2), flat[N * sp * 2:].view(N, C - sp, 2)))
+            else:
+                res.append(o)
 
-    def run():
-        _l.check(_L().rsuper_conv3_wgrad_reduce_batch(*args, _stream()), 'conv3_wgrad_reduce_batch')
+        def run():
+            _l.check(_L().rsuper_conv3_wgrad_reduce_batch_stats(*args, *sargs, _stream()), 'conv3_wgrad_reduce_batch_stats')
+    else:
+        def run():
+            _l.check(_L().rsuper_conv3_wgrad_reduce_batch(*args, _stream()), 'conv3_wgrad_reduce_batch')
     if TIMER is not None:
         TIMER.launch('conv3d_wgrad_reduce', 0.0, run)
     else:
         run()
+    return res
 
 
 def _defer_reduce(ws, splits, Cin_t, Ya, Yb, dwa, dwb):
@@ -811,21 +841,34 @@ class BasicBlockFn(torch.autograd.Function):
         sa = Src(xa, mr=mra)
         sb = None if xb is None else Src(xb, mr=mrb)
         g0 = torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
+        # With the slab reductions deferred to one launch per block, that launch also finalises the InstanceNorm-backward rows of this data gradient
+        # (flush_wgrad_reduces(stats=...)): it then runs BEFORE the InstanceNorm-backward tail instead of after it.
+        fuse = FUSE_STATS_REDUCE and DEFER_WGRAD_REDUCE and not ov and not sr
+        pending = []
         if len(bpk[0]) == 3:                  # one launch per forward source (block_pack_specs / split_dgrad_sources)
             gm0 = []
             for (c0, cn, src, wp_, bn) in ((0, Ca, sa, bpk[0][1], bpk[1][1]), (Ca, Cb, sb, bpk[0][2], bpk[1][2])):
                 part0 = part_buffer(dt, dims, cn, bn, dev, epi=1)
                 igemm(1, Src(dy1), sdo if has_sc else None, wp_, cn, bn, dims, g0[..., c0:], out_ld=Cin, part=part0, ea=src)
-                gm0.append(stats_finalize(part0, cnt, mode=1))
+                if fuse:
+                    pending.append((part0, cnt, 1, 0))
+                else:
+                    gm0.append(stats_finalize(part0, cnt, mode=1))
         else:
             bn, wpd1 = bpk[1][1], bpk[0][1]
             part0 = part_buffer(dt, dims, Cin, bn, dev, epi=1)
             igemm(1, Src(dy1), sdo if has_sc else None, wpd1, Cin, bn, dims, g0, part=part0, ea=sa, eb=sb)
-            gm0 = stats_finalize(part0, cnt, mode=1, split=0 if xb is None else Ca)
+            if fuse:
+                pending.append((part0, cnt, 1, 0 if xb is None else Ca))
+            else:
+                gm0 = stats_finalize(part0, cnt, mode=1, split=0 if xb is None else Ca)
         dw1 = grad_dest(w1)
         dws = grad_dest(ws) if has_sc else None
         with _Side(ov, (xa, mra, xb, mrb, dy1, dout, dw1, dws)):
             wgrad(sa, sb, Src(dy1), sdo if has_sc else None, dw1, dws, dims, side_reduce=sr, defer=DEFER_WGRAD_REDUCE and not ov)
+        if fuse:
+            fin = flush_wgrad_reduces(stats=pending)
+            gm0 = fin if len(bpk[0]) == 3 else fin[0]
         if xb is None:
             dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca, add1=None if has_sc else dout)
             dxb = None
