@@ -38,9 +38,12 @@ rm -rf gpurun_out/pmc_step_fetch gpurun_out/pmc_step_write
 timeout 900 python bench.py > gpurun_out/r06_bench_default.json 2> gpurun_out/r06_bench_default.err
 tail -c 600 gpurun_out/r06_bench_default.json
 
-# MedFormer: kernel statistics of the replay-free eager step (the network R-Super trains)
+# MedFormer (4 warm-up + 12 timed eager steps = 16 in the trace): kernel statistics of the eager step (the network R-Super trains)
 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_r06m -o r -- python tools/medformer_step.py 12 bf16 > /dev/null 2>&1
-python tools/kernel_stats.py $(ls /tmp/kt_r06m/*kernel_trace.csv | head -1) 12 > gpurun_out/r06_medformer_kernel_stats.txt 2>/dev/null
+python tools/kernel_stats.py $(ls /tmp/kt_r06m/*kernel_trace.csv | head -1) 16 > gpurun_out/r06_medformer_kernel_stats.txt 2>/dev/null
 # per-launch rates of the InstanceNorm-backward tail (bytes = 3 or 4 tensors of the layer x 2 B) from the bench trace
 python tools/in_bwd_rates.py > gpurun_out/r06_in_bwd_rates.txt 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06_smoke.txt 2>&1
+python -m pytest tests -m gpu -q -rs > gpurun_out/r06_gputest_full.txt 2>&1
+grep -v "Warning\|^  \|^$\|warnings.warn" gpurun_out/r06_gputest_full.txt | tail -25 > gpurun_out/r06_gputest.txt
+tail -3 gpurun_out/r06_gputest.txt
