@@ -305,22 +305,36 @@ class KernelTimer:
             busy += cur_e - cur_s
         return busy
 
-    def summary(self):
+    def summary(self, tol=0.05):
+        """Per-kind totals over the steps whose conv time (union of the launch intervals) lies within `tol` of the median step.  A bracket opens when its start
+        event executes and closes after the kernel: whenever the host falls behind the device (a 20 ms hiccup between recording the event and launching the
+        kernel was seen about once in 40 passes; the device then idles INSIDE the bracket, and the next few steps run with a drained queue) the bracket measures
+        the host, not the kernel.  `step_busy_ms` lists every step, `steps_used` the ones that count."""
         torch.cuda.synchronize()
-        out = {}
-        spans, per_step = [], {}
+        spans, per_step, recs = [], {}, []
         for kind, flops, s, e, step in self.records:
-            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0, max_ms=0.0))
-            d['launches'] += 1
-            d['flops'] += flops
             el = self._elapsed(s, e)
-            d['ms'] += el
-            d['max_ms'] = max(d['max_ms'], el)
             sp = (self._elapsed(self.base, s), self._elapsed(self.base, e))
             spans.append(sp)
             per_step.setdefault(step, []).append(sp)
-        self.busy_ms = self._union(spans)
-        self.step_busy_ms = [self._union(v) for _, v in sorted(per_step.items())]     # union of the launch intervals of every step
+            recs.append((kind, flops, el, step))
+        self.busy_ms_all = self._union(spans)
+        steps = sorted(per_step)
+        self.step_busy_ms = [self._union(per_step[k]) for k in steps]     # union of the launch intervals of every step
+        sb = sorted(self.step_busy_ms)
+        med = (sb[len(sb) // 2] if len(sb) % 2 else 0.5 * (sb[len(sb) // 2 - 1] + sb[len(sb) // 2])) if sb else 0.0
+        good = {k for k, v in zip(steps, self.step_busy_ms) if abs(v - med) <= tol * med} if len(steps) > 1 else set(steps)
+        self.steps_used = len(good)
+        self.busy_ms = sum(v for k, v in zip(steps, self.step_busy_ms) if k in good)
+        out = {}
+        for kind, flops, el, step in recs:
+            if step not in good:
+                continue
+            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0, max_ms=0.0))
+            d['launches'] += 1
+            d['flops'] += flops
+            d['ms'] += el
+            d['max_ms'] = max(d['max_ms'], el)
         for h in self._pool:
             _L().rsuper_timer_event_destroy(h)
         self._pool = []

@@ -16,7 +16,10 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # per-GPU batch (the layer
 # (name, S, Ca, Cb, Cout, fused_sc)
 LAYERS = [('inc 32->32', 96, 32, 0, 32, False), ('up4.0 96->32+sc', 96, 32, 64, 32, True), ('down1.0 32->64+sc', 48, 32, 0, 64, True),
           ('64->64', 48, 64, 0, 64, False), ('up3.0 192->64+sc', 48, 64, 128, 64, True), ('128->128', 24, 128, 0, 128, False),
-          ('up2.0 384->128+sc', 24, 128, 256, 128, True), ('256->256', 12, 256, 0, 256, False), ('320->320', 6, 320, 0, 320, False)]
+          ('up2.0 384->128+sc', 24, 128, 256, 128, True), ('256->256', 12, 256, 0, 256, False), ('320->320', 6, 320, 0, 320, False),
+          # the fused [conv1 | shortcut] members of the low-resolution blocks (round 6: up1.0's weight gradient was the slowest per FLOP of the step and in no table)
+          ('down2.0 64->128+sc', 24, 64, 0, 128, True), ('down3.0 128->256+sc', 12, 128, 0, 256, True), ('down4.0 256->320+sc', 6, 256, 0, 320, True),
+          ('up1.0 576->256+sc', 12, 256, 320, 256, True)]
 
 if os.environ.get('BC_EXTRA'):                           # extra rows: the two column ranges of up4.0's data gradient as launches of their own (K = 64 -> 64 / 32 columns)
     LAYERS = [('up4.0 dgrad cols 32..95', 96, 64, 0, 32, True), ('up4.0 dgrad cols 0..31', 96, 32, 0, 32, True)]

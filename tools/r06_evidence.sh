@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_r06s -o r -- pyt
 cp $(ls /tmp/kt_r06s/*kernel_stats.csv | head -1) gpurun_out/r06_bench_rocprofv3_kernel_stats.csv 2>/dev/null
 rm -rf gpurun_out/pmc_step_fetch gpurun_out/pmc_step_write
 timeout 600 bash tools/pmc_step.sh
-python tools/pmc_step_summary.py gpurun_out/pmc_step_fetch gpurun_out/pmc_step_write 6 r06 > gpurun_out/r06_pmc_step.md 2>&1
+python tools/pmc_step_summary.py gpurun_out/pmc_step_fetch gpurun_out/pmc_step_write 6 r06 > gpurun_out/r06_pmc_step.md 2>&1; cp profiles/conv_traffic.json gpurun_out/conv_traffic.json
 for L in "0 fwd" "0 dgrad" "1 fwd" "1 dgrad" "3 fwd" "3 dgrad" "4 fwd" "4 dgrad" "5 fwd" "5 dgrad"; do
   set -- $L
   rm -rf gpurun_out/pmc5_${1}_${2}_*
