@@ -938,7 +938,10 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemParams p) {
 constexpr int SMALL_WS_ROW = 1024 + 32;
 constexpr int SMALL_WS_BLOCKS = 512;
 
-template <typename T, int MODE>
+// BF (head, bf16 activations; round 6): the two products of the head's backward on v_mfma_f32_32x32x16_bf16 -- 16 voxels (weight gradient) / 16 classes (data
+// gradient) per instruction of 32 cycles instead of 2 per 64-cycle exact-f32 instruction; the staged dlogits are rounded to bf16 as they enter the operand vector
+// (round-to-nearest-even, the rounding every convolution's dY already carries in this mode), the features and the bias gradient are exact as before.
+template <typename T, int MODE, bool BF = false>
 __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, HeadParams hp, int k0, int c0, float* __restrict__ ws) {
     // Chunks of 256 consecutive voxels are staged block-cooperatively with wide coalesced loads (per-lane 2/4-byte
     // gathers saturated the address unit): tb = channels-last operand [256][33] as f32; ta = head: dlogits planes
@@ -1013,6 +1016,21 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
             }
         }
     };
+    uint4 wfrag[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};      // BF: W[k][c] as the B operand of the data gradient, k = 16 s + 8 kk + j, c = idx
+    if constexpr (MODE == 1 && BF) {
+        if (with_dx) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float wv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s2 + 8 * kk + j;
+                    wv[j] = (k < hp.K && idx < hp.C) ? hp.w[k * hp.C + idx] : 0.f;
+                }
+                wfrag[s2] = make_uint4(f2bf2(wv[0], wv[1]), f2bf2(wv[2], wv[3]), f2bf2(wv[4], wv[5]), f2bf2(wv[6], wv[7]));
+            }
+        }
+    }
     if ((long)blockIdx.x < items) load_chunk(blockIdx.x);
     for (long it = blockIdx.x; it < items; it += gridDim.x) {
         // ---- registers -> LDS: tb [256][33] channels-last operand as f32; ta = head [32][257] planes / stem [256][29] taps
@@ -1036,6 +1054,18 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
         }
         __syncthreads();
         if (it + gridDim.x < items) load_chunk(it + gridDim.x);
+        if constexpr (MODE == 1 && BF) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                        // this wave's 64 voxels: four k-steps of 16 (lane half kk: voxels 8 kk .. 8 kk + 7 of the step)
+                const int vb = wave * 64 + 16 * s + 8 * kk;
+                float af[8], xf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { af[j] = ta[idx * 257 + vb + j]; xf[j] = tb[(vb + j) * 33 + idx]; bias_acc += af[j]; }
+                const uint4 a4 = make_uint4(f2bf2(af[0], af[1]), f2bf2(af[2], af[3]), f2bf2(af[4], af[5]), f2bf2(af[6], af[7]));
+                const uint4 b4 = make_uint4(f2bf2(xf[0], xf[1]), f2bf2(xf[2], xf[3]), f2bf2(xf[4], xf[5]), f2bf2(xf[6], xf[7]));
+                mma32<bf16_t>(acc, a4, b4);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             const int vl = wave * 64 + 2 * s + kk;
@@ -1044,6 +1074,7 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
             else { av = ta[idx * 257 + vl]; bv = tb[vl * 33 + idx]; bias_acc += av; }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
+        }
         if (with_dx) {
             const int n = (int)(it / per), v0 = (int)(it % per) * 256;
 #pragma unroll
@@ -1051,10 +1082,20 @@ __global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(StemParams sp, He
                 f32x16_t d;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                if constexpr (MODE == 1 && BF) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        float af[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) af[j] = ta[(16 * s2 + 8 * kk + j) * 257 + wave * 64 + g * 32 + idx];
+                        mma32<bf16_t>(d, make_uint4(f2bf2(af[0], af[1]), f2bf2(af[2], af[3]), f2bf2(af[4], af[5]), f2bf2(af[6], af[7])), wfrag[s2]);
+                    }
+                } else {
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const int k = 2 * s + kk;
                     d = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[k * 257 + wave * 64 + g * 32 + idx], wl[k * 33 + idx], d, 0, 0, 0);
+                }
                 }
                 // through the wave's own rows of tb (no other wave reads them, and a wave's LDS accesses are ordered): accumulator layout (lane = channel,
                 // register = voxel row) -> voxel-major, then 16-byte stores, consecutive lanes -> consecutive addresses
@@ -1360,7 +1401,8 @@ int rs_launch_head(const HeadParams& p, int dtype, int which, hipStream_t st) {
                     (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
                     hipLaunchKernelGGL(kf, g2, dim3(256), smem, st, sp, p, k0, c0, ws);
                 } else {
-                    auto kf = small_wgrad_mfma_kernel<bf16_t, 1>;
+                    static const bool bf = !(getenv("RSUPER_HEAD_BF16") && atoi(getenv("RSUPER_HEAD_BF16")) == 0);      // =0: the exact-f32 chains of rounds 4-5 (A/B)
+                    auto kf = bf ? small_wgrad_mfma_kernel<bf16_t, 1, true> : small_wgrad_mfma_kernel<bf16_t, 1, false>;
                     (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
                     hipLaunchKernelGGL(kf, g2, dim3(256), smem, st, sp, p, k0, c0, ws);
                 }
