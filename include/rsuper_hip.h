@@ -275,6 +275,14 @@ int rsuper_plane_partials_fwd2(const float* x, size_t xstride, const uint8_t* t,
                                const float* w1, const uint8_t* w2, double* sums, int flags, int planes, size_t V, void* stream);
 int rsuper_plane_partials_bwd2(const float* x, size_t xstride, const uint8_t* t, const uint8_t* tpk, int tP, int tC, const uint8_t* k, const uint8_t* kflags,
                                const float* w1, const uint8_t* w2, const float* g, float* dx, int flags, int planes, size_t V, void* stream);
+/* The forward sums without a float atomic (round 6): every block of the launch stores its six partial sums to pblk[plane][block][6]
+ * (blocks = rsuper_plane_partials_blocks(V) per plane; no pre-zeroing) and rsuper_plane_sums_reduce adds them in block order and converts to f32:
+ * out[row][6] for `rows` consecutive planes of one or several _fwd3 launches.  Bit-reproducible by construction; one launch less than the atomic form
+ * (zero fill + sums + f64 -> f32 conversion). */
+int rsuper_plane_partials_blocks(size_t V);
+int rsuper_plane_partials_fwd3(const float* x, size_t xstride, const uint8_t* t, const uint8_t* tpk, int tP, int tC, const uint8_t* k, const uint8_t* kflags,
+                               const float* w1, const uint8_t* w2, double* pblk, int flags, int planes, size_t V, void* stream);
+int rsuper_plane_sums_reduce(const double* pblk, int rows, int nb, float* out, void* stream);
 /* Segmentation term from the sums of the (B*C) label planes: loss[0] = scale * ( sum(S*cw)/(B*C*V) + DiceLossMultiClass ),
  * :945-956 with the adaptive-Tversky Dice of :541-607 (alpha_c = clamp(sum_b FP / (sum_b FP + sum_b FN + 1e-5), 0.2, 0.8),
  * dice = TP / (TP + alpha FP + (1-alpha) FN + 1e-5), mean over (b, c) of (1 - dice) * cw).  sums f32 [B*C][6] as produced

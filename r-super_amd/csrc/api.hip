@@ -579,13 +579,25 @@ int rsuper_plane_partials_fwd2(const float* x, size_t xstride, const uint8_t* t,
                                const float* w1, const uint8_t* w2, double* sums, int flags, int planes, size_t V, void* stream) {
     if (!x || !sums || planes <= 0 || V == 0 || (flags & ~2) || (t && tpk)) return RS_ERR_ARG;
     if (tpk && (tC <= 0 || tP * 8 < tC || planes % tC)) return RS_ERR_ARG;
-    PlaneParams p = {x, xstride, t, k, w1, w2, sums, nullptr, nullptr, 0, V, k ? (flags >> 1) & 1 : 0, tpk, tP, tC, kflags};
+    PlaneParams p = {x, xstride, t, k, w1, w2, sums, nullptr, nullptr, 0, V, k ? (flags >> 1) & 1 : 0, tpk, tP, tC, kflags, nullptr};
     return rs_launch_plane_partials(p, planes, 0, ST(stream));
+}
+int rsuper_plane_partials_blocks(size_t V) { return V ? rs_plane_partials_blocks(V) : 0; }
+int rsuper_plane_partials_fwd3(const float* x, size_t xstride, const uint8_t* t, const uint8_t* tpk, int tP, int tC, const uint8_t* k, const uint8_t* kflags,
+                               const float* w1, const uint8_t* w2, double* pblk, int flags, int planes, size_t V, void* stream) {
+    if (!x || !pblk || planes <= 0 || V == 0 || (flags & ~2) || (t && tpk)) return RS_ERR_ARG;
+    if (tpk && (tC <= 0 || tP * 8 < tC || planes % tC)) return RS_ERR_ARG;
+    PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, nullptr, nullptr, 0, V, k ? (flags >> 1) & 1 : 0, tpk, tP, tC, kflags, pblk};
+    return rs_launch_plane_partials(p, planes, 0, ST(stream));
+}
+int rsuper_plane_sums_reduce(const double* pblk, int rows, int nb, float* out, void* stream) {
+    if (!pblk || !out || rows <= 0 || nb <= 0) return RS_ERR_ARG;
+    return rs_launch_plane_sums_reduce(pblk, rows, nb, out, ST(stream));
 }
 int rsuper_plane_partials_bwd(const float* x, size_t xstride, const uint8_t* t, const uint8_t* k, const float* w1, const uint8_t* w2,
                               const float* g, float* dx, int flags, int planes, size_t V, void* stream) {
     if (!x || !g || !dx || planes <= 0 || V == 0 || (flags & ~3)) return RS_ERR_ARG;
-    PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, flags & 1, V, k ? (flags >> 1) & 1 : 0, nullptr, 0, 0, nullptr};
+    PlaneParams p = {x, xstride, t, k, w1, w2, nullptr, g, dx, flags & 1, V, k ? (flags >> 1) & 1 : 0, nullptr, 0, 0, nullptr, nullptr};
     return rs_launch_plane_partials(p, planes, 1, ST(stream));
 }
 int rsuper_plane_partials_bwd2(const float* x, size_t xstride, const uint8_t* t, const uint8_t* tpk, int tP, int tC, const uint8_t* k, const uint8_t* kflags,

@@ -117,8 +117,21 @@ __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) 
     __syncthreads();
     if (threadIdx.x < 6) {
         const double v = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
-        atomicAdd(p.sums + (size_t)plane * 6 + threadIdx.x, v);
+        if (p.pblk) p.pblk[((size_t)plane * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = v;      // fixed-order reduction follows (plane_sums_reduce_kernel)
+        else atomicAdd(p.sums + (size_t)plane * 6 + threadIdx.x, v);
     }
+}
+
+// out[row][q] = (float) sum_b pblk[row][b][q], b ascending: the per-block sums of plane_partials_fwd_kernel added in a fixed order -- no float atomic is left on
+// the training path, and neither is the zero-fill of the accumulator nor the f64 -> f32 conversion pass of the atomic form.
+__global__ __launch_bounds__(256) void plane_sums_reduce_kernel(const double* __restrict__ pblk, int rows, int nb, float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * 6) return;
+    const int row = e / 6, q = e - row * 6;
+    const double* src = pblk + (size_t)row * nb * 6 + q;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += src[(size_t)b * 6];
+    out[e] = (float)s;
 }
 
 // dx = k * ( (gS + gF1*w1 + gF2*(1-w2)) * (sig - t) + sig*(1-sig) * (gA + gB*t) ),  g: [planes][6] floats
@@ -344,10 +357,18 @@ __global__ __launch_bounds__(256) void window_normalize_kernel(float* __restrict
 }
 }  // namespace
 
-int rs_launch_plane_partials(const PlaneParams& p, int planes, int bwd, hipStream_t st) {
-    int blocks = (int)((p.V + 4095) / 4096);
+int rs_plane_partials_blocks(size_t V) {
+    int blocks = (int)((V + 4095) / 4096);
     if (blocks > 64) blocks = 64;
     if (blocks < 1) blocks = 1;
+    return blocks;
+}
+int rs_launch_plane_sums_reduce(const double* pblk, int rows, int nb, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(plane_sums_reduce_kernel, dim3((unsigned)((rows * 6 + 255) / 256)), dim3(256), 0, st, pblk, rows, nb, out);
+    return rs_check_launch();
+}
+int rs_launch_plane_partials(const PlaneParams& p, int planes, int bwd, hipStream_t st) {
+    const int blocks = rs_plane_partials_blocks(p.V);
     if (!bwd) {
         hipLaunchKernelGGL(plane_partials_fwd_kernel, dim3(blocks, planes), dim3(256), 0, st, p);
     } else {

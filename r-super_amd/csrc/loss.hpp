@@ -18,7 +18,10 @@ struct PlaneParams {
     int kinv;
     const uint8_t* tpk; int tP, tC;   // bit-packed target [samples][tP][V] for planes = samples x tC classes (replaces t), or nullptr
     const uint8_t* kflags;            // with kinv: [planes] any-flags of the UNdilated unknown map; 0 = the plane of k is all zero and is not read (nullptr: read every plane)
+    double* pblk;                     // forward, round 6: [planes][gridDim.x][6] per-block sums written with plain stores (no atomics, no pre-zeroing); nullptr: atomics into `sums`
 };
+int rs_plane_partials_blocks(size_t V);
+int rs_launch_plane_sums_reduce(const double* pblk, int rows, int nb, float* out, hipStream_t st);
 
 // Segmentation loss from the per-plane sums (losses_foundation.py:945-956 + DiceLossMultiClass :541-607) and its Jacobian.
 struct SegSumsParams {

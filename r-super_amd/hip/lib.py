@@ -64,6 +64,9 @@ _SIGS = {
     'rsuper_head_bwd': (c_int, [c_int, P, c_int, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     'rsuper_plane_partials_fwd': (c_int, [P, c_size_t, P, P, P, P, P, c_int, c_int, c_size_t, P]),
     'rsuper_plane_partials_fwd2': (c_int, [P, c_size_t, P, P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_size_t, P]),
+    'rsuper_plane_partials_fwd3': (c_int, [P, c_size_t, P, P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_size_t, P]),
+    'rsuper_plane_partials_blocks': (c_int, [c_size_t]),
+    'rsuper_plane_sums_reduce': (c_int, [P, c_int, c_int, P, P]),
     'rsuper_plane_partials_bwd2': (c_int, [P, c_size_t, P, P, c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_size_t, P]),
     'rsuper_cnorm_rows': (c_int, [c_long]),
     'rsuper_cnorm_small': (c_int, [P, P, P, P, P, c_int, c_long, c_int, c_int, c_float, c_int, P]),

@@ -144,13 +144,17 @@ class _PartialsFn(torch.autograd.Function):
         assert logits.is_contiguous() and logits.dtype == torch.float32
         V = logits[0, 0].numel()
         total = sum(tm.planes for tm in terms)
-        acc = torch.zeros((total, 6), device=logits.device, dtype=torch.float64)
+        # per-block sums stored, then added in block order (rsuper_plane_partials_fwd3 / rsuper_plane_sums_reduce): no float atomic, no zero fill, no
+        # f64 -> f32 conversion pass
+        nb = _L().rsuper_plane_partials_blocks(V)
+        pblk = torch.empty((total, nb, 6), device=logits.device, dtype=torch.float64)
         row = 0
         for tm in terms:
-            _l.check(_L().rsuper_plane_partials_fwd2(_ptr(logits, tm.x_off), tm.xstride, *tm.targs(), _ptr(tm.w1), _ptr(tm.w2),
-                                                     _ptr(acc, row * 6), 2 if tm.kinv else 0, tm.planes, V, _stream()), 'plane_partials_fwd')
+            _l.check(_L().rsuper_plane_partials_fwd3(_ptr(logits, tm.x_off), tm.xstride, *tm.targs(), _ptr(tm.w1), _ptr(tm.w2),
+                                                     _ptr(pblk, row * nb * 6), 2 if tm.kinv else 0, tm.planes, V, _stream()), 'plane_partials_fwd')
             row += tm.planes
-        out = acc.to(torch.float32)
+        out = torch.empty((total, 6), device=logits.device, dtype=torch.float32)
+        _l.check(_L().rsuper_plane_sums_reduce(_ptr(pblk), total, nb, _ptr(out), _stream()), 'plane_sums_reduce')
         ctx.terms = terms
         ctx.save_for_backward(logits)
         return out[:terms[0].planes], out[terms[0].planes:]

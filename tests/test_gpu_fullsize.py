@@ -381,8 +381,8 @@ def test_bf16_training_tracks_f32_over_an_ensemble_of_seeds():
 def test_training_is_bit_reproducible_across_processes(mode):
     """two SEPARATE processes give bit-identical loss curves at full size (B = 2, 96^3, 26 classes; 12 optimiser steps each,
     f32 and bf16).  (The differing 70-step f32 losses of the round-5 evidence runs came from different commits: the same tree printed 0.35382044315338135
-    in three processes on two boxes in round 6, profiles/r06_drift_bisect.txt.)  Every reduction on the path has a fixed order; the one float atomic
-    (csrc/loss.hip plane sums, f64) feeds an f32 rounding whose input would have to sit within 1e-16 relative of a tie to notice the order."""
+    in three processes on two boxes in round 6, profiles/r06_drift_bisect.txt.)  Every reduction on the path has a fixed order -- since round 6 also the
+    plane sums of the loss (per-block sums stored and added in block order, rsuper_plane_partials_fwd3 / rsuper_plane_sums_reduce; they were f64 atomics)."""
     a = _drift_runs(mode, [0], 12)[0]['loss']
     b = _drift_runs(mode, [0], 12)[0]['loss']
     assert a == b, (a, b)
