@@ -84,9 +84,13 @@ class PackedBits:
         if self._flags is None:
             B, P = self.packed.shape[:2]
             V = self.packed[0, 0].numel()
-            self._flags = torch.empty(B * self.C, device=self.packed.device, dtype=torch.uint8)
-            _l.check(_l.lib().rsuper_plane_any_bits(self.packed.data_ptr(), B, P, self.C, V, self._flags.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                     'plane_any_bits')
+            if V % 16 == 0 and self.packed.data_ptr() % 16 == 0:
+                self._flags = torch.empty(B * self.C, device=self.packed.device, dtype=torch.uint8)
+                _l.check(_l.lib().rsuper_plane_any_bits(self.packed.data_ptr(), B, P, self.C, V, self._flags.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                         'plane_any_bits')
+            else:       # voxel counts that are not a multiple of 16 (the kernel reads 16-byte vectors): per bit, the maximum of (byte & bit) over the plane
+                bits = torch.stack([(self.packed.flatten(2) & (0x80 >> k)).amax(2) for k in range(8)], 2)   # (B, P, 8)
+                self._flags = (bits.reshape(B, P * 8)[:, :self.C] != 0).to(torch.uint8).reshape(-1).contiguous()
         return self._flags
 
     def planes(self, chs, with_flagged=False):
