@@ -27,7 +27,8 @@ __device__ __forceinline__ void sig_bce(float x, float t, float& sg, float& bce)
 }
 __device__ __forceinline__ float sigmoidf(float x) { float s, b; sig_bce(x, 0.f, s, b); return s; }
 
-// grid: (blocks, planes).  sums: [planes][6] doubles, pre-zeroed, accumulated with f64 atomics.
+// grid: (blocks, planes).  p.pblk (calculate_loss, round 6): every block stores its six sums to pblk[plane][block][6], plane_sums_reduce_kernel adds them in block
+// order; p.sums (the one-launch form of rsuper_plane_partials_fwd / _fwd2): [planes][6] doubles, pre-zeroed, accumulated with f64 atomics.
 __global__ __launch_bounds__(256) void plane_partials_fwd_kernel(PlaneParams p) {
     const int plane = blockIdx.y;
     const size_t base = (size_t)plane * p.V;
