@@ -1222,6 +1222,41 @@ def test_train_epoch_with_hip_graph_on_a_packed_dataset_matches_eager(tmp_path, 
 
 
 @pytest.mark.gpu
+def test_update_output_layer_loads_the_pretrained_checkpoint_before_the_surgery(tmp_path):
+    """--update_output_layer (train_ddp.py:552-590, medformer.py:224-319): the old-class network is built, --pretrained is loaded INTO it, then the heads are
+    rebuilt for the new class list -- rows of classes both lists name carry the checkpoint's weights, everything below the heads is the checkpoint (ADVICE r05:
+    the surgery used to run on a freshly initialised head); without a checkpoint it refuses."""
+    from rsuper_amd.train_ddp import get_parser, init_network
+    from rsuper_amd.model.utils import get_model
+    old = sorted(['kidney_left', 'kidney_right', 'liver', 'pancreas', 'pancreatic_lesion'])
+    new = sorted(old + ['spleen', 'kidney_lesion'])
+    base = ['--epochs', '1', '--batch_size', '2', '--cp_path', str(tmp_path) + '/', '--unique_name', 'onk', '--model', 'medformer']
+    a0 = get_parser(base)
+    torch.manual_seed(5)
+    net_old = get_model(a0, pretrain=a0.pretrain, classes=old)
+    path = str(tmp_path / 'old.pth')
+    torch.save({'epoch': 1, 'model_state_dict': net_old.state_dict()}, path)
+    a1 = get_parser(base + ['--update_output_layer', '--pretrained', path])
+    torch.manual_seed(6)                                     # another seed: whatever agrees with net_old afterwards came from the file
+    net, ema = init_network(a1, classes=new, old_classes=old)
+    sd_old, sd = net_old.state_dict(), net.state_dict()
+    for k, v in sd_old.items():
+        if k.startswith('outc.') or k.startswith('aux_out.'):
+            continue
+        assert torch.equal(v, sd[k].cpu()), k
+    for head in ('outc', 'aux_out'):
+        if f'{head}.weight' not in sd:
+            continue
+        assert sd[f'{head}.weight'].shape[0] == len(new)
+        for c in old:
+            assert torch.equal(sd[f'{head}.weight'][new.index(c)].cpu(), sd_old[f'{head}.weight'][old.index(c)]), (head, c)
+            assert torch.equal(sd[f'{head}.bias'][new.index(c)].cpu(), sd_old[f'{head}.bias'][old.index(c)]), (head, c)
+    a2 = get_parser(base + ['--update_output_layer'])
+    with pytest.raises(ValueError, match='pretrained'):
+        init_network(a2, classes=new, old_classes=old)
+
+
+@pytest.mark.gpu
 def test_dispatcher_ops_forward_only_and_autograd_paths_agree():
     """rsuper::maxpool2 / rsuper::head_conv through the dispatcher: the AutogradCUDA kernel (forward + autograd node) and the CUDA kernel
     alone (inference_mode skips the autograd key) give identical results, and gradients flow through the registered op."""
