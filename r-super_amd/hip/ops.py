@@ -854,16 +854,23 @@ class BasicBlockFn(torch.autograd.Function):
         # conv1 (+ shortcut): fused data gradient over [dY1 | dOut], fused weight gradient
         sa = Src(xa, mr=mra)
         sb = None if xb is None else Src(xb, mr=mrb)
-        g0 = torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
+        # one gradient tensor per forward source when each source has its own launch (a 32-channel slice of a 96-channel row is 64 of every 192 bytes: the
+        # InstanceNorm-backward tails then fetch half-used cache lines -- up4.0: 80 / 145 us for the two tails against 61 / 123 us on contiguous tensors)
+        split_g0 = len(bpk[0]) == 3 and os.environ.get('RSUPER_SPLIT_G0', '1') == '1'
+        g0 = None if split_g0 else torch.empty((N, D, H, W, Cin), device=dev, dtype=dt)
+        g0s = [torch.empty((N, D, H, W, Ca), device=dev, dtype=dt), torch.empty((N, D, H, W, Cb), device=dev, dtype=dt)] if split_g0 else None
         # With the slab reductions deferred to one launch per block, that launch also finalises the InstanceNorm-backward rows of this data gradient
         # (flush_wgrad_reduces(stats=...)): it then runs BEFORE the InstanceNorm-backward tail instead of after it.
         fuse = FUSE_STATS_REDUCE and DEFER_WGRAD_REDUCE and not ov and not sr
         pending = []
         if len(bpk[0]) == 3:                  # one launch per forward source (block_pack_specs / split_dgrad_sources)
             gm0 = []
-            for (c0, cn, src, wp_, bn) in ((0, Ca, sa, bpk[0][1], bpk[1][1]), (Ca, Cb, sb, bpk[0][2], bpk[1][2])):
+            for si, (c0, cn, src, wp_, bn) in enumerate(((0, Ca, sa, bpk[0][1], bpk[1][1]), (Ca, Cb, sb, bpk[0][2], bpk[1][2]))):
                 part0 = part_buffer(dt, dims, cn, bn, dev, epi=1)
-                igemm(1, Src(dy1), sdo if has_sc else None, wp_, cn, bn, dims, g0[..., c0:], out_ld=Cin, part=part0, ea=src)
+                if split_g0:
+                    igemm(1, Src(dy1), sdo if has_sc else None, wp_, cn, bn, dims, g0s[si], part=part0, ea=src)
+                else:
+                    igemm(1, Src(dy1), sdo if has_sc else None, wp_, cn, bn, dims, g0[..., c0:], out_ld=Cin, part=part0, ea=src)
                 if fuse:
                     pending.append((part0, cnt, 1, 0))
                 else:
@@ -886,6 +893,9 @@ class BasicBlockFn(torch.autograd.Function):
         if xb is None:
             dxa = in_bwd_finalize(Src(g0), sa, gm0, Ca, add1=None if has_sc else dout)
             dxb = None
+        elif split_g0:
+            dxa = in_bwd_finalize(Src(g0s[0]), sa, gm0[0], Ca)
+            dxb = in_bwd_finalize(Src(g0s[1]), sb, gm0[1], Cb)
         else:
             dxa = in_bwd_finalize(Src(g0, C=Ca), sa, gm0[0], Ca)
             dxb = in_bwd_finalize(Src(g0, C=Cb, off=Ca), sb, gm0[1], Cb)
