@@ -120,6 +120,18 @@ int rsuper_conv3_igemm(int dtype, int epi,
                        void* out, int ldo, const void* res, int ldr, float* part,
                        const void* exa, int elda, int eCa, const float* emra,
                        const void* exb, int eldb, int eCb, const float* emrb, void* stream);
+/* The same launch with TWO output tensors: columns [0, out_split) go to `out`, columns [out_split, n_cols) to a tensor `out_part` ELEMENTS behind it (allocate
+ * both from one buffer), each with row stride ldo.  For the fused [conv1 | shortcut] GEMM of a BasicBlock whose halves are narrower than a 128-byte line (32 bf16
+ * channels: up4.0): every consumer of one half -- conv2's staging, its weight gradient, the ReLU mask of its data gradient, the InstanceNorm-backward tail -- then
+ * reads whole lines instead of half-used ones.  out_split a multiple of 32; only launches the depth-reuse kernel takes (rsuper_conv3_kd_bn(...) == bn),
+ * RS_ERR_UNSUPPORTED otherwise: the caller falls back to the interleaved output. */
+int rsuper_conv3_igemm_split_out(int dtype, int epi,
+                                 const void* xa, int lda, int Ca, const float* mra,
+                                 const void* xb, int ldb, int Cb, const float* mrb,
+                                 const void* packed, int n_cols, int bn, int N, int D, int H, int W,
+                                 void* out, int ldo, const void* res, int ldr, float* part,
+                                 const void* exa, int elda, int eCa, const float* emra,
+                                 const void* exb, int eldb, int eCb, const float* emrb, int out_split, long long out_part, void* stream);
 /* The STRIDED member: Conv3d(k=3, stride=2, pad=1, bias=False) of down_block(pool=False) (unet_utils.py:38-39; BasicBlock conv1 + shortcut,
  * conv_layers.py:29-38,82-84) and its data gradient, with the minimal MFMA work (the 27 taps split over the 8 parity classes of the input /
  * of the gradient's output; conv3d_igemm_s2.hip).  FD x FH x FW = the full-resolution grid; the half-resolution one is ceil(F / 2).

@@ -287,14 +287,18 @@ int rsuper_conv3_igemm_s2(int dtype, int mode, const void* xa, int lda, int Ca, 
     return rs_launch_igemm_s2(p, dtype, mode, FD, FH, FW, ST(stream));
 }
 
-int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, const float* mra,
+static int conv3_igemm_impl(int dtype, int epi, const void* xa, int lda, int Ca, const float* mra,
                        const void* xb, int ldb, int Cb, const float* mrb,
                        const void* packed, int n_cols, int bn, int N, int D, int H, int W,
                        void* out, int ldo, const void* res, int ldr, float* part,
                        const void* exa, int elda, int eCa, const float* emra,
-                       const void* exb, int eldb, int eCb, const float* emrb, void* stream) {
+                       const void* exb, int eldb, int eCb, const float* emrb, void* stream, int out_split, long long out_part) {
     if (!dt_ok(dtype) || (epi != 0 && epi != 1) || !xa || !packed || !out) return RS_ERR_ARG;
-    if (!ch_ok(Ca, lda) || Ca == 0 || (Cb > 0 && (!xb || !ch_ok(Cb, ldb))) || n_cols <= 0 || (n_cols % 8) || (ldo % 8) || ldo < n_cols) return RS_ERR_ARG;
+    if (out_split) {        // two output tensors: columns [0, out_split) and [out_split, n_cols), row stride ldo each
+        if (out_split < 0 || (out_split % 32) || out_split >= n_cols || out_part <= 0 || (out_part % 8) || ldo < out_split || ldo < n_cols - out_split) return RS_ERR_ARG;
+        if ((unsigned long long)(out_part + (long long)N * D * H * W * ldo) * 2ull >= (1ull << 32)) return RS_ERR_UNSUPPORTED;
+    }
+    if (!ch_ok(Ca, lda) || Ca == 0 || (Cb > 0 && (!xb || !ch_ok(Cb, ldb))) || n_cols <= 0 || (n_cols % 8) || (ldo % 8) || (!out_split && ldo < n_cols)) return RS_ERR_ARG;
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return RS_ERR_ARG;
     if (res && ((ldr % 8) || ldr < n_cols)) return RS_ERR_ARG;
     if (epi == 1 && (!exa || !emra || eCa + eCb != n_cols || (eCb > 0 && (!exb || !emrb)))) return RS_ERR_ARG;
@@ -327,7 +331,30 @@ int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, cons
     if (bn == kd_bn_for(dtype, epi, N, D, H, W, n_cols, src_flags)) { p.pc = 3; p.box = 0; }
     else if (bn == 96) return RS_ERR_UNSUPPORTED;                  // 96-column blocks exist on the depth-reuse kernel only
     if (p.pc && bn == 32 && (g_variant == 4 || (g_variant == 3 && (Ca + 31) / 32 + (Cb + 31) / 32 == 1))) p.pc = 2;
+    if (out_split) {
+        if (p.pc != 3 || !rs_igemm_kd_supported(p, dtype)) return RS_ERR_UNSUPPORTED;      // the split store exists in the depth-reuse kernel's epilogue only
+        p.out_split = out_split; p.out_part = out_part;
+    }
     return rs_launch_igemm(p, dtype, epi, ST(stream));
+}
+int rsuper_conv3_igemm(int dtype, int epi, const void* xa, int lda, int Ca, const float* mra,
+                       const void* xb, int ldb, int Cb, const float* mrb,
+                       const void* packed, int n_cols, int bn, int N, int D, int H, int W,
+                       void* out, int ldo, const void* res, int ldr, float* part,
+                       const void* exa, int elda, int eCa, const float* emra,
+                       const void* exb, int eldb, int eCb, const float* emrb, void* stream) {
+    return conv3_igemm_impl(dtype, epi, xa, lda, Ca, mra, xb, ldb, Cb, mrb, packed, n_cols, bn, N, D, H, W, out, ldo, res, ldr, part,
+                            exa, elda, eCa, emra, exb, eldb, eCb, emrb, stream, 0, 0);
+}
+int rsuper_conv3_igemm_split_out(int dtype, int epi, const void* xa, int lda, int Ca, const float* mra,
+                                 const void* xb, int ldb, int Cb, const float* mrb,
+                                 const void* packed, int n_cols, int bn, int N, int D, int H, int W,
+                                 void* out, int ldo, const void* res, int ldr, float* part,
+                                 const void* exa, int elda, int eCa, const float* emra,
+                                 const void* exb, int eldb, int eCb, const float* emrb, int out_split, long long out_part, void* stream) {
+    if (out_split <= 0) return RS_ERR_ARG;
+    return conv3_igemm_impl(dtype, epi, xa, lda, Ca, mra, xb, ldb, Cb, mrb, packed, n_cols, bn, N, D, H, W, out, ldo, res, ldr, part,
+                            exa, elda, eCa, emra, exb, eldb, eCb, emrb, stream, out_split, out_part);
 }
 
 int rsuper_conv3_wgrad_splits(int dtype, int Ca, int Cb, int Ya, int Yb, int N, int D, int H, int W) {

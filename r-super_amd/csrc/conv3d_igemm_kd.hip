@@ -88,6 +88,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
     const void* const exa = UP(p.ea.x); const void* const exb = UP(p.eb.x);
     const float* const emra = (const float*)UP(p.ea.mr); const float* const emrb = (const float*)UP(p.eb.mr);
     const int pD = p.D, pH = p.H, pW = p.W, pN = p.N, Cout = p.Cout, ldo = p.ldo, ldr = p.ldr, ntiles = p.ntiles;
+    const uint32_t osplit = (uint32_t)p.out_split, opart = (uint32_t)p.out_part;       // (locals, like every other kernel-argument field: see the note on captures below)
     const void* const wpk = p.wp; void* const outp = p.out; const void* const resp = p.res; float* const partp = p.part;
     const int ctot = Ca + Cb;
     char* bufs = smem;                                                  // 2 x HB
@@ -306,7 +307,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
         row_to_hw_nt(er0 + 16, rhs[1], rw[1]);
         float* scr = (float*)(scr_base + wave * SCR_BYTES);
         float* sw = sacc + wave * 128;
-        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(outp, 0, nvox_total * (uint32_t)ldo * 2u, 0x00020000);
+        // p.out_split > 0: the columns from out_split on live in a second tensor of the same row stride, out_part elements behind the first (the two halves of a
+        // fused [conv1 | shortcut] output whose halves are narrower than a cache line: consumers then read whole lines)
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (nvox_total * (uint32_t)ldo + (osplit ? opart : 0u)) * 2u, 0x00020000);
         // epilogue operand (residual / forward input of the ReLU mask) of column fragment nf: source, row pitch, this lane's first column -- recomputed
         // where needed (a few operations) instead of living in registers across the MFMA loop
         auto ep_desc = [&](int nf, const bf16_t*& x, uint32_t& ld, int& c0, bool& cok) {
@@ -585,7 +588,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_kd_kernel(IgemmParams p) {
                             s2[q] = __builtin_elementwise_fma(r, EPI == 1 ? xn : r, s2[q]);
                         }
                         const u32x4_t pk = {ow[0], ow[1], ow[2], ow[3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(pk, ors, ok ? (vx * (uint32_t)ldo + (uint32_t)col0) * 2u : 0xFFFFFFF0u, 0, 0);
+                        const uint32_t ocol = (osplit && (uint32_t)col0 >= osplit) ? (uint32_t)col0 - osplit + opart : (uint32_t)col0;
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, ors, ok ? (vx * (uint32_t)ldo + ocol) * 2u : 0xFFFFFFF0u, 0, 0);
                     }
                     if (EPI != 0 && f + EVF < NF * TD) epi_load(f + EVF, true);   // the slot just consumed takes the operands of fragment f + EVF
                     // 3) statistics of this fragment: lanes with the same column group hold partial sums over their rows -> reduce, accumulate per wave in LDS

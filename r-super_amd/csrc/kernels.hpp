@@ -26,6 +26,7 @@ struct IgemmParams {
     ConvSrc ea, eb;        // EPI 1: forward inputs (with mr) whose relu mask / x_n the data-gradient needs
     int box;               // > 0: volume-fitted K-split kernel (conv3d_igemm_box.hip), value = rs_box_config (3: one box per sample, reduction split over blocks)
     float* ws; int nsplit; // box == 3: f32 workspace [nsplit][N * D * H * W][Cout] and the number of chunk ranges
+    int out_split; long long out_part;   // out_split > 0 (depth-reuse kernel only): columns >= out_split go to a second tensor `out_part` ELEMENTS behind `out`, both with row stride ldo
 };
 
 struct PackParams {

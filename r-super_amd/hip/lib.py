@@ -5,7 +5,7 @@ The product path has no CPU fallback: `lib()` raises if the shared library is mi
 """
 import ctypes
 import os
-from ctypes import c_int, c_long, c_size_t, c_float, c_double, c_void_p, c_uint32, c_uint
+from ctypes import c_int, c_long, c_longlong, c_size_t, c_float, c_double, c_void_p, c_uint32, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'librsuper_hip.so')
@@ -33,6 +33,8 @@ _SIGS = {
     'rsuper_conv3_igemm_s2': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, P, P]),
     'rsuper_conv3_igemm': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                    P, c_int, P, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, P]),
+    'rsuper_conv3_igemm_split_out': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             P, c_int, P, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_longlong, P]),
     'rsuper_conv3_wgrad': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int,
                                    P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'rsuper_conv3_wgrad_partial': (c_int, [c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int,

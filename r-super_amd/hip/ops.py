@@ -451,13 +451,22 @@ class _Side:
         return False
 
 
-def igemm(epi, a, b, packed, n_cols, bn, dims, out, out_ld=None, res=None, part=None, ea=None, eb=None):
-    """a, b, ea, eb: Src (b/eb may be None).  res: Src or None.  dims = (N, D, H, W)."""
+def igemm(epi, a, b, packed, n_cols, bn, dims, out, out_ld=None, res=None, part=None, ea=None, eb=None, out2=None, out_split=0):
+    """a, b, ea, eb: Src (b/eb may be None).  res: Src or None.  dims = (N, D, H, W).
+    out2 / out_split: columns [out_split, n_cols) go to the tensor `out2` (same row stride as `out`, allocated behind it in the same buffer) --
+    rsuper_conv3_igemm_split_out, depth-reuse kernel only."""
     dt = _DT[a.t.dtype]
     N, D, H, W = dims
     ra = (None, 0) if res is None else (_ptr(res.t, res.off), res.ld)
 
     def run():
+        if out2 is not None:
+            delta = (out2.data_ptr() - out.data_ptr()) // out.element_size()
+            _l.check(_L().rsuper_conv3_igemm_split_out(dt, epi, *a.args(), *(b.args() if b is not None else _NONE), _ptr(packed), n_cols, bn,
+                                                       N, D, H, W, _ptr(out), out.shape[-1] if out_ld is None else out_ld, ra[0], ra[1], _ptr(part),
+                                                       *(ea.args() if ea is not None else _NONE), *(eb.args() if eb is not None else _NONE),
+                                                       out_split, delta, _stream()), 'conv3_igemm_split_out')
+            return
         _l.check(_L().rsuper_conv3_igemm(dt, epi, *a.args(), *(b.args() if b is not None else _NONE), _ptr(packed), n_cols, bn,
                                          N, D, H, W, _ptr(out), out.shape[-1] if out_ld is None else out_ld, ra[0], ra[1], _ptr(part),
                                          *(ea.args() if ea is not None else _NONE), *(eb.args() if eb is not None else _NONE),
@@ -693,15 +702,25 @@ class BasicBlockFn(torch.autograd.Function):
             both = os.environ.get('RSUPER_PACK_BOTH', '1') == '1' and any(ctx.needs_input_grad)
             packs = block_packs(w1, w2, ws, Ca, Cb, dt, tiles * N, both, dims)
         bn1, wp1 = packs[1][0], packs[0][0]
-        ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
         part = part_buffer(dt, dims, nc1, bn1, dev)
-        igemm(0, sa, sb, wp1, nc1, bn1, dims, ys, part=part)
+        # [y1 | shortcut] halves narrower than a 128-byte line (32 bf16 channels: up4.0): two tensors instead of an interleaved one, so that conv2's staging,
+        # its weight gradient, the mask of its data gradient and the InstanceNorm-backward tail read whole cache lines (rsuper_conv3_igemm_split_out; the
+        # depth-reuse kernel's epilogue only -- other kernels keep the interleaved output)
+        split_ys = (has_sc and Cout * xa.element_size() < 128 and Cout % 32 == 0 and os.environ.get('RSUPER_SPLIT_YS', '1') == '1'
+                    and _L().rsuper_conv3_kd_bn(_DT[dt], 0, N, D, H, W, nc1, 0) == bn1)
+        if split_ys:
+            ys2 = torch.empty((2, N, D, H, W, Cout), device=dev, dtype=dt)
+            ys, sc_t = ys2[0], ys2[1]
+            igemm(0, sa, sb, wp1, nc1, bn1, dims, ys, part=part, out2=sc_t, out_split=Cout)
+        else:
+            ys = torch.empty((N, D, H, W, nc1), device=dev, dtype=dt)
+            igemm(0, sa, sb, wp1, nc1, bn1, dims, ys, part=part)
         mr_y1 = stats_finalize(part, cnt, split=Cout)[0] if has_sc else stats_finalize(part, cnt)
         # conv2 + residual
         bn2, wp2 = packs[1][1], packs[0][1]
         out = torch.empty((N, D, H, W, Cout), device=dev, dtype=dt)
         part2 = part_buffer(dt, dims, Cout, bn2, dev)
-        res = Src(ys, C=Cout, off=Cout) if has_sc else Src(xa)
+        res = (Src(sc_t) if split_ys else Src(ys, C=Cout, off=Cout)) if has_sc else Src(xa)
         igemm(0, Src(ys, C=Cout, mr=mr_y1), None, wp2, Cout, bn2, dims, out, res=res, part=part2)
         mr_out = stats_finalize(part2, cnt)
         ctx.save_for_backward(xa, mra, xb, mrb, ys, mr_y1, w1, w2, ws)
